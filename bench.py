@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- fk() frames/s on MI355X, 22-joint skeleton (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the fk hot path over one device-resident batch of synthetic frames
+(config 2 of BASELINE.json: 2^20 frames x 22 joints per GPU, fp32, quaternions not
+pre-normalised, metre-scale offsets).  Frames shard across ranks with no data-path collective
+(weak scaling: per-GPU batch fixed); the optional output all-gather is timed separately.
+Rank 0 prints ONE JSON line.  Extra objects in that line:
+
+  roofline      the fk kernel against the HBM roofline: algorithmic bytes (64*J+12 per frame)
+                / average launch time measured with HIP events on the launch stream.
+  cpu_baseline  the cost-equivalent NumPy restatement of the reference's fk (oracle/numpy_ref.py,
+                kind "port") timed on this box's host cores over the same workload (N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy reaches
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames-per-gpu", type=int, default=1 << 20)
+    ap.add_argument("--joints", type=int, default=22, choices=[22, 52])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-frames", type=int, default=1 << 20)
+    ap.add_argument("--gather", action="store_true", help="also time the RCCL all-gather of (pos, rotmats) (N>1)")
+    ap.add_argument("--seed", type=int, default=0)
+    return ap.parse_args()
+
+
+def cpu_baseline(rot, root, off, parents, sample_frames):
+    """Time the NumPy port of the reference fk on a bounded sample; also return its outputs."""
+    import numpy as np
+
+    from oracle import numpy_ref as nr
+
+    n = min(sample_frames, rot.shape[0])
+    r, g = rot[:n], root[:n]
+    nr.fk(r[:1000], g[:1000], off, parents)  # warm NumPy / page in
+    c0, t0 = os.times(), time.perf_counter()
+    pos, rm = nr.fk_chunked(r, g, off, parents, chunk=1 << 17)
+    t1, c1 = time.perf_counter(), os.times()
+    wall = t1 - t0
+    cpu = (c1.user - c0.user) + (c1.system - c0.system)
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    info = {
+        "value": n / wall,
+        "unit": "frames/s",
+        "cores": max(1, int(round(cpu / wall))),
+        "kind": "port",
+        "sample": f"{n} frames x {rot.shape[1]} joints, oracle/numpy_ref.fk_chunked (f64 [F,J,4,4] scratch, "
+                  f"per-joint batched matmul, chunks of 2^17), {wall:.1f} s wall",
+        "host_cpus_visible": len(os.sched_getaffinity(0)),
+        "cpu_model": model,
+    }
+    return info, pos, rm
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from pymotion_amd import _lib
+    from pymotion_amd import synthetic as syn
+    import pymotion_amd.ops.skeleton_torch as skt
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        a.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    J = a.joints
+    parents = syn.PARENTS_22 if J == 22 else syn.PARENTS_52
+    F = a.frames_per_gpu
+    # synthetic workload born on the device from (seed, rank): no host->device copy is ever timed
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(a.seed * 1000 + rank)
+    rot = torch.randn((F, J, 4), generator=gen, device=dev, dtype=torch.float32)
+    root = torch.rand((F, 3), generator=gen, device=dev, dtype=torch.float32) * 4 - 2
+    off_np = syn.make_offsets(J, np.random.default_rng(a.seed), 0.3 if J == 22 else 0.15)
+    off = torch.from_numpy(off_np).to(dev)
+    par_t = torch.from_numpy(parents)
+
+    # steady-state launch path = what skeleton_torch.fk does after its tensor plumbing: one C-ABI call
+    pos = torch.empty((F, J, 3), device=dev, dtype=torch.float32)
+    rm = torch.empty((F, J, 3, 3), device=dev, dtype=torch.float32)
+    stream = torch.cuda.current_stream(dev)
+    sptr = C.c_void_p(stream.cuda_stream)
+    pp = parents.ctypes.data_as(C.c_void_p)
+
+    def step():
+        _lib.call("pm_fk_f32", C.c_void_p(rot.data_ptr()), C.c_void_p(root.data_ptr()), C.c_void_p(off.data_ptr()), 0, pp,
+                  F, J, C.c_void_p(pos.data_ptr()), C.c_void_p(rm.data_ptr()), sptr)
+
+    # the public front door must give the same bytes as the raw call
+    with torch.no_grad():
+        p2, r2 = skt.fk(rot[:4096], root[:4096], off, par_t)
+    step()
+    torch.cuda.synchronize()
+    assert torch.equal(p2, pos[:4096]) and torch.equal(r2, rm[:4096])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    ev0, ev1 = C.c_void_p(), C.c_void_p()
+    _lib.call("pm_event_create", C.byref(ev0))
+    _lib.call("pm_event_create", C.byref(ev1))
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    _lib.call("pm_event_record", ev0, sptr)
+    for _ in range(a.steps):
+        step()
+    _lib.call("pm_event_record", ev1, sptr)
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    ms = C.c_float()
+    _lib.call("pm_event_elapsed_ms", ev0, ev1, C.byref(ms))
+    wall = t1 - t0
+    kern_ms = ms.value / a.steps  # average launch-to-launch time of the fk kernel on its stream
+
+    if world > 1:
+        tt = torch.tensor([wall, kern_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall, kern_ms = float(tt[0]), float(tt[1])
+
+    extra = {}
+    if world > 1 and a.gather:
+        from pymotion_amd.parallel import all_gather_frames
+
+        torch.cuda.synchronize()
+        barrier()
+        g0 = time.perf_counter()
+        gp = all_gather_frames(pos, F * world)
+        gr = all_gather_frames(rm, F * world)
+        torch.cuda.synchronize()
+        barrier()
+        g1 = time.perf_counter()
+        shard_bytes = F * J * 48
+        extra["gather"] = {"ms": (g1 - g0) * 1e3, "shard_GB": shard_bytes / 1e9,
+                           "busbw_GBps_per_gpu": shard_bytes * (world - 1) / (g1 - g0) / 1e9,
+                           "note": "one all_gather_into_tensor per output; compute-only value excludes it"}
+        del gp, gr
+
+    if rank == 0:
+        bytes_per_frame = 64 * J + 12
+        achieved = bytes_per_frame * F / (kern_ms * 1e-3) / 1e9
+        line = {
+            "metric": "fk() frames/sec, %d-joint skeleton" % J,
+            "value": F * world * a.steps / wall,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": wall / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "fk: %d frames x %d joints per GPU, fp32 (BASELINE.json configs[1])" % (F, J),
+                       "frames_per_gpu": F, "joints": J, "sharding": "frames, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "pm::fk_kernel<20,true,false,0,false>", "kernel_ms": kern_ms,
+                         "bytes_per_frame": bytes_per_frame},
+        }
+        line.update(extra)
+        if world == 1 and not a.no_cpu_baseline:
+            rot_h, root_h = rot.cpu().numpy(), root.cpu().numpy()
+            info, p_cpu, r_cpu = cpu_baseline(rot_h, root_h, off_np, parents, a.cpu_sample_frames)
+            n = p_cpu.shape[0]
+            line["cpu_baseline"] = info
+            line["max_abs_err_vs_cpu_baseline"] = {
+                "pos": float(np.abs(pos[:n].cpu().numpy() - p_cpu).max()),
+                "rotmats": float(np.abs(rm[:n].cpu().numpy() - r_cpu).max()),
+                "frames_checked": n,
+            }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

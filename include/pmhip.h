@@ -1,0 +1,161 @@
+/*
+ * pmhip.h -- C ABI of libpmhip.so: MI355X (gfx950) kernels for batched forward kinematics,
+ * root-centred dual quaternions and the quaternion / dual-quaternion / 6D element-wise
+ * conversions.  This is the drop-in boundary for the hot path of UPC-ViRVIG/pymotion
+ * (pure Python, no FFI of its own): each entry point names the reference function
+ * (file:line under pymotion/) whose semantics it reproduces.
+ *
+ * Conventions
+ *   - All data pointers are DEVICE pointers to C-contiguous fp32 arrays unless the
+ *     parameter is documented as "host".  The caller allocates and owns every buffer;
+ *     the library never retains a caller pointer past the call's stream work.
+ *   - Shapes use the reference's layout: joints axis = -2, components axis = -1,
+ *     quaternions [w,x,y,z], matrices row-major [row][col], dual quats [qr(4), qd(4)],
+ *     ortho6d [3][2].  Leading dims are flattened by the caller: F frames, N elements.
+ *   - `parents` is a HOST int32[J] array; it is validated (parents[i] < i for i >= 1, the
+ *     order the reference's in-place loops rely on, ops/skeleton.py:51-58) and passed to
+ *     the kernel by value.  parents[0] is ignored like the reference does (:53).
+ *   - Calls are asynchronous on `stream` (a hipStream_t; NULL = the default stream),
+ *     re-entrant, and keep no global mutable state besides the thread-local error string.
+ *   - Return 0 (PM_OK) or a negative PM_E* code; nothing throws or aborts across the ABI.
+ *   - Fast path needs 16-byte aligned base pointers (anything from hipMalloc / torch is);
+ *     other alignments take a scalar-access path with identical results.
+ */
+#ifndef PMHIP_H
+#define PMHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PM_OK 0
+#define PM_EINVAL (-1)       /* null pointer, negative size, J out of range            */
+#define PM_ETOPOLOGY (-2)    /* parents not in topological order (parents[i] >= i)     */
+#define PM_EHIP (-3)         /* a HIP runtime call failed (see pm_last_error_string)   */
+#define PM_EUNSUPPORTED (-4) /* configuration the kernels do not cover                 */
+
+#define PM_MAX_JOINTS 512
+
+typedef void *pm_stream_t; /* hipStream_t */
+
+/* ---- library / device plumbing ------------------------------------------------------------ */
+int pm_version(void);                      /* ABI version, currently 1 */
+const char *pm_last_error_string(void);    /* thread-local, valid until the next failing call */
+int pm_device_count(void);                 /* number of visible HIP devices, <0 on error */
+int pm_set_device(int device);
+int pm_get_device(int *device);
+/* Plain device memory for callers without their own allocator (the NumPy front-end). */
+int pm_malloc(void **dptr, size_t bytes);
+int pm_free(void *dptr);
+int pm_memcpy_h2d(void *dst, const void *src, size_t bytes, pm_stream_t stream);
+int pm_memcpy_d2h(void *dst, const void *src, size_t bytes, pm_stream_t stream);
+int pm_memset(void *dst, int value, size_t bytes, pm_stream_t stream);
+int pm_stream_synchronize(pm_stream_t stream);
+/* Time `fn`-agnostic sections on a stream with HIP events (used by bench.py). */
+int pm_event_create(void **ev);
+int pm_event_destroy(void *ev);
+int pm_event_record(void *ev, pm_stream_t stream);
+int pm_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on `stop` */
+
+/* ---- skeleton ops ---------------------------------------------------------------------------- */
+
+/* ops/skeleton.py:16-61 / ops/skeleton_torch.py:16-66  fk(rot, global_pos, offsets, parents).
+ * rot [F,J,4] (normalised internally, q/(|q|+1e-8)), root_pos [F,3], offsets [J,3] or, with
+ * offsets_per_frame != 0, [F,J,3]; out pos [F,J,3], rotmats [F,J,3,3].  offsets[0] ignored. */
+int pm_fk_f32(const float *rot, const float *root_pos, const float *offsets, int offsets_per_frame,
+              const int32_t *parents /*host*/, int64_t F, int32_t J, float *pos, float *rotmats,
+              pm_stream_t stream);
+
+/* rotations/ortho6d.py:50-64 (to_quat) fused into fk (SURVEY config 4).  o6d [F,J,3,2];
+ * eps: Gram-Schmidt denominators are max(norm, eps) -- 0 = NumPy reference behaviour,
+ * 1e-12 = torch twin (ortho6d_torch.py:84-89).  quat_out [F,J,4] may be NULL. */
+int pm_fk_from_ortho6d_f32(const float *o6d, const float *root_pos, const float *offsets,
+                           int offsets_per_frame, const int32_t *parents /*host*/, int64_t F,
+                           int32_t J, float eps, float *pos, float *rotmats, float *quat_out,
+                           pm_stream_t stream);
+
+/* ops/skeleton.py:207-244 / skeleton_torch.py:217-259  to_root_dual_quat(rotations, global_pos,
+ * parents, offsets) -- note the argument order differs from fk.  rot [F,J,4] NOT normalised,
+ * offsets [J,3] with offsets[0] == 0 (the caller checks, like the reference's assert :227);
+ * out dq [F,J,8].  Joints whose parent is 0 stay local (:236-237). */
+int pm_to_root_dq_f32(const float *rot, const float *root_pos, const int32_t *parents /*host*/,
+                      const float *offsets, int64_t F, int32_t J, float *dq, pm_stream_t stream);
+
+/* ops/skeleton.py:173-204 / skeleton_torch.py:183-214  from_root_dual_quat(dq, parents)
+ * -> (translations [F,J,3], rotations [F,J,4]) in that order (:204). */
+int pm_from_root_dq_f32(const float *dq, const int32_t *parents /*host*/, int64_t F, int32_t J,
+                        float *trans, float *rot, pm_stream_t stream);
+
+/* ops/skeleton.py:64-93  from_global_rotations(global_quats, parents) -> local quats [F,J,4]. */
+int pm_from_global_rotations_f32(const float *global_quats, const int32_t *parents /*host*/,
+                                 int64_t F, int32_t J, float *local_quats, pm_stream_t stream);
+
+/* ---- element-wise conversions: N elements, inputs already broadcast by the caller ------------ */
+
+/* rotations/quat.py:411-423  normalize(q, eps) = q / (|q| + eps) */
+int pm_quat_normalize_f32(const float *q, int64_t N, float eps, float *out, pm_stream_t stream);
+/* rotations/quat.py:364-376  length(q) -> [N] */
+int pm_quat_length_f32(const float *q, int64_t N, float *out, pm_stream_t stream);
+/* rotations/quat.py:276-317  to_matrix(q) -> [N,3,3] (no normalisation) */
+int pm_quat_to_matrix_f32(const float *q, int64_t N, float *out, pm_stream_t stream);
+/* rotations/quat.py:85-156  from_matrix(m [N,3,3]) -> [N,4] (4-branch select, then normalize) */
+int pm_quat_from_matrix_f32(const float *m, int64_t N, float *out, pm_stream_t stream);
+/* rotations/quat.py:337-361  mul(q0, q1) */
+int pm_quat_mul_f32(const float *q0, const float *q1, int64_t N, float *out, pm_stream_t stream);
+/* rotations/quat.py:320-334  mul_vec(q, v [N,3]) -> [N,3] */
+int pm_quat_mul_vec_f32(const float *q, const float *v, int64_t N, float *out, pm_stream_t stream);
+/* rotations/quat.py:396-408 (conjugate) and :379-393 (inverse == conjugate) */
+int pm_quat_conjugate_f32(const float *q, int64_t N, float *out, pm_stream_t stream);
+
+/* rotations/dual_quat.py:12-36  from_rotation_translation(q [N,4], t [N,3]) -> [N,8] */
+int pm_dq_from_rt_f32(const float *q, const float *t, int64_t N, float *out, pm_stream_t stream);
+/* rotations/dual_quat.py:62-83  to_rotation_translation(dq [N,8]) -> (q [N,4], t [N,3]) */
+int pm_dq_to_rt_f32(const float *dq, int64_t N, float *q, float *t, pm_stream_t stream);
+/* rotations/dual_quat.py:39-59  from_translation(t [N,3]) -> [N,8] */
+int pm_dq_from_t_f32(const float *t, int64_t N, float *out, pm_stream_t stream);
+
+/* rotations/ortho6d.py:67-90  to_matrix(x [N,3,2]) -> [N,3,3]; eps as in pm_fk_from_ortho6d_f32 */
+int pm_o6d_to_matrix_f32(const float *x, int64_t N, float eps, float *out, pm_stream_t stream);
+/* rotations/ortho6d.py:50-64  to_quat(x [N,3,2]) -> [N,4] */
+int pm_o6d_to_quat_f32(const float *x, int64_t N, float eps, float *out, pm_stream_t stream);
+/* rotations/ortho6d.py:14-28  from_quat(q) -> [N,3,2] */
+int pm_o6d_from_quat_f32(const float *q, int64_t N, float *out, pm_stream_t stream);
+/* rotations/ortho6d.py:31-47  from_matrix(m [N,3,3]) -> [N,3,2] (contiguous copy of m[..., :2]) */
+int pm_o6d_from_matrix_f32(const float *m, int64_t N, float *out, pm_stream_t stream);
+
+/* ---- second wave: trig conversions --------------------------------------------------------------- */
+
+/* rotations/quat.py:24-40  from_angle_axis(angle [N,1], axis [N,3]) */
+int pm_quat_from_angle_axis_f32(const float *angle, const float *axis, int64_t N, float *out, pm_stream_t stream);
+/* rotations/quat.py:6-21  from_scaled_angle_axis(v [N,3]) (zero vector -> NaN, as the reference) */
+int pm_quat_from_scaled_angle_axis_f32(const float *v, int64_t N, float *out, pm_stream_t stream);
+/* rotations/quat.py:247-273  to_angle_axis(q) -> (angle [N,1], axis [N,3]) */
+int pm_quat_to_angle_axis_f32(const float *q, int64_t N, float *angle, float *axis, pm_stream_t stream);
+/* rotations/quat.py:230-244  to_scaled_angle_axis(q) -> [N,3] */
+int pm_quat_to_scaled_angle_axis_f32(const float *q, int64_t N, float *out, pm_stream_t stream);
+/* rotations/quat.py:43-82  from_euler(euler [N,3], order): order = device uint8 [N,3] codes
+ * 0/1/2 for 'x'/'y'/'z', or, with order_per_element == 0, a single uint8[3] triple (device). */
+int pm_quat_from_euler_f32(const float *euler, const uint8_t *order, int order_per_element, int64_t N,
+                           float *out, pm_stream_t stream);
+/* rotations/quat.py:159-227  to_euler(q, order) -> [N,3] in [0, 2pi) */
+int pm_quat_to_euler_f32(const float *q, const uint8_t *order, int order_per_element, int64_t N,
+                         float *out, pm_stream_t stream);
+/* rotations/quat.py:465-501  slerp(q0, q1, t [N,1], shortest) */
+int pm_quat_slerp_f32(const float *q0, const float *q1, const float *t, int64_t N, int shortest,
+                      float *out, pm_stream_t stream);
+
+/* ---- measurement helper --------------------------------------------------------------------------- */
+
+/* Streaming ceiling with fk's traffic shape: per frame read rd_floats and write wr_floats
+ * (contiguous tiles, no arithmetic).  Used only by bench.py to state what fraction of an
+ * achievable copy rate the fk kernel reaches; not part of the reference's surface. */
+int pm_stream_ceiling_f32(const float *src, float *dst, int64_t F, int32_t rd_floats,
+                          int32_t wr_floats, pm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMHIP_H */

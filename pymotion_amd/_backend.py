@@ -1,0 +1,249 @@
+"""Array adapters between the reference-style Python API and the device-pointer C ABI.
+
+Two front doors, one engine:
+
+* ``NUMPY``  -- ``np.ndarray`` in / out.  Host arrays are cast to contiguous fp32, copied to a
+  pooled device buffer (``pm_malloc`` / ``pm_memcpy_h2d``), the kernel runs on the default
+  stream, results are copied back and cast to the dtype the reference would return.
+  No torch import.
+* ``TORCH``  -- ``torch.Tensor`` in / out.  HIP tensors are used zero-copy (``data_ptr()`` on
+  torch's current stream); CPU tensors are moved to ``cuda:current`` and the result moved back,
+  mirroring "result lives where the input lives" of the reference's eager twins.
+
+Both compute in fp32 on the GPU (BASELINE.json north_star).  There is no autograd support:
+the reference gets it for free from eager torch ops, hand-written kernels do not (out of
+scope, stated in DESIGN.md); tensors that require grad are rejected instead of silently
+detached.
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import _lib
+
+
+def _prod(shape):
+    n = 1
+    for s in shape:
+        n *= int(s)
+    return n
+
+
+# ---------------------------------------------------------------------------------------------
+# NumPy front door
+# ---------------------------------------------------------------------------------------------
+class _DevPool:
+    """Tiny size-class pool over pm_malloc so repeated NumPy-path calls do not pay hipMalloc."""
+
+    def __init__(self, cap_bytes=8 << 30):
+        self.free = {}
+        self.cached = 0
+        self.cap = cap_bytes
+        self.lock = threading.Lock()
+
+    @staticmethod
+    def _cls(nbytes):
+        n = max(int(nbytes), 256)
+        return 1 << (n - 1).bit_length()
+
+    def get(self, nbytes):
+        c = self._cls(nbytes)
+        with self.lock:
+            lst = self.free.get(c)
+            if lst:
+                self.cached -= c
+                return lst.pop(), c
+        p = C.c_void_p()
+        try:
+            _lib.call("pm_malloc", C.byref(p), c)
+        except _lib.PmhipError:
+            self.trim()
+            _lib.call("pm_malloc", C.byref(p), c)
+        return p.value, c
+
+    def put(self, ptr, c):
+        with self.lock:
+            if self.cached + c <= self.cap:
+                self.free.setdefault(c, []).append(ptr)
+                self.cached += c
+                return
+        _lib.call("pm_free", C.c_void_p(ptr))
+
+    def trim(self):
+        with self.lock:
+            blocks = [p for lst in self.free.values() for p in lst]
+            self.free.clear()
+            self.cached = 0
+        for p in blocks:
+            _lib.call("pm_free", C.c_void_p(p))
+
+
+_pool = _DevPool()
+
+
+class _DevBuf:
+    def __init__(self, nbytes):
+        self.ptr, self.cls = _pool.get(nbytes)
+        self.nbytes = nbytes
+
+    def release(self):
+        if self.ptr is not None:
+            _pool.put(self.ptr, self.cls)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class NumpyBackend:
+    name = "numpy"
+
+    def __init__(self):
+        self._live = []
+
+    # -- introspection
+    @staticmethod
+    def shape(x):
+        return tuple(np.shape(x))
+
+    @staticmethod
+    def result_dtype(*xs):
+        dt = np.result_type(*[np.asarray(x).dtype for x in xs])
+        return dt if dt.kind == "f" else np.dtype(np.float64)
+
+    always64 = np.dtype(np.float64)  # what the reference hard-codes for some outputs
+
+    def stream(self):
+        return None
+
+    def begin(self, *_):
+        _lib.require_device()
+        self._live = []
+
+    # -- data movement
+    def dev_in(self, x, shape=None, dtype=np.float32):
+        a = np.asarray(x)
+        if shape is not None and a.shape != tuple(shape):
+            a = np.broadcast_to(a, shape)
+        a = np.ascontiguousarray(a, dtype=dtype)
+        buf = _DevBuf(a.nbytes)
+        _lib.call("pm_memcpy_h2d", C.c_void_p(buf.ptr), a.ctypes.data_as(C.c_void_p), a.nbytes, None)
+        self._live.append((buf, a))
+        return C.c_void_p(buf.ptr)
+
+    def dev_out(self, shape):
+        buf = _DevBuf(_prod(shape) * 4)
+        self._live.append((buf, None))
+        return C.c_void_p(buf.ptr), (buf, tuple(shape))
+
+    def result(self, handle, dtype):
+        buf, shape = handle
+        out = np.empty(shape, dtype=np.float32)
+        _lib.call("pm_memcpy_d2h", out.ctypes.data_as(C.c_void_p), C.c_void_p(buf.ptr), out.nbytes, None)
+        _lib.call("pm_stream_synchronize", None)
+        return out if np.dtype(dtype) == np.float32 else out.astype(dtype)
+
+    def end(self):
+        _lib.call("pm_stream_synchronize", None)
+        for buf, _ in self._live:
+            buf.release()
+        self._live = []
+
+    @staticmethod
+    def host_ints(x):
+        return np.ascontiguousarray(np.asarray(x), dtype=np.int32)
+
+
+# ---------------------------------------------------------------------------------------------
+# torch front door
+# ---------------------------------------------------------------------------------------------
+class TorchBackend:
+    name = "torch"
+
+    def __init__(self):
+        import torch
+
+        self.torch = torch
+        self.dev = None
+        self.home = None
+        self._keep = []
+
+    @staticmethod
+    def shape(x):
+        return tuple(x.shape)
+
+    def result_dtype(self, *xs):
+        torch = self.torch
+        dt = xs[0].dtype
+        for x in xs[1:]:
+            dt = torch.promote_types(dt, x.dtype)
+        return dt if dt.is_floating_point else torch.get_default_dtype()
+
+    @property
+    def always64(self):  # the torch twins allocate default-dtype outputs where NumPy hard-codes f64
+        return self.torch.get_default_dtype()
+
+    def begin(self, *tensors):
+        torch = self.torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("pymotion_amd (torch path): no HIP device visible and there is no CPU fallback")
+        for t in tensors:
+            if isinstance(t, torch.Tensor) and t.requires_grad and torch.is_grad_enabled():
+                raise NotImplementedError(
+                    "pymotion_amd kernels have no autograd; call under torch.no_grad() or detach() inputs"
+                )
+        devs = [t.device for t in tensors if isinstance(t, torch.Tensor) and t.is_cuda]
+        self.home = tensors[0].device if isinstance(tensors[0], torch.Tensor) else torch.device("cpu")
+        self.dev = devs[0] if devs else torch.device("cuda", torch.cuda.current_device())
+        self._guard = torch.cuda.device(self.dev)
+        self._guard.__enter__()
+        self._keep = []
+
+    def stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def dev_in(self, x, shape=None, dtype=None):
+        torch = self.torch
+        dtype = dtype or torch.float32
+        t = x if isinstance(x, torch.Tensor) else torch.as_tensor(x)
+        t = t.to(device=self.dev, dtype=dtype, non_blocking=True)
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            t = t.expand(shape)
+        t = t.contiguous()
+        self._keep.append(t)
+        return C.c_void_p(t.data_ptr())
+
+    def dev_out(self, shape):
+        t = self.torch.empty(tuple(shape), dtype=self.torch.float32, device=self.dev)
+        self._keep.append(t)
+        return C.c_void_p(t.data_ptr()), t
+
+    def result(self, handle, dtype):
+        t = handle
+        if t.dtype != dtype:
+            t = t.to(dtype)
+        if self.home.type != "cuda":
+            t = t.to(self.home)
+        return t
+
+    def end(self):
+        self._keep = []
+        self._guard.__exit__(None, None, None)
+
+    def host_ints(self, x):
+        torch = self.torch
+        if isinstance(x, torch.Tensor):
+            x = x.detach().cpu().numpy()  # J integers; on a HIP tensor this is the only sync of the call
+        return np.ascontiguousarray(np.asarray(x), dtype=np.int32)
+
+
+def numpy_backend():
+    return NumpyBackend()
+
+
+def torch_backend():
+    return TorchBackend()

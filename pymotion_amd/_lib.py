@@ -1,0 +1,118 @@
+"""ctypes binding of ``libpmhip.so`` (the C ABI declared in ``include/pmhip.h``).
+
+The library is the product: there is NO CPU fallback.  If the shared object is missing
+(or no HIP device is visible when a kernel is called) every entry point raises
+``RuntimeError`` -- loudly, by design (parity claims are about the HIP path only).
+Build it in-tree with ``python __graft_entry__.py`` or ``make -C pymotion_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpmhip.so")
+
+PM_OK, PM_EINVAL, PM_ETOPOLOGY, PM_EHIP, PM_EUNSUPPORTED = 0, -1, -2, -3, -4
+
+_f = C.c_void_p  # device float*
+_i64, _i32, _int, _flt, _strm = C.c_int64, C.c_int32, C.c_int, C.c_float, C.c_void_p
+
+# name -> argtypes; every function returns int.  Kept in the same order as include/pmhip.h.
+SIGNATURES = {
+    "pm_version": [],
+    "pm_device_count": [],
+    "pm_set_device": [_int],
+    "pm_get_device": [C.POINTER(_int)],
+    "pm_malloc": [C.POINTER(C.c_void_p), C.c_size_t],
+    "pm_free": [C.c_void_p],
+    "pm_memcpy_h2d": [C.c_void_p, C.c_void_p, C.c_size_t, _strm],
+    "pm_memcpy_d2h": [C.c_void_p, C.c_void_p, C.c_size_t, _strm],
+    "pm_memset": [C.c_void_p, _int, C.c_size_t, _strm],
+    "pm_stream_synchronize": [_strm],
+    "pm_event_create": [C.POINTER(C.c_void_p)],
+    "pm_event_destroy": [C.c_void_p],
+    "pm_event_record": [C.c_void_p, _strm],
+    "pm_event_elapsed_ms": [C.c_void_p, C.c_void_p, C.POINTER(_flt)],
+    # skeleton ops
+    "pm_fk_f32": [_f, _f, _f, _int, C.c_void_p, _i64, _i32, _f, _f, _strm],
+    "pm_fk_from_ortho6d_f32": [_f, _f, _f, _int, C.c_void_p, _i64, _i32, _flt, _f, _f, _f, _strm],
+    "pm_to_root_dq_f32": [_f, _f, C.c_void_p, _f, _i64, _i32, _f, _strm],
+    "pm_from_root_dq_f32": [_f, C.c_void_p, _i64, _i32, _f, _f, _strm],
+    "pm_from_global_rotations_f32": [_f, C.c_void_p, _i64, _i32, _f, _strm],
+    # element-wise
+    "pm_quat_normalize_f32": [_f, _i64, _flt, _f, _strm],
+    "pm_quat_length_f32": [_f, _i64, _f, _strm],
+    "pm_quat_to_matrix_f32": [_f, _i64, _f, _strm],
+    "pm_quat_from_matrix_f32": [_f, _i64, _f, _strm],
+    "pm_quat_mul_f32": [_f, _f, _i64, _f, _strm],
+    "pm_quat_mul_vec_f32": [_f, _f, _i64, _f, _strm],
+    "pm_quat_conjugate_f32": [_f, _i64, _f, _strm],
+    "pm_dq_from_rt_f32": [_f, _f, _i64, _f, _strm],
+    "pm_dq_to_rt_f32": [_f, _i64, _f, _f, _strm],
+    "pm_dq_from_t_f32": [_f, _i64, _f, _strm],
+    "pm_o6d_to_matrix_f32": [_f, _i64, _flt, _f, _strm],
+    "pm_o6d_to_quat_f32": [_f, _i64, _flt, _f, _strm],
+    "pm_o6d_from_quat_f32": [_f, _i64, _f, _strm],
+    "pm_o6d_from_matrix_f32": [_f, _i64, _f, _strm],
+    # second wave
+    "pm_quat_from_angle_axis_f32": [_f, _f, _i64, _f, _strm],
+    "pm_quat_from_scaled_angle_axis_f32": [_f, _i64, _f, _strm],
+    "pm_quat_to_angle_axis_f32": [_f, _i64, _f, _f, _strm],
+    "pm_quat_to_scaled_angle_axis_f32": [_f, _i64, _f, _strm],
+    "pm_quat_from_euler_f32": [_f, C.c_void_p, _int, _i64, _f, _strm],
+    "pm_quat_to_euler_f32": [_f, C.c_void_p, _int, _i64, _f, _strm],
+    "pm_quat_slerp_f32": [_f, _f, _f, _i64, _int, _f, _strm],
+    # measurement helper
+    "pm_stream_ceiling_f32": [_f, _f, _i64, _i32, _i32, _strm],
+}
+
+_lib = None
+
+
+class PmhipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libpmhip error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP extension is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is not built and pymotion_amd has no CPU "
+                "fallback. Run `python __graft_entry__.py` (or `make -C pymotion_amd/csrc`)."
+            )
+        h = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(h, name)  # AttributeError = ABI mismatch, let it surface
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        h.pm_last_error_string.argtypes = []
+        h.pm_last_error_string.restype = C.c_char_p
+        _lib = h
+    return _lib
+
+
+def check(code):
+    if code != PM_OK:
+        msg = lib().pm_last_error_string().decode("utf-8", "replace")
+        if code in (PM_EINVAL, PM_ETOPOLOGY):
+            raise ValueError(f"libpmhip: {msg}")
+        raise PmhipError(code, msg)
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args))
+
+
+def device_count():
+    n = lib().pm_device_count()
+    if n < 0:
+        check(n)
+    return n
+
+
+def require_device():
+    if device_count() < 1:
+        raise RuntimeError("pymotion_amd: no HIP device visible and there is no CPU fallback")

@@ -1,0 +1,327 @@
+"""Backend-agnostic bodies of the public functions (NumPy and torch front doors share them).
+
+Every function flattens the reference's ``[..., C]`` / ``[..., J, C]`` shapes to the
+``[N, C]`` / ``[F, J, C]`` the C ABI takes, launches ONE kernel from ``libpmhip.so`` and
+reshapes back.  Reference citations (``pymotion/...:line``) are on the public wrappers in
+``pymotion_amd/rotations`` and ``pymotion_amd/ops``.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+_AXIS = {"x": 0, "y": 1, "z": 2}
+
+
+def _prod(shape):
+    n = 1
+    for s in shape:
+        n *= int(s)
+    return n
+
+
+def _bshape(*shapes):
+    return tuple(np.broadcast_shapes(*shapes))
+
+
+def ew(be, fname, ins, in_trail, out_trail, out_dtypes, pre=(), mid=()):
+    """Generic element-wise launch.
+
+    ins[k] has trailing shape in_trail[k]; leading shapes broadcast against each other.
+    C call: fname(in_ptrs..., *pre, N, *mid, out_ptrs..., stream).
+    """
+    be.begin(*ins)
+    try:
+        leads = [be.shape(x)[: len(be.shape(x)) - len(t)] for x, t in zip(ins, in_trail)]
+        for x, t in zip(ins, in_trail):
+            if tuple(be.shape(x)[len(be.shape(x)) - len(t):]) != tuple(t):
+                raise ValueError(f"{fname}: expected trailing shape {tuple(t)}, got array of shape {be.shape(x)}")
+        lead = _bshape(*leads)
+        n = _prod(lead)
+        in_ptrs = [be.dev_in(x, lead + tuple(t)) for x, t in zip(ins, in_trail)]
+        outs = [be.dev_out(lead + tuple(t)) for t in out_trail]
+        if n > 0:
+            _lib.call(fname, *in_ptrs, *pre, n, *mid, *[p for p, _ in outs], be.stream())
+        res = [be.result(h, dt) for (_, h), dt in zip(outs, out_dtypes)]
+    finally:
+        be.end()
+    return res[0] if len(res) == 1 else tuple(res)
+
+
+# ---- quaternions ---------------------------------------------------------------------------------
+
+def quat_normalize(be, q, eps=1e-8):
+    return ew(be, "pm_quat_normalize_f32", [q], [(4,)], [(4,)], [be.result_dtype(q)], mid=[C.c_float(eps)])
+
+
+def quat_length(be, q):
+    return ew(be, "pm_quat_length_f32", [q], [(4,)], [()], [be.result_dtype(q)])
+
+
+def quat_to_matrix(be, q):
+    return ew(be, "pm_quat_to_matrix_f32", [q], [(4,)], [(3, 3)], [be.always64])
+
+
+def quat_from_matrix(be, m):
+    return ew(be, "pm_quat_from_matrix_f32", [m], [(3, 3)], [(4,)], [be.result_dtype(m)])
+
+
+def quat_mul(be, q0, q1):
+    return ew(be, "pm_quat_mul_f32", [q0, q1], [(4,), (4,)], [(4,)], [be.result_dtype(q0, q1)])
+
+
+def quat_mul_vec(be, q, v):
+    return ew(be, "pm_quat_mul_vec_f32", [q, v], [(4,), (3,)], [(3,)], [be.result_dtype(q, v)])
+
+
+def quat_conjugate(be, q):
+    return ew(be, "pm_quat_conjugate_f32", [q], [(4,)], [(4,)], [be.result_dtype(q)])
+
+
+def quat_from_angle_axis(be, angle, axis):
+    return ew(be, "pm_quat_from_angle_axis_f32", [angle, axis], [(1,), (3,)], [(4,)], [be.result_dtype(angle, axis)])
+
+
+def quat_from_scaled_angle_axis(be, v):
+    return ew(be, "pm_quat_from_scaled_angle_axis_f32", [v], [(3,)], [(4,)], [be.result_dtype(v)])
+
+
+def quat_to_angle_axis(be, q):
+    dt = be.result_dtype(q)
+    return ew(be, "pm_quat_to_angle_axis_f32", [q], [(4,)], [(1,), (3,)], [dt, dt])
+
+
+def quat_to_scaled_angle_axis(be, q):
+    return ew(be, "pm_quat_to_scaled_angle_axis_f32", [q], [(4,)], [(3,)], [be.result_dtype(q)])
+
+
+def _order_codes(order, lead):
+    """The reference takes a NumPy array of 'x'|'y'|'z' strings shaped like euler (quat.py:51-53).
+    Encode as uint8 codes; a single triple (or a constant array) becomes the per-call form."""
+    order = np.asarray(order)
+    if order.dtype.kind in "US":
+        codes = np.zeros(order.shape, dtype=np.uint8)
+        for ch, v in _AXIS.items():
+            codes[order == ch] = v
+        if not np.isin(order, list(_AXIS)).all():
+            raise ValueError("order entries must be 'x', 'y' or 'z'")
+    else:
+        codes = order.astype(np.uint8)
+    if codes.shape[-1] != 3:
+        raise ValueError("order must have a trailing dimension of 3")
+    if tuple(codes.shape[:-1]) != tuple(lead):
+        # same assertion as the reference (quat.py:60-62)
+        raise AssertionError("euler and order must have the same shape except for the last dimension")
+    flat = codes.reshape(-1, 3)
+    if len(flat) and (flat == flat[0]).all():
+        return np.ascontiguousarray(flat[0]), 0
+    return np.ascontiguousarray(flat), 1
+
+
+def _euler_like(be, fname, x, trail, out_trail, order, out_dtype):
+    lead = be.shape(x)[: len(be.shape(x)) - 1]
+    codes, per_elem = _order_codes(order, lead)
+    be.begin(x)
+    try:
+        n = _prod(lead)
+        xp = be.dev_in(x, tuple(lead) + tuple(trail))
+        op = be.dev_in(codes, None, dtype=_u8(be))
+        out_p, h = be.dev_out(tuple(lead) + tuple(out_trail))
+        if n > 0:
+            _lib.call(fname, xp, op, per_elem, n, out_p, be.stream())
+        res = be.result(h, out_dtype)
+    finally:
+        be.end()
+    return res
+
+
+def _u8(be):
+    return np.uint8 if be.name == "numpy" else be.torch.uint8
+
+
+def quat_from_euler(be, euler, order):
+    return _euler_like(be, "pm_quat_from_euler_f32", euler, (3,), (4,), order, be.result_dtype(euler))
+
+
+def quat_to_euler(be, q, order):
+    return _euler_like(be, "pm_quat_to_euler_f32", q, (4,), (3,), order, be.always64)
+
+
+def quat_slerp(be, q0, q1, t, shortest=True):
+    dt = be.result_dtype(q0, q1)
+    if not hasattr(t, "shape") or len(be.shape(t)) == 0:
+        t = np.full((1,), float(t), dtype=np.float32)
+    return ew(be, "pm_quat_slerp_f32", [q0, q1, t], [(4,), (4,), (1,)], [(4,)], [dt], mid=[int(bool(shortest))])
+
+
+# ---- dual quaternions ----------------------------------------------------------------------------
+
+def dq_from_rt(be, q, t):
+    # NumPy reference: float64 out (dual_quat.py:32); torch twin: rotations.dtype (dual_quat_torch.py:32)
+    dt = be.always64 if be.name == "numpy" else q.dtype
+    return ew(be, "pm_dq_from_rt_f32", [q, t], [(4,), (3,)], [(8,)], [dt])
+
+
+def dq_to_rt(be, dq):
+    dt = be.result_dtype(dq)
+    return ew(be, "pm_dq_to_rt_f32", [dq], [(8,)], [(4,), (3,)], [dt, dt])
+
+
+def dq_from_t(be, t):
+    dt = be.always64 if be.name == "numpy" else t.dtype
+    return ew(be, "pm_dq_from_t_f32", [t], [(3,)], [(8,)], [dt])
+
+
+# ---- ortho6d -------------------------------------------------------------------------------------------
+
+def o6d_eps(be):
+    # NumPy reference divides by the raw norm (ortho6d.py:83-85: zero column -> NaN); the torch
+    # twin uses F.normalize(eps=1e-12) (ortho6d_torch.py:84-89: zero column -> zeros).
+    return 0.0 if be.name == "numpy" else 1e-12
+
+
+def o6d_to_matrix(be, x):
+    return ew(be, "pm_o6d_to_matrix_f32", [x], [(3, 2)], [(3, 3)], [be.result_dtype(x)], mid=[C.c_float(o6d_eps(be))])
+
+
+def o6d_to_quat(be, x):
+    return ew(be, "pm_o6d_to_quat_f32", [x], [(3, 2)], [(4,)], [be.result_dtype(x)], mid=[C.c_float(o6d_eps(be))])
+
+
+def o6d_from_quat(be, q):
+    return ew(be, "pm_o6d_from_quat_f32", [q], [(4,)], [(3, 2)], [be.always64])
+
+
+def o6d_from_matrix(be, m):
+    return ew(be, "pm_o6d_from_matrix_f32", [m], [(3, 3)], [(3, 2)], [be.result_dtype(m)])
+
+
+# ---- skeleton ops --------------------------------------------------------------------------------------
+
+def _parents_host(be, parents, J):
+    p = be.host_ints(parents)
+    if p.ndim != 1 or p.shape[0] != J:
+        raise ValueError(f"parents must have shape [{J}], got {p.shape}")
+    return p
+
+
+def fk(be, rot, global_pos, offsets, parents):
+    shp = be.shape(rot)
+    if len(shp) < 2 or shp[-1] != 4:
+        raise ValueError(f"rot must be [..., n_joints, 4], got {shp}")
+    lead, J = shp[:-2], shp[-2]
+    p = _parents_host(be, parents, J)
+    oshape = be.shape(offsets)
+    per_frame = len(oshape) > 2
+    out_dt = be.always64 if be.name == "numpy" else rot.dtype  # skeleton.py:44 / skeleton_torch.py:45-49
+    be.begin(rot, global_pos, offsets)
+    try:
+        F = _prod(lead)
+        rp = be.dev_in(rot)
+        gp = be.dev_in(global_pos, lead + (3,))
+        op = be.dev_in(offsets, lead + (J, 3) if per_frame else (J, 3))
+        pos_p, pos_h = be.dev_out(lead + (J, 3))
+        rm_p, rm_h = be.dev_out(lead + (J, 3, 3))
+        if F > 0:
+            _lib.call("pm_fk_f32", rp, gp, op, int(per_frame), p.ctypes.data_as(C.c_void_p), F, J, pos_p, rm_p, be.stream())
+        res = be.result(pos_h, out_dt), be.result(rm_h, out_dt)
+    finally:
+        be.end()
+    return res
+
+
+def fk_from_ortho6d(be, o6d, global_pos, offsets, parents, return_quat=False):
+    shp = be.shape(o6d)
+    if len(shp) < 3 or shp[-2:] != (3, 2):
+        raise ValueError(f"ortho6D must be [..., n_joints, 3, 2], got {shp}")
+    lead, J = shp[:-3], shp[-3]
+    p = _parents_host(be, parents, J)
+    per_frame = len(be.shape(offsets)) > 2
+    out_dt = be.always64 if be.name == "numpy" else o6d.dtype
+    q_dt = be.result_dtype(o6d)
+    be.begin(o6d, global_pos, offsets)
+    try:
+        F = _prod(lead)
+        xp = be.dev_in(o6d)
+        gp = be.dev_in(global_pos, lead + (3,))
+        op = be.dev_in(offsets, lead + (J, 3) if per_frame else (J, 3))
+        pos_p, pos_h = be.dev_out(lead + (J, 3))
+        rm_p, rm_h = be.dev_out(lead + (J, 3, 3))
+        q_p, q_h = be.dev_out(lead + (J, 4)) if return_quat else (None, None)
+        if F > 0:
+            _lib.call("pm_fk_from_ortho6d_f32", xp, gp, op, int(per_frame), p.ctypes.data_as(C.c_void_p), F, J,
+                      C.c_float(o6d_eps(be)), pos_p, rm_p, q_p, be.stream())
+        res = (be.result(pos_h, out_dt), be.result(rm_h, out_dt))
+        if return_quat:
+            res = res + (be.result(q_h, q_dt),)
+    finally:
+        be.end()
+    return res
+
+
+def to_root_dual_quat(be, rotations, global_pos, parents, offsets):
+    shp = be.shape(rotations)
+    if len(shp) < 2 or shp[-1] != 4:
+        raise ValueError(f"rotations must be [..., n_joints, 4], got {shp}")
+    lead, J = shp[:-2], shp[-2]  # joint axis is -2 (the reference's shape[1] is a latent bug)
+    p = _parents_host(be, parents, J)
+    if be.shape(offsets) != (J, 3):
+        raise ValueError(f"offsets must be [{J}, 3], got {be.shape(offsets)}")
+    off0 = np.asarray(offsets[0].detach().cpu() if be.name == "torch" else offsets[0])
+    assert (off0 == 0).all()  # skeleton.py:227
+    out_dt = be.always64 if be.name == "numpy" else rotations.dtype
+    be.begin(rotations, global_pos, offsets)
+    try:
+        F = _prod(lead)
+        rp = be.dev_in(rotations)
+        gp = be.dev_in(global_pos, lead + (3,))
+        op = be.dev_in(offsets)
+        dq_p, dq_h = be.dev_out(lead + (J, 8))
+        if F > 0:
+            _lib.call("pm_to_root_dq_f32", rp, gp, p.ctypes.data_as(C.c_void_p), op, F, J, dq_p, be.stream())
+        res = be.result(dq_h, out_dt)
+    finally:
+        be.end()
+    return res
+
+
+def from_root_dual_quat(be, dq, parents):
+    shp = be.shape(dq)
+    if len(shp) < 2 or shp[-1] != 8:
+        raise ValueError(f"dq must be [..., n_joints, 8], got {shp}")
+    lead, J = shp[:-2], shp[-2]
+    p = _parents_host(be, parents, J)
+    dt = be.result_dtype(dq)
+    be.begin(dq)
+    try:
+        F = _prod(lead)
+        dp = be.dev_in(dq)
+        t_p, t_h = be.dev_out(lead + (J, 3))
+        q_p, q_h = be.dev_out(lead + (J, 4))
+        if F > 0:
+            _lib.call("pm_from_root_dq_f32", dp, p.ctypes.data_as(C.c_void_p), F, J, t_p, q_p, be.stream())
+        res = be.result(t_h, dt), be.result(q_h, dt)  # (translations, rotations): skeleton.py:204
+    finally:
+        be.end()
+    return res
+
+
+def from_global_rotations(be, global_quats, parents):
+    shp = be.shape(global_quats)
+    if len(shp) < 2 or shp[-1] != 4:
+        raise ValueError(f"global_quats must be [..., n_joints, 4], got {shp}")
+    lead, J = shp[:-2], shp[-2]
+    p = _parents_host(be, parents, J)
+    dt = be.result_dtype(global_quats)
+    be.begin(global_quats)
+    try:
+        F = _prod(lead)
+        gp = be.dev_in(global_quats)
+        o_p, o_h = be.dev_out(lead + (J, 4))
+        if F > 0:
+            _lib.call("pm_from_global_rotations_f32", gp, p.ctypes.data_as(C.c_void_p), F, J, o_p, be.stream())
+        res = be.result(o_h, dt)
+    finally:
+        be.end()
+    return res

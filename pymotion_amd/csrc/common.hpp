@@ -1,0 +1,246 @@
+// common.hpp -- shared device helpers for the gfx950 kernels of libpmhip.so.
+//
+// Execution model used by every kernel in this library: ONE WAVE (64 lanes) PER WORKGROUP
+// owns a contiguous tile of frames / elements and a private LDS slice.  The tile moves
+//     HBM --(coalesced 16 B/lane loads)--> LDS --(per-lane AoS reads)--> VALU
+//     VALU --(per-lane AoS writes)--> LDS --(coalesced 16 B/lane stores)--> HBM
+// so no s_barrier is ever needed: LDS operations of one wave execute in program order, and
+// the only fence required is a compiler-level one (wave_sync below).  Waves on a CU are fully
+// independent pipelines, which is what keeps HBM requests in flight while others compute.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pmhip.h"
+
+#define PM_WAVE 64
+#define PM_NXCD 8
+
+namespace pm {
+
+typedef float v4f __attribute__((ext_vector_type(4)));  // native vectors: nontemporal builtins need them
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Compiler-level ordering of LDS traffic inside one wave (hardware already executes a wave's
+// DS instructions in order).  Emits no instruction beyond the waitcnt the compiler needs.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// blockIdx -> tile index.  Workgroup b runs on XCD b % 8 (observed dispatch order); give every
+// XCD one contiguous range of tiles so that the partial cache lines at tile boundaries are
+// written by neighbours that share an L2 and merge there before going to HBM.
+// Launch with grid = 8 * ceil(ntiles / 8); returns -1 for the padding blocks.
+__device__ __forceinline__ int64_t xcd_tile(int64_t ntiles) {
+    const int64_t per_xcd = (ntiles + PM_NXCD - 1) / PM_NXCD;
+    const int64_t b = blockIdx.x;
+    const int64_t t = (b % PM_NXCD) * per_xcd + b / PM_NXCD;
+    return t < ntiles ? t : -1;
+}
+
+// ---- wave-private linear tile copies ------------------------------------------------------------
+
+// global -> LDS, n floats, contiguous.  VEC: g is 16-byte aligned -> dwordx4 per lane, loads
+// batched 4 deep so that up to 4 KiB per wave is in flight before the first LDS write.
+template <bool VEC>
+__device__ __forceinline__ void tile_load(const float *__restrict__ g, float *lds, int n, int lane) {
+    if (VEC) {
+        const v4f *g4 = reinterpret_cast<const v4f *>(g);
+        v4f *l4 = reinterpret_cast<v4f *>(lds);
+        const int n4 = n >> 2;
+        int i = lane;
+        for (; i + 3 * PM_WAVE < n4; i += 4 * PM_WAVE) {
+            v4f a = __builtin_nontemporal_load(g4 + i);
+            v4f b = __builtin_nontemporal_load(g4 + i + PM_WAVE);
+            v4f c = __builtin_nontemporal_load(g4 + i + 2 * PM_WAVE);
+            v4f d = __builtin_nontemporal_load(g4 + i + 3 * PM_WAVE);
+            l4[i] = a;
+            l4[i + PM_WAVE] = b;
+            l4[i + 2 * PM_WAVE] = c;
+            l4[i + 3 * PM_WAVE] = d;
+        }
+        for (; i < n4; i += PM_WAVE) l4[i] = __builtin_nontemporal_load(g4 + i);
+        for (int k = (n4 << 2) + lane; k < n; k += PM_WAVE) lds[k] = g[k];
+    } else {
+        for (int k = lane; k < n; k += PM_WAVE) lds[k] = g[k];
+    }
+}
+
+// LDS -> global, n floats, contiguous, streaming (write-once) stores.
+template <bool VEC>
+__device__ __forceinline__ void tile_store(float *__restrict__ g, const float *lds, int n, int lane) {
+    if (VEC) {
+        v4f *g4 = reinterpret_cast<v4f *>(g);
+        const v4f *l4 = reinterpret_cast<const v4f *>(lds);
+        const int n4 = n >> 2;
+        for (int i = lane; i < n4; i += PM_WAVE) __builtin_nontemporal_store(l4[i], g4 + i);
+        for (int k = (n4 << 2) + lane; k < n; k += PM_WAVE) g[k] = lds[k];
+    } else {
+        for (int k = lane; k < n; k += PM_WAVE) g[k] = lds[k];
+    }
+}
+
+// ---- per-lane AoS access to LDS with the widest conflict-free instruction per width -------------
+
+template <int W>
+__device__ __forceinline__ void lds_get(const float *base, int idx, float (&v)[W]) {
+    const float *p = base + idx * W;
+    if constexpr (W % 4 == 0) {
+#pragma unroll
+        for (int k = 0; k < W / 4; ++k) {
+            v4f t = reinterpret_cast<const v4f *>(p)[k];
+            v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+        }
+    } else if constexpr (W % 2 == 0) {
+#pragma unroll
+        for (int k = 0; k < W / 2; ++k) {
+            v2f t = reinterpret_cast<const v2f *>(p)[k];
+            v[2 * k] = t.x; v[2 * k + 1] = t.y;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < W; ++k) v[k] = p[k];
+    }
+}
+
+template <int W>
+__device__ __forceinline__ void lds_put(float *base, int idx, const float (&v)[W]) {
+    float *p = base + idx * W;
+    if constexpr (W % 4 == 0) {
+#pragma unroll
+        for (int k = 0; k < W / 4; ++k)
+            reinterpret_cast<v4f *>(p)[k] = v4f{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+    } else if constexpr (W % 2 == 0) {
+#pragma unroll
+        for (int k = 0; k < W / 2; ++k) reinterpret_cast<v2f *>(p)[k] = v2f{v[2 * k], v[2 * k + 1]};
+    } else {
+#pragma unroll
+        for (int k = 0; k < W; ++k) p[k] = v[k];
+    }
+}
+
+// 1-ulp hardware sqrt / reciprocal (v_sqrt_f32, v_rcp_f32): ~8 VALU instructions cheaper per use than
+// the correctly-rounded expansions and two orders of magnitude inside the 1e-5 parity budget.
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// ---- rotation arithmetic (fp32, term order of the reference kept; file:line = pymotion/...) -------
+
+// rotations/quat.py:337-361
+__device__ __forceinline__ void qmul(const float (&a)[4], const float (&b)[4], float (&o)[4]) {
+    o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    o[1] = a[0] * b[1] + b[0] * a[1] + a[2] * b[3] - a[3] * b[2];
+    o[2] = a[0] * b[2] + b[0] * a[2] + a[3] * b[1] - a[1] * b[3];
+    o[3] = a[0] * b[3] + b[0] * a[3] + a[1] * b[2] - a[2] * b[1];
+}
+
+// rotations/quat.py:320-334 : t = 2 (qv x v); v' = v + w t + qv x t
+__device__ __forceinline__ void qmulvec(const float (&q)[4], const float (&v)[3], float (&o)[3]) {
+    const float t0 = 2.0f * (q[2] * v[2] - q[3] * v[1]);
+    const float t1 = 2.0f * (q[3] * v[0] - q[1] * v[2]);
+    const float t2 = 2.0f * (q[1] * v[1] - q[2] * v[0]);
+    o[0] = v[0] + q[0] * t0 + (q[2] * t2 - q[3] * t1);
+    o[1] = v[1] + q[0] * t1 + (q[3] * t0 - q[1] * t2);
+    o[2] = v[2] + q[0] * t2 + (q[1] * t1 - q[2] * t0);
+}
+
+// rotations/quat.py:364-376, 411-423 : q / (|q| + eps)  (eps ADDED TO THE NORM)
+__device__ __forceinline__ void qnormalize(const float (&q)[4], float eps, float (&o)[4]) {
+    const float n = fsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const float inv = frcp(n + eps);
+    o[0] = q[0] * inv; o[1] = q[1] * inv; o[2] = q[2] * inv; o[3] = q[3] * inv;
+}
+
+// rotations/quat.py:276-317
+__device__ __forceinline__ void q2m(const float (&q)[4], float (&m)[9]) {
+    const float x2 = q[1] + q[1], y2 = q[2] + q[2], z2 = q[3] + q[3];
+    const float xx = q[1] * x2, yy = q[2] * y2, wx = q[0] * x2;
+    const float xy = q[1] * y2, yz = q[2] * z2, wy = q[0] * y2;
+    const float xz = q[1] * z2, zz = q[3] * z2, wz = q[0] * z2;
+    m[0] = 1.0f - (yy + zz); m[1] = xy - wz;          m[2] = xz + wy;
+    m[3] = xy + wz;          m[4] = 1.0f - (xx + zz); m[5] = yz - wx;
+    m[6] = xz - wy;          m[7] = yz + wx;          m[8] = 1.0f - (xx + yy);
+}
+
+// rotations/quat.py:85-156 : same predicates and candidates, then normalize(eps = 1e-8).
+// Branch-free selects (v_cndmask) keep the wave converged.
+__device__ __forceinline__ void m2q(const float (&m)[9], float (&o)[4]) {
+    const float r00 = m[0], r01 = m[1], r02 = m[2], r10 = m[3], r11 = m[4], r12 = m[5], r20 = m[6],
+                r21 = m[7], r22 = m[8];
+    const bool neg = r22 < 0.0f, a = r00 > r11, b = r00 < -r11;
+    float c[4];
+    c[0] = neg ? (a ? r21 - r12 : r02 - r20) : (b ? r10 - r01 : 1.0f + r00 + r11 + r22);
+    c[1] = neg ? (a ? 1.0f + r00 - r11 - r22 : r10 + r01) : (b ? r02 + r20 : r21 - r12);
+    c[2] = neg ? (a ? r10 + r01 : 1.0f - r00 + r11 - r22) : (b ? r21 + r12 : r02 - r20);
+    c[3] = neg ? (a ? r02 + r20 : r21 + r12) : (b ? 1.0f - r00 - r11 + r22 : r10 - r01);
+    qnormalize(c, 1e-8f, o);
+}
+
+// rotations/ortho6d.py:67-90 : Gram-Schmidt on the two COLUMNS of x[3][2]; denominators
+// max(norm, eps): eps = 0 -> NumPy path (NaN on a zero column), 1e-12 -> torch twin.
+__device__ __forceinline__ void o6d2m(const float (&x)[6], float eps, float (&m)[9]) {
+    const float a0 = x[0], a1 = x[2], a2 = x[4], b0 = x[1], b1 = x[3], b2 = x[5];
+    const float ia = frcp(fmaxf(fsqrt(a0 * a0 + a1 * a1 + a2 * a2), eps));
+    const float c10 = a0 * ia, c11 = a1 * ia, c12 = a2 * ia;
+    const float d = c10 * b0 + c11 * b1 + c12 * b2;
+    float c20 = b0 - d * c10, c21 = b1 - d * c11, c22 = b2 - d * c12;
+    const float ib = frcp(fmaxf(fsqrt(c20 * c20 + c21 * c21 + c22 * c22), eps));
+    c20 *= ib; c21 *= ib; c22 *= ib;
+    m[0] = c10; m[1] = c20; m[2] = c11 * c22 - c12 * c21;
+    m[3] = c11; m[4] = c21; m[5] = c12 * c20 - c10 * c22;
+    m[6] = c12; m[7] = c22; m[8] = c10 * c21 - c11 * c20;
+}
+
+// rotations/dual_quat.py:12-36 : dq = [qr, 0.5 * (0,t) (x) qr]
+__device__ __forceinline__ void rt2dq(const float (&q)[4], const float (&t)[3], float (&dq)[8]) {
+    const float tq[4] = {0.0f, t[0], t[1], t[2]};
+    float d[4];
+    qmul(tq, q, d);
+    dq[0] = q[0]; dq[1] = q[1]; dq[2] = q[2]; dq[3] = q[3];
+    dq[4] = 0.5f * d[0]; dq[5] = 0.5f * d[1]; dq[6] = 0.5f * d[2]; dq[7] = 0.5f * d[3];
+}
+
+// rotations/dual_quat.py:62-83 : t = (2 * qd (x) conj(qr))[1:]
+__device__ __forceinline__ void dq2rt(const float (&dq)[8], float (&q)[4], float (&t)[3]) {
+    const float cj[4] = {dq[0], -dq[1], -dq[2], -dq[3]};
+    const float qd[4] = {dq[4], dq[5], dq[6], dq[7]};
+    float d[4];
+    qmul(qd, cj, d);
+    q[0] = dq[0]; q[1] = dq[1]; q[2] = dq[2]; q[3] = dq[3];
+    t[0] = 2.0f * d[1]; t[1] = 2.0f * d[2]; t[2] = 2.0f * d[3];
+}
+
+// ---- host-side helpers -------------------------------------------------------------------------------
+
+struct Parents {  // passed to kernels BY VALUE (kernarg segment -> s_load_dword, uniform index)
+    int32_t p[PM_MAX_JOINTS];
+};
+
+void set_error(const char *fmt, ...);
+int check_hip(hipError_t e, const char *what);
+int pack_parents(const int32_t *parents, int32_t J, Parents &out);  // validates topology
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Dynamic LDS above 64 KiB needs an explicit opt-in per kernel function.
+template <class K>
+int allow_lds(K kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return PM_OK;
+    return check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes),
+                     "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+}
+
+constexpr size_t kMaxLds = 160 * 1024;
+
+}  // namespace pm
+
+#define PM_CHECK_ARGS(cond, msg)       \
+    do {                               \
+        if (!(cond)) {                 \
+            pm::set_error("%s", msg);  \
+            return PM_EINVAL;          \
+        }                              \
+    } while (0)

@@ -1,0 +1,337 @@
+// elementwise.hip -- quaternion / dual-quaternion / ortho6d element-wise conversions for gfx950.
+//
+// One templated streaming kernel: a wave owns a tile of 256 elements (4 per lane).  Each operand is
+// an AoS record of W floats (W in {1,3,4,6,8,9}); records of odd width cannot be moved with aligned
+// dwordx4 per lane directly, so every operand goes HBM -> LDS (contiguous dwordx4, perfectly coalesced,
+// tile bases are multiples of 1 KiB) -> registers (per-record read, widest conflict-free DS op), and
+// results go back the same way.  All of these ops are HBM-bound (16-60 B per element, a few dozen
+// flops): the kernel's job is to keep every byte it touches inside full 128-byte lines.
+#include "common.hpp"
+
+namespace pm {
+
+constexpr int EW_TILE = 256;  // elements per wave
+constexpr int EW_PER_LANE = EW_TILE / PM_WAVE;
+
+struct EwArgs {
+    const float *in0, *in1, *in2;
+    float *out0, *out1;
+    const uint8_t *order;  // euler ops
+    int64_t N;
+    float eps;
+    int flag;  // slerp: shortest; euler: order_per_element
+};
+
+template <int W, bool VEC>
+__device__ __forceinline__ void ew_stage_in(const float *g, float *s, int64_t e0, int n, int lane) {
+    if constexpr (W > 0) tile_load<VEC>(g + e0 * W, s, n * W, lane);
+}
+template <int W, bool VEC>
+__device__ __forceinline__ void ew_stage_out(float *g, const float *s, int64_t e0, int n, int lane) {
+    if constexpr (W > 0) tile_store<VEC>(g + e0 * W, s, n * W, lane);
+}
+
+// Op concept: static constexpr int I0,I1,I2,O0,O1 (0 = absent);
+//   static __device__ void apply(const float(&)[I0|1], const float(&)[I1|1], const float(&)[I2|1],
+//                                float(&)[O0|1], float(&)[O1|1], const EwArgs&, int64_t elem)
+template <class Op, bool VEC>
+__global__ __launch_bounds__(PM_WAVE) void ew_kernel(const EwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int I0 = Op::I0, I1 = Op::I1, I2 = Op::I2, O0 = Op::O0, O1 = Op::O1;
+    const int lane = threadIdx.x;
+    const int64_t ntiles = (a.N + EW_TILE - 1) / EW_TILE;
+    const int64_t tile = xcd_tile(ntiles);
+    if (tile < 0) return;
+    const int64_t e0 = tile * EW_TILE;
+    const int n = (int)((a.N - e0) < EW_TILE ? (a.N - e0) : EW_TILE);
+
+    float *s0 = smem;
+    float *s1 = s0 + EW_TILE * I0;
+    float *s2 = s1 + EW_TILE * I1;
+    float *t0 = s2 + EW_TILE * I2;
+    float *t1 = t0 + EW_TILE * O0;
+
+    ew_stage_in<I0, VEC>(a.in0, s0, e0, n, lane);
+    ew_stage_in<I1, VEC>(a.in1, s1, e0, n, lane);
+    ew_stage_in<I2, VEC>(a.in2, s2, e0, n, lane);
+    wave_sync();
+#pragma unroll
+    for (int m = 0; m < EW_PER_LANE; ++m) {
+        const int idx = m * PM_WAVE + lane;
+        if (idx < n) {
+            float x0[I0 ? I0 : 1], x1[I1 ? I1 : 1], x2[I2 ? I2 : 1], y0[O0 ? O0 : 1], y1[O1 ? O1 : 1];
+            if constexpr (I0 > 0) lds_get<I0>(s0, idx, reinterpret_cast<float(&)[I0]>(x0));
+            if constexpr (I1 > 0) lds_get<I1>(s1, idx, reinterpret_cast<float(&)[I1]>(x1));
+            if constexpr (I2 > 0) lds_get<I2>(s2, idx, reinterpret_cast<float(&)[I2]>(x2));
+            Op::apply(x0, x1, x2, y0, y1, a, e0 + idx);
+            if constexpr (O0 > 0) lds_put<O0>(t0, idx, reinterpret_cast<float(&)[O0]>(y0));
+            if constexpr (O1 > 0) lds_put<O1>(t1, idx, reinterpret_cast<float(&)[O1]>(y1));
+        }
+    }
+    wave_sync();
+    ew_stage_out<O0, VEC>(a.out0, t0, e0, n, lane);
+    ew_stage_out<O1, VEC>(a.out1, t1, e0, n, lane);
+}
+
+template <class Op>
+static int launch_ew(const EwArgs &a, pm_stream_t stream, const char *name) {
+    if (a.N < 0) { set_error("%s: negative N", name); return PM_EINVAL; }
+    if (a.N == 0) return PM_OK;
+    if ((Op::I0 && !a.in0) || (Op::I1 && !a.in1) || (Op::I2 && !a.in2) || (Op::O0 && !a.out0) || (Op::O1 && !a.out1)) {
+        set_error("%s: null pointer", name);
+        return PM_EINVAL;
+    }
+    constexpr size_t lds = (size_t)EW_TILE * (Op::I0 + Op::I1 + Op::I2 + Op::O0 + Op::O1) * sizeof(float);
+    const int64_t ntiles = (a.N + EW_TILE - 1) / EW_TILE;
+    const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
+    if (grid > 0x7fffffffLL) { set_error("%s: grid too large", name); return PM_EUNSUPPORTED; }
+    const bool vec = aligned16(a.in0) && aligned16(a.in1) && aligned16(a.in2) && aligned16(a.out0) && aligned16(a.out1);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (vec) hipLaunchKernelGGL((ew_kernel<Op, true>), dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
+    else hipLaunchKernelGGL((ew_kernel<Op, false>), dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
+    return check_hip(hipGetLastError(), name);
+}
+
+#define PM_OP(NAME, i0, i1, i2, o0, o1)                                                          \
+    struct NAME {                                                                                \
+        static constexpr int I0 = i0, I1 = i1, I2 = i2, O0 = o0, O1 = o1;                        \
+        static __device__ __forceinline__ void apply(const float(&x0)[i0 ? i0 : 1], const float(&x1)[i1 ? i1 : 1], \
+                                                     const float(&x2)[i2 ? i2 : 1], float(&y0)[o0 ? o0 : 1],       \
+                                                     float(&y1)[o1 ? o1 : 1], const EwArgs &a, int64_t elem)
+#define PM_OP_END };
+
+// rotations/quat.py:411-423
+PM_OP(OpNormalize, 4, 0, 0, 4, 0) { qnormalize(x0, a.eps, y0); } PM_OP_END
+// rotations/quat.py:364-376
+PM_OP(OpLength, 4, 0, 0, 1, 0) { y0[0] = __fsqrt_rn(x0[0] * x0[0] + x0[1] * x0[1] + x0[2] * x0[2] + x0[3] * x0[3]); } PM_OP_END
+// rotations/quat.py:276-317
+PM_OP(OpToMatrix, 4, 0, 0, 9, 0) { q2m(x0, y0); } PM_OP_END
+// rotations/quat.py:85-156
+PM_OP(OpFromMatrix, 9, 0, 0, 4, 0) { m2q(x0, y0); } PM_OP_END
+// rotations/quat.py:337-361
+PM_OP(OpMul, 4, 4, 0, 4, 0) { qmul(x0, x1, y0); } PM_OP_END
+// rotations/quat.py:320-334
+PM_OP(OpMulVec, 4, 3, 0, 3, 0) { qmulvec(x0, x1, y0); } PM_OP_END
+// rotations/quat.py:396-408
+PM_OP(OpConj, 4, 0, 0, 4, 0) { y0[0] = x0[0]; y0[1] = -x0[1]; y0[2] = -x0[2]; y0[3] = -x0[3]; } PM_OP_END
+// rotations/dual_quat.py:12-36
+PM_OP(OpDqFromRt, 4, 3, 0, 8, 0) { rt2dq(x0, x1, y0); } PM_OP_END
+// rotations/dual_quat.py:62-83
+PM_OP(OpDqToRt, 8, 0, 0, 4, 3) { dq2rt(x0, y0, y1); } PM_OP_END
+// rotations/dual_quat.py:39-59
+PM_OP(OpDqFromT, 3, 0, 0, 8, 0) {
+    y0[0] = 1.0f; y0[1] = y0[2] = y0[3] = y0[4] = 0.0f;
+    y0[5] = x0[0] * 0.5f; y0[6] = x0[1] * 0.5f; y0[7] = x0[2] * 0.5f;
+} PM_OP_END
+// rotations/ortho6d.py:67-90
+PM_OP(OpO6dToMatrix, 6, 0, 0, 9, 0) { o6d2m(x0, a.eps, y0); } PM_OP_END
+// rotations/ortho6d.py:50-64
+PM_OP(OpO6dToQuat, 6, 0, 0, 4, 0) { float m[9]; o6d2m(x0, a.eps, m); m2q(m, y0); } PM_OP_END
+// rotations/ortho6d.py:14-28
+PM_OP(OpO6dFromQuat, 4, 0, 0, 6, 0) {
+    float m[9]; q2m(x0, m);
+    y0[0] = m[0]; y0[1] = m[1]; y0[2] = m[3]; y0[3] = m[4]; y0[4] = m[6]; y0[5] = m[7];
+} PM_OP_END
+// rotations/ortho6d.py:31-47
+PM_OP(OpO6dFromMatrix, 9, 0, 0, 6, 0) {
+    y0[0] = x0[0]; y0[1] = x0[1]; y0[2] = x0[3]; y0[3] = x0[4]; y0[4] = x0[6]; y0[5] = x0[7];
+} PM_OP_END
+
+// ---- second wave: trig-heavy conversions (accurate libm-grade sin/cos/acos/atan2: parity first) ----
+
+// rotations/quat.py:24-40
+__device__ __forceinline__ void aa2q(float angle, float ax, float ay, float az, float (&o)[4]) {
+    const float h = angle / 2.0f;
+    const float c = cosf(h), s = sinf(h);
+    o[0] = c; o[1] = s * ax; o[2] = s * ay; o[3] = s * az;
+}
+PM_OP(OpFromAngleAxis, 1, 3, 0, 4, 0) { aa2q(x0[0], x1[0], x1[1], x1[2], y0); } PM_OP_END
+// rotations/quat.py:6-21 (zero vector: 0/0 -> NaN, like the reference)
+PM_OP(OpFromScaledAA, 3, 0, 0, 4, 0) {
+    const float ang = __fsqrt_rn(x0[0] * x0[0] + x0[1] * x0[1] + x0[2] * x0[2]);
+    aa2q(ang, x0[0] / ang, x0[1] / ang, x0[2] / ang, y0);
+} PM_OP_END
+// rotations/quat.py:247-273
+__device__ __forceinline__ void q2aa(const float (&q)[4], float &angle, float (&axis)[3]) {
+    const float w = q[0];
+    angle = 2.0f * acosf(fminf(fmaxf(w, -1.0f), 1.0f));
+    const float s = __fsqrt_rn(fminf(fmaxf(1.0f - w * w, 0.0f), 1.0f));
+    const bool ok = s > 1e-8f;
+    axis[0] = ok ? q[1] / s : 0.0f; axis[1] = ok ? q[2] / s : 0.0f; axis[2] = ok ? q[3] / s : 0.0f;
+}
+PM_OP(OpToAngleAxis, 4, 0, 0, 1, 3) { q2aa(x0, y0[0], y1); } PM_OP_END
+// rotations/quat.py:230-244
+PM_OP(OpToScaledAA, 4, 0, 0, 3, 0) {
+    float ang, ax[3]; q2aa(x0, ang, ax);
+    y0[0] = ang * ax[0]; y0[1] = ang * ax[1]; y0[2] = ang * ax[2];
+} PM_OP_END
+
+__device__ __forceinline__ void load_order(const EwArgs &a, int64_t elem, int (&o)[3]) {
+    const uint8_t *p = a.order + (a.flag ? elem * 3 : 0);
+    o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+}
+// rotations/quat.py:43-82 : q = q0 (x) (q1 (x) q2), each an axis rotation about order[k]
+PM_OP(OpFromEuler, 3, 0, 0, 4, 0) {
+    int o[3]; load_order(a, elem, o);
+    float q[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        aa2q(x0[k], o[k] == 0 ? 1.0f : 0.0f, o[k] == 1 ? 1.0f : 0.0f, o[k] == 2 ? 1.0f : 0.0f, q[k]);
+    float t[4];
+    qmul(q[1], q[2], t);
+    qmul(q[0], t, y0);
+} PM_OP_END
+// rotations/quat.py:159-227
+PM_OP(OpToEuler, 4, 0, 0, 3, 0) {
+    int o[3]; load_order(a, elem, o);
+    const int i = o[2], j = o[1], k = o[0];
+    const int prod = (i - j) * (j - k) * (k - i);
+    const float sg = (float)(prod >= 0 ? prod / 2 : -((-prod + 1) / 2));  // python floor division
+    const float qi = (i == 0) ? x0[1] : (i == 1 ? x0[2] : x0[3]);
+    const float qj = (j == 0) ? x0[1] : (j == 1 ? x0[2] : x0[3]);
+    const float qk = (k == 0) ? x0[1] : (k == 1 ? x0[2] : x0[3]);
+    const float aa = x0[0] - qj, bb = qi + qk * sg, cc = qj + x0[0], dd = qk * sg - qi;
+    const float two_pi = 6.283185307179586f;
+    float e[3];
+    e[1] = 2.0f * atan2f(hypotf(cc, dd), hypotf(aa, bb)) - 1.5707963267948966f;
+    const float hs = atan2f(bb, aa), hd = atan2f(dd, cc);
+    e[2] = hs - hd;
+    e[0] = (hs + hd) * sg;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {  // np.mod(e, 2pi): result carries the divisor's sign
+        float r = fmodf(e[c], two_pi);
+        if (r < 0.0f) r += two_pi;
+        y0[c] = r;
+    }
+} PM_OP_END
+// rotations/quat.py:465-501
+PM_OP(OpSlerp, 4, 4, 1, 4, 0) {
+    float b[4] = {x1[0], x1[1], x1[2], x1[3]};
+    float dot = x0[0] * b[0] + x0[1] * b[1] + x0[2] * b[2] + x0[3] * b[3];
+    if (a.flag && dot < 0.0f) { b[0] = -b[0]; b[1] = -b[1]; b[2] = -b[2]; b[3] = -b[3]; dot = -dot; }
+    dot = fminf(fmaxf(dot, -1.0f), 1.0f);
+    const float th = acosf(dot) * x2[0];
+    float q2[4], nn = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { q2[c] = b[c] - x0[c] * dot; const float u = q2[c] + 0.000001f; nn += u * u; }
+    nn = __fsqrt_rn(nn);
+    const float cs = cosf(th), sn = sinf(th);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) y0[c] = cs * x0[c] + sn * (q2[c] / nn);
+} PM_OP_END
+
+static EwArgs mk(const float *i0, const float *i1, const float *i2, float *o0, float *o1, int64_t N, float eps = 0.0f,
+                 int flag = 0, const uint8_t *order = nullptr) {
+    EwArgs a;
+    a.in0 = i0; a.in1 = i1; a.in2 = i2; a.out0 = o0; a.out1 = o1; a.order = order; a.N = N; a.eps = eps; a.flag = flag;
+    return a;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Streaming ceiling probe: fk's traffic shape (contiguous tiles, rd floats in / wr floats out per
+// frame) with no arithmetic.  Same one-wave-per-workgroup tiling, data passes through LDS once.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PM_WAVE) void ceiling_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                          int64_t F, int rd, int wr, int fpw) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int64_t ntiles = (F + fpw - 1) / fpw;
+    const int64_t tile = xcd_tile(ntiles);
+    if (tile < 0) return;
+    const int64_t f0 = tile * fpw;
+    const int nf = (int)((F - f0) < fpw ? (F - f0) : fpw);
+    tile_load<true>(src + f0 * rd, smem, nf * rd, lane);
+    wave_sync();
+    // replicate the staged input over the (larger) output tile
+    const v4f *l4 = reinterpret_cast<const v4f *>(smem);
+    v4f *g4 = reinterpret_cast<v4f *>(dst + f0 * wr);
+    const int n4 = (nf * wr) >> 2, m4 = (nf * rd) >> 2;
+    for (int i = lane; i < n4; i += PM_WAVE) __builtin_nontemporal_store(l4[i % m4], g4 + i);
+}
+
+}  // namespace pm
+
+using namespace pm;
+
+extern "C" int pm_quat_normalize_f32(const float *q, int64_t N, float eps, float *out, pm_stream_t s) {
+    return launch_ew<OpNormalize>(mk(q, nullptr, nullptr, out, nullptr, N, eps), s, "quat_normalize");
+}
+extern "C" int pm_quat_length_f32(const float *q, int64_t N, float *out, pm_stream_t s) {
+    return launch_ew<OpLength>(mk(q, nullptr, nullptr, out, nullptr, N), s, "quat_length");
+}
+extern "C" int pm_quat_to_matrix_f32(const float *q, int64_t N, float *out, pm_stream_t s) {
+    return launch_ew<OpToMatrix>(mk(q, nullptr, nullptr, out, nullptr, N), s, "quat_to_matrix");
+}
+extern "C" int pm_quat_from_matrix_f32(const float *m, int64_t N, float *out, pm_stream_t s) {
+    return launch_ew<OpFromMatrix>(mk(m, nullptr, nullptr, out, nullptr, N), s, "quat_from_matrix");
+}
+extern "C" int pm_quat_mul_f32(const float *q0, const float *q1, int64_t N, float *out, pm_stream_t s) {
+    return launch_ew<OpMul>(mk(q0, q1, nullptr, out, nullptr, N), s, "quat_mul");
+}
+extern "C" int pm_quat_mul_vec_f32(const float *q, const float *v, int64_t N, float *out, pm_stream_t s) {
+    return launch_ew<OpMulVec>(mk(q, v, nullptr, out, nullptr, N), s, "quat_mul_vec");
+}
+extern "C" int pm_quat_conjugate_f32(const float *q, int64_t N, float *out, pm_stream_t s) {
+    return launch_ew<OpConj>(mk(q, nullptr, nullptr, out, nullptr, N), s, "quat_conjugate");
+}
+extern "C" int pm_dq_from_rt_f32(const float *q, const float *t, int64_t N, float *out, pm_stream_t s) {
+    return launch_ew<OpDqFromRt>(mk(q, t, nullptr, out, nullptr, N), s, "dq_from_rt");
+}
+extern "C" int pm_dq_to_rt_f32(const float *dq, int64_t N, float *q, float *t, pm_stream_t s) {
+    return launch_ew<OpDqToRt>(mk(dq, nullptr, nullptr, q, t, N), s, "dq_to_rt");
+}
+extern "C" int pm_dq_from_t_f32(const float *t, int64_t N, float *out, pm_stream_t s) {
+    return launch_ew<OpDqFromT>(mk(t, nullptr, nullptr, out, nullptr, N), s, "dq_from_t");
+}
+extern "C" int pm_o6d_to_matrix_f32(const float *x, int64_t N, float eps, float *out, pm_stream_t s) {
+    return launch_ew<OpO6dToMatrix>(mk(x, nullptr, nullptr, out, nullptr, N, eps), s, "o6d_to_matrix");
+}
+extern "C" int pm_o6d_to_quat_f32(const float *x, int64_t N, float eps, float *out, pm_stream_t s) {
+    return launch_ew<OpO6dToQuat>(mk(x, nullptr, nullptr, out, nullptr, N, eps), s, "o6d_to_quat");
+}
+extern "C" int pm_o6d_from_quat_f32(const float *q, int64_t N, float *out, pm_stream_t s) {
+    return launch_ew<OpO6dFromQuat>(mk(q, nullptr, nullptr, out, nullptr, N), s, "o6d_from_quat");
+}
+extern "C" int pm_o6d_from_matrix_f32(const float *m, int64_t N, float *out, pm_stream_t s) {
+    return launch_ew<OpO6dFromMatrix>(mk(m, nullptr, nullptr, out, nullptr, N), s, "o6d_from_matrix");
+}
+extern "C" int pm_quat_from_angle_axis_f32(const float *angle, const float *axis, int64_t N, float *out, pm_stream_t s) {
+    return launch_ew<OpFromAngleAxis>(mk(angle, axis, nullptr, out, nullptr, N), s, "quat_from_angle_axis");
+}
+extern "C" int pm_quat_from_scaled_angle_axis_f32(const float *v, int64_t N, float *out, pm_stream_t s) {
+    return launch_ew<OpFromScaledAA>(mk(v, nullptr, nullptr, out, nullptr, N), s, "quat_from_scaled_angle_axis");
+}
+extern "C" int pm_quat_to_angle_axis_f32(const float *q, int64_t N, float *angle, float *axis, pm_stream_t s) {
+    return launch_ew<OpToAngleAxis>(mk(q, nullptr, nullptr, angle, axis, N), s, "quat_to_angle_axis");
+}
+extern "C" int pm_quat_to_scaled_angle_axis_f32(const float *q, int64_t N, float *out, pm_stream_t s) {
+    return launch_ew<OpToScaledAA>(mk(q, nullptr, nullptr, out, nullptr, N), s, "quat_to_scaled_angle_axis");
+}
+extern "C" int pm_quat_from_euler_f32(const float *euler, const uint8_t *order, int order_per_element, int64_t N,
+                                      float *out, pm_stream_t s) {
+    PM_CHECK_ARGS(order != nullptr || N == 0, "quat_from_euler: null order");
+    return launch_ew<OpFromEuler>(mk(euler, nullptr, nullptr, out, nullptr, N, 0.0f, order_per_element, order), s, "quat_from_euler");
+}
+extern "C" int pm_quat_to_euler_f32(const float *q, const uint8_t *order, int order_per_element, int64_t N, float *out,
+                                    pm_stream_t s) {
+    PM_CHECK_ARGS(order != nullptr || N == 0, "quat_to_euler: null order");
+    return launch_ew<OpToEuler>(mk(q, nullptr, nullptr, out, nullptr, N, 0.0f, order_per_element, order), s, "quat_to_euler");
+}
+extern "C" int pm_quat_slerp_f32(const float *q0, const float *q1, const float *t, int64_t N, int shortest, float *out,
+                                 pm_stream_t s) {
+    return launch_ew<OpSlerp>(mk(q0, q1, t, out, nullptr, N, 0.0f, shortest), s, "quat_slerp");
+}
+
+extern "C" int pm_stream_ceiling_f32(const float *src, float *dst, int64_t F, int32_t rd, int32_t wr, pm_stream_t stream) {
+    PM_CHECK_ARGS(src && dst && F >= 0 && rd >= 4 && wr >= 4 && rd % 4 == 0 && wr % 4 == 0 && aligned16(src) && aligned16(dst),
+                  "stream_ceiling: need aligned pointers and rd, wr multiples of 4 floats");
+    if (F == 0) return PM_OK;
+    const int fpw = 20;
+    const size_t lds = (size_t)fpw * (rd > wr ? rd : wr) * sizeof(float);
+    if (lds > 64 * 1024) { set_error("stream_ceiling: tile too large"); return PM_EUNSUPPORTED; }
+    const int64_t ntiles = (F + fpw - 1) / fpw;
+    const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
+    hipLaunchKernelGGL(ceiling_kernel, dim3((unsigned)grid), dim3(PM_WAVE), lds, static_cast<hipStream_t>(stream), src, dst, F,
+                       (int)rd, (int)wr, fpw);
+    return check_hip(hipGetLastError(), "stream_ceiling");
+}

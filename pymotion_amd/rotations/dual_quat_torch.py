@@ -1,0 +1,28 @@
+"""Dual quaternions ``[..., 8] = [qr(4), qd(4)]`` -- drop-in for ``pymotion.rotations.dual_quat_torch``.
+
+Reference: ``pymotion/rotations/dual_quat_torch.py``.  One gfx950 kernel per call, fp32 on the GPU.
+Not covered here: ``unroll`` (sequential in time).
+"""
+import torch
+
+from .. import _backend, _ops
+
+
+def _be():
+    return _backend.torch_backend()
+
+
+def from_rotation_translation(rotations: torch.Tensor, translations: torch.Tensor) -> torch.Tensor:
+    """``dq = [q, 0.5 (0,t) (x) q]``.  Reference: dual_quat_torch.py:12-36."""
+    return _ops.dq_from_rt(_be(), rotations, translations)
+
+
+def from_translation(translations: torch.Tensor) -> torch.Tensor:
+    """``[1,0,0,0, 0, t/2]``.  Reference: dual_quat_torch.py:39-61."""
+    return _ops.dq_from_t(_be(), translations)
+
+
+def to_rotation_translation(dq: torch.Tensor):
+    """-> ``(rotations [..., 4], translations [..., 3])``, ``t = (2 qd (x) conj(qr))[1:]``.
+    Reference: dual_quat_torch.py:64-85."""
+    return _ops.dq_to_rt(_be(), dq)

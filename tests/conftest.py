@@ -1,0 +1,70 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class Golden:
+    """tests/golden/<name>.npz written by oracle/make_golden.py: keys '<case>|<kind>|<array>'."""
+
+    def __init__(self, name):
+        self.z = np.load(os.path.join(GOLDEN, name))
+        self.cases = {}
+        for k in self.z.files:
+            case, kind, arr = k.split("|")
+            self.cases.setdefault(case, {}).setdefault(kind, {})[arr] = k
+
+    def names(self, prefix=""):
+        return sorted(c for c in self.cases if c.startswith(prefix))
+
+    def get(self, case, kind):
+        return {a: self.z[k] for a, k in self.cases[case].get(kind, {}).items()}
+
+
+_cache = {}
+
+
+def golden(name):
+    if name not in _cache:
+        _cache[name] = Golden(name)
+    return _cache[name]
+
+
+@pytest.fixture(scope="session")
+def g_elementwise():
+    return golden("elementwise.npz")
+
+
+@pytest.fixture(scope="session")
+def g_trig():
+    return golden("trig.npz")
+
+
+@pytest.fixture(scope="session")
+def g_skeleton():
+    return golden("skeleton.npz")
+
+
+def up64(d):
+    return {k: (v.astype(np.float64) if v.dtype == np.float32 else v) for k, v in d.items()}
+
+
+def assert_close(a, b, atol, what=""):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
+    nan_a, nan_b = np.isnan(a), np.isnan(b)
+    assert (nan_a == nan_b).all(), f"{what}: NaN pattern differs"
+    if a.size:
+        err = np.abs(np.where(nan_a, 0, a) - np.where(nan_b, 0, b)).max()
+        assert err <= atol, f"{what}: max abs err {err:.3e} > {atol:.1e}"

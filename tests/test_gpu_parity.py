@@ -1,0 +1,330 @@
+"""GPU parity: the HIP path (through the public NumPy / torch front doors, i.e. through the C ABI)
+against (1) the golden vectors the reference itself produced, (2) the CPU oracle on seeded
+random inputs at awkward sizes.  Tolerance: 1e-5 max abs error, fp32 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from conftest import assert_close, golden
+from oracle import c_oracle as co
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-5
+
+import pymotion_amd.ops.skeleton as sk  # noqa: E402
+import pymotion_amd.rotations.dual_quat as dq  # noqa: E402
+import pymotion_amd.rotations.ortho6d as o6  # noqa: E402
+import pymotion_amd.rotations.quat as quat  # noqa: E402
+
+
+def _torch_mods():
+    import torch
+
+    import pymotion_amd.ops.skeleton_torch as skt
+    import pymotion_amd.rotations.dual_quat_torch as dqt
+    import pymotion_amd.rotations.ortho6d_torch as o6t
+    import pymotion_amd.rotations.quat_torch as quatt
+
+    return torch, skt, dqt, o6t, quatt
+
+
+# case -> (numpy-callable(ins), torch-callable(mods, ins_as_tensors), output names)
+EW = {
+    "normalize": (lambda i: quat.normalize(i["q"]), lambda m, i: m[4].normalize(i["q"]), ["out"]),
+    "length": (lambda i: quat.length(i["q"]), lambda m, i: m[4].length(i["q"]), ["out"]),
+    "to_matrix_unit": (lambda i: quat.to_matrix(i["q"]), lambda m, i: m[4].to_matrix(i["q"]), ["out"]),
+    "to_matrix_nonunit": (lambda i: quat.to_matrix(i["q"]), lambda m, i: m[4].to_matrix(i["q"]), ["out"]),
+    "to_matrix_lit": (lambda i: quat.to_matrix(i["q"]), lambda m, i: m[4].to_matrix(i["q"]), ["out"]),
+    "from_matrix": (lambda i: quat.from_matrix(i["m"]), lambda m, i: m[4].from_matrix(i["m"]), ["out"]),
+    "mul": (lambda i: quat.mul(i["a"], i["b"]), lambda m, i: m[4].mul(i["a"], i["b"]), ["out"]),
+    "mul_nonunit": (lambda i: quat.mul(i["a"], i["b"]), lambda m, i: m[4].mul(i["a"], i["b"]), ["out"]),
+    "mul_bcast": (lambda i: quat.mul(i["a"], i["b"]), lambda m, i: m[4].mul(i["a"], i["b"]), ["out"]),
+    "mul_vec": (lambda i: quat.mul_vec(i["q"], i["v"]), lambda m, i: m[4].mul_vec(i["q"], i["v"]), ["out"]),
+    "conjugate": (lambda i: quat.conjugate(i["q"]), lambda m, i: m[4].conjugate(i["q"]), ["out"]),
+    "inverse": (lambda i: quat.inverse(i["q"]), lambda m, i: m[4].inverse(i["q"]), ["out"]),
+    "dq_from_rt": (lambda i: dq.from_rotation_translation(i["q"], i["t"]), lambda m, i: m[2].from_rotation_translation(i["q"], i["t"]), ["out"]),
+    "dq_to_rt": (lambda i: dq.to_rotation_translation(i["dq"]), lambda m, i: m[2].to_rotation_translation(i["dq"]), ["q", "t"]),
+    "dq_from_t": (lambda i: dq.from_translation(i["t"]), lambda m, i: m[2].from_translation(i["t"]), ["out"]),
+    "o6d_to_matrix": (lambda i: o6.to_matrix(i["x"]), lambda m, i: m[3].to_matrix(i["x"]), ["out"]),
+    "o6d_to_quat": (lambda i: o6.to_quat(i["x"]), lambda m, i: m[3].to_quat(i["x"]), ["out"]),
+    "o6d_from_quat": (lambda i: o6.from_quat(i["q"]), lambda m, i: m[3].from_quat(i["q"]), ["out"]),
+    "o6d_from_matrix": (lambda i: o6.from_matrix(i["m"]), lambda m, i: m[3].from_matrix(i["m"]), ["out"]),
+}
+
+TRIG = {
+    "from_angle_axis": (lambda i: quat.from_angle_axis(i["angle"], i["axis"]), lambda m, i: m[4].from_angle_axis(i["angle"], i["axis"]), ["out"]),
+    "from_angle_axis_lit": (lambda i: quat.from_angle_axis(i["angle"], i["axis"]), lambda m, i: m[4].from_angle_axis(i["angle"], i["axis"]), ["out"]),
+    "from_scaled_angle_axis": (lambda i: quat.from_scaled_angle_axis(i["v"]), lambda m, i: m[4].from_scaled_angle_axis(i["v"]), ["out"]),
+    "to_angle_axis": (lambda i: quat.to_angle_axis(i["q"]), lambda m, i: m[4].to_angle_axis(i["q"]), ["angle", "axis"]),
+    "to_scaled_angle_axis": (lambda i: quat.to_scaled_angle_axis(i["q"]), lambda m, i: m[4].to_scaled_angle_axis(i["q"]), ["out"]),
+    "slerp_shortest1": (lambda i: quat.slerp(i["q0"], i["q1"], i["t"], True), lambda m, i: m[4].slerp(i["q0"], i["q1"], i["t"], True), ["out"]),
+    "slerp_shortest0": (lambda i: quat.slerp(i["q0"], i["q1"], i["t"], False), lambda m, i: m[4].slerp(i["q0"], i["q1"], i["t"], False), ["out"]),
+    "slerp_scalar_t": (lambda i: quat.slerp(i["q0"], i["q1"], 0.3), lambda m, i: m[4].slerp(i["q0"], i["q1"], 0.3), ["out"]),
+}
+
+# acos / sqrt(1 - w^2) near |w| = 1 amplify fp32 input rounding: the reference's own fp32 (torch)
+# twin is only ~1e-3 accurate there (its tests use low_atol = 1e-3, test_quat.py:29)
+LOOSE = {"to_angle_axis": 2e-3, "to_scaled_angle_axis": 2e-3}
+
+
+def _tup(x):
+    return x if isinstance(x, tuple) else (x,)
+
+
+def _check(case, names, got, g, atol=ATOL):
+    want = g.get(case, "out64")
+    for n, a in zip(names, _tup(got)):
+        assert_close(np.asarray(a, dtype=np.float64), want[n], atol, f"{case}.{n}")
+
+
+@pytest.mark.parametrize("case", sorted(EW))
+def test_elementwise_numpy_vs_reference_golden(case):
+    g = golden("elementwise.npz")
+    fn, _, names = EW[case]
+    _check(case, names, fn(g.get(case, "in")), g)
+
+
+@pytest.mark.parametrize("case", sorted(EW))
+def test_elementwise_torch_vs_reference_golden(case):
+    m = _torch_mods()
+    torch = m[0]
+    g = golden("elementwise.npz")
+    _, fn, names = EW[case]
+    ins = {k: torch.from_numpy(v).cuda() for k, v in g.get(case, "in").items()}
+    got = _tup(fn(m, ins))
+    assert all(t.is_cuda for t in got), "result must stay on the input's device"
+    _check(case, names, tuple(t.cpu().numpy() for t in got), g)
+    # CPU tensors: copied over and back, result on the CPU
+    got_cpu = _tup(fn(m, {k: v.cpu() for k, v in ins.items()}))
+    assert all(not t.is_cuda for t in got_cpu)
+    _check(case, names, tuple(t.numpy() for t in got_cpu), g)
+
+
+@pytest.mark.parametrize("case", sorted(TRIG))
+def test_trig_vs_reference_golden(case):
+    g = golden("trig.npz")
+    fn, fn_t, names = TRIG[case]
+    atol = LOOSE.get(case, ATOL)
+    _check(case, names, fn(g.get(case, "in")), g, atol)
+    m = _torch_mods()
+    ins = {k: m[0].from_numpy(v).cuda() for k, v in g.get(case, "in").items()}
+    _check(case, names, tuple(t.cpu().numpy() for t in _tup(fn_t(m, ins))), g, atol)
+
+
+def _order_strings(codes):
+    return np.array(list("xyz"))[codes]
+
+
+def test_euler_vs_reference_golden():
+    g = golden("trig.npz")
+    i = g.get("from_euler", "in")
+    order = _order_strings(i["order"])
+    _check("from_euler", ["out"], quat.from_euler(i["e"], order), g)
+    i = g.get("to_euler", "in")
+    got = quat.to_euler(i["q"], _order_strings(i["order"]))
+    want = g.get("to_euler", "out64")["out"]
+    d = np.abs(got - want)
+    d = np.minimum(d, 2 * np.pi - d)  # angles live on a circle
+    assert d.max() < 5e-4  # atan2 conditioning in fp32; reference twin pair agrees to ~1e-3 (low_atol)
+    # a single order triple for the whole batch takes the per-call path
+    e = i["q"][:7]
+    o1 = np.tile(np.array(["z", "x", "y"]), (7, 1))
+    a = quat.to_euler(e, o1)
+    b = co.quat_to_euler(e.astype(np.float64), o1)
+    d = np.abs(a - b)
+    assert np.minimum(d, 2 * np.pi - d).max() < 5e-4
+
+
+def test_o6d_zero_column_matches_each_front_door():
+    g = golden("elementwise.npz")
+    x = g.get("o6d_to_matrix_zero_col", "in")["x"]
+    got = o6.to_matrix(x)
+    want = g.get("o6d_to_matrix_zero_col", "out_np")["out"]
+    assert np.isnan(got[0]).any() and (np.isnan(got) == np.isnan(want)).all()  # NumPy reference: NaN
+    assert_close(got[1:], g.get("o6d_to_matrix_zero_col", "out64")["out"][1:], ATOL)
+    m = _torch_mods()
+    got_t = m[3].to_matrix(m[0].from_numpy(x).cuda()).cpu().numpy()
+    want_t = g.get("o6d_to_matrix_zero_col", "out_t")["out"]
+    assert np.isfinite(got_t).all()  # torch twin: F.normalize eps -> zeros, no NaN
+    assert_close(got_t, want_t, ATOL)
+
+
+def test_output_dtypes_follow_the_reference():
+    g = golden("elementwise.npz")
+    q32 = g.get("mul", "in")["a"]
+    assert quat.to_matrix(q32).dtype == np.float64  # quat.py:306
+    assert quat.mul(q32, q32).dtype == np.float32
+    assert quat.mul(q32.astype(np.float64), q32).dtype == np.float64
+    assert quat.normalize(q32).dtype == np.float32
+    assert dq.from_rotation_translation(q32, q32[:, :3]).dtype == np.float64  # dual_quat.py:32
+    m = _torch_mods()
+    torch = m[0]
+    t = torch.from_numpy(q32).cuda()
+    assert m[4].to_matrix(t.double()).dtype == torch.get_default_dtype()  # quat_torch.py:318
+    assert m[4].mul(t.double(), t).dtype == torch.float64
+    assert m[2].from_rotation_translation(t, t[:, :3]).dtype == torch.float32
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 255, 256, 257, 1000, 100_003])
+def test_elementwise_vs_oracle_sizes(n):
+    rng = np.random.default_rng(n)
+    q = rng.standard_normal((n, 4)).astype(np.float32)
+    q2 = rng.standard_normal((n, 4)).astype(np.float32)
+    v = rng.uniform(-2, 2, (n, 3)).astype(np.float32)
+    x = rng.standard_normal((n, 3, 2)).astype(np.float32)
+    qn = q / np.linalg.norm(q, axis=-1, keepdims=True)
+    f64 = lambda a: a.astype(np.float64)  # noqa: E731
+    assert_close(quat.to_matrix(q), co.quat_to_matrix(f64(q)), 2e-5, "to_matrix (entries up to ~40)")
+    assert_close(quat.to_matrix(qn), co.quat_to_matrix(f64(qn)), ATOL, "to_matrix unit")
+    assert_close(quat.normalize(q), co.quat_normalize(f64(q)), ATOL, "normalize")
+    assert_close(quat.mul(qn, q2), co.quat_mul(f64(qn), f64(q2)), ATOL, "mul")
+    assert_close(quat.mul_vec(qn, v), co.quat_mul_vec(f64(qn), f64(v)), ATOL, "mul_vec")
+    m = co.quat_to_matrix(f64(qn)).astype(np.float32)
+    assert_close(quat.from_matrix(m), co.quat_from_matrix(f64(m)), ATOL, "from_matrix")
+    assert_close(o6.to_matrix(x), co.o6d_to_matrix(f64(x)), 5e-5, "o6d.to_matrix (ill-conditioned rows allowed)")
+    d = dq.from_rotation_translation(qn, v)
+    assert_close(d, co.dq_from_rt(f64(qn), f64(v)), ATOL, "dq.from_rt")
+    r, t = dq.to_rotation_translation(d.astype(np.float32))
+    assert_close(r, qn, ATOL, "dq round trip q")
+    assert_close(t, v, ATOL, "dq round trip t")
+
+
+# ---- skeleton ops ---------------------------------------------------------------------------------
+
+def _skel(prefix):
+    return golden("skeleton.npz").names(prefix)
+
+
+@pytest.mark.parametrize("case", [c for c in _skel("fk_") if not c.startswith("fk_from_o6d")])
+def test_fk_numpy_and_torch_vs_reference_golden(case):
+    g = golden("skeleton.npz")
+    i, want = g.get(case, "in"), g.get(case, "out64")
+    pos, rm = sk.fk(i["rot"], i["gpos"], i["off"], i["parents"])
+    assert pos.dtype == np.float64 and pos.flags.c_contiguous  # skeleton.py:44 (f64), contiguous by design
+    assert_close(pos, want["pos"], ATOL, case + " pos")
+    assert_close(rm, want["rotmats"], ATOL, case + " rotmats")
+    torch, skt = _torch_mods()[:2]
+    tp, tr = skt.fk(*[torch.from_numpy(i[k]).cuda() for k in ("rot", "gpos", "off")], torch.from_numpy(i["parents"]))
+    assert tp.dtype == torch.float32 and tp.is_cuda
+    assert_close(tp.cpu().numpy(), want["pos"], ATOL, case + " torch pos")
+    assert_close(tr.cpu().numpy(), want["rotmats"], ATOL, case + " torch rotmats")
+
+
+def test_fk_from_ortho6d_vs_reference_golden():
+    g = golden("skeleton.npz")
+    case = "fk_from_o6d_J52"
+    i, want = g.get(case, "in"), g.get(case, "out64")
+    pos, rm, q = sk.fk_from_ortho6d(i["x"], i["gpos"], i["off"], i["parents"], return_quat=True)
+    assert_close(pos, want["pos"], ATOL, "pos")
+    assert_close(rm, want["rotmats"], ATOL, "rotmats")
+    assert_close(q, want["quat"], ATOL, "quat")
+    pos2, rm2 = sk.fk_from_ortho6d(i["x"], i["gpos"], i["off"], i["parents"])
+    assert_close(pos2, pos, 0, "quat output must not change the transforms")
+    # and the fused kernel equals the two-launch chain on the GPU
+    p3, r3 = sk.fk(o6.to_quat(i["x"]), i["gpos"], i["off"], i["parents"])
+    assert_close(p3, pos, 1e-6, "fused vs chained")
+
+
+@pytest.mark.parametrize("case", _skel("to_root_dq_"))
+def test_to_root_dq_vs_reference_golden(case):
+    g = golden("skeleton.npz")
+    i, want = g.get(case, "in"), g.get(case, "out64")
+    d = sk.to_root_dual_quat(i["rot"], i["gpos"], i["parents"], i["off"])
+    assert d.dtype == np.float64
+    assert_close(d, want["dq"], ATOL, case)
+    torch, skt = _torch_mods()[:2]
+    dt = skt.to_root_dual_quat(torch.from_numpy(i["rot"]).cuda(), torch.from_numpy(i["gpos"]).cuda(),
+                               torch.from_numpy(i["parents"]), torch.from_numpy(i["off"]).cuda())
+    assert_close(dt.cpu().numpy(), want["dq"], ATOL, case + " torch")
+
+
+@pytest.mark.parametrize("case", _skel("from_root_dq_"))
+def test_from_root_dq_vs_reference_golden(case):
+    g = golden("skeleton.npz")
+    i, want = g.get(case, "in"), g.get(case, "out64")
+    t, q = sk.from_root_dual_quat(i["dq"], i["parents"])  # (translations, rotations): skeleton.py:204
+    assert_close(t, want["trans"], ATOL, case + " trans")
+    assert_close(q, want["rot"], ATOL, case + " rot")
+
+
+@pytest.mark.parametrize("case", _skel("from_global_rot_"))
+def test_from_global_rotations_vs_reference_golden(case):
+    g = golden("skeleton.npz")
+    i, want = g.get(case, "in"), g.get(case, "out64")
+    assert_close(sk.from_global_rotations(i["gq"], i["parents"]), want["out"], ATOL, case)
+
+
+def test_reference_style_dq_round_trip():
+    """Reads like ops/tests/test_skeleton.py:test_dq: encode, decode, recover the pose."""
+    g = golden("skeleton.npz")
+    i = g.get("to_root_dq_rand_J22", "in")
+    d = sk.to_root_dual_quat(i["rot"], i["gpos"], i["parents"], i["off"])
+    t, q = sk.from_root_dual_quat(d, i["parents"])
+    assert_close(q, i["rot"], ATOL, "rotations")
+    assert_close(t[:, 1:, :], np.tile(i["off"][1:], (t.shape[0], 1, 1)), ATOL, "offsets")
+    assert_close(t[:, 0, :], i["gpos"], ATOL, "global position")
+    # multi-dim leading shape: joint axis is -2 (fix of the reference's shape[1])
+    rot6 = np.tile(i["rot"][:4].reshape(2, 2, 22, 4), (3, 1, 1, 1, 1))
+    gp6 = np.tile(i["gpos"][:4].reshape(2, 2, 3), (3, 1, 1, 1))
+    d6 = sk.to_root_dual_quat(rot6, gp6, i["parents"], i["off"])
+    assert d6.shape == (3, 2, 2, 22, 8)
+    assert_close(d6[1].reshape(4, 22, 8), d[:4], 1e-7, "leading dims are just batch")
+
+
+@pytest.mark.parametrize("F,J", [(1, 1), (1, 22), (19, 22), (20, 22), (21, 22), (1000, 22), (100_003, 22), (777, 52),
+                                 (50, 3), (333, 128), (7, 300)])
+def test_fk_and_dq_vs_oracle_sizes(F, J):
+    from pymotion_amd import synthetic as syn
+
+    rng = np.random.default_rng(F * 1000 + J)
+    parents = {22: syn.PARENTS_22, 52: syn.PARENTS_52}.get(J)
+    if parents is None:
+        parents = syn.random_parents(J, rng)
+    rot = rng.standard_normal((F, J, 4)).astype(np.float32)
+    gpos = rng.uniform(-2, 2, (F, 3)).astype(np.float32)
+    off = syn.make_offsets(J, rng, 0.3 if J <= 52 else 0.05)
+    f64 = lambda a: a.astype(np.float64)  # noqa: E731
+    pos, rm = sk.fk(rot, gpos, off, parents)
+    p_o, r_o = co.fk(f64(rot), f64(gpos), f64(off), parents)
+    assert_close(pos, p_o, ATOL, "fk pos")
+    assert_close(rm, r_o, ATOL, "fk rotmats")
+    rn = rot / np.linalg.norm(rot, axis=-1, keepdims=True)
+    d = sk.to_root_dual_quat(rn, gpos, parents, off)
+    d_o = co.to_root_dual_quat(f64(rn), f64(gpos), parents, f64(off))
+    assert_close(d, d_o, ATOL, "to_root_dq")
+    t, q = sk.from_root_dual_quat(d_o.astype(np.float32), parents)
+    t_o, q_o = co.from_root_dual_quat(f64(d_o.astype(np.float32)), parents)
+    assert_close(t, t_o, ATOL, "from_root_dq trans")
+    assert_close(q, q_o, ATOL, "from_root_dq rot")
+
+
+def test_fk_per_frame_offsets_and_unaligned_views():
+    from pymotion_amd import synthetic as syn
+
+    torch, skt = _torch_mods()[:2]
+    rot, gpos, off, parents = syn.fk_workload(501, seed=3)
+    offs = np.tile(off, (501, 1, 1)) * np.linspace(0.5, 1.5, 501, dtype=np.float32)[:, None, None]
+    pos, rm = sk.fk(rot, gpos, offs, parents)
+    p_o, r_o = co.fk(rot.astype(np.float64), gpos.astype(np.float64), offs.astype(np.float64), parents)
+    assert_close(pos, p_o, ATOL, "per-frame offsets pos")
+    # a torch view whose data_ptr is only 4-byte aligned takes the scalar path of the kernels
+    big = torch.from_numpy(np.concatenate([np.zeros(1, np.float32), rot.ravel()])).cuda()
+    rot_view = big[1:].view(501, 22, 4)
+    assert rot_view.data_ptr() % 16 != 0
+    tp, tr = skt.fk(rot_view, torch.from_numpy(gpos).cuda(), torch.from_numpy(off).cuda(), torch.from_numpy(parents))
+    p1, r1 = co.fk(rot.astype(np.float64), gpos.astype(np.float64), off.astype(np.float64), parents)
+    assert_close(tp.cpu().numpy(), p1, ATOL, "unaligned pos")
+    assert_close(tr.cpu().numpy(), r1, ATOL, "unaligned rotmats")
+
+
+def test_bad_topology_raises_value_error():
+    rot = np.zeros((2, 3, 4), np.float32)
+    with pytest.raises(ValueError, match="topological"):
+        sk.fk(rot, np.zeros((2, 3), np.float32), np.zeros((3, 3), np.float32), np.array([0, 2, 1]))
+
+
+def test_empty_batch():
+    pos, rm = sk.fk(np.zeros((0, 22, 4), np.float32), np.zeros((0, 3), np.float32), np.zeros((22, 3), np.float32),
+                    np.maximum(np.arange(22) - 1, 0))
+    assert pos.shape == (0, 22, 3) and rm.shape == (0, 22, 3, 3)
+    assert quat.mul(np.zeros((0, 4)), np.zeros((0, 4))).shape == (0, 4)
