@@ -68,6 +68,35 @@ SIGNATURES = {
 _lib = None
 
 
+def _preload_hip_runtime():
+    """Make sure the process ends up with ONE HIP runtime.
+
+    PyTorch-ROCm wheels bundle their own ``libamdhip64.so`` (SONAME ``libamdhip64.so.7``) and ask
+    for it by the un-versioned file name, while ``libpmhip.so`` asks for the SONAME.  If the system
+    runtime under /opt/rocm were mapped first, a later ``import torch`` would map a SECOND runtime and
+    whichever initialises second sees no device.  Mapping torch's copy first (by path, no torch
+    import) lets the loader satisfy our SONAME request with it, so both share streams and memory
+    whatever the import order.  Without torch installed the system runtime is used.
+    """
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 class PmhipError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"libpmhip error {code}: {msg}")
@@ -83,6 +112,7 @@ def lib():
                 f"{LIB_PATH} is missing: the HIP extension is not built and pymotion_amd has no CPU "
                 "fallback. Run `python __graft_entry__.py` (or `make -C pymotion_amd/csrc`)."
             )
+        _preload_hip_runtime()
         h = C.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(h, name)  # AttributeError = ABI mismatch, let it surface

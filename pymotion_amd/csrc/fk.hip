@@ -1,21 +1,31 @@
 // fk.hip -- batched forward kinematics for gfx950 (reference: pymotion/ops/skeleton.py:16-61).
 //
-// Mapping ("row-parallel tree walk").  A world transform G_j = [R_j | p_j] obeys
-//     G_j = G_parent(j) . [L_j | t_j]      =>      row r of G_j = (row r of R_parent) . [L_j | t_j] + [0 | p_parent[r]]
-// i.e. the three rows of a frame's transforms never mix.  THREE LANES own one frame (lane = 3*f + r,
-// r = row), so a 64-lane wave walks FPW = 20 skeletons at once (60 lanes), each lane carrying just the
-// 4 floats of its row of the previous joint's transform in registers.  Joints are visited in index
-// order (parents[j] < j); when parents[j] == j-1 -- the common case in DFS-ordered skeletons -- the
-// parent row is already in registers, otherwise it is re-read from the LDS output tile.  The branch is
-// wave-uniform (topology is shared by all frames) and `parents` arrives in the kernarg segment, so it
-// costs scalar instructions only.
+// One wave (= one workgroup) owns a tile of FPW = 20 consecutive frames and a private LDS image of
+// that tile's OUTPUTS, laid out exactly like HBM (`rotmats` tile then `pos` tile).  Two phases:
 //
-// Data movement per wave-tile (J joints, FPW frames): rot tile (FPW*J*16 B, contiguous in HBM) is
-// loaded with dwordx4 per lane into LDS; each step reads one quaternion per frame from LDS
-// (ds_read_b128, broadcast inside the lane triple), normalises it, builds L_j and emits 3+1 floats per
-// lane into the LDS images of `rotmats` / `pos`, which are laid out EXACTLY like the HBM outputs.  The
-// finished images leave with contiguous dwordx4 streaming stores.  Algorithmic HBM bytes per frame:
-// 16J + 12 read, 48J written -- nothing is read or written twice.
+//  A. "local" phase, one lane per (frame, joint) element, 64 elements per pass: the lane loads its
+//     quaternion straight from HBM (dwordx4, consecutive lanes = consecutive 16 B: perfectly
+//     coalesced, all passes' loads issued before the first use), normalises it (skeleton.py:45),
+//     expands it to the local rotation L (quat.py:276-317) and parks the 9 floats in the element's
+//     own slot of the `rotmats` image.  All the transcendental / divide work happens here, fully
+//     lane-parallel and off the dependency chain.
+//
+//  B. "row-parallel tree walk".  A world transform G_j = [R_j | p_j] obeys
+//         G_j = G_parent(j) . [L_j | t_j]   =>   row r of G_j = (row r of R_parent) . [L_j | t_j] + [0 | p_parent[r]]
+//     so the three rows of a frame's transforms never mix: THREE LANES own one frame (lane = 3 f + r),
+//     60 of 64 lanes walk 20 skeletons at once, each lane carrying only its 4-float row of the
+//     previous joint in registers.  Per joint a lane reads L_j (broadcast inside the lane triple,
+//     fetched one joint ahead), does 12 FMAs and overwrites its row of slot j in place.  Joints are
+//     visited in index order (parents[j] < j); when parents[j] == j-1 -- the common case in
+//     DFS-ordered skeletons -- the parent row is already in registers, otherwise it is re-read from
+//     the image.  That branch is wave-uniform and `parents` / `offsets` arrive through scalar loads
+//     issued one joint ahead, so the per-joint critical path is 3 dependent FMAs.
+//
+// The finished image leaves with contiguous dwordx4 streaming stores.  Algorithmic HBM bytes per
+// frame: 16 J + 12 read, 48 J written -- nothing is read or written twice, and the LDS
+// footprint is just the output tile (48 J B per frame: 21 KiB for J = 22 -> 7 waves per CU).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace pm {
@@ -32,20 +42,27 @@ struct FkArgs {
     int64_t F;
     int32_t J;
     float eps;              // ortho6d Gram-Schmidt floor
+    int32_t ablate;         // tuning aid (env PM_FK_ABLATE): 1 = no local math, 2 = no tree walk; 0 in production
     Parents parents;
 };
 
 template <int SRC>
 constexpr int src_width() { return SRC == SRC_QUAT ? 4 : 6; }
 
-// LDS floats per frame-joint: pos 3 + rot 9 + source + (per-frame offsets 3) + (quat_out 4)
+// LDS floats per frame-joint: rot 9 + pos 3 (+ staged ortho6d 6) (+ per-frame offsets 3) (+ quat_out 4)
 template <int SRC, bool PFO, bool QOUT>
-constexpr int fk_lds_floats() { return 12 + src_width<SRC>() + (PFO ? 3 : 0) + (QOUT ? 4 : 0); }
+constexpr int fk_lds_floats() { return 12 + (SRC == SRC_O6D ? 6 : 0) + (PFO ? 3 : 0) + (QOUT ? 4 : 0); }
+
+// quaternion -> local rotation of fk: normalise (skeleton.py:45, quat.py:423) then quat.py:276-317
+__device__ __forceinline__ void local_from_quat(const float (&qi)[4], float (&L)[9]) {
+    float q[4];
+    qnormalize(qi, 1e-8f, q);
+    q2m(q, L);
+}
 
 template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT>
 __global__ __launch_bounds__(PM_WAVE) void fk_kernel(const FkArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int SW = src_width<SRC>();
     const int lane = threadIdx.x;
     const int J = a.J;
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
@@ -54,86 +71,161 @@ __global__ __launch_bounds__(PM_WAVE) void fk_kernel(const FkArgs a) {
     const int64_t f0 = tile * FPW;
     const int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
     const int FJ = FPW * J;
+    const int n = nf * J;  // (frame, joint) elements in this tile
 
-    float *sRot = smem;                 // [FPW*J*9]   16B-aligned: FPW*J*9*4 with FPW % 4 == 0
-    float *sPos = sRot + FJ * 9;        // [FPW*J*3]
-    float *sSrc = sPos + FJ * 3;        // [FPW*J*SW]
-    float *sOff = sSrc + FJ * SW;       // [FPW*J*3]   (PFO)
-    float *sQo = sOff + (PFO ? FJ * 3 : 0);  // [FPW*J*4] (QOUT)
+    float *sRot = smem;                                // [FPW*J*9]  FPW % 4 == 0 keeps every carve 16 B aligned
+    float *sPos = sRot + FJ * 9;                       // [FPW*J*3]
+    float *sSrc = sPos + FJ * 3;                       // [FPW*J*6]  (ortho6d: 24 B records need the LDS hop)
+    float *sOff = sSrc + (SRC == SRC_O6D ? FJ * 6 : 0);  // [FPW*J*3] (PFO)
+    float *sQo = sOff + (PFO ? FJ * 3 : 0);            // [FPW*J*4]  (QOUT)
+    float *sConst = sQo + (QOUT ? FJ * 4 : 0);         // [(J+1)*4]  per joint {parent (int bits), t0, t1, t2}
 
-    tile_load<VEC>(a.src + f0 * J * SW, sSrc, nf * J * SW, lane);
-    if (PFO) tile_load<VEC>(a.offsets + f0 * J * 3, sOff, nf * J * 3, lane);
+    // Every global load of the tile is issued up front, back to back, so the wave pays ONE memory
+    // latency: root position (used first by phase B), skeleton constants, then the rotations.
+    // Lanes >= 3*FPW shadow lanes 0.. (same frame, same row, same values, same addresses) and frames
+    // past the end of a partial tile walk uninitialised slots of their own: phase B needs no masking.
+    const int wl = lane % (3 * FPW);
+    const int f = wl / 3;
+    const int r = wl - 3 * f;
+    const float gp = (f < nf) ? a.root_pos[f0 * 3 + wl] : 0.0f;
 
-    const int f = lane / 3;
-    const int r = lane - 3 * f;
-    const bool act = f < nf;  // lanes 3*FPW.. and frames past F idle
-    const int fc = act ? f : 0;
-    const float gp = act ? a.root_pos[f0 * 3 + lane] : 0.0f;
-    wave_sync();
+    // Skeleton constants -> LDS once per tile, {parent (int bits), t0, t1, t2} per joint.  (Scalar loads
+    // inside the walk would share lgkmcnt with the DS traffic and, returning out of order, force full
+    // lgkmcnt(0) drains on every joint.)  Entry J is a clamp copy for the walk's look-ahead.
+    auto load_const = [&](const int j) {
+        const int jc = j < J ? j : J - 1;
+        v4f c;
+        c.x = __int_as_float(j == 0 ? -1 : a.parents.p[jc]);  // joint 0: "parent" = the seed row of phase B
+        c.y = PFO ? 0.0f : a.offsets[3 * jc];
+        c.z = PFO ? 0.0f : a.offsets[3 * jc + 1];
+        c.w = PFO ? 0.0f : a.offsets[3 * jc + 2];
+        return c;
+    };
+    const v4f c_first = load_const(lane <= J ? lane : J);  // joints 0..63 (all of them for J < 64)
 
-    // row r of the transform of joint j-1 (registers) -- seeded so that joint 0 falls out of the
-    // same formula: e_r . L = row r of L (exact: 1*x + 0*y + 0*z), translation = root_pos[r].
-    float g0 = (r == 0) ? 1.0f : 0.0f, g1 = (r == 1) ? 1.0f : 0.0f, g2 = (r == 2) ? 1.0f : 0.0f, gt = gp;
-    const float *fSrc = sSrc + fc * J * SW;
-    float *fRot = sRot + fc * J * 9 + r * 3;
-    float *fPos = sPos + fc * J * 3 + r;
-
-    // Skeleton constants for joint j are fetched one iteration ahead with scalar loads (kernarg
-    // `parents`, global `offsets`), so neither sits on the per-joint dependency chain.
-    int par_n = -1;  // joint 0: "parent" = the seed above
-    float t0n = 0.0f, t1n = 0.0f, t2n = 0.0f;
-    for (int j = 0; j < J; ++j) {
-        const int par = par_n;
-        float t0 = t0n, t1 = t1n, t2 = t2n;
-        {
-            const int jn = (j + 1 < J) ? j + 1 : j;
-            par_n = a.parents.p[jn];
-            if (!PFO) { t0n = a.offsets[3 * jn]; t1n = a.offsets[3 * jn + 1]; t2n = a.offsets[3 * jn + 2]; }
+    // ---- phase A -------------------------------------------------------------------------------------
+    if constexpr (SRC == SRC_QUAT) {
+        const float *gsrc = a.src + f0 * J * 4;
+        auto load_batch = [&](const int e0, float (&qi)[4][4]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * PM_WAVE + lane;
+                if (e < n) {
+                    if (VEC) {
+                        const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(gsrc) + e);
+                        qi[u][0] = t.x; qi[u][1] = t.y; qi[u][2] = t.z; qi[u][3] = t.w;
+                    } else {
+                        qi[u][0] = gsrc[4 * e]; qi[u][1] = gsrc[4 * e + 1]; qi[u][2] = gsrc[4 * e + 2]; qi[u][3] = gsrc[4 * e + 3];
+                    }
+                }
+            }
+        };
+        auto do_batch = [&](const int e0, const float (&qi)[4][4]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * PM_WAVE + lane;
+                if (e < n) {
+                    float L[9];
+                    if (a.ablate & 1) {
+#pragma unroll
+                        for (int c = 0; c < 9; ++c) L[c] = qi[u][c & 3];
+                    } else {
+                        local_from_quat(qi[u], L);
+                    }
+                    lds_put<9>(sRot, e, L);
+                }
+            }
+        };
+        // two batches (8 x 16 B per lane = 8 KiB per wave) in flight before the first use, then
+        // ping-pong: batch k+2 is requested before batch k is consumed
+        constexpr int B = 4 * PM_WAVE;
+        float qa[4][4], qb[4][4];
+        load_batch(0, qa);
+        load_batch(B, qb);
+        if (lane <= J) reinterpret_cast<v4f *>(sConst)[lane] = c_first;
+        for (int j = lane + PM_WAVE; j <= J; j += PM_WAVE) reinterpret_cast<v4f *>(sConst)[j] = load_const(j);
+        for (int e0 = 0; e0 < n; e0 += 2 * B) {
+            do_batch(e0, qa);
+            load_batch(e0 + 2 * B, qa);
+            do_batch(e0 + B, qb);
+            load_batch(e0 + 3 * B, qb);
         }
-        float q[4], L[9];
-        if constexpr (SRC == SRC_QUAT) {
-            float qi[4];
-            lds_get<4>(fSrc, j, qi);
-            qnormalize(qi, 1e-8f, q);  // skeleton.py:45 normalises inside fk
-        } else {
-            // rotations/ortho6d.py:50-64 : 6D -> matrix -> quaternion (itself normalised), then fk's
-            // own normalise, exactly the chain ortho6d.to_quat -> fk of the reference.
-            float x[6], m[9], qi[4];
-            lds_get<6>(fSrc, j, x);
+    } else {
+        // rotations/ortho6d.py:50-64 : 6D -> matrix -> quaternion (itself normalised), then fk's own
+        // normalise and to_matrix: exactly the chain ortho6d.to_quat -> fk of the reference.
+        tile_load<VEC>(a.src + f0 * J * 6, sSrc, n * 6, lane);
+        if (lane <= J) reinterpret_cast<v4f *>(sConst)[lane] = c_first;
+        for (int j = lane + PM_WAVE; j <= J; j += PM_WAVE) reinterpret_cast<v4f *>(sConst)[j] = load_const(j);
+        wave_sync();
+        for (int e = lane; e < n; e += PM_WAVE) {
+            float x[6], m[9], qi[4], L[9];
+            lds_get<6>(sSrc, e, x);
             o6d2m(x, a.eps, m);
             m2q(m, qi);
-            if (QOUT && act && r == 0) lds_put<4>(sQo, fc * J + j, qi);
-            qnormalize(qi, 1e-8f, q);
+            if (QOUT) lds_put<4>(sQo, e, qi);
+            local_from_quat(qi, L);
+            lds_put<9>(sRot, e, L);
         }
-        q2m(q, L);
+    }
+    if (PFO) tile_load<VEC>(a.offsets + f0 * J * 3, sOff, n * 3, lane);
 
+    // ---- phase B -------------------------------------------------------------------------------------
+    wave_sync();
+
+    float *fL = sRot + f * J * 9;         // this frame's slots (L before, G after)
+    float *fRot = fL + r * 3;             // this lane's row inside a slot
+    float *fPos = sPos + f * J * 3 + r;
+    const float *fOff = sOff + f * J * 3;
+
+    // Row r of joint j-1's transform, seeded so that joint 0 falls out of the same formula:
+    // e_r . L = row r of L (exact: 1*x + 0*y + 0*z) and translation = root_pos[r] (offsets[0] ignored).
+    float g0 = (r == 0) ? 1.0f : 0.0f, g1 = (r == 1) ? 1.0f : 0.0f, g2 = (r == 2) ? 1.0f : 0.0f, gt = gp;
+
+    // One joint of the walk.  `L` and the joint's constants `c` were fetched a joint ahead.
+    auto joint = [&](const int j, const float (&L)[9], const v4f c) {
+        const int par = __builtin_amdgcn_readfirstlane(__float_as_int(c.x));
+        float t0 = c.y, t1 = c.z, t2 = c.w;
         float p0 = g0, p1 = g1, p2 = g2, pt = gt;
-        if (par != j - 1) {  // wave-uniform: not the previous joint -> its row is in the LDS image
+        if (par != j - 1) {  // wave-uniform: not the previous joint -> its row is in the image
             p0 = fRot[par * 9]; p1 = fRot[par * 9 + 1]; p2 = fRot[par * 9 + 2];
             pt = fPos[par * 3];
         }
-        if (PFO && j > 0) {
-            const float *o = sOff + (fc * J + j) * 3;
-            t0 = o[0]; t1 = o[1]; t2 = o[2];
-        }
+        if (PFO && j > 0) { t0 = fOff[3 * j]; t1 = fOff[3 * j + 1]; t2 = fOff[3 * j + 2]; }
         g0 = p0 * L[0] + p1 * L[3] + p2 * L[6];
         g1 = p0 * L[1] + p1 * L[4] + p2 * L[7];
         g2 = p0 * L[2] + p1 * L[5] + p2 * L[8];
         gt = p0 * t0 + p1 * t1 + p2 * t2 + pt;
-        if (act) {
-            fRot[j * 9] = g0; fRot[j * 9 + 1] = g1; fRot[j * 9 + 2] = g2;
-            fPos[j * 3] = gt;
-        }
+        // all three lanes of the frame have read slot j (in-order DS) -> overwrite in place
+        fRot[j * 9] = g0; fRot[j * 9 + 1] = g1; fRot[j * 9 + 2] = g2;
+        fPos[j * 3] = gt;
+    };
+
+    // Two joints per trip with ping-pong register sets, so the look-ahead costs no moves.  Slot j+1
+    // still holds L_{j+1} while joint j is processed (it is only overwritten at step j+1); the slot
+    // read past the last joint lies inside the LDS allocation (sPos follows sRot).
+    const v4f *cst = reinterpret_cast<const v4f *>(sConst);
+    float La[9], Lb[9];
+    v4f ca, cb;
+    lds_get<9>(fL, 0, La);
+    ca = cst[0];
+    for (int j = (a.ablate & 2) ? J : 0; j < J; j += 2) {
+        lds_get<9>(fL, j + 1, Lb);
+        cb = cst[j + 1];
+        joint(j, La, ca);
+        if (j + 1 >= J) break;
+        lds_get<9>(fL, j + 2, La);
+        ca = cst[j + 2 <= J ? j + 2 : J];
+        joint(j + 1, Lb, cb);
     }
     wave_sync();
-    tile_store<VEC>(a.rotmats + f0 * J * 9, sRot, nf * J * 9, lane);
-    tile_store<VEC>(a.pos + f0 * J * 3, sPos, nf * J * 3, lane);
-    if (QOUT) tile_store<VEC>(a.quat_out + f0 * J * 4, sQo, nf * J * 4, lane);
+    tile_store<VEC>(a.rotmats + f0 * J * 9, sRot, n * 9, lane);
+    tile_store<VEC>(a.pos + f0 * J * 3, sPos, n * 3, lane);
+    if (QOUT) tile_store<VEC>(a.quat_out + f0 * J * 4, sQo, n * 4, lane);
 }
 
 template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT>
 static int launch_fk(const FkArgs &a, hipStream_t s) {
-    const size_t lds = (size_t)FPW * a.J * fk_lds_floats<SRC, PFO, QOUT>() * sizeof(float);
+    const size_t lds = ((size_t)FPW * a.J * fk_lds_floats<SRC, PFO, QOUT>() + 4 * (a.J + 1)) * sizeof(float);
     auto k = fk_kernel<FPW, VEC, PFO, SRC, QOUT>;
     if (int e = allow_lds(k, lds)) return e;
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
@@ -171,7 +263,7 @@ static int dispatch_fk2(const FkArgs &a, bool vec, bool pfo, hipStream_t s) {
 template <int SRC>
 static int dispatch_fk(const FkArgs &a, bool vec, bool pfo, hipStream_t s) {
     const size_t per_frame =
-        (size_t)a.J * (12 + src_width<SRC>() + (pfo ? 3 : 0) + (a.quat_out ? 4 : 0)) * sizeof(float);
+        (size_t)a.J * (12 + (SRC == SRC_O6D ? 6 : 0) + (pfo ? 3 : 0) + (a.quat_out ? 4 : 0)) * sizeof(float);
     if (20 * per_frame <= kMaxLds / 2) return dispatch_fk2<20, SRC>(a, vec, pfo, s);
     if (8 * per_frame <= kMaxLds / 2) return dispatch_fk2<8, SRC>(a, vec, pfo, s);
     if (4 * per_frame <= kMaxLds) return dispatch_fk2<4, SRC>(a, vec, pfo, s);
@@ -188,6 +280,10 @@ static int fk_common(int src_kind, const float *src, const float *root_pos, cons
     FkArgs a;
     a.src = src; a.root_pos = root_pos; a.offsets = offsets; a.pos = pos; a.rotmats = rotmats;
     a.quat_out = quat_out; a.F = F; a.J = J; a.eps = eps;
+    {
+        const char *ab = getenv("PM_FK_ABLATE");
+        a.ablate = ab ? atoi(ab) : 0;
+    }
     if (int e = pack_parents(parents, J, a.parents)) return e;
     const bool vec = aligned16(src) && aligned16(pos) && aligned16(rotmats) &&
                      (!offsets_per_frame || aligned16(offsets)) && (!quat_out || aligned16(quat_out));

@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Per-kernel timing probe (HIP events on the launch stream, device-resident data, median of reps).
+Prints one line per kernel: time, algorithmic GB/s, fraction of the 8 TB/s HBM spec.
+Not part of the graded bench; used while tuning and to produce profiles/ summaries."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy as np
+import torch
+
+from pymotion_amd import _lib
+from pymotion_amd import synthetic as syn
+
+PEAK = 8000.0
+
+
+def timeit(fn, reps=20, warm=3):
+    ev = [C.c_void_p() for _ in range(2)]
+    for e in ev:
+        _lib.call("pm_event_create", C.byref(e))
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        _lib.call("pm_event_record", ev[0], None)
+        fn()
+        _lib.call("pm_event_record", ev[1], None)
+        ms = C.c_float()
+        _lib.call("pm_event_elapsed_ms", ev[0], ev[1], C.byref(ms))
+        ts.append(ms.value)
+    return float(np.median(ts)), float(np.min(ts))
+
+
+def p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def report(name, ms, mn, nbytes):
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    print(f"{name:34s} {ms * 1e3:9.1f} us (min {mn * 1e3:8.1f})  {gbs:8.1f} GB/s  {gbs / PEAK * 100:5.1f}% of 8 TB/s", flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=1 << 20)
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    F = a.frames
+    want = lambda k: (not a.only) or any(s in k for s in a.only.split(","))  # noqa: E731
+
+    for J, parents in ((22, syn.PARENTS_22), (52, syn.PARENTS_52)):
+        Fj = F if J == 22 else F // 4
+        rot = torch.randn((Fj, J, 4), device=dev)
+        rotn = rot / rot.norm(dim=-1, keepdim=True)
+        root = torch.rand((Fj, 3), device=dev) * 4 - 2
+        off = torch.from_numpy(syn.make_offsets(J, np.random.default_rng(0))).to(dev)
+        pos = torch.empty((Fj, J, 3), device=dev)
+        rm = torch.empty((Fj, J, 3, 3), device=dev)
+        dq = torch.empty((Fj, J, 8), device=dev)
+        tr = torch.empty((Fj, J, 3), device=dev)
+        qo = torch.empty((Fj, J, 4), device=dev)
+        pp = parents.ctypes.data_as(C.c_void_p)
+        if want("fk"):
+            ms, mn = timeit(lambda: _lib.call("pm_fk_f32", p(rot), p(root), p(off), 0, pp, Fj, J, p(pos), p(rm), None))
+            report(f"fk J={J} F={Fj}", ms, mn, Fj * (64 * J + 12))
+        if want("ceiling"):
+            rd, wr = 16 * J // 4, 48 * J // 4
+            src = rot.view(-1)
+            dst = rm.view(-1)  # 36 J B/frame < 48 J: use a dedicated buffer
+            dst = torch.empty(Fj * wr, device=dev)
+            ms, mn = timeit(lambda: _lib.call("pm_stream_ceiling_f32", p(src), p(dst), Fj, rd, wr, None))
+            report(f"ceiling (copy, fk shape) J={J}", ms, mn, Fj * (rd + wr) * 4)
+            del dst
+        if want("dq"):
+            ms, mn = timeit(lambda: _lib.call("pm_to_root_dq_f32", p(rotn), p(root), pp, p(off), Fj, J, p(dq), None))
+            report(f"to_root_dq J={J}", ms, mn, Fj * (48 * J + 12))
+            ms, mn = timeit(lambda: _lib.call("pm_from_root_dq_f32", p(dq), pp, Fj, J, p(tr), p(qo), None))
+            report(f"from_root_dq J={J}", ms, mn, Fj * 60 * J)
+        if want("o6d") and J == 52:
+            x = torch.randn((Fj, J, 3, 2), device=dev)
+            ms, mn = timeit(lambda: _lib.call("pm_fk_from_ortho6d_f32", p(x), p(root), p(off), 0, pp, Fj, J, C.c_float(0.0),
+                                              p(pos), p(rm), None, None))
+            report(f"fk_from_ortho6d J={J} F={Fj}", ms, mn, Fj * (72 * J + 12))
+        if want("ew") and J == 22:
+            N = Fj * J
+            q = rotn.view(N, 4)
+            m = rm.view(N, 9)
+            ms, mn = timeit(lambda: _lib.call("pm_quat_to_matrix_f32", p(q), N, p(m), None))
+            report("quat.to_matrix", ms, mn, N * 52)
+            ms, mn = timeit(lambda: _lib.call("pm_quat_from_matrix_f32", p(m), N, p(qo), None))
+            report("quat.from_matrix", ms, mn, N * 52)
+            ms, mn = timeit(lambda: _lib.call("pm_quat_mul_f32", p(q), p(q), N, p(qo), None))
+            report("quat.mul", ms, mn, N * 48)
+            ms, mn = timeit(lambda: _lib.call("pm_quat_normalize_f32", p(q), N, C.c_float(1e-8), p(qo), None))
+            report("quat.normalize", ms, mn, N * 32)
+            qo2 = qo.view(N, 4)
+            ms, mn = timeit(lambda: qo2.copy_(q))
+            report("torch copy_ (16 B/elem r+w)", ms, mn, N * 32)
+        del rot, rotn, pos, rm, dq, tr, qo
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
