@@ -60,6 +60,73 @@ __device__ __forceinline__ void local_from_quat(const float (&qi)[4], float (&L)
     q2m(q, L);
 }
 
+
+// ---- phase B: row-parallel tree walk over one LDS tile ----------------------------------------------
+// sRot slot (f, j) holds the local rotation L_j on entry and row-by-row the world rotation on exit;
+// sPos receives the positions.  sConst[j] = {parent (int bits), t0, t1, t2}, entry J = clamp copy.
+// Lane (f, r) owns row r of frame f; `gp` = root_pos[f][r].
+template <bool PFO>
+__device__ __forceinline__ void tree_walk(float *sRot, float *sPos, const float *sOff, const float *sConst,
+                                          const int J, const int f, const int r, const float gp, const bool skip) {
+    float *fL = sRot + f * J * 9;         // this frame's slots (L before, G after)
+    float *fRot = fL + r * 3;             // this lane's row inside a slot
+    float *fPos = sPos + f * J * 3 + r;
+    const float *fOff = sOff + f * J * 3;
+
+    // Row r of joint j-1's transform, seeded so that joint 0 falls out of the same formula:
+    // e_r . L = row r of L (exact: 1*x + 0*y + 0*z) and translation = root_pos[r] (offsets[0] ignored).
+    float g0 = (r == 0) ? 1.0f : 0.0f, g1 = (r == 1) ? 1.0f : 0.0f, g2 = (r == 2) ? 1.0f : 0.0f, gt = gp;
+
+    // One joint of the walk.  `L` and the joint's constants `c` were fetched a joint ahead.
+    auto joint = [&](const int j, const float (&L)[9], const v4f c) {
+        const int par = __builtin_amdgcn_readfirstlane(__float_as_int(c.x));
+        float t0 = c.y, t1 = c.z, t2 = c.w;
+        float p0 = g0, p1 = g1, p2 = g2, pt = gt;
+        if (par != j - 1) {  // wave-uniform: not the previous joint -> its row is in the image
+            p0 = fRot[par * 9]; p1 = fRot[par * 9 + 1]; p2 = fRot[par * 9 + 2];
+            pt = fPos[par * 3];
+        }
+        if (PFO && j > 0) { t0 = fOff[3 * j]; t1 = fOff[3 * j + 1]; t2 = fOff[3 * j + 2]; }
+        g0 = p0 * L[0] + p1 * L[3] + p2 * L[6];
+        g1 = p0 * L[1] + p1 * L[4] + p2 * L[7];
+        g2 = p0 * L[2] + p1 * L[5] + p2 * L[8];
+        gt = p0 * t0 + p1 * t1 + p2 * t2 + pt;
+        // all three lanes of the frame have read slot j (in-order DS) -> overwrite in place
+        fRot[j * 9] = g0; fRot[j * 9 + 1] = g1; fRot[j * 9 + 2] = g2;
+        fPos[j * 3] = gt;
+    };
+
+    // Two joints per trip with ping-pong register sets, so the look-ahead costs no moves.  Slot j+1
+    // still holds L_{j+1} while joint j is processed (it is only overwritten at step j+1); the slot
+    // read past the last joint lies inside the LDS allocation (sPos follows sRot).
+    const v4f *cst = reinterpret_cast<const v4f *>(sConst);
+    float La[9], Lb[9];
+    v4f ca, cb;
+    lds_get<9>(fL, 0, La);
+    ca = cst[0];
+    for (int j = skip ? J : 0; j < J; j += 2) {
+        lds_get<9>(fL, j + 1, Lb);
+        cb = cst[j + 1];
+        joint(j, La, ca);
+        if (j + 1 >= J) break;
+        lds_get<9>(fL, j + 2, La);
+        ca = cst[j + 2 <= J ? j + 2 : J];
+        joint(j + 1, Lb, cb);
+    }
+}
+
+// {parent (int bits), t0, t1, t2} of joint j, clamped to the last joint; joint 0's "parent" is the seed row
+template <bool PFO>
+__device__ __forceinline__ v4f load_joint_const(const Parents &parents, const float *offsets, const int J, const int j) {
+    const int jc = j < J ? j : J - 1;
+    v4f c;
+    c.x = __int_as_float(j == 0 ? -1 : parents.p[jc]);
+    c.y = PFO ? 0.0f : offsets[3 * jc];
+    c.z = PFO ? 0.0f : offsets[3 * jc + 1];
+    c.w = PFO ? 0.0f : offsets[3 * jc + 2];
+    return c;
+}
+
 template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT>
 __global__ __launch_bounds__(PM_WAVE) void fk_kernel(const FkArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -92,15 +159,7 @@ __global__ __launch_bounds__(PM_WAVE) void fk_kernel(const FkArgs a) {
     // Skeleton constants -> LDS once per tile, {parent (int bits), t0, t1, t2} per joint.  (Scalar loads
     // inside the walk would share lgkmcnt with the DS traffic and, returning out of order, force full
     // lgkmcnt(0) drains on every joint.)  Entry J is a clamp copy for the walk's look-ahead.
-    auto load_const = [&](const int j) {
-        const int jc = j < J ? j : J - 1;
-        v4f c;
-        c.x = __int_as_float(j == 0 ? -1 : a.parents.p[jc]);  // joint 0: "parent" = the seed row of phase B
-        c.y = PFO ? 0.0f : a.offsets[3 * jc];
-        c.z = PFO ? 0.0f : a.offsets[3 * jc + 1];
-        c.w = PFO ? 0.0f : a.offsets[3 * jc + 2];
-        return c;
-    };
+    auto load_const = [&](const int j) { return load_joint_const<PFO>(a.parents, a.offsets, J, j); };
     const v4f c_first = load_const(lane <= J ? lane : J);  // joints 0..63 (all of them for J < 64)
 
     // ---- phase A -------------------------------------------------------------------------------------
@@ -172,55 +231,149 @@ __global__ __launch_bounds__(PM_WAVE) void fk_kernel(const FkArgs a) {
     // ---- phase B -------------------------------------------------------------------------------------
     wave_sync();
 
-    float *fL = sRot + f * J * 9;         // this frame's slots (L before, G after)
-    float *fRot = fL + r * 3;             // this lane's row inside a slot
-    float *fPos = sPos + f * J * 3 + r;
-    const float *fOff = sOff + f * J * 3;
-
-    // Row r of joint j-1's transform, seeded so that joint 0 falls out of the same formula:
-    // e_r . L = row r of L (exact: 1*x + 0*y + 0*z) and translation = root_pos[r] (offsets[0] ignored).
-    float g0 = (r == 0) ? 1.0f : 0.0f, g1 = (r == 1) ? 1.0f : 0.0f, g2 = (r == 2) ? 1.0f : 0.0f, gt = gp;
-
-    // One joint of the walk.  `L` and the joint's constants `c` were fetched a joint ahead.
-    auto joint = [&](const int j, const float (&L)[9], const v4f c) {
-        const int par = __builtin_amdgcn_readfirstlane(__float_as_int(c.x));
-        float t0 = c.y, t1 = c.z, t2 = c.w;
-        float p0 = g0, p1 = g1, p2 = g2, pt = gt;
-        if (par != j - 1) {  // wave-uniform: not the previous joint -> its row is in the image
-            p0 = fRot[par * 9]; p1 = fRot[par * 9 + 1]; p2 = fRot[par * 9 + 2];
-            pt = fPos[par * 3];
-        }
-        if (PFO && j > 0) { t0 = fOff[3 * j]; t1 = fOff[3 * j + 1]; t2 = fOff[3 * j + 2]; }
-        g0 = p0 * L[0] + p1 * L[3] + p2 * L[6];
-        g1 = p0 * L[1] + p1 * L[4] + p2 * L[7];
-        g2 = p0 * L[2] + p1 * L[5] + p2 * L[8];
-        gt = p0 * t0 + p1 * t1 + p2 * t2 + pt;
-        // all three lanes of the frame have read slot j (in-order DS) -> overwrite in place
-        fRot[j * 9] = g0; fRot[j * 9 + 1] = g1; fRot[j * 9 + 2] = g2;
-        fPos[j * 3] = gt;
-    };
-
-    // Two joints per trip with ping-pong register sets, so the look-ahead costs no moves.  Slot j+1
-    // still holds L_{j+1} while joint j is processed (it is only overwritten at step j+1); the slot
-    // read past the last joint lies inside the LDS allocation (sPos follows sRot).
-    const v4f *cst = reinterpret_cast<const v4f *>(sConst);
-    float La[9], Lb[9];
-    v4f ca, cb;
-    lds_get<9>(fL, 0, La);
-    ca = cst[0];
-    for (int j = (a.ablate & 2) ? J : 0; j < J; j += 2) {
-        lds_get<9>(fL, j + 1, Lb);
-        cb = cst[j + 1];
-        joint(j, La, ca);
-        if (j + 1 >= J) break;
-        lds_get<9>(fL, j + 2, La);
-        ca = cst[j + 2 <= J ? j + 2 : J];
-        joint(j + 1, Lb, cb);
-    }
+    tree_walk<PFO>(sRot, sPos, sOff, sConst, J, f, r, gp, (a.ablate & 2) != 0);
     wave_sync();
     tile_store<VEC>(a.rotmats + f0 * J * 9, sRot, n * 9, lane);
     tile_store<VEC>(a.pos + f0 * J * 3, sPos, n * 3, lane);
     if (QOUT) tile_store<VEC>(a.quat_out + f0 * J * 4, sQo, n * 4, lane);
+}
+
+
+// ---- persistent variant: quaternion source, static offsets, compile-time joint count ------------------
+// Same two phases, but (1) a wave loops over FULL tiles and keeps the rotations of the next TWO tiles
+// in flight (two register sets, requested right after the set's previous contents were consumed), so
+// every resident wave always has HBM reads outstanding while it computes -- with only ~7 waves per CU
+// (LDS-bound) that is what keeps the memory system busy; (2) with J a template parameter every loop
+// has a compile-time trip count and no load/store is predicated (out-of-range lanes are clamped onto
+// the last element: duplicate, identical accesses), so the compiler can count vmcnt exactly: a wave
+// never waits for its own stores to be acknowledged before it starts the next tile.
+// Tile assignment is XCD-aware: workgroup b sits on XCD b % 8 and strides through that XCD's contiguous
+// eighth of the tiles, so neighbouring tiles (which share cache lines at their edges) meet in one L2.
+// A trailing partial tile is handled by the generic kernel (second launch on the tail frames).
+template <int FPW, int JT, bool VEC>
+__global__ __launch_bounds__(PM_WAVE) void fk_persist_kernel(const FkArgs a, const int64_t ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int J = JT;
+    constexpr int N = FPW * J;                       // (frame, joint) elements per tile
+    constexpr int NQ = (N + PM_WAVE - 1) / PM_WAVE;  // dwordx4 loads per lane per tile
+    constexpr int R4 = N * 9 / 4, P4 = N * 3 / 4;    // dwordx4 stores per tile (FPW % 4 == 0)
+    constexpr int NR = (R4 + PM_WAVE - 1) / PM_WAVE, NP = (P4 + PM_WAVE - 1) / PM_WAVE;
+    const int lane = threadIdx.x;
+    float *sRot = smem;
+    float *sPos = sRot + N * 9;
+    float *sConst = sPos + N * 3;
+
+    const int64_t per_xcd = (ntiles + PM_NXCD - 1) / PM_NXCD;
+    const int xcd = blockIdx.x % PM_NXCD;
+    const int64_t stride = gridDim.x / PM_NXCD;
+    const int64_t lo = xcd * per_xcd;
+    const int64_t hi = (lo + per_xcd) < ntiles ? (lo + per_xcd) : ntiles;
+    const int64_t first = lo + blockIdx.x / PM_NXCD;
+    if (first >= hi) return;
+    const int64_t last = first + ((hi - 1 - first) / stride) * stride;  // this wave's final tile
+
+    const int wl = lane % (3 * FPW);
+    const int f = wl / 3;
+    const int r = wl - 3 * f;
+
+    auto request = [&](int64_t t, v4f (&q)[NQ], float &gp) {  // all global loads of tile t, back to back
+        t = t < last ? t : last;  // past the end: re-request the final tile (keeps the count static)
+        gp = a.root_pos[t * (FPW * 3) + wl];
+        const float *gsrc = a.src + t * (N * 4);
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            int e = u * PM_WAVE + lane;
+            e = e < N ? e : N - 1;
+            if (VEC) q[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(gsrc) + e);
+            else q[u] = v4f{gsrc[4 * e], gsrc[4 * e + 1], gsrc[4 * e + 2], gsrc[4 * e + 3]};
+        }
+    };
+    auto phase_a = [&](const v4f (&q)[NQ]) {  // registers -> local rotations -> LDS
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            int e = u * PM_WAVE + lane;
+            e = e < N ? e : N - 1;
+            const float qi[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+            float L[9];
+            if (a.ablate & 1) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c) L[c] = qi[c & 3];
+            } else {
+                local_from_quat(qi, L);
+            }
+            lds_put<9>(sRot, e, L);
+        }
+    };
+    auto walk_and_store = [&](const int64_t t, const float gp) {
+        wave_sync();
+        tree_walk<false>(sRot, sPos, nullptr, sConst, J, f, r, gp, (a.ablate & 2) != 0);
+        wave_sync();
+        float *grot = a.rotmats + t * (N * 9);
+        float *gpos = a.pos + t * (N * 3);
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            int i = k * PM_WAVE + lane;
+            i = i < R4 ? i : R4 - 1;
+            const v4f v = reinterpret_cast<const v4f *>(sRot)[i];
+            if (VEC) __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(grot) + i);
+            else { grot[4 * i] = v.x; grot[4 * i + 1] = v.y; grot[4 * i + 2] = v.z; grot[4 * i + 3] = v.w; }
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            int i = k * PM_WAVE + lane;
+            i = i < P4 ? i : P4 - 1;
+            const v4f v = reinterpret_cast<const v4f *>(sPos)[i];
+            if (VEC) __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(gpos) + i);
+            else { gpos[4 * i] = v.x; gpos[4 * i + 1] = v.y; gpos[4 * i + 2] = v.z; gpos[4 * i + 3] = v.w; }
+        }
+        wave_sync();  // the image is reused by the next tile's phase A
+    };
+
+    v4f qa[NQ], qb[NQ];
+    float gpa, gpb;
+    request(first, qa, gpa);
+    request(first + stride, qb, gpb);
+    for (int j = lane; j <= J; j += PM_WAVE)
+        reinterpret_cast<v4f *>(sConst)[j] = load_joint_const<false>(a.parents, a.offsets, J, j);
+
+    for (int64_t t = first; t < hi; t += 2 * stride) {
+        phase_a(qa);
+        float gp = gpa;
+        request(t + 2 * stride, qa, gpa);
+        walk_and_store(t, gp);
+        if (t + stride >= hi) break;
+        phase_a(qb);
+        gp = gpb;
+        request(t + 3 * stride, qb, gpb);
+        walk_and_store(t + stride, gp);
+    }
+}
+
+template <int FPW, int JT>
+static int launch_fk_persist(const FkArgs &a, const int64_t ntiles, bool vec, hipStream_t s) {
+    const size_t lds = ((size_t)FPW * JT * 12 + 4 * (JT + 1)) * sizeof(float);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int per_cu = (int)(kMaxLds / (lds + 256));  // LDS-bound residency (allocation granularity slack)
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    const char *ov = getenv("PM_FK_WAVES_PER_CU");  // tuning aid
+    if (ov && atoi(ov) > 0) per_cu = atoi(ov);
+    int64_t grid = (int64_t)cus * per_cu;
+    grid = (grid / PM_NXCD) * PM_NXCD;
+    const int64_t need = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
+    if (grid > need) grid = need;
+    if (grid < PM_NXCD) grid = PM_NXCD;
+    if (vec) {
+        auto k = fk_persist_kernel<FPW, JT, true>;
+        if (int e = allow_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a, ntiles);
+    } else {
+        auto k = fk_persist_kernel<FPW, JT, false>;
+        if (int e = allow_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a, ntiles);
+    }
+    return check_hip(hipGetLastError(), "fk (persistent) launch");
 }
 
 template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT>
@@ -288,6 +441,17 @@ static int fk_common(int src_kind, const float *src, const float *root_pos, cons
     const bool vec = aligned16(src) && aligned16(pos) && aligned16(rotmats) &&
                      (!offsets_per_frame || aligned16(offsets)) && (!quat_out || aligned16(quat_out));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const char *np_ = getenv("PM_FK_NO_PERSIST");  // tuning aid: force the one-tile-per-workgroup kernel
+    if (src_kind == SRC_QUAT && !offsets_per_frame && F >= 20 * 4096 && !(np_ && atoi(np_)) && (J == 22 || J == 24)) {
+        // full tiles through the persistent kernel, the trailing partial tile through the generic one
+        const int64_t nfull = F / 20;
+        int e = (J == 22) ? launch_fk_persist<20, 22>(a, nfull, vec, s) : launch_fk_persist<20, 24>(a, nfull, vec, s);
+        if (e || nfull * 20 == F) return e;
+        FkArgs t = a;
+        const int64_t done = nfull * 20;
+        t.src += done * J * 4; t.root_pos += done * 3; t.pos += done * J * 3; t.rotmats += done * J * 9; t.F = F - done;
+        return dispatch_fk<SRC_QUAT>(t, vec, false, s);
+    }
     if (src_kind == SRC_QUAT) return dispatch_fk<SRC_QUAT>(a, vec, offsets_per_frame != 0, s);
     return dispatch_fk<SRC_O6D>(a, vec, offsets_per_frame != 0, s);
 }
