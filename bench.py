@@ -33,8 +33,11 @@ HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s is what 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--prewarm-ms", type=float, default=400.0,
+                    help="untimed back-to-back launches before the W warmup steps so that the GPU's clocks/power state "
+                         "settle (the first ~20 ms after idle run ~15%% slower); 0 disables")
     ap.add_argument("--frames-per-gpu", type=int, default=1 << 20)
     ap.add_argument("--joints", type=int, default=22, choices=[22, 52])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -126,17 +129,24 @@ def main():
         _lib.call("pm_fk_f32", C.c_void_p(rot.data_ptr()), C.c_void_p(root.data_ptr()), C.c_void_p(off.data_ptr()), 0, pp,
                   F, J, C.c_void_p(pos.data_ptr()), C.c_void_p(rm.data_ptr()), sptr)
 
-    # the public front door must give the same bytes as the raw call
+    # the public front door (here: the one-tile-per-workgroup kernel, small batch) and the raw call
+    # (persistent kernel) must agree to fp32 rounding
     with torch.no_grad():
         p2, r2 = skt.fk(rot[:4096], root[:4096], off, par_t)
     step()
     torch.cuda.synchronize()
-    assert torch.equal(p2, pos[:4096]) and torch.equal(r2, rm[:4096])
+    assert float((p2 - pos[:4096]).abs().max()) < 5e-6 and float((r2 - rm[:4096]).abs().max()) < 5e-6
 
     def barrier():
         if world > 1:
             dist.barrier()
 
+    if a.prewarm_ms > 0:  # DVFS settling: untimed, not part of W or K
+        tp = time.perf_counter()
+        while (time.perf_counter() - tp) * 1e3 < a.prewarm_ms:
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize()
     for _ in range(a.warmup):
         step()
     ev0, ev1 = C.c_void_p(), C.c_void_p()
@@ -196,6 +206,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "prewarm_ms": a.prewarm_ms,
             "config": {"workload": "fk: %d frames x %d joints per GPU, fp32 (BASELINE.json configs[1])" % (F, J),
                        "frames_per_gpu": F, "joints": J, "sharding": "frames, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -18,8 +18,9 @@
 //     fetched one joint ahead), does 12 FMAs and overwrites its row of slot j in place.  Joints are
 //     visited in index order (parents[j] < j); when parents[j] == j-1 -- the common case in
 //     DFS-ordered skeletons -- the parent row is already in registers, otherwise it is re-read from
-//     the image.  That branch is wave-uniform and `parents` / `offsets` arrive through scalar loads
-//     issued one joint ahead, so the per-joint critical path is 3 dependent FMAs.
+//     the image.  That branch is wave-uniform; the skeleton constants {parent, offset} are staged once
+//     per tile in LDS and read one joint ahead (a broadcast ds_read_b128), so nothing but DS traffic
+//     shares lgkmcnt inside the walk and the per-joint critical path is 3 dependent FMAs.
 //
 // The finished image leaves with contiguous dwordx4 streaming stores.  Algorithmic HBM bytes per
 // frame: 16 J + 12 read, 48 J written -- nothing is read or written twice, and the LDS
@@ -128,15 +129,8 @@ __device__ __forceinline__ v4f load_joint_const(const Parents &parents, const fl
 }
 
 template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT>
-__global__ __launch_bounds__(PM_WAVE) void fk_kernel(const FkArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x;
+__device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int64_t f0, const int nf, const int lane) {
     const int J = a.J;
-    const int64_t ntiles = (a.F + FPW - 1) / FPW;
-    const int64_t tile = xcd_tile(ntiles);
-    if (tile < 0) return;
-    const int64_t f0 = tile * FPW;
-    const int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
     const int FJ = FPW * J;
     const int n = nf * J;  // (frame, joint) elements in this tile
 
@@ -238,143 +232,18 @@ __global__ __launch_bounds__(PM_WAVE) void fk_kernel(const FkArgs a) {
     if (QOUT) tile_store<VEC>(a.quat_out + f0 * J * 4, sQo, n * 4, lane);
 }
 
-
-// ---- persistent variant: quaternion source, static offsets, compile-time joint count ------------------
-// Same two phases, but (1) a wave loops over FULL tiles and keeps the rotations of the next TWO tiles
-// in flight (two register sets, requested right after the set's previous contents were consumed), so
-// every resident wave always has HBM reads outstanding while it computes -- with only ~7 waves per CU
-// (LDS-bound) that is what keeps the memory system busy; (2) with J a template parameter every loop
-// has a compile-time trip count and no load/store is predicated (out-of-range lanes are clamped onto
-// the last element: duplicate, identical accesses), so the compiler can count vmcnt exactly: a wave
-// never waits for its own stores to be acknowledged before it starts the next tile.
-// Tile assignment is XCD-aware: workgroup b sits on XCD b % 8 and strides through that XCD's contiguous
-// eighth of the tiles, so neighbouring tiles (which share cache lines at their edges) meet in one L2.
-// A trailing partial tile is handled by the generic kernel (second launch on the tail frames).
-template <int FPW, int JT, bool VEC>
-__global__ __launch_bounds__(PM_WAVE) void fk_persist_kernel(const FkArgs a, const int64_t ntiles) {
+// One tile (FPW frames) per single-wave workgroup; XCD-aware tile order (common.hpp).
+template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT>
+__global__ __launch_bounds__(PM_WAVE) void fk_kernel(const FkArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int J = JT;
-    constexpr int N = FPW * J;                       // (frame, joint) elements per tile
-    constexpr int NQ = (N + PM_WAVE - 1) / PM_WAVE;  // dwordx4 loads per lane per tile
-    constexpr int R4 = N * 9 / 4, P4 = N * 3 / 4;    // dwordx4 stores per tile (FPW % 4 == 0)
-    constexpr int NR = (R4 + PM_WAVE - 1) / PM_WAVE, NP = (P4 + PM_WAVE - 1) / PM_WAVE;
-    const int lane = threadIdx.x;
-    float *sRot = smem;
-    float *sPos = sRot + N * 9;
-    float *sConst = sPos + N * 3;
-
-    const int64_t per_xcd = (ntiles + PM_NXCD - 1) / PM_NXCD;
-    const int xcd = blockIdx.x % PM_NXCD;
-    const int64_t stride = gridDim.x / PM_NXCD;
-    const int64_t lo = xcd * per_xcd;
-    const int64_t hi = (lo + per_xcd) < ntiles ? (lo + per_xcd) : ntiles;
-    const int64_t first = lo + blockIdx.x / PM_NXCD;
-    if (first >= hi) return;
-    const int64_t last = first + ((hi - 1 - first) / stride) * stride;  // this wave's final tile
-
-    const int wl = lane % (3 * FPW);
-    const int f = wl / 3;
-    const int r = wl - 3 * f;
-
-    auto request = [&](int64_t t, v4f (&q)[NQ], float &gp) {  // all global loads of tile t, back to back
-        t = t < last ? t : last;  // past the end: re-request the final tile (keeps the count static)
-        gp = a.root_pos[t * (FPW * 3) + wl];
-        const float *gsrc = a.src + t * (N * 4);
-#pragma unroll
-        for (int u = 0; u < NQ; ++u) {
-            int e = u * PM_WAVE + lane;
-            e = e < N ? e : N - 1;
-            if (VEC) q[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(gsrc) + e);
-            else q[u] = v4f{gsrc[4 * e], gsrc[4 * e + 1], gsrc[4 * e + 2], gsrc[4 * e + 3]};
-        }
-    };
-    auto phase_a = [&](const v4f (&q)[NQ]) {  // registers -> local rotations -> LDS
-#pragma unroll
-        for (int u = 0; u < NQ; ++u) {
-            int e = u * PM_WAVE + lane;
-            e = e < N ? e : N - 1;
-            const float qi[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
-            float L[9];
-            if (a.ablate & 1) {
-#pragma unroll
-                for (int c = 0; c < 9; ++c) L[c] = qi[c & 3];
-            } else {
-                local_from_quat(qi, L);
-            }
-            lds_put<9>(sRot, e, L);
-        }
-    };
-    auto walk_and_store = [&](const int64_t t, const float gp) {
-        wave_sync();
-        tree_walk<false>(sRot, sPos, nullptr, sConst, J, f, r, gp, (a.ablate & 2) != 0);
-        wave_sync();
-        float *grot = a.rotmats + t * (N * 9);
-        float *gpos = a.pos + t * (N * 3);
-#pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            int i = k * PM_WAVE + lane;
-            i = i < R4 ? i : R4 - 1;
-            const v4f v = reinterpret_cast<const v4f *>(sRot)[i];
-            if (VEC) __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(grot) + i);
-            else { grot[4 * i] = v.x; grot[4 * i + 1] = v.y; grot[4 * i + 2] = v.z; grot[4 * i + 3] = v.w; }
-        }
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            int i = k * PM_WAVE + lane;
-            i = i < P4 ? i : P4 - 1;
-            const v4f v = reinterpret_cast<const v4f *>(sPos)[i];
-            if (VEC) __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(gpos) + i);
-            else { gpos[4 * i] = v.x; gpos[4 * i + 1] = v.y; gpos[4 * i + 2] = v.z; gpos[4 * i + 3] = v.w; }
-        }
-        wave_sync();  // the image is reused by the next tile's phase A
-    };
-
-    v4f qa[NQ], qb[NQ];
-    float gpa, gpb;
-    request(first, qa, gpa);
-    request(first + stride, qb, gpb);
-    for (int j = lane; j <= J; j += PM_WAVE)
-        reinterpret_cast<v4f *>(sConst)[j] = load_joint_const<false>(a.parents, a.offsets, J, j);
-
-    for (int64_t t = first; t < hi; t += 2 * stride) {
-        phase_a(qa);
-        float gp = gpa;
-        request(t + 2 * stride, qa, gpa);
-        walk_and_store(t, gp);
-        if (t + stride >= hi) break;
-        phase_a(qb);
-        gp = gpb;
-        request(t + 3 * stride, qb, gpb);
-        walk_and_store(t + stride, gp);
-    }
+    const int64_t ntiles = (a.F + FPW - 1) / FPW;
+    const int64_t tile = xcd_tile(ntiles);
+    if (tile < 0) return;
+    const int64_t f0 = tile * FPW;
+    const int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
+    fk_tile<FPW, VEC, PFO, SRC, QOUT>(a, smem, f0, nf, threadIdx.x);
 }
 
-template <int FPW, int JT>
-static int launch_fk_persist(const FkArgs &a, const int64_t ntiles, bool vec, hipStream_t s) {
-    const size_t lds = ((size_t)FPW * JT * 12 + 4 * (JT + 1)) * sizeof(float);
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    int per_cu = (int)(kMaxLds / (lds + 256));  // LDS-bound residency (allocation granularity slack)
-    if (per_cu > 8) per_cu = 8;
-    if (per_cu < 1) per_cu = 1;
-    const char *ov = getenv("PM_FK_WAVES_PER_CU");  // tuning aid
-    if (ov && atoi(ov) > 0) per_cu = atoi(ov);
-    int64_t grid = (int64_t)cus * per_cu;
-    grid = (grid / PM_NXCD) * PM_NXCD;
-    const int64_t need = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
-    if (grid > need) grid = need;
-    if (grid < PM_NXCD) grid = PM_NXCD;
-    if (vec) {
-        auto k = fk_persist_kernel<FPW, JT, true>;
-        if (int e = allow_lds(k, lds)) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a, ntiles);
-    } else {
-        auto k = fk_persist_kernel<FPW, JT, false>;
-        if (int e = allow_lds(k, lds)) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a, ntiles);
-    }
-    return check_hip(hipGetLastError(), "fk (persistent) launch");
-}
 
 template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT>
 static int launch_fk(const FkArgs &a, hipStream_t s) {
@@ -441,17 +310,6 @@ static int fk_common(int src_kind, const float *src, const float *root_pos, cons
     const bool vec = aligned16(src) && aligned16(pos) && aligned16(rotmats) &&
                      (!offsets_per_frame || aligned16(offsets)) && (!quat_out || aligned16(quat_out));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const char *np_ = getenv("PM_FK_NO_PERSIST");  // tuning aid: force the one-tile-per-workgroup kernel
-    if (src_kind == SRC_QUAT && !offsets_per_frame && F >= 20 * 4096 && !(np_ && atoi(np_)) && (J == 22 || J == 24)) {
-        // full tiles through the persistent kernel, the trailing partial tile through the generic one
-        const int64_t nfull = F / 20;
-        int e = (J == 22) ? launch_fk_persist<20, 22>(a, nfull, vec, s) : launch_fk_persist<20, 24>(a, nfull, vec, s);
-        if (e || nfull * 20 == F) return e;
-        FkArgs t = a;
-        const int64_t done = nfull * 20;
-        t.src += done * J * 4; t.root_pos += done * 3; t.pos += done * J * 3; t.rotmats += done * J * 9; t.F = F - done;
-        return dispatch_fk<SRC_QUAT>(t, vec, false, s);
-    }
     if (src_kind == SRC_QUAT) return dispatch_fk<SRC_QUAT>(a, vec, offsets_per_frame != 0, s);
     return dispatch_fk<SRC_O6D>(a, vec, offsets_per_frame != 0, s);
 }

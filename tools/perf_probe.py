@@ -18,12 +18,23 @@ from pymotion_amd import synthetic as syn
 PEAK = 8000.0
 
 
+SUSTAINED = 0
+
+
 def timeit(fn, reps=20, warm=3):
     ev = [C.c_void_p() for _ in range(2)]
     for e in ev:
         _lib.call("pm_event_create", C.byref(e))
     for _ in range(warm):
         fn()
+    if SUSTAINED:  # back-to-back launches, one pair of events around all of them (what bench.py does)
+        _lib.call("pm_event_record", ev[0], None)
+        for _ in range(SUSTAINED):
+            fn()
+        _lib.call("pm_event_record", ev[1], None)
+        ms = C.c_float()
+        _lib.call("pm_event_elapsed_ms", ev[0], ev[1], C.byref(ms))
+        return ms.value / SUSTAINED, ms.value / SUSTAINED
     ts = []
     for _ in range(reps):
         _lib.call("pm_event_record", ev[0], None)
@@ -48,7 +59,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=1 << 20)
     ap.add_argument("--only", default="")
+    ap.add_argument("--sustained", type=int, default=0, help="time N back-to-back launches instead of isolated ones")
     a = ap.parse_args()
+    global SUSTAINED
+    SUSTAINED = a.sustained
     dev = torch.device("cuda:0")
     F = a.frames
     want = lambda k: (not a.only) or any(s in k for s in a.only.split(","))  # noqa: E731
