@@ -193,6 +193,16 @@ def main():
     if rank == 0:
         bytes_per_frame = 64 * J + 12
         achieved = bytes_per_frame * F / (kern_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE,
+        # corrections per MI355X_MICROARCH.md, calibrated on a known-byte copy kernel); same workload only.
+        traffic = None
+        try:
+            latest = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_fk_hbm_traffic.json"))[-1]
+            prof = json.load(open(os.path.join(ROOT, "profiles", latest)))
+            if prof["workload"] == {"frames": F, "joints": J}:
+                traffic = prof["corrected_bytes_per_launch"]["total"]
+        except (OSError, IndexError, KeyError, ValueError):
+            pass
         line = {
             "metric": "fk() frames/sec, %d-joint skeleton" % J,
             "value": F * world * a.steps / wall,
@@ -210,7 +220,8 @@ def main():
             "config": {"workload": "fk: %d frames x %d joints per GPU, fp32 (BASELINE.json configs[1])" % (F, J),
                        "frames_per_gpu": F, "joints": J, "sharding": "frames, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "algorithmic_bytes": bytes_per_frame * F,
                          "kernel": "pm::fk_kernel<20,true,false,0,false>", "kernel_ms": kern_ms,
                          "bytes_per_frame": bytes_per_frame},
         }
