@@ -3,16 +3,25 @@
 //   from_root_dual_quat  pymotion/ops/skeleton.py:173-204   (every joint needs only its parent's INPUT)
 //   from_global_rotations pymotion/ops/skeleton.py:64-93    (same gather shape)
 // Same wave-private tiling as fk.hip: HBM <-> LDS with contiguous dwordx4, AoS access from LDS.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace pm {
 
 // ---------------------------------------------------------------------------------------------------
-// to_root_dual_quat: a quaternion payload does not split by rows, so ONE LANE walks ONE frame
-// (FPW frames per wave, lanes >= FPW idle).  State per lane: the previous joint's root-space (q, t)
-// in registers; other parents are re-read from the LDS image of the output.  LDS per frame-joint:
-// 16 B staged input quaternion + 32 B output dual quaternion; the root-space (q,t) of a joint is
-// recovered from that image when needed as a parent (q = dq[0:4]; t kept in a 12 B side image).
+// to_root_dual_quat: a quaternion payload does not split by rows the way fk's matrices do, so ONE LANE
+// walks ONE frame (FPW = 32 frames per wave).  The LDS image is the tile's OUTPUT (32 J B per frame)
+// with one 16-byte pad per frame: the pad makes the per-lane ds_read/write_b128 of the walk conflict
+// free (frame stride 8J+4 dwords instead of 8J, which for J = 22 is = 48 mod 64 banks: 4-way) and,
+// being a whole dwordx4, keeps the copy-out a dwordx4 stream.
+//   phase A  lane per (frame, joint): quaternion straight from HBM (coalesced dwordx4, all loads of the
+//            tile issued up front) into the first half of the joint's 32-byte output slot;
+//   walk     per joint: q_j from the own slot, parent (q,t) from registers when parents[j] == j-1, else
+//            from the parent's slot; compose (skeleton.py:238-241); write root-space (q, t) to the slot;
+//   phase C  lane per (frame, joint): (q, t) -> [q, 0.5 (0,t) (x) q] in place (dual_quat.py:28-36);
+//   out      contiguous dwordx4 streaming stores.
+// Skeleton constants {parent, offset} sit in a small LDS table (one broadcast ds_read_b128 per joint).
 // ---------------------------------------------------------------------------------------------------
 struct ToRootArgs {
     const float *rot;       // [F,J,4]
@@ -34,39 +43,86 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
     if (tile < 0) return;
     const int64_t f0 = tile * FPW;
     const int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
-    const int FJ = FPW * J;
-    float *sDq = smem;            // [FPW*J*8]  image of the output tile
-    float *sQ = sDq + FJ * 8;     // [FPW*J*4]  staged input
-    float *sT = sQ + FJ * 4;      // [FPW*J*3]  root-space translations (parents' lookup)
+    const int n = nf * J;
+    const int FS = 8 * J + 4;           // padded frame stride in floats
+    float *sDq = smem;                  // [FPW * FS]
+    float *sConst = sDq + FPW * FS;     // [(J+1)*4]
+    const float invJ = 1.0f / (float)J;
 
-    tile_load<VEC>(a.rot + f0 * J * 4, sQ, nf * J * 4, lane);
-    const bool act = lane < nf;
-    const int fc = act ? lane : 0;
-    float rp[3] = {0.0f, 0.0f, 0.0f};
-    if (act) {
-        rp[0] = a.root_pos[(f0 + lane) * 3];
-        rp[1] = a.root_pos[(f0 + lane) * 3 + 1];
-        rp[2] = a.root_pos[(f0 + lane) * 3 + 2];
+    // all global loads first: root position, constants, then the rotations in batches of 4
+    // lanes >= nf shadow frame 0 (same inputs, same values, same addresses): the walk needs no masking
+    const int fc = lane < nf ? lane : 0;
+    const float rp[3] = {a.root_pos[(f0 + fc) * 3], a.root_pos[(f0 + fc) * 3 + 1], a.root_pos[(f0 + fc) * 3 + 2]};
+    for (int j = lane; j <= J; j += PM_WAVE) {
+        const int jc = j < J ? j : J - 1;
+        v4f c;
+        c.x = __int_as_float(a.parents.p[jc]);
+        c.y = a.offsets[3 * jc]; c.z = a.offsets[3 * jc + 1]; c.w = a.offsets[3 * jc + 2];
+        reinterpret_cast<v4f *>(sConst)[j] = c;
+    }
+    const float *gsrc = a.rot + f0 * J * 4;
+    auto load_batch = [&](const int e0, v4f (&q)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * PM_WAVE + lane;
+            if (e < n) {
+                if (VEC) q[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(gsrc) + e);
+                else q[u] = v4f{gsrc[4 * e], gsrc[4 * e + 1], gsrc[4 * e + 2], gsrc[4 * e + 3]};
+            }
+        }
+    };
+    auto park_batch = [&](const int e0, const v4f (&q)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * PM_WAVE + lane;
+            if (e < n) {
+                const int f = (int)(((float)e + 0.5f) * invJ);  // e / J, exact for e < 2^22
+                const int j = e - f * J;
+                *reinterpret_cast<v4f *>(sDq + f * FS + j * 8) = q[u];
+            }
+        }
+    };
+    {   // two batches (8 KiB per wave) in flight, batch k+2 requested before batch k is consumed
+        constexpr int B = 4 * PM_WAVE;
+        v4f qa[4], qb[4];
+        load_batch(0, qa);
+        load_batch(B, qb);
+        for (int e0 = 0; e0 < n; e0 += 2 * B) {
+            park_batch(e0, qa);
+            load_batch(e0 + 2 * B, qa);
+            park_batch(e0 + B, qb);
+            load_batch(e0 + 3 * B, qb);
+        }
     }
     wave_sync();
 
+    float *fD = sDq + fc * FS;
+    const v4f *cst = reinterpret_cast<const v4f *>(sConst);
     float gq[4] = {1.0f, 0.0f, 0.0f, 0.0f}, gt[3] = {0.0f, 0.0f, 0.0f};  // joint j-1, root space
+    v4f qn = *reinterpret_cast<const v4f *>(fD);
+    v4f cn = cst[0];
     for (int j = 0; j < J; ++j) {
-        float q[4], t[3];
-        lds_get<4>(sQ, fc * J + j, q);
-        const int par = (j == 0) ? 0 : a.parents.p[j];
+        float q[4] = {qn.x, qn.y, qn.z, qn.w};
+        const v4f c = cn;
+        const int jn = (j + 1 < J) ? j + 1 : j;
+        qn = *reinterpret_cast<const v4f *>(fD + jn * 8);  // slot j+1 still holds its input quaternion
+        cn = cst[j + 1];
+        const int par = __builtin_amdgcn_readfirstlane(__float_as_int(c.x));
+        float t[3];
         if (j == 0) {
             t[0] = rp[0]; t[1] = rp[1]; t[2] = rp[2];  // skeleton.py:232
         } else {
-            t[0] = a.offsets[3 * j]; t[1] = a.offsets[3 * j + 1]; t[2] = a.offsets[3 * j + 2];
+            t[0] = c.y; t[1] = c.z; t[2] = c.w;
             if (par != 0) {  // skeleton.py:236-241 ; joints hanging off the root stay local
                 float pq[4], pt[3];
                 if (par == j - 1) {
                     pq[0] = gq[0]; pq[1] = gq[1]; pq[2] = gq[2]; pq[3] = gq[3];
                     pt[0] = gt[0]; pt[1] = gt[1]; pt[2] = gt[2];
-                } else {
-                    lds_get<4>(sDq, (fc * J + par) * 2, pq);  // real part of the parent's dq
-                    lds_get<3>(sT, fc * J + par, pt);
+                } else {  // the parent's slot holds its root-space (q, t) until phase C
+                    float pd[8];
+                    lds_get<8>(fD, par, pd);
+                    pq[0] = pd[0]; pq[1] = pd[1]; pq[2] = pd[2]; pq[3] = pd[3];
+                    pt[0] = pd[4]; pt[1] = pd[5]; pt[2] = pd[6];
                 }
                 float tv[3], qq[4];
                 qmulvec(pq, t, tv);
@@ -75,22 +131,40 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
                 q[0] = qq[0]; q[1] = qq[1]; q[2] = qq[2]; q[3] = qq[3];
             }
         }
-        float d[8];
-        rt2dq(q, t, d);
-        if (act) {
-            lds_put<8>(sDq, fc * J + j, d);
-            lds_put<3>(sT, fc * J + j, t);
-        }
+        const float d[8] = {q[0], q[1], q[2], q[3], t[0], t[1], t[2], 0.0f};
+        lds_put<8>(fD, j, d);  // root-space (q, t); the dual part is formed lane-parallel in phase C
         gq[0] = q[0]; gq[1] = q[1]; gq[2] = q[2]; gq[3] = q[3];
         gt[0] = t[0]; gt[1] = t[1]; gt[2] = t[2];
     }
     wave_sync();
-    tile_store<VEC>(a.dq + f0 * J * 8, sDq, nf * J * 8, lane);
+    // phase C, lane per (frame, joint): (q, t) -> [q, 0.5 (0,t) (x) q]  (dual_quat.py:28-36), off the chain
+    for (int e = lane; e < n; e += PM_WAVE) {
+        const int f = (int)(((float)e + 0.5f) * invJ);
+        const int j = e - f * J;
+        float *slot = sDq + f * FS + j * 8;
+        float qt[8], d[8];
+        lds_get<8>(slot, 0, qt);
+        const float q[4] = {qt[0], qt[1], qt[2], qt[3]}, t[3] = {qt[4], qt[5], qt[6]};
+        rt2dq(q, t, d);
+        *reinterpret_cast<v4f *>(slot + 4) = v4f{d[4], d[5], d[6], d[7]};
+    }
+    wave_sync();
+    // copy-out: dwordx4 i of the tile lives at frame i / 2J, chunk i % 2J of the padded image
+    float *gout = a.dq + f0 * J * 8;
+    const int n4 = n * 2, J2 = 2 * J;
+    const float invJ2 = 1.0f / (float)J2;
+    for (int i = lane; i < n4; i += PM_WAVE) {
+        const int f = (int)(((float)i + 0.5f) * invJ2);
+        const int r = i - f * J2;
+        const v4f v = *reinterpret_cast<const v4f *>(sDq + f * FS + r * 4);
+        if (VEC) __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(gout) + i);
+        else { gout[4 * i] = v.x; gout[4 * i + 1] = v.y; gout[4 * i + 2] = v.z; gout[4 * i + 3] = v.w; }
+    }
 }
 
 template <int FPW>
 static int launch_to_root(const ToRootArgs &a, bool vec, hipStream_t s) {
-    const size_t lds = (size_t)FPW * a.J * 15 * sizeof(float);
+    const size_t lds = ((size_t)FPW * (8 * a.J + 4) + 4 * (a.J + 1)) * sizeof(float);
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
     const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
     if (grid > 0x7fffffffLL) { set_error("to_root_dq: grid too large"); return PM_EUNSUPPORTED; }
@@ -143,11 +217,15 @@ __global__ __launch_bounds__(PM_WAVE) void gather_parent_kernel(const GatherArgs
     float *sO1 = sO0 + FJ * (MODE == 0 ? 3 : 4);
 
     tile_load<VEC>(a.in + f0 * J * IW, sIn, nf * J * IW, lane);
+    int *sPar = reinterpret_cast<int *>(sO1 + FJ * (MODE == 0 ? 4 : 0));  // [J] parents, staged once
+    for (int j = lane; j < J; j += PM_WAVE) sPar[j] = (j == 0) ? 0 : a.parents.p[j];
     wave_sync();
     const int n = nf * J;
+    const float invJ = 1.0f / (float)J;
     for (int e = lane; e < n; e += PM_WAVE) {
-        const int f = e / J, j = e - f * J;
-        const int par = (j == 0) ? 0 : a.parents.p[j];
+        const int f = (int)(((float)e + 0.5f) * invJ);  // e / J without an integer divide (exact for e < 2^22)
+        const int j = e - f * J;
+        const int par = sPar[j];
         if constexpr (MODE == 0) {
             float d[8], q[4], t[3];
             lds_get<8>(sIn, e, d);
@@ -192,11 +270,12 @@ template <int MODE>
 static int launch_gather(const GatherArgs &a, bool vec, hipStream_t s) {
     // frames per wave: multiple of 4 (16-byte tile bases), ~256 (frame,joint) items per wave
     const size_t per_frame = (size_t)a.J * gather_lds_w<MODE>() * sizeof(float);
+    const size_t extra = (size_t)a.J * sizeof(int);  // parents table
     int fpw = (int)((256 + a.J - 1) / a.J);
     fpw = (fpw + 3) & ~3;
-    while (fpw > 4 && fpw * per_frame > kMaxLds / 4) fpw -= 4;
-    if (fpw * per_frame > kMaxLds) { set_error("gather: J too large for LDS"); return PM_EUNSUPPORTED; }
-    const size_t lds = fpw * per_frame;
+    while (fpw > 4 && fpw * per_frame + extra > kMaxLds / 4) fpw -= 4;
+    if (fpw * per_frame + extra > kMaxLds) { set_error("gather: J too large for LDS"); return PM_EUNSUPPORTED; }
+    const size_t lds = fpw * per_frame + extra;
     const int64_t ntiles = (a.F + fpw - 1) / fpw;
     const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
     if (grid > 0x7fffffffLL) { set_error("gather: grid too large"); return PM_EUNSUPPORTED; }
@@ -225,10 +304,15 @@ extern "C" int pm_to_root_dq_f32(const float *rot, const float *root_pos, const 
     if (int e = pack_parents(parents, J, a.parents)) return e;
     const bool vec = aligned16(rot) && aligned16(dq);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t per_frame = (size_t)J * 15 * sizeof(float);
+    const size_t per_frame = ((size_t)J * 8 + 4) * sizeof(float);
+    {
+        const char *e = getenv("PM_DQ_FPW");  // tuning aid
+        if (e && atoi(e) == 64 && 64 * per_frame <= kMaxLds / 2) return launch_to_root<64>(a, vec, s);
+        if (e && atoi(e) == 16) return launch_to_root<16>(a, vec, s);
+    }
     if (32 * per_frame <= kMaxLds / 4) return launch_to_root<32>(a, vec, s);
     if (16 * per_frame <= kMaxLds / 2) return launch_to_root<16>(a, vec, s);
-    if (4 * per_frame <= kMaxLds) return launch_to_root<4>(a, vec, s);
+    if (4 * per_frame + 8192 <= kMaxLds) return launch_to_root<4>(a, vec, s);
     set_error("to_root_dq: J=%d does not fit the LDS tile", J);
     return PM_EUNSUPPORTED;
 }
