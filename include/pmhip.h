@@ -147,6 +147,17 @@ int pm_quat_to_euler_f32(const float *q, const uint8_t *order, int order_per_ele
 int pm_quat_slerp_f32(const float *q0, const float *q1, const float *t, int64_t N, int shortest,
                       float *out, pm_stream_t stream);
 
+/* rotations/dual_quat.py:86-136  normalize / is_unit.  The reference picks ONE branch for the whole batch
+ * from global `.all()` reductions; the kernels add violation counts to three DEVICE ints that the caller
+ * zeroes first (pm_memset) and reads back:  flags[0] += #(|qr|^2 !~ 0), flags[1] += #(|qr|^2 !~ 1),
+ * flags[2] += #(qr.qd !~ 0 within atol)  (np.isclose rules, NaN never close).
+ * pm_dq_normalize_f32: orthogonalize == 0 -> out = dq / |qr| and flags describe THAT result (:102-106);
+ *                      orthogonalize != 0 -> the branch of :107-113 (flags may be NULL).
+ * pm_dq_unit_flags_f32: flags of the input itself (is_unit, :118-136). */
+int pm_dq_normalize_f32(const float *dq, int64_t N, int orthogonalize, float atol, float *out, int32_t *flags,
+                        pm_stream_t stream);
+int pm_dq_unit_flags_f32(const float *dq, int64_t N, float atol, int32_t *flags, pm_stream_t stream);
+
 /* ---- measurement helper --------------------------------------------------------------------------- */
 
 /* Streaming ceiling with fk's traffic shape: per frame read rd_floats and write wr_floats

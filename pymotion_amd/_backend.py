@@ -147,6 +147,20 @@ class NumpyBackend:
         _lib.call("pm_stream_synchronize", None)
         return out if np.dtype(dtype) == np.float32 else out.astype(dtype)
 
+    def flags_alloc(self, n=3):
+        """Zeroed device int32[n] for kernels that report batch-wide predicates."""
+        buf = _DevBuf(4 * n)
+        _lib.call("pm_memset", C.c_void_p(buf.ptr), 0, 4 * n, None)
+        self._live.append((buf, None))
+        return C.c_void_p(buf.ptr), (buf, n)
+
+    def flags_read(self, handle):
+        buf, n = handle
+        out = np.empty(n, dtype=np.int32)
+        _lib.call("pm_memcpy_d2h", out.ctypes.data_as(C.c_void_p), C.c_void_p(buf.ptr), out.nbytes, None)
+        _lib.call("pm_stream_synchronize", None)
+        return [int(v) for v in out]
+
     def end(self):
         _lib.call("pm_stream_synchronize", None)
         for buf, _ in self._live:
@@ -229,6 +243,14 @@ class TorchBackend:
         if self.home.type != "cuda":
             t = t.to(self.home)
         return t
+
+    def flags_alloc(self, n=3):
+        t = self.torch.zeros(n, dtype=self.torch.int32, device=self.dev)
+        self._keep.append(t)
+        return C.c_void_p(t.data_ptr()), t
+
+    def flags_read(self, handle):
+        return [int(v) for v in handle.cpu().tolist()]  # the one host sync, where the reference's `if` syncs too
 
     def end(self):
         self._keep = []

@@ -61,6 +61,8 @@ SIGNATURES = {
     "pm_quat_from_euler_f32": [_f, C.c_void_p, _int, _i64, _f, _strm],
     "pm_quat_to_euler_f32": [_f, C.c_void_p, _int, _i64, _f, _strm],
     "pm_quat_slerp_f32": [_f, _f, _f, _i64, _int, _f, _strm],
+    "pm_dq_normalize_f32": [_f, _i64, _int, _flt, _f, C.c_void_p, _strm],
+    "pm_dq_unit_flags_f32": [_f, _i64, _flt, C.c_void_p, _strm],
     # measurement helper
     "pm_stream_ceiling_f32": [_f, _f, _i64, _i32, _i32, _strm],
 }

@@ -173,6 +173,54 @@ def dq_from_t(be, t):
     return ew(be, "pm_dq_from_t_f32", [t], [(3,)], [(8,)], [dt])
 
 
+def _unit_from_flags(flags):
+    # dual_quat.py:130-136: all |qr|^2 ~ 0 -> True; else (all ~ 1) and (all qr.qd ~ 0)
+    not_zero, not_one, not_orth = flags
+    if not_zero == 0:
+        return True
+    return not_one == 0 and not_orth == 0
+
+
+def dq_is_unit(be, dq, atol=1e-3):
+    shp = be.shape(dq)
+    if shp[-1] != 8:
+        raise ValueError(f"dq must be [..., 8], got {shp}")
+    be.begin(dq)
+    try:
+        n = _prod(shp[:-1])
+        dp = be.dev_in(dq)
+        fp, fh = be.flags_alloc()
+        if n > 0:
+            _lib.call("pm_dq_unit_flags_f32", dp, n, C.c_float(atol), fp, be.stream())
+        flags = be.flags_read(fh)
+    finally:
+        be.end()
+    return _unit_from_flags(flags)
+
+
+def dq_normalize(be, dq):
+    shp = be.shape(dq)
+    if shp[-1] != 8:
+        raise ValueError(f"dq must be [..., 8], got {shp}")
+    dt = be.result_dtype(dq)
+    be.begin(dq)
+    try:
+        n = _prod(shp[:-1])
+        dp = be.dev_in(dq)
+        op, oh = be.dev_out(shp)
+        fp, fh = be.flags_alloc()
+        if n > 0:
+            # first pass: plain division by |qr| and the is_unit verdict on THAT result (dual_quat.py:102-106)
+            _lib.call("pm_dq_normalize_f32", dp, n, 0, C.c_float(1e-3), op, fp, be.stream())
+            if not _unit_from_flags(be.flags_read(fh)):
+                # whole-batch branch of the reference: also make qd orthogonal to qr (:107-113)
+                _lib.call("pm_dq_normalize_f32", dp, n, 1, C.c_float(1e-3), op, None, be.stream())
+        res = be.result(oh, dt)
+    finally:
+        be.end()
+    return res
+
+
 # ---- ortho6d -------------------------------------------------------------------------------------------
 
 def o6d_eps(be):

@@ -228,6 +228,77 @@ static EwArgs mk(const float *i0, const float *i1, const float *i2, float *o0, f
 }
 
 // ---------------------------------------------------------------------------------------------------
+// dual_quat.normalize / is_unit (rotations/dual_quat.py:86-136).  The reference decides ONE branch for
+// the whole batch from a global `.all()`; here the kernels accumulate violation counts in three device
+// ints (wave ballot + one atomic per wave) and the host front-end reads them, exactly where the
+// reference's Python `if` synchronises.
+//   flags[0] += #(|qr|^2 not close to 0)   flags[1] += #(|qr|^2 not close to 1)   flags[2] += #(qr.qd not close to 0)
+// np.isclose semantics: |a - b| <= atol + rtol |b| with rtol 1e-5, atol 1e-8 (NaN is never close).
+// MODE 0: out = [qr, qd] / |qr|, flags evaluated on that result (normalize's is_unit test, :102-106)
+// MODE 1: out = [qr/|qr|, qd/|qr| - qr/|qr| * (qr.qd)/|qr|^2]  (the orthogonalising branch, :107-113)
+// MODE 2: no output, flags evaluated on the input (is_unit itself)
+// ---------------------------------------------------------------------------------------------------
+template <int MODE, bool VEC>
+__global__ __launch_bounds__(PM_WAVE) void dq_norm_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t N,
+                                                          float atol, int *__restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int64_t ntiles = (N + EW_TILE - 1) / EW_TILE;
+    const int64_t tile = xcd_tile(ntiles);
+    if (tile < 0) return;
+    const int64_t e0 = tile * EW_TILE;
+    const int n = (int)((N - e0) < EW_TILE ? (N - e0) : EW_TILE);
+    float *sIn = smem, *sOut = smem + EW_TILE * 8;
+    tile_load<VEC>(in + e0 * 8, sIn, n * 8, lane);
+    wave_sync();
+    int bad0 = 0, bad1 = 0, bad2 = 0;
+#pragma unroll
+    for (int m = 0; m < EW_PER_LANE; ++m) {
+        const int idx = m * PM_WAVE + lane;
+        if (idx < n) {
+            float d[8], o[8];
+            lds_get<8>(sIn, idx, d);
+            const float n2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+            const float dot = d[0] * d[4] + d[1] * d[5] + d[2] * d[6] + d[3] * d[7];
+            float sq = n2, dt = dot;
+            if (MODE != 2) {
+                const float nrm = fsqrt(n2);
+                const float inv = 1.0f / nrm;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) o[c] = d[c] * inv;
+                if (MODE == 1) {
+                    const float k = dot / (nrm * nrm);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[4 + c] -= o[c] * k;
+                }
+                sq = o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
+                dt = o[0] * o[4] + o[1] * o[5] + o[2] * o[6] + o[3] * o[7];
+                lds_put<8>(sOut, idx, o);
+            }
+            bad0 += !(fabsf(sq) <= 1e-8f);
+            bad1 += !(fabsf(sq - 1.0f) <= 1e-8f + 1e-5f);
+            bad2 += !(fabsf(dt) <= atol);
+        }
+    }
+    if (flags) {
+        for (int off = 32; off > 0; off >>= 1) {
+            bad0 += __shfl_down(bad0, off);
+            bad1 += __shfl_down(bad1, off);
+            bad2 += __shfl_down(bad2, off);
+        }
+        if (lane == 0) {
+            if (bad0) atomicAdd(flags, bad0);
+            if (bad1) atomicAdd(flags + 1, bad1);
+            if (bad2) atomicAdd(flags + 2, bad2);
+        }
+    }
+    if (MODE != 2) {
+        wave_sync();
+        tile_store<VEC>(out + e0 * 8, sOut, n * 8, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Streaming ceiling probe: fk's traffic shape (contiguous tiles, rd floats in / wr floats out per
 // frame) with no arithmetic.  Same one-wave-per-workgroup tiling, data passes through LDS once.
 // ---------------------------------------------------------------------------------------------------
@@ -334,4 +405,39 @@ extern "C" int pm_stream_ceiling_f32(const float *src, float *dst, int64_t F, in
     hipLaunchKernelGGL(ceiling_kernel, dim3((unsigned)grid), dim3(PM_WAVE), lds, static_cast<hipStream_t>(stream), src, dst, F,
                        (int)rd, (int)wr, fpw);
     return check_hip(hipGetLastError(), "stream_ceiling");
+}
+
+extern "C" int pm_dq_normalize_f32(const float *dq, int64_t N, int orthogonalize, float atol, float *out, int32_t *flags,
+                                   pm_stream_t stream) {
+    PM_CHECK_ARGS(N >= 0, "dq_normalize: negative N");
+    if (N == 0) return PM_OK;
+    PM_CHECK_ARGS(dq && out, "dq_normalize: null pointer");
+    const int64_t ntiles = (N + EW_TILE - 1) / EW_TILE;
+    const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
+    if (grid > 0x7fffffffLL) { set_error("dq_normalize: grid too large"); return PM_EUNSUPPORTED; }
+    const size_t lds = (size_t)EW_TILE * 16 * sizeof(float);
+    const bool vec = aligned16(dq) && aligned16(out);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (orthogonalize) {
+        if (vec) hipLaunchKernelGGL((dq_norm_kernel<1, true>), dim3((unsigned)grid), dim3(PM_WAVE), lds, s, dq, out, N, atol, flags);
+        else hipLaunchKernelGGL((dq_norm_kernel<1, false>), dim3((unsigned)grid), dim3(PM_WAVE), lds, s, dq, out, N, atol, flags);
+    } else {
+        if (vec) hipLaunchKernelGGL((dq_norm_kernel<0, true>), dim3((unsigned)grid), dim3(PM_WAVE), lds, s, dq, out, N, atol, flags);
+        else hipLaunchKernelGGL((dq_norm_kernel<0, false>), dim3((unsigned)grid), dim3(PM_WAVE), lds, s, dq, out, N, atol, flags);
+    }
+    return check_hip(hipGetLastError(), "dq_normalize");
+}
+
+extern "C" int pm_dq_unit_flags_f32(const float *dq, int64_t N, float atol, int32_t *flags, pm_stream_t stream) {
+    PM_CHECK_ARGS(N >= 0, "dq_unit_flags: negative N");
+    if (N == 0) return PM_OK;
+    PM_CHECK_ARGS(dq && flags, "dq_unit_flags: null pointer");
+    const int64_t ntiles = (N + EW_TILE - 1) / EW_TILE;
+    const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
+    if (grid > 0x7fffffffLL) { set_error("dq_unit_flags: grid too large"); return PM_EUNSUPPORTED; }
+    const size_t lds = (size_t)EW_TILE * 16 * sizeof(float);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (aligned16(dq)) hipLaunchKernelGGL((dq_norm_kernel<2, true>), dim3((unsigned)grid), dim3(PM_WAVE), lds, s, dq, nullptr, N, atol, flags);
+    else hipLaunchKernelGGL((dq_norm_kernel<2, false>), dim3((unsigned)grid), dim3(PM_WAVE), lds, s, dq, nullptr, N, atol, flags);
+    return check_hip(hipGetLastError(), "dq_unit_flags");
 }

@@ -1,7 +1,8 @@
 """Dual quaternions ``[..., 8] = [qr(4), qd(4)]`` -- drop-in for ``pymotion.rotations.dual_quat_torch``.
 
 Reference: ``pymotion/rotations/dual_quat_torch.py``.  One gfx950 kernel per call, fp32 on the GPU.
-Not covered here: ``unroll`` (sequential in time).
+``normalize`` / ``is_unit`` keep the reference's whole-batch branch (one host read of three device
+counters where the reference's Python ``if`` synchronises).  Not covered here: ``unroll``.
 """
 import torch
 
@@ -26,3 +27,16 @@ def to_rotation_translation(dq: torch.Tensor):
     """-> ``(rotations [..., 4], translations [..., 3])``, ``t = (2 qd (x) conj(qr))[1:]``.
     Reference: dual_quat_torch.py:64-85."""
     return _ops.dq_to_rt(_be(), dq)
+
+
+def normalize(dq: torch.Tensor) -> torch.Tensor:
+    """Unit dual quaternion: divide by ``|qr|``; if the batch as a whole is then not unit
+    (``is_unit``), also remove the component of ``qd`` along ``qr`` -- the reference decides this
+    ONCE for the whole batch.  Reference: dual_quat_torch.py:88-117."""
+    return _ops.dq_normalize(_be(), dq)
+
+
+def is_unit(dq: torch.Tensor, atol: float = 1e-03) -> bool:
+    """``|qr|^2 ~ 1`` and ``qr . qd ~ 0`` for every element (or ``|qr|^2 ~ 0`` for every element).
+    Reference: dual_quat_torch.py:120-143."""
+    return _ops.dq_is_unit(_be(), dq, atol)

@@ -341,3 +341,25 @@ def test_empty_batch():
                     np.maximum(np.arange(22) - 1, 0))
     assert pos.shape == (0, 22, 3) and rm.shape == (0, 22, 3, 3)
     assert quat.mul(np.zeros((0, 4)), np.zeros((0, 4))).shape == (0, 4)
+
+
+def test_dual_quat_normalize_and_is_unit_vs_reference_golden():
+    g = golden("elementwise.npz")
+    m = _torch_mods()
+    torch, dqt = m[0], m[2]
+    for case in ("dq_normalize_scaled", "dq_normalize_skew"):
+        x = g.get(case, "in")["dq"]
+        want = g.get(case, "out64")["out"]
+        assert_close(dq.normalize(x), want, ATOL, case)
+        assert_close(dqt.normalize(torch.from_numpy(x).cuda()).cpu().numpy(), want, ATOL, case + " torch")
+    for nm in ("unit", "scaled", "skew", "zero"):
+        case = f"dq_is_unit_{nm}"
+        x = g.get(case, "in")["dq"]
+        want = bool(g.get(case, "out_np")["out"])
+        assert dq.is_unit(x) is want, case
+        assert dqt.is_unit(torch.from_numpy(x).cuda()) is want, case
+    # a single bad element flips the verdict for the whole batch (global .all(), dual_quat.py:132-136)
+    x = g.get("dq_is_unit_unit", "in")["dq"].copy()
+    assert dq.is_unit(x)
+    x[17, 4:] += 0.5 * x[17, :4]
+    assert not dq.is_unit(x)
