@@ -50,9 +50,9 @@ struct FkArgs {
 template <int SRC>
 constexpr int src_width() { return SRC == SRC_QUAT ? 4 : 6; }
 
-// LDS floats per frame-joint: rot 9 + pos 3 (+ staged ortho6d 6) (+ per-frame offsets 3) (+ quat_out 4)
+// LDS floats per frame-joint: rot 9 + pos 3 (+ per-frame offsets 3) (+ quat_out 4)
 template <int SRC, bool PFO, bool QOUT>
-constexpr int fk_lds_floats() { return 12 + (SRC == SRC_O6D ? 6 : 0) + (PFO ? 3 : 0) + (QOUT ? 4 : 0); }
+constexpr int fk_lds_floats() { return 12 + (PFO ? 3 : 0) + (QOUT ? 4 : 0); }
 
 // quaternion -> local rotation of fk: normalise (skeleton.py:45, quat.py:423) then quat.py:276-317
 __device__ __forceinline__ void local_from_quat(const float (&qi)[4], float (&L)[9]) {
@@ -136,8 +136,7 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
 
     float *sRot = smem;                                // [FPW*J*9]  FPW % 4 == 0 keeps every carve 16 B aligned
     float *sPos = sRot + FJ * 9;                       // [FPW*J*3]
-    float *sSrc = sPos + FJ * 3;                       // [FPW*J*6]  (ortho6d: 24 B records need the LDS hop)
-    float *sOff = sSrc + (SRC == SRC_O6D ? FJ * 6 : 0);  // [FPW*J*3] (PFO)
+    float *sOff = sPos + FJ * 3;                       // [FPW*J*3]  (PFO)
     float *sQo = sOff + (PFO ? FJ * 3 : 0);            // [FPW*J*4]  (QOUT)
     float *sConst = sQo + (QOUT ? FJ * 4 : 0);         // [(J+1)*4]  per joint {parent (int bits), t0, t1, t2}
 
@@ -206,18 +205,53 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
     } else {
         // rotations/ortho6d.py:50-64 : 6D -> matrix -> quaternion (itself normalised), then fk's own
         // normalise and to_matrix: exactly the chain ortho6d.to_quat -> fk of the reference.
-        tile_load<VEC>(a.src + f0 * J * 6, sSrc, n * 6, lane);
+        // A 24-byte record is 8-byte aligned: three dwordx2 per lane straight from HBM (the three
+        // instructions of a wave cover the same 1.5 KiB, so every fetched line is fully used) -- no LDS
+        // staging of the input, which at J = 52 is what buys a third resident wave per CU.
+        const float *gsrc = a.src + f0 * J * 6;
+        auto load_batch = [&](const int e0, v2f (&x)[2][3]) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = e0 + u * PM_WAVE + lane;
+                if (e < n) {
+                    if (VEC) {
+                        const v2f *p = reinterpret_cast<const v2f *>(gsrc) + 3 * e;
+                        x[u][0] = __builtin_nontemporal_load(p);
+                        x[u][1] = __builtin_nontemporal_load(p + 1);
+                        x[u][2] = __builtin_nontemporal_load(p + 2);
+                    } else {
+                        const float *p = gsrc + 6 * e;
+                        x[u][0] = v2f{p[0], p[1]}; x[u][1] = v2f{p[2], p[3]}; x[u][2] = v2f{p[4], p[5]};
+                    }
+                }
+            }
+        };
+        auto do_batch = [&](const int e0, const v2f (&x)[2][3]) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = e0 + u * PM_WAVE + lane;
+                if (e < n) {
+                    const float xx[6] = {x[u][0].x, x[u][0].y, x[u][1].x, x[u][1].y, x[u][2].x, x[u][2].y};
+                    float m[9], qi[4], L[9];
+                    o6d2m(xx, a.eps, m);
+                    m2q(m, qi);
+                    if (QOUT) lds_put<4>(sQo, e, qi);
+                    local_from_quat(qi, L);
+                    lds_put<9>(sRot, e, L);
+                }
+            }
+        };
+        constexpr int B = 2 * PM_WAVE;
+        v2f xa[2][3], xb[2][3];
+        load_batch(0, xa);
+        load_batch(B, xb);
         if (lane <= J) reinterpret_cast<v4f *>(sConst)[lane] = c_first;
         for (int j = lane + PM_WAVE; j <= J; j += PM_WAVE) reinterpret_cast<v4f *>(sConst)[j] = load_const(j);
-        wave_sync();
-        for (int e = lane; e < n; e += PM_WAVE) {
-            float x[6], m[9], qi[4], L[9];
-            lds_get<6>(sSrc, e, x);
-            o6d2m(x, a.eps, m);
-            m2q(m, qi);
-            if (QOUT) lds_put<4>(sQo, e, qi);
-            local_from_quat(qi, L);
-            lds_put<9>(sRot, e, L);
+        for (int e0 = 0; e0 < n; e0 += 2 * B) {
+            do_batch(e0, xa);
+            load_batch(e0 + 2 * B, xa);
+            do_batch(e0 + B, xb);
+            load_batch(e0 + 3 * B, xb);
         }
     }
     if (PFO) tile_load<VEC>(a.offsets + f0 * J * 3, sOff, n * 3, lane);
@@ -280,15 +314,29 @@ static int dispatch_fk2(const FkArgs &a, bool vec, bool pfo, hipStream_t s) {
     return PM_EUNSUPPORTED;
 }
 
-// Frames per wave: 20 (60 lanes busy; 20*J*{3,9,4,6} floats are all multiples of 4, which keeps every
-// tile base 16-byte aligned for any J) while at least two tiles fit a CU's LDS, else 8, 4.
+// Frames per wave (FPW, a multiple of 4 so that every tile base stays 16-byte aligned for any J):
+// 20 fills 60 of 64 lanes in the walk, but the LDS image (48 J B per frame) bounds residency, and with
+// fewer than ~7 waves per CU nothing hides the walk's latency (measured at J = 52: FPW 20/16/12/8 ->
+// 376/311/307/255 us).  Pick the largest FPW that still leaves 7 resident waves, else 5, 3, 1.
+// J = 22 -> 20, J = 52 -> 8.
 template <int SRC>
 static int dispatch_fk(const FkArgs &a, bool vec, bool pfo, hipStream_t s) {
-    const size_t per_frame =
-        (size_t)a.J * (12 + (SRC == SRC_O6D ? 6 : 0) + (pfo ? 3 : 0) + (a.quat_out ? 4 : 0)) * sizeof(float);
-    if (20 * per_frame <= kMaxLds / 2) return dispatch_fk2<20, SRC>(a, vec, pfo, s);
-    if (8 * per_frame <= kMaxLds / 2) return dispatch_fk2<8, SRC>(a, vec, pfo, s);
-    if (4 * per_frame <= kMaxLds) return dispatch_fk2<4, SRC>(a, vec, pfo, s);
+    const size_t per_frame = (size_t)a.J * (12 + (pfo ? 3 : 0) + (a.quat_out ? 4 : 0)) * sizeof(float);
+    const size_t fixed = 4 * ((size_t)a.J + 1) * sizeof(float) + 256;
+    static const int cand[] = {20, 16, 12, 8, 4};
+    int pick = 0;
+    const char *ov = getenv("PM_FK_FPW");  // tuning aid
+    if (ov && atoi(ov) > 0) pick = atoi(ov);
+    for (int want = 7; !pick && want >= 1; want -= 2)
+        for (int c : cand)
+            if ((size_t)want * (c * per_frame + fixed) <= kMaxLds) { pick = c; break; }
+    switch (pick) {
+        case 20: return dispatch_fk2<20, SRC>(a, vec, pfo, s);
+        case 16: return dispatch_fk2<16, SRC>(a, vec, pfo, s);
+        case 12: return dispatch_fk2<12, SRC>(a, vec, pfo, s);
+        case 8: return dispatch_fk2<8, SRC>(a, vec, pfo, s);
+        case 4: return dispatch_fk2<4, SRC>(a, vec, pfo, s);
+    }
     set_error("fk: J=%d does not fit the LDS tile", a.J);
     return PM_EUNSUPPORTED;
 }
