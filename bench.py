@@ -102,9 +102,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("PM_BENCH_FORCE_DIST") == "1"
+    if use_dist:  # one rank per GPU over RCCL (backend "nccl" on ROCm); also taken by `torchrun --nproc-per-node 1`
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     J = a.joints
     parents = syn.PARENTS_22 if J == 22 else syn.PARENTS_52
@@ -138,7 +140,7 @@ def main():
     assert float((p2 - pos[:4096]).abs().max()) < 5e-6 and float((r2 - rm[:4096]).abs().max()) < 5e-6
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     if a.prewarm_ms > 0:  # DVFS settling: untimed, not part of W or K
@@ -167,13 +169,13 @@ def main():
     wall = t1 - t0
     kern_ms = ms.value / a.steps  # average launch-to-launch time of the fk kernel on its stream
 
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([wall, kern_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, kern_ms = float(tt[0]), float(tt[1])
 
     extra = {}
-    if world > 1 and a.gather:
+    if use_dist and a.gather:
         from pymotion_amd.parallel import all_gather_frames
 
         torch.cuda.synchronize()
@@ -237,7 +239,7 @@ def main():
                 "frames_checked": n,
             }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -147,6 +147,15 @@ int pm_quat_to_euler_f32(const float *q, const uint8_t *order, int order_per_ele
 int pm_quat_slerp_f32(const float *q0, const float *q1, const float *t, int64_t N, int shortest,
                       float *out, pm_stream_t stream);
 
+/* rotations/quat.py:426-462  unroll(quaternions, axis): q is [T, S, 4] with the unroll axis FIRST (the
+ * front-end moves it there); frame i is negated when the running sign says so: a prefix XOR of
+ * sgn(dot(q_i, q_{i-1})) < 0 along T per series, computed as a three-kernel scan.  `workspace` is a
+ * device buffer of pm_quat_unroll_workspace_bytes(T, S) bytes.  pm_dq_unroll_f32 is
+ * rotations/dual_quat.py:139-167: dq [T,S,8], sign decided by the real part, applied to all 8 floats. */
+int64_t pm_quat_unroll_workspace_bytes(int64_t T, int32_t S);
+int pm_quat_unroll_f32(const float *q, int64_t T, int32_t S, float *out, void *workspace, pm_stream_t stream);
+int pm_dq_unroll_f32(const float *dq, int64_t T, int32_t S, float *out, void *workspace, pm_stream_t stream);
+
 /* rotations/dual_quat.py:86-136  normalize / is_unit.  The reference picks ONE branch for the whole batch
  * from global `.all()` reductions; the kernels add violation counts to three DEVICE ints that the caller
  * zeroes first (pm_memset) and reads back:  flags[0] += #(|qr|^2 !~ 0), flags[1] += #(|qr|^2 !~ 1),

@@ -211,6 +211,17 @@ def quat_to_scaled_angle_axis(q):
     return o
 
 
+def quat_unroll(q, axis):
+    """rotations/quat.py:426-462"""
+    dt = _dt(q)
+    a = np.moveaxis(_prep(q, dt), axis, 0)
+    shp = a.shape
+    a = np.ascontiguousarray(a).reshape(shp[0], -1, 4)
+    o = np.empty_like(a)
+    _call("oracle_quat_unroll", dt, a, _i64(a.shape[0]), _i32(a.shape[1]), o)
+    return np.moveaxis(o.reshape(shp), 0, axis)
+
+
 _AX = {"x": 0, "y": 1, "z": 2}
 
 

@@ -320,6 +320,92 @@ def gen_skeleton():
     s.save("skeleton.npz")
 
 
+def write_synthetic_bvh(path, n_frames=48, seed=7):
+    """Deterministic 22-joint BVH (joint names of the reference's README.md:49, topology
+    synthetic.PARENTS_22, metre-scale offsets, End Sites on the leaves).  Angles drift smoothly over
+    several turns so that consecutive quaternions cross the double cover and `unroll` has work to do."""
+    rng = np.random.default_rng(seed)
+    names, parents = syn.JOINT_NAMES_22, syn.PARENTS_22
+    J = len(names)
+    off = syn.make_offsets(J, rng, 0.3).astype(np.float64).round(6)
+    kids = [[] for _ in range(J)]
+    for j in range(1, J):
+        kids[parents[j]].append(j)
+    lines = ["HIERARCHY"]
+
+    def emit(j, depth):
+        tab = "\t" * depth
+        lines.append(f"{tab}{'ROOT' if j == 0 else 'JOINT'} {names[j]}")
+        lines.append(tab + "{")
+        lines.append(f"{tab}\tOFFSET {off[j, 0]:.6f} {off[j, 1]:.6f} {off[j, 2]:.6f}")
+        if j == 0:
+            lines.append(f"{tab}\tCHANNELS 6 Xposition Yposition Zposition Zrotation Xrotation Yrotation")
+        else:
+            lines.append(f"{tab}\tCHANNELS 3 " + ("Zrotation Xrotation Yrotation" if j % 2 else "Yrotation Zrotation Xrotation"))
+        for c in kids[j]:
+            emit(c, depth + 1)
+        if not kids[j]:
+            lines.append(f"{tab}\tEnd Site")
+            lines.append(tab + "\t{")
+            lines.append(f"{tab}\t\tOFFSET 0.000000 0.100000 0.000000")
+            lines.append(tab + "\t}")
+        lines.append(tab + "}")
+
+    emit(0, 0)
+    lines += ["MOTION", f"Frames: {n_frames}", "Frame Time: 0.016667"]
+    t = np.arange(n_frames)[:, None, None]
+    rate = rng.uniform(-25, 25, (1, J, 3))
+    ang = rng.uniform(-180, 180, (1, J, 3)) + rate * t + rng.normal(0, 2, (n_frames, J, 3))
+    root = np.cumsum(rng.normal(0, 0.01, (n_frames, 3)), axis=0) + [0.0, 0.9, 0.0]
+    for f in range(n_frames):
+        vals = list(root[f]) + list(ang[f, 0])
+        for j in range(1, J):
+            vals += list(ang[f, j])
+        lines.append(" ".join(f"{v:.6f}" for v in vals))
+    with open(path, "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+
+
+def gen_bvh():
+    from pymotion.io.bvh import BVH
+
+    s = Store()
+    path = os.path.join(OUT, "synthetic22.bvh")
+    write_synthetic_bvh(path)
+    b = BVH()
+    b.load(path)
+    d = b.data
+    s.add("load", "out64", offsets=d["offsets"], end_sites=d["end_sites"], end_sites_parents=d["end_sites_parents"].astype(np.int32),
+          parents=d["parents"].astype(np.int32), positions=d["positions"], rotations=d["rotations"],
+          rot_order=np.vectorize(lambda c: "xyz".index(c), otypes=[np.uint8])(d["rot_order"]),
+          frame_time=np.array(d["frame_time"]))
+    s.add("load", "in", names=np.array([n.encode() for n in d["names"]]))
+    rots, pos, parents, offsets, es, esp = b.get_data()
+    s.add("get_data", "out64", rots=rots, pos=pos)
+    p, r = sk.fk(rots, pos[:, 0, :], offsets, parents)  # README.md:73-78
+    s.add("fk", "out64", pos=p, rotmats=r)
+    b.set_data(rots, pos)
+    s.add("set_data", "out64", rotations=b.data["rotations"])
+    # unroll on its own: random unit quaternions with random sign flips, several axes; dual quats too
+    rng = np.random.default_rng(11)
+    q = rand_quats(rng, 300 * 5).reshape(300, 5, 4).astype(np.float32)
+    base = np.cumsum(rng.normal(0, 0.05, (300, 5, 4)), axis=0) + rng.normal(0, 1, (1, 5, 4))
+    base /= np.linalg.norm(base, axis=-1, keepdims=True)
+    flips = rng.choice([-1.0, 1.0], (300, 5, 1))
+    qs = (base * flips).astype(np.float32)  # a smooth path with random cover flips
+    for nm, arr, ax in (("unroll_smooth_ax0", qs, 0), ("unroll_random_ax0", q, 0),
+                        ("unroll_ax1", np.ascontiguousarray(qs.transpose(1, 0, 2)), 1),
+                        ("unroll_4d_ax-3", np.ascontiguousarray(qs[:, None, :, :].repeat(2, axis=1).transpose(1, 0, 2, 3)), -3)):
+        s.add(nm, "in", q=arr, axis=np.array(ax))
+        s.add(nm, "out64", out=qt.unroll(arr.astype(np.float64).copy(), ax))
+        s.add(nm, "out_t", out=qtt.unroll(T(arr.copy()), ax))
+    t3 = rng.uniform(-1, 1, (300, 5, 3)).astype(np.float32)
+    d8 = dq.from_rotation_translation(qs, t3).astype(np.float32)
+    s.add("dq_unroll_ax0", "in", dq=d8, axis=np.array(0))
+    s.add("dq_unroll_ax0", "out64", out=dq.unroll(d8.astype(np.float64).copy(), 0))
+    s.save("bvh.npz")
+
+
 # ---- optional cross-check of oracle/ against the import ------------------------------------------------
 
 def check_oracle():
@@ -371,5 +457,6 @@ if __name__ == "__main__":
     gen_elementwise()
     gen_trig()
     gen_skeleton()
+    gen_bvh()
     if args.check:
         check_oracle()

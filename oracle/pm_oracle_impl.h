@@ -292,6 +292,19 @@ void FN(oracle_quat_slerp)(const REAL *q0, const REAL *q1, const REAL *t, int64_
     }
 }
 
+/* rotations/quat.py:426-462 with the unroll axis first: q [T,S,4]; frame i is flipped when its dot with
+ * the (already corrected) frame i-1 is negative (the reference's d0 < d1). */
+void FN(oracle_quat_unroll)(const REAL *q, int64_t T, int32_t S, REAL *out) {
+    for (int64_t i = 0; i < T * S * 4; ++i) out[i] = q[i];
+    for (int64_t t = 1; t < T; ++t)
+        for (int32_t s = 0; s < S; ++s) {
+            REAL *c = out + (t * S + s) * 4;
+            const REAL *p = out + ((t - 1) * S + s) * 4;
+            REAL d0 = c[0] * p[0] + c[1] * p[1] + c[2] * p[2] + c[3] * p[3];
+            if (d0 < -d0) { c[0] = -c[0]; c[1] = -c[1]; c[2] = -c[2]; c[3] = -c[3]; }
+        }
+}
+
 /* ---- skeleton ops -------------------------------------------------------------------- */
 
 /* ops/skeleton.py:16-61.  G_0 = [R(qhat_0) | root_pos]; G_i = G_parent(i) . [R(qhat_i) | off_i],

@@ -147,6 +147,15 @@ class NumpyBackend:
         _lib.call("pm_stream_synchronize", None)
         return out if np.dtype(dtype) == np.float32 else out.astype(dtype)
 
+    def scratch(self, nbytes):
+        buf = _DevBuf(max(int(nbytes), 4))
+        self._live.append((buf, None))
+        return C.c_void_p(buf.ptr)
+
+    @staticmethod
+    def moveaxis(x, src, dst):
+        return np.moveaxis(np.asarray(x), src, dst)
+
     def flags_alloc(self, n=3):
         """Zeroed device int32[n] for kernels that report batch-wide predicates."""
         buf = _DevBuf(4 * n)
@@ -243,6 +252,15 @@ class TorchBackend:
         if self.home.type != "cuda":
             t = t.to(self.home)
         return t
+
+    def scratch(self, nbytes):
+        t = self.torch.empty(max(int(nbytes), 4), dtype=self.torch.uint8, device=self.dev)
+        self._keep.append(t)
+        return C.c_void_p(t.data_ptr())
+
+    @staticmethod
+    def moveaxis(x, src, dst):
+        return x.movedim(src, dst)
 
     def flags_alloc(self, n=3):
         t = self.torch.zeros(n, dtype=self.torch.int32, device=self.dev)

@@ -61,6 +61,9 @@ SIGNATURES = {
     "pm_quat_from_euler_f32": [_f, C.c_void_p, _int, _i64, _f, _strm],
     "pm_quat_to_euler_f32": [_f, C.c_void_p, _int, _i64, _f, _strm],
     "pm_quat_slerp_f32": [_f, _f, _f, _i64, _int, _f, _strm],
+    "pm_quat_unroll_workspace_bytes": [_i64, _i32],
+    "pm_quat_unroll_f32": [_f, _i64, _i32, _f, C.c_void_p, _strm],
+    "pm_dq_unroll_f32": [_f, _i64, _i32, _f, C.c_void_p, _strm],
     "pm_dq_normalize_f32": [_f, _i64, _int, _flt, _f, C.c_void_p, _strm],
     "pm_dq_unit_flags_f32": [_f, _i64, _flt, C.c_void_p, _strm],
     # measurement helper
@@ -119,7 +122,7 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(h, name)  # AttributeError = ABI mismatch, let it surface
             fn.argtypes = argtypes
-            fn.restype = C.c_int
+            fn.restype = C.c_int64 if name.endswith("_bytes") else C.c_int
         h.pm_last_error_string.argtypes = []
         h.pm_last_error_string.restype = C.c_char_p
         _lib = h

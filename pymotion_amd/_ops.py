@@ -155,6 +155,40 @@ def quat_slerp(be, q0, q1, t, shortest=True):
     return ew(be, "pm_quat_slerp_f32", [q0, q1, t], [(4,), (4,), (1,)], [(4,)], [dt], mid=[int(bool(shortest))])
 
 
+def _unroll(be, x, axis, width, fname):
+    shp = be.shape(x)
+    if len(shp) < 2 or shp[-1] != width:
+        raise ValueError(f"expected [..., {width}] with an unroll axis, got {shp}")
+    nd = len(shp)
+    ax = axis % nd
+    if ax == nd - 1:
+        raise ValueError("the unroll axis cannot be the component axis")
+    dt = be.result_dtype(x)
+    moved = be.moveaxis(x, ax, 0)          # unroll axis first; every other index is an independent series
+    mshape = be.shape(moved)
+    T = mshape[0]
+    S = _prod(mshape[1:-1])
+    be.begin(x)
+    try:
+        xp = be.dev_in(moved)
+        op, oh = be.dev_out(mshape)
+        if T > 0 and S > 0:
+            ws = be.scratch(_lib.lib().pm_quat_unroll_workspace_bytes(T, S))
+            _lib.call(fname, xp, T, S, op, ws, be.stream())
+        res = be.result(oh, dt)
+    finally:
+        be.end()
+    return be.moveaxis(res, 0, ax)
+
+
+def quat_unroll(be, q, axis):
+    return _unroll(be, q, axis, 4, "pm_quat_unroll_f32")
+
+
+def dq_unroll(be, dq, axis):
+    return _unroll(be, dq, axis, 8, "pm_dq_unroll_f32")
+
+
 # ---- dual quaternions ----------------------------------------------------------------------------
 
 def dq_from_rt(be, q, t):

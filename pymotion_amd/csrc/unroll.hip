@@ -1,0 +1,143 @@
+// unroll.hip -- quat.unroll (pymotion/rotations/quat.py:426-462) for gfx950: the first frame-COUPLED op.
+//
+// Reference: walk the unroll axis; flip quaternion i when dot(q_i, q_{i-1}) < 0, q_{i-1} being the
+// already-corrected one.  Flipping both operands leaves the dot's sign unchanged, so the correction is a
+// prefix product of signs of the ORIGINAL neighbours:  s_i = prod_{k<=i} sgn(dot(q_k, q_{k-1}))  with
+// sgn = -1 iff dot < 0 (the reference's `d0 < d1`), s_0 = +1.  That is a prefix XOR along time per
+// series -- a scan, not a loop:
+//   pass 1  each wave owns a chunk of 1024 consecutive frames of up to 64 series; per 64-frame sub-tile
+//           the rows are staged in LDS (coalesced), lane = frame computes its flip bit per series,
+//           one wave ballot per series gives every lane its inclusive prefix parity; the chunk's total
+//           parity per series goes to the workspace;
+//   pass 2  exclusive prefix XOR over chunks (lane = series; a few thousand independent loads);
+//   pass 3  pass 1 again with the carry-in, writing +-q.
+// (LDS: 65 rows x 65 records x 16|32 B = 66|132 KiB at most.)
+// Layout: q [T, S, 4] (unroll axis first; the front-end moves it there), out same.
+// Algorithmic HBM bytes: 16 (pass 1) + 16 + 16 (pass 3) = 48 B per quaternion.
+#include "common.hpp"
+
+namespace pm {
+
+constexpr int UR_SUB = PM_WAVE;   // frames per sub-tile (lane = frame)
+constexpr int UR_CHUNK = 1024;    // frames per wave
+constexpr int UR_SB = 64;         // series per block
+
+struct UnrollArgs {
+    const float *q;
+    float *out;
+    int32_t *ws;      // [nchunks][S] chunk parities (pass 1 out), then exclusive prefixes (pass 2, in place)
+    int64_t T;
+    int32_t S;
+    int32_t nchunks;
+};
+
+// W = 4: quaternions; W = 8: dual quaternions (sign decided by the real part, applied to all 8 floats,
+// rotations/dual_quat.py:139-167).
+template <bool APPLY, int W>
+__global__ __launch_bounds__(PM_WAVE) void unroll_kernel(const UnrollArgs a) {
+    constexpr int V = W / 4;  // dwordx4 per record
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int chunk = blockIdx.x;
+    const int s0 = blockIdx.y * UR_SB;
+    const int sb = (a.S - s0) < UR_SB ? (a.S - s0) : UR_SB;  // series in this block
+    const int64_t t0 = (int64_t)chunk * UR_CHUNK;
+    const int64_t t1 = (t0 + UR_CHUNK) < a.T ? (t0 + UR_CHUNK) : a.T;
+    const int rs = sb | 1;  // row stride in quaternions, odd: per-lane ds_read_b128 down a column is conflict-free
+    v4f *rows = reinterpret_cast<v4f *>(smem);  // [(UR_SUB + 1)][rs][V]: row 0 = the frame before the sub-tile
+
+    // carry-in parity per series (lane = series): exclusive prefix over earlier chunks (pass 3 only)
+    unsigned long long carry = 0;  // bit j = parity of series s0 + j
+    if (APPLY) {
+        const int c = (lane < sb) ? a.ws[(int64_t)chunk * a.S + s0 + lane] : 0;
+        carry = __ballot(c & 1);
+    }
+    for (int64_t ts = t0; ts < t1; ts += UR_SUB) {
+        const int nfr = (int)((t1 - ts) < UR_SUB ? (t1 - ts) : UR_SUB);
+        // stage rows ts-1 .. ts+nfr-1 (row segments of sb quaternions are contiguous in HBM)
+        const int first = (ts == 0) ? 1 : 0;  // no predecessor for the very first frame
+        for (int i = lane + first * sb * V; i < (nfr + 1) * sb * V; i += PM_WAVE) {
+            const int r = i / (sb * V), c = i - r * (sb * V);
+            rows[r * rs * V + c] = *(reinterpret_cast<const v4f *>(a.q) + ((ts - 1 + r) * a.S + s0) * V + c);
+        }
+        wave_sync();
+        const bool act = lane < nfr;
+        unsigned long long newcarry = carry;
+        for (int j = 0; j < sb; ++j) {
+            const v4f cur = rows[((lane + 1) * rs + j) * V];
+            bool flip = false;
+            if (act && !(ts == 0 && lane == 0)) {
+                const v4f prv = rows[(lane * rs + j) * V];
+                flip = (cur.x * prv.x + cur.y * prv.y + cur.z * prv.z + cur.w * prv.w) < 0.0f;
+            }
+            const unsigned long long m = __ballot(flip);
+            if (APPLY) {
+                const unsigned long long upto = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+                const int par = (__popcll(m & upto) + (int)((carry >> j) & 1ull)) & 1;
+                if (act) {
+                    const float sg = par ? -1.0f : 1.0f;
+                    v4f *o = reinterpret_cast<v4f *>(a.out) + ((ts + lane) * a.S + s0 + j) * V;
+                    o[0] = v4f{cur.x * sg, cur.y * sg, cur.z * sg, cur.w * sg};
+                    if constexpr (V == 2) {
+                        const v4f du = rows[((lane + 1) * rs + j) * V + 1];
+                        o[1] = v4f{du.x * sg, du.y * sg, du.z * sg, du.w * sg};
+                    }
+                }
+            }
+            if (__popcll(m) & 1) newcarry ^= (1ull << j);
+        }
+        carry = newcarry;
+        wave_sync();
+    }
+    if (!APPLY && lane < sb) a.ws[(int64_t)chunk * a.S + s0 + lane] = (int)((carry >> lane) & 1ull);
+}
+
+// exclusive prefix XOR over chunks, in place; lane = series
+__global__ __launch_bounds__(PM_WAVE) void unroll_scan_kernel(int32_t *ws, int nchunks, int S) {
+    const int s = blockIdx.x * PM_WAVE + threadIdx.x;
+    if (s >= S) return;
+    int acc = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        const int v = ws[(int64_t)c * S + s];
+        ws[(int64_t)c * S + s] = acc;
+        acc ^= v & 1;
+    }
+}
+
+}  // namespace pm
+
+using namespace pm;
+
+extern "C" int64_t pm_quat_unroll_workspace_bytes(int64_t T, int32_t S) {
+    if (T <= 0 || S <= 0) return 0;
+    return ((T + UR_CHUNK - 1) / UR_CHUNK) * (int64_t)S * (int64_t)sizeof(int32_t);
+}
+
+template <int W>
+static int unroll_launch(const float *q, int64_t T, int32_t S, float *out, void *workspace, pm_stream_t stream) {
+    PM_CHECK_ARGS(T >= 0 && S >= 0, "quat_unroll: negative size");
+    if (T == 0 || S == 0) return PM_OK;
+    PM_CHECK_ARGS(q && out && workspace, "quat_unroll: null pointer");
+    PM_CHECK_ARGS(aligned16(q) && aligned16(out), "quat_unroll: q and out must be 16-byte aligned");
+    const int64_t nchunks = (T + UR_CHUNK - 1) / UR_CHUNK;
+    const int sblocks = (S + UR_SB - 1) / UR_SB;
+    if (nchunks > 0x7fffffffLL || sblocks > 65535) { set_error("quat_unroll: problem too large"); return PM_EUNSUPPORTED; }
+    UnrollArgs a;
+    a.q = q; a.out = out; a.ws = static_cast<int32_t *>(workspace); a.T = T; a.S = S; a.nchunks = (int)nchunks;
+    const size_t lds = (size_t)(UR_SUB + 1) * ((S < UR_SB ? S : UR_SB) | 1) * 4 * W;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int e = allow_lds(unroll_kernel<false, W>, lds)) return e;
+    if (int e = allow_lds(unroll_kernel<true, W>, lds)) return e;
+    const dim3 grid((unsigned)nchunks, (unsigned)sblocks);
+    hipLaunchKernelGGL((unroll_kernel<false, W>), grid, dim3(PM_WAVE), lds, s, a);
+    hipLaunchKernelGGL(unroll_scan_kernel, dim3((unsigned)((S + PM_WAVE - 1) / PM_WAVE)), dim3(PM_WAVE), 0, s, a.ws, (int)nchunks, (int)S);
+    hipLaunchKernelGGL((unroll_kernel<true, W>), grid, dim3(PM_WAVE), lds, s, a);
+    return check_hip(hipGetLastError(), "quat_unroll");
+}
+
+extern "C" int pm_quat_unroll_f32(const float *q, int64_t T, int32_t S, float *out, void *workspace, pm_stream_t stream) {
+    return unroll_launch<4>(q, T, S, out, workspace, stream);
+}
+extern "C" int pm_dq_unroll_f32(const float *dq, int64_t T, int32_t S, float *out, void *workspace, pm_stream_t stream) {
+    return unroll_launch<8>(dq, T, S, out, workspace, stream);
+}

@@ -2,7 +2,7 @@
 
 Reference: ``pymotion/rotations/dual_quat.py``.  One gfx950 kernel per call, fp32 on the GPU.
 ``normalize`` / ``is_unit`` keep the reference's whole-batch branch (one host read of three device
-counters where the reference's Python ``if`` synchronises).  Not covered here: ``unroll``.
+counters where the reference's Python ``if`` synchronises).
 """
 import numpy as np
 
@@ -40,3 +40,9 @@ def is_unit(dq: np.array, atol: float = 1e-03) -> bool:
     """``|qr|^2 ~ 1`` and ``qr . qd ~ 0`` for every element (or ``|qr|^2 ~ 0`` for every element).
     Reference: dual_quat.py:118-136."""
     return _ops.dq_is_unit(_be(), dq, atol)
+
+
+def unroll(dq: np.array, axis: int) -> np.array:
+    """Dual-quaternion continuity along ``axis``: the sign is decided by the real part and applied to
+    all eight components.  Reference: dual_quat.py:139-167."""
+    return _ops.dq_unroll(_be(), dq, axis)

@@ -2,7 +2,7 @@
 
 Reference: ``pymotion/rotations/dual_quat_torch.py``.  One gfx950 kernel per call, fp32 on the GPU.
 ``normalize`` / ``is_unit`` keep the reference's whole-batch branch (one host read of three device
-counters where the reference's Python ``if`` synchronises).  Not covered here: ``unroll``.
+counters where the reference's Python ``if`` synchronises).
 """
 import torch
 
@@ -40,3 +40,9 @@ def is_unit(dq: torch.Tensor, atol: float = 1e-03) -> bool:
     """``|qr|^2 ~ 1`` and ``qr . qd ~ 0`` for every element (or ``|qr|^2 ~ 0`` for every element).
     Reference: dual_quat_torch.py:120-143."""
     return _ops.dq_is_unit(_be(), dq, atol)
+
+
+def unroll(dq: torch.Tensor, dim: int) -> torch.Tensor:
+    """Dual-quaternion continuity along ``dim``: the sign is decided by the real part and applied to
+    all eight components.  Reference: dual_quat_torch.py:146-174."""
+    return _ops.dq_unroll(_be(), dq, dim)

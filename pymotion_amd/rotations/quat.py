@@ -5,8 +5,7 @@ Same function names, positional arguments and conventions as the reference
 ``[..., 3, 3]`` row-major.  Every function launches one hand-written gfx950 kernel from
 ``libpmhip.so`` (fp32 on the GPU); there is no CPU fallback.
 NumPy arrays are copied to the GPU and back; outputs use the dtype the reference would return.
-Not covered here (frame-coupled / data-dependent scatter): ``unroll``,
-``from_to``, ``from_to_axis``.
+Not covered here (data-dependent scatter): ``from_to``, ``from_to_axis``.
 """
 import numpy as np
 
@@ -98,3 +97,11 @@ def normalize(quaternions: np.array, eps: float = 1e-8) -> np.array:
 def slerp(q0: np.array, q1: np.array, t, shortest: bool = True) -> np.array:
     """Spherical interpolation, ``t`` a float or ``[..., 1]``.  Reference: quat.py:465-501."""
     return _ops.quat_slerp(_be(), q0, q1, t, shortest)
+
+
+def unroll(quaternions: np.array, axis: int) -> np.array:
+    """Remove double-cover sign flips along ``axis``: each quaternion takes the sign closest to its
+    (already corrected) predecessor, the first one is kept.  A prefix-XOR scan on the GPU instead of the
+    reference's Python loop over frames; returns a new array (the reference flips its argument in
+    place through a view).  Reference: quat.py:426-462."""
+    return _ops.quat_unroll(_be(), quaternions, axis)

@@ -5,8 +5,7 @@ Same function names, positional arguments and conventions as the reference
 ``[..., 3, 3]`` row-major.  Every function launches one hand-written gfx950 kernel from
 ``libpmhip.so`` (fp32 on the GPU); there is no CPU fallback.
 Tensors may live on a HIP device (zero-copy, torch's current stream) or on the CPU (copied over and back).
-Not covered here (frame-coupled / data-dependent scatter): ``unroll``,
-``from_to``, ``from_to_axis``.
+Not covered here (data-dependent scatter): ``from_to``, ``from_to_axis``.
 """
 import torch
 
@@ -98,3 +97,11 @@ def normalize(quaternions: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
 def slerp(q0: torch.Tensor, q1: torch.Tensor, t, shortest: bool = True) -> torch.Tensor:
     """Spherical interpolation, ``t`` a float or ``[..., 1]``.  Reference: quat_torch.py:465-501."""
     return _ops.quat_slerp(_be(), q0, q1, t, shortest)
+
+
+def unroll(quaternions: torch.Tensor, dim: int) -> torch.Tensor:
+    """Remove double-cover sign flips along ``dim``: each quaternion takes the sign closest to its
+    (already corrected) predecessor, the first one is kept.  A prefix-XOR scan on the GPU instead of the
+    reference's Python loop over frames; returns a new array (the reference flips its argument in
+    place through a view).  Reference: quat_torch.py:441-477."""
+    return _ops.quat_unroll(_be(), quaternions, dim)

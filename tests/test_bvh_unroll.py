@@ -1,0 +1,101 @@
+"""BVH ingest and quat/dual_quat.unroll: host parser and oracle on the CPU, the GPU
+path (from_euler -> unroll -> normalize, then fk) against vectors the reference produced from the
+same committed synthetic22.bvh (oracle/make_golden.py: gen_bvh)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, assert_close, golden
+from oracle import c_oracle as co
+from pymotion_amd.io.bvh import BVH
+
+BVH_PATH = os.path.join(GOLDEN, "synthetic22.bvh")
+
+
+def test_bvh_parser_matches_reference_load():
+    g = golden("bvh.npz")
+    want = g.get("load", "out64")
+    b = BVH()
+    b.load(BVH_PATH)
+    d = b.data
+    assert [n.decode() for n in g.get("load", "in")["names"]] == list(d["names"])
+    np.testing.assert_array_equal(d["parents"], want["parents"])
+    np.testing.assert_array_equal(d["end_sites_parents"], want["end_sites_parents"])
+    np.testing.assert_array_equal(np.vectorize("xyz".index)(d["rot_order"]), want["rot_order"])
+    for k in ("offsets", "end_sites", "positions", "rotations"):
+        np.testing.assert_array_equal(d[k], want[k], err_msg=k)
+    assert d["frame_time"] == float(want["frame_time"])
+    assert d["positions"].shape == (48, 22, 3) and d["rotations"].shape == (48, 22, 3)
+
+
+@pytest.mark.parametrize("case", ["unroll_smooth_ax0", "unroll_random_ax0", "unroll_ax1", "unroll_4d_ax-3"])
+def test_oracle_unroll_matches_reference(case):
+    g = golden("bvh.npz")
+    i, want = g.get(case, "in"), g.get(case, "out64")["out"]
+    got = co.quat_unroll(i["q"].astype(np.float64), int(np.asarray(i["axis"]).reshape(-1)[0]))
+    assert_close(got, want, 0.0, case)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["unroll_smooth_ax0", "unroll_random_ax0", "unroll_ax1", "unroll_4d_ax-3"])
+def test_gpu_unroll_matches_reference(case):
+    import torch
+
+    import pymotion_amd.rotations.quat as quat
+    import pymotion_amd.rotations.quat_torch as quat_t
+
+    g = golden("bvh.npz")
+    i, want = g.get(case, "in"), g.get(case, "out64")["out"]
+    ax = int(np.asarray(i["axis"]).reshape(-1)[0])
+    q0 = i["q"].copy()
+    got = quat.unroll(i["q"], ax)
+    assert got.shape == i["q"].shape and got.dtype == np.float32
+    assert_close(got, want, 1e-7, case)  # only signs change
+    np.testing.assert_array_equal(i["q"], q0)  # the argument is not modified (the reference flips it in place)
+    got_t = quat_t.unroll(torch.from_numpy(i["q"]).cuda(), ax)
+    assert_close(got_t.cpu().numpy(), want, 1e-7, case + " torch")
+
+
+@pytest.mark.gpu
+def test_gpu_dq_unroll_and_long_sequences():
+    import pymotion_amd.rotations.dual_quat as dq
+    import pymotion_amd.rotations.quat as quat
+
+    g = golden("bvh.npz")
+    i, want = g.get("dq_unroll_ax0", "in"), g.get("dq_unroll_ax0", "out64")["out"]
+    assert_close(dq.unroll(i["dq"], 0), want, 1e-7, "dq unroll")
+    # many chunks (T > 1024), more series than one block (S > 64), ragged tail: against the sequential oracle
+    rng = np.random.default_rng(3)
+    for T, S in ((5000, 22), (1025, 70), (1, 3), (2, 1), (64, 64), (4097, 130)):
+        base = np.cumsum(rng.normal(0, 0.08, (T, S, 4)), axis=0) + rng.normal(0, 1, (1, S, 4))
+        q = (base * rng.choice([-1.0, 1.0], (T, S, 1))).astype(np.float32)
+        got = quat.unroll(q, 0)
+        ref = co.quat_unroll(q.astype(np.float64), 0)
+        assert_close(got, ref, 1e-7, f"T={T} S={S}")
+        d = np.sum(got[1:] * got[:-1], axis=-1)
+        assert (d >= 0).all()  # the defining property: neighbours never sit on opposite covers
+
+
+@pytest.mark.gpu
+def test_gpu_bvh_get_data_and_fk_match_reference():
+    import pymotion_amd.ops.skeleton as sk
+
+    g = golden("bvh.npz")
+    b = BVH()
+    b.load(BVH_PATH)
+    rots, pos, parents, offsets, end_sites, end_sites_parents = b.get_data()
+    want = g.get("get_data", "out64")
+    assert rots.shape == (48, 22, 4)
+    assert_close(rots, want["rots"], 1e-6, "get_data rots")
+    np.testing.assert_array_equal(pos, want["pos"])
+    # README.md:73-78 of the reference: fk on the file's data
+    p, r = sk.fk(rots, pos[:, 0, :], offsets, parents)
+    wfk = g.get("fk", "out64")
+    assert_close(p, wfk["pos"], 1e-5, "fk pos from BVH")
+    assert_close(r, wfk["rotmats"], 1e-5, "fk rotmats from BVH")
+    # set_data: quaternions back to the file's Euler channels (degrees); compare as rotations, modulo 360
+    b.set_data(rots, pos)
+    d = np.abs(b.data["rotations"] - g.get("set_data", "out64")["rotations"])
+    d = np.minimum(d, 360.0 - d)
+    assert d.max() < 0.05  # fp32 atan2 near gimbal configurations, in degrees
