@@ -107,6 +107,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.barrier()  # pay RCCL's lazy communicator set-up now, not inside the barrier that opens the timed region
 
     J = a.joints
     parents = syn.PARENTS_22 if J == 22 else syn.PARENTS_52
@@ -149,11 +150,12 @@ def main():
             for _ in range(20):
                 step()
             torch.cuda.synchronize()
-    for _ in range(a.warmup):
-        step()
     ev0, ev1 = C.c_void_p(), C.c_void_p()
     _lib.call("pm_event_create", C.byref(ev0))
     _lib.call("pm_event_create", C.byref(ev1))
+    barrier()  # a warm one: an idle gap of >= 3 ms before the timed region would cost ~20 ms of re-ramp
+    for _ in range(a.warmup):
+        step()
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
