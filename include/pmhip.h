@@ -93,6 +93,13 @@ int pm_from_root_dq_f32(const float *dq, const int32_t *parents /*host*/, int64_
 int pm_from_global_rotations_f32(const float *global_quats, const int32_t *parents /*host*/,
                                  int64_t F, int32_t J, float *local_quats, pm_stream_t stream);
 
+/* ops/skeleton.py:247-344 mirror (modes 'all', 'symmetry') / :347-418 _true_mirror -- the rotation part,
+ * fused: fk -> quat.from_matrix -> gather joints_mapping -> negate two quaternion components ->
+ * from_global_rotations in one kernel.  mapping is a HOST int32[J] (NULL = identity, mode 'all');
+ * axis 0/1/2 = X/Y/Z.  Translations / offsets / end sites are sign flips the front-end does. */
+int pm_mirror_rotations_f32(const float *rot, const int32_t *parents /*host*/, const int32_t *mapping /*host*/,
+                            int axis, int64_t F, int32_t J, float *out, pm_stream_t stream);
+
 /* ---- element-wise conversions: N elements, inputs already broadcast by the caller ------------ */
 
 /* rotations/quat.py:411-423  normalize(q, eps) = q / (|q| + eps) */

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate tests/golden/*.npz by IMPORTING the reference (this container only).
 
-    python oracle/make_golden.py            # writes tests/golden/{elementwise,skeleton,trig}.npz
+    python oracle/make_golden.py            # writes tests/golden/{elementwise,trig,skeleton,bvh,mirror}.npz + synthetic22.bvh
     python oracle/make_golden.py --check    # also cross-checks oracle/ (C + NumPy) against the import
 
 The reference (UPC-ViRVIG/pymotion v0.2.3, pure Python) lives at /root/reference and
@@ -406,6 +406,25 @@ def gen_bvh():
     s.save("bvh.npz")
 
 
+def gen_mirror():
+    """tests/golden/mirror.npz: reference mirror(mode in {'all','symmetry'}, axis in XYZ) on a 22-joint pose."""
+    d = {}
+    rng = np.random.default_rng(77)
+    rot, root, off, par = syn.fk_workload(40, seed=77, normalized=True)
+    end = rng.uniform(-0.1, 0.1, (5, 3)).astype(np.float32)
+    mp = np.arange(22)
+    mp[1:5], mp[5:9], mp[14:18], mp[18:22] = np.arange(5, 9), np.arange(1, 5), np.arange(18, 22), np.arange(14, 18)
+    for ax in "XYZ":
+        for mode in ("all", "symmetry"):
+            r, g, o, e = sk.mirror(rot.astype(np.float64), root.astype(np.float64).copy(), par, off.astype(np.float64),
+                                   end.astype(np.float64), mp if mode == "symmetry" else None, mode, ax)
+            k = f"mirror_{mode}_{ax}"
+            d[k + "|out64|rot"], d[k + "|out64|gt"], d[k + "|out64|off"], d[k + "|out64|end"] = r, g, o, e
+    for k, v in (("rot", rot), ("root", root), ("off", off), ("parents", par), ("end", end), ("mapping", mp.astype(np.int32))):
+        d["inputs|in|" + k] = v
+    np.savez_compressed(os.path.join(OUT, "mirror.npz"), **d)
+
+
 # ---- optional cross-check of oracle/ against the import ------------------------------------------------
 
 def check_oracle():
@@ -458,5 +477,7 @@ if __name__ == "__main__":
     gen_trig()
     gen_skeleton()
     gen_bvh()
+    gen_mirror()
     if args.check:
         check_oracle()
+

@@ -407,3 +407,55 @@ def from_global_rotations(be, global_quats, parents):
     finally:
         be.end()
     return res
+
+
+_MIRROR_AXIS = {"X": 0, "Y": 1, "Z": 2}
+
+
+def mirror(be, local_rotations, global_translation, parents, offsets, end_sites=None, joints_mapping=None,
+           mode="all", axis="X"):
+    if mode not in ("all", "symmetry", "positions"):
+        raise ValueError("Invalid mode. Choose 'symmetry', 'all', or 'positions'")
+    if axis not in _MIRROR_AXIS:
+        raise ValueError("Invalid axis. Choose 'X', 'Y', or 'Z'")
+    if mode == "positions":
+        raise NotImplementedError("mirror(mode='positions') needs from_root_positions, which is not part of the GPU hot path yet")
+    shp = be.shape(local_rotations)
+    if len(shp) < 2 or shp[-1] != 4:
+        raise ValueError(f"local_rotations must be [..., n_joints, 4], got {shp}")
+    lead, J = shp[:-2], shp[-2]
+    p = _parents_host(be, parents, J)
+    mp = None
+    if mode == "symmetry":
+        if joints_mapping is None:
+            raise ValueError("joints_mapping must be provided for mode 'symmetry'")
+        if len(joints_mapping) != J:
+            raise ValueError("joints_mapping must have the same length as the number of joints")
+        mp = be.host_ints(joints_mapping)
+    ax = _MIRROR_AXIS[axis]
+    # world rotations come out of fk (float64 through the NumPy door, rot.dtype through torch), then
+    # from_matrix / from_global_rotations keep that dtype
+    out_dt = be.always64 if be.name == "numpy" else local_rotations.dtype
+    be.begin(local_rotations)
+    try:
+        F = _prod(lead)
+        rp = be.dev_in(local_rotations)
+        op, oh = be.dev_out(shp)
+        if F > 0:
+            _lib.call("pm_mirror_rotations_f32", rp, p.ctypes.data_as(C.c_void_p),
+                      mp.ctypes.data_as(C.c_void_p) if mp is not None else None, ax, F, J, op, be.stream())
+        rots = be.result(oh, out_dt)
+    finally:
+        be.end()
+    # sign flips of the translation (and, for the true mirror, of the skeleton itself): new arrays -- the
+    # reference's 'symmetry' mode writes into the caller's global_translation (skeleton.py:325)
+    clone = (lambda t: t.copy()) if be.name == "numpy" else (lambda t: t.clone())
+    gt = clone(global_translation)
+    gt[..., ax] = -gt[..., ax]
+    if mode == "all":
+        offsets = clone(offsets)
+        offsets[:, ax] = -offsets[:, ax]
+        if end_sites is not None:
+            end_sites = clone(end_sites)
+            end_sites[:, ax] = -end_sites[:, ax]
+    return rots, gt, offsets, end_sites

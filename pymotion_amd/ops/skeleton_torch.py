@@ -57,3 +57,23 @@ def to_root_dual_quat(rotations: torch.Tensor, global_pos: torch.Tensor, parents
     (the reference reads ``shape[1]``, which is only right for ``[F, J, 4]``).
     Reference: ops/skeleton_torch.py:217-259."""
     return _ops.to_root_dual_quat(_be(), rotations, global_pos, parents, offsets)
+
+
+def mirror(
+    local_rotations: torch.Tensor,
+    global_translation: torch.Tensor,
+    parents,
+    offsets: torch.Tensor,
+    end_sites: torch.Tensor = None,
+    joints_mapping=None,
+    mode: str = "all",
+    axis: str = "X",
+):
+    """Mirror a skeleton pose along ``axis``.  ``mode='all'``: perfect mirror, topology mirrored too
+    (offsets / end sites change sign); ``mode='symmetry'``: joints swapped through ``joints_mapping``,
+    skeleton unchanged.  One fused kernel (fk -> from_matrix -> permute/negate -> from_global_rotations).
+    ``mode='positions'`` (IK through from_root_positions) is not on the GPU path.  Unlike the reference's
+    'symmetry' mode the caller's ``global_translation`` is not modified in place.
+    Returns ``(local_rotations, global_translation, offsets, end_sites)``.
+    Reference: ops/skeleton_torch.py:262-359 (and _true_mirror below it)."""
+    return _ops.mirror(_be(), local_rotations, global_translation, parents, offsets, end_sites, joints_mapping, mode, axis)

@@ -363,3 +363,44 @@ def test_dual_quat_normalize_and_is_unit_vs_reference_golden():
     assert dq.is_unit(x)
     x[17, 4:] += 0.5 * x[17, :4]
     assert not dq.is_unit(x)
+
+
+@pytest.mark.parametrize("mode", ["all", "symmetry"])
+@pytest.mark.parametrize("axis", ["X", "Y", "Z"])
+def test_mirror_vs_reference_golden(mode, axis):
+    g = golden("mirror.npz")
+    i = g.get("inputs", "in")
+    want = g.get(f"mirror_{mode}_{axis}", "out64")
+    root0 = i["root"].copy()
+    r, gt, off, end = sk.mirror(i["rot"], i["root"], i["parents"], i["off"], i["end"],
+                                i["mapping"] if mode == "symmetry" else None, mode, axis)
+    np.testing.assert_array_equal(i["root"], root0)  # not modified in place (the reference's 'symmetry' does)
+    # quat.from_matrix picks one of four branches: a quaternion and its negative are the same rotation
+    err = np.minimum(np.abs(r - want["rot"]).max(-1), np.abs(r + want["rot"]).max(-1)).max()
+    assert err <= ATOL, err
+    assert (np.abs(r - want["rot"]).max(-1) <= ATOL).mean() > 0.99  # and almost always the same sign
+    assert_close(gt, want["gt"], 1e-7, "translation")
+    assert_close(off, want["off"], 1e-7, "offsets")
+    assert_close(end, want["end"], 1e-7, "end sites")
+    torch, skt = _torch_mods()[:2]
+    rt, *_ = skt.mirror(torch.from_numpy(i["rot"]).cuda(), torch.from_numpy(i["root"]).cuda(), torch.from_numpy(i["parents"]),
+                        torch.from_numpy(i["off"]).cuda(), None, i["mapping"] if mode == "symmetry" else None, mode, axis)
+    rt = rt.cpu().numpy()
+    assert np.minimum(np.abs(rt - want["rot"]).max(-1), np.abs(rt + want["rot"]).max(-1)).max() <= ATOL
+    # mirroring twice is the identity (up to the double cover)
+    r2, gt2, off2, _ = sk.mirror(r, gt, i["parents"], off, None, i["mapping"] if mode == "symmetry" else None, mode, axis)
+    assert np.minimum(np.abs(r2 - i["rot"]).max(-1), np.abs(r2 + i["rot"]).max(-1)).max() <= ATOL
+    assert_close(gt2, i["root"], 1e-7, "translation twice")
+
+
+def test_mirror_argument_errors():
+    rot = np.zeros((2, 3, 4), np.float32)
+    args = (rot, np.zeros((2, 3), np.float32), np.array([0, 0, 1]), np.zeros((3, 3), np.float32))
+    with pytest.raises(ValueError):
+        sk.mirror(*args, mode="symmetry")  # joints_mapping required
+    with pytest.raises(ValueError):
+        sk.mirror(*args, mode="nope")
+    with pytest.raises(ValueError):
+        sk.mirror(*args, axis="W")
+    with pytest.raises(NotImplementedError):
+        sk.mirror(*args, mode="positions")
