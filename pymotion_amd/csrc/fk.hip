@@ -116,6 +116,52 @@ __device__ __forceinline__ void tree_walk(float *sRot, float *sPos, const float 
     }
 }
 
+// ---- phase B, wide form: TWELVE lanes per frame (row r x column c of [R | p]) -------------------------
+// For big skeletons the LDS image (48 J B per frame) leaves room for few frames per CU, and with three
+// lanes per frame a wave needs 8-20 frames to be worth its instructions.  Here a QUAD (4 consecutive
+// lanes) owns row r of a frame and each lane ONE element of it (c < 3: R[r][c], c = 3: p[r]):
+//     G[r][c] = sum_k Gp[r][k] * [L | t][k][c]  (+ Gp[r][3] for c = 3)
+// The parent row lives in the quad's own registers (previous joint) and is broadcast with DPP quad_perm,
+// so a chain step is 3 FMAs per lane and never goes through LDS; a wave walks only FPW <= 5 frames
+// (4 KiB of LDS at J = 22, 10 KiB at J = 52) and many more waves are resident to hide latency.
+template <int K>
+__device__ __forceinline__ float quad_bcast(const float v) {  // value of lane K of this lane's quad
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), K | (K << 2) | (K << 4) | (K << 6), 0xf, 0xf, true));
+}
+
+template <bool PFO>
+__device__ __forceinline__ void tree_walk_quad(float *sRot, float *sPos, const float *sOff, const float *sConst,
+                                               const int J, const int f, const int r, const int c, const float seed) {
+    float *fL = sRot + f * J * 9;
+    float *fPos = sPos + f * J * 3;
+    // what this lane multiplies the parent row with at joint j: column c of L_j (stride 3 in the slot) or,
+    // for the position lane, the offset t_j (from the constant table, or the per-frame offsets tile)
+    const float *coef0 = (c < 3) ? (fL + c) : (PFO ? sOff + f * J * 3 : sConst + 1);
+    const int cstep = (c < 3) ? 9 : (PFO ? 3 : 4), kstep = (c < 3) ? 3 : 1;
+    // where this lane's element of joint j lives in the image
+    float *own0 = (c < 3) ? (fL + r * 3 + c) : (fPos + r);
+    const int ostep = (c < 3) ? 9 : 3;
+    const v4f *cst = reinterpret_cast<const v4f *>(sConst);
+
+    float g = seed;  // element (r, c) of joint j-1: joint 0 multiplies the seed row e_r | root_pos[r] (exact)
+    float a0 = coef0[0], a1 = coef0[kstep], a2 = coef0[2 * kstep];
+    if (c == 3) { a0 = 0.0f; a1 = 0.0f; a2 = 0.0f; }  // root: translation = the seed itself (offsets[0] ignored)
+    int par = -1;
+    for (int j = 0; j < J; ++j) {
+        // look-ahead (independent of the chain): coefficients and parent of joint j+1; slot j+1 still holds L
+        const int jn = j + 1;  // the table has J+1 entries and the image one slot of slack past the last joint
+        const float n0 = coef0[jn * cstep], n1 = coef0[jn * cstep + kstep], n2 = coef0[jn * cstep + 2 * kstep];
+        const int parn = __builtin_amdgcn_readfirstlane(__float_as_int(cst[jn].x));
+        float e = g;
+        if (par != j - 1) e = own0[par * ostep];  // wave-uniform: parent is not the previous joint
+        const float p0 = quad_bcast<0>(e), p1 = quad_bcast<1>(e), p2 = quad_bcast<2>(e), pt = quad_bcast<3>(e);
+        g = p0 * a0 + p1 * a1 + p2 * a2 + ((c == 3) ? pt : 0.0f);
+        own0[j * ostep] = g;
+        a0 = n0; a1 = n1; a2 = n2;
+        par = parn;
+    }
+}
+
 // {parent (int bits), t0, t1, t2} of joint j, clamped to the last joint; joint 0's "parent" is the seed row
 template <bool PFO>
 __device__ __forceinline__ v4f load_joint_const(const Parents &parents, const float *offsets, const int J, const int j) {
@@ -144,10 +190,12 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
     // latency: root position (used first by phase B), skeleton constants, then the rotations.
     // Lanes >= 3*FPW shadow lanes 0.. (same frame, same row, same values, same addresses) and frames
     // past the end of a partial tile walk uninitialised slots of their own: phase B needs no masking.
-    const int wl = lane % (3 * FPW);
-    const int f = wl / 3;
-    const int r = wl - 3 * f;
-    const float gp = (f < nf) ? a.root_pos[f0 * 3 + wl] : 0.0f;
+    constexpr bool QUAD = FPW <= 5;  // few frames per wave (big J): 12 lanes per frame, see tree_walk_quad
+    const int wl = lane % ((QUAD ? 12 : 3) * FPW);
+    const int f = QUAD ? wl / 12 : wl / 3;
+    const int r = QUAD ? (wl - 12 * f) / 4 : wl - 3 * f;
+    const int c = wl & 3;  // QUAD only: column of [R | p]
+    const float gp = (f < nf) ? a.root_pos[f0 * 3 + f * 3 + r] : 0.0f;
 
     // Skeleton constants -> LDS once per tile, {parent (int bits), t0, t1, t2} per joint.  (Scalar loads
     // inside the walk would share lgkmcnt with the DS traffic and, returning out of order, force full
@@ -259,7 +307,12 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
     // ---- phase B -------------------------------------------------------------------------------------
     wave_sync();
 
-    tree_walk<PFO>(sRot, sPos, sOff, sConst, J, f, r, gp, (a.ablate & 2) != 0);
+    if constexpr (QUAD) {
+        const float seed = (c == 3) ? gp : ((c == r) ? 1.0f : 0.0f);
+        if (!(a.ablate & 2)) tree_walk_quad<PFO>(sRot, sPos, sOff, sConst, J, f, r, c, seed);
+    } else {
+        tree_walk<PFO>(sRot, sPos, sOff, sConst, J, f, r, gp, (a.ablate & 2) != 0);
+    }
     wave_sync();
     tile_store<VEC>(a.rotmats + f0 * J * 9, sRot, n * 9, lane);
     tile_store<VEC>(a.pos + f0 * J * 3, sPos, n * 3, lane);
@@ -402,28 +455,24 @@ static int dispatch_fk2(const FkArgs &a, bool vec, bool pfo, hipStream_t s) {
     return PM_EUNSUPPORTED;
 }
 
-// Frames per wave (FPW, a multiple of 4 so that every tile base stays 16-byte aligned for any J):
-// 20 fills 60 of 64 lanes in the walk, but the LDS image (48 J B per frame) bounds residency, and with
-// fewer than ~7 waves per CU nothing hides the walk's latency (measured at J = 52: FPW 20/16/12/8 ->
-// 376/311/307/255 us).  Pick the largest FPW that still leaves 7 resident waves, else 5, 3, 1.
-// J = 22 -> 20, J = 52 -> 8.
+// Frames per wave (FPW, a multiple of 4 so that every tile base stays 16-byte aligned for any J).
+// The LDS image (48 J B per frame) bounds residency, and with fewer than ~7 waves per CU nothing hides
+// the walk's latency.  Two shapes cover the range (measured, 2^18 frames x 52 joints: FPW 20/16/12/8 with
+// three lanes per frame 376/311/307/253 us, FPW 4 with twelve lanes per frame 203 us):
+//   FPW 20, 3 lanes per frame  while 7 tiles fit a CU's LDS (J <= 23 without extras),
+//   FPW 4, 12 lanes per frame (tree_walk_quad) beyond that.
 template <int SRC>
 static int dispatch_fk(const FkArgs &a, bool vec, bool pfo, hipStream_t s) {
     const size_t per_frame = (size_t)a.J * (12 + (pfo ? 3 : 0) + (a.quat_out ? 4 : 0)) * sizeof(float);
     const size_t fixed = 4 * ((size_t)a.J + 1) * sizeof(float) + 256;
-    static const int cand[] = {20, 16, 12, 8, 4};
-    int pick = 0;
-    const char *ov = getenv("PM_FK_FPW");  // tuning aid
+    int pick = (7 * (20 * per_frame + fixed) <= kMaxLds) ? 20 : 4;
+    const char *ov = getenv("PM_FK_FPW");  // tuning aid: 20, 8 or 4
     if (ov && atoi(ov) > 0) pick = atoi(ov);
-    for (int want = 7; !pick && want >= 1; want -= 2)
-        for (int c : cand)
-            if ((size_t)want * (c * per_frame + fixed) <= kMaxLds) { pick = c; break; }
+    if ((size_t)pick * per_frame + fixed > kMaxLds) pick = 4;
     switch (pick) {
         case 20: return dispatch_fk2<20, SRC>(a, vec, pfo, s);
-        case 16: return dispatch_fk2<16, SRC>(a, vec, pfo, s);
-        case 12: return dispatch_fk2<12, SRC>(a, vec, pfo, s);
         case 8: return dispatch_fk2<8, SRC>(a, vec, pfo, s);
-        case 4: return dispatch_fk2<4, SRC>(a, vec, pfo, s);
+        case 4: if (4 * per_frame + fixed <= kMaxLds) return dispatch_fk2<4, SRC>(a, vec, pfo, s);
     }
     set_error("fk: J=%d does not fit the LDS tile", a.J);
     return PM_EUNSUPPORTED;
