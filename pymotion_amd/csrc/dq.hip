@@ -10,18 +10,23 @@
 namespace pm {
 
 // ---------------------------------------------------------------------------------------------------
-// to_root_dual_quat: a quaternion payload does not split by rows the way fk's matrices do, so ONE LANE
-// walks ONE frame (FPW = 32 frames per wave).  The LDS image is the tile's OUTPUT (32 J B per frame)
-// with one 16-byte pad per frame: the pad makes the per-lane ds_read/write_b128 of the walk conflict
-// free (frame stride 8J+4 dwords instead of 8J, which for J = 22 is = 48 mod 64 banks: 4-way) and,
-// being a whole dwordx4, keeps the copy-out a dwordx4 stream.
-//   phase A  lane per (frame, joint): quaternion straight from HBM (coalesced dwordx4, all loads of the
-//            tile issued up front) into the first half of the joint's 32-byte output slot;
-//   walk     per joint: q_j from the own slot, parent (q,t) from registers when parents[j] == j-1, else
-//            from the parent's slot; compose (skeleton.py:238-241); write root-space (q, t) to the slot;
+// to_root_dual_quat.  The payload is a quaternion + a translation; a QUAD (4 consecutive lanes) owns a
+// frame, lane c holding component c of the running root-space quaternion and of the translation written
+// as the pure quaternion (0, t).  Products with a distributed left operand use
+//     (a (x) b)_c = sum_k S[c][k] a_k b_{c xor k}          (Klein-group structure of the Hamilton product)
+// with a_k a DPP quad broadcast and the b's read from LDS at per-lane permuted addresses; cross products
+// of the rotate-a-vector formula (quat.py:320-334) use DPP rotations of lanes 1..3.  A chain step is ~40
+// instructions for 16 frames, never waits on LDS, and a wave needs only 16 frames of LDS image (11.5 KiB
+// at J = 22 -> 13 waves per CU).
+// The LDS image is the tile's OUTPUT (32 J B per frame) with one 16-byte pad per frame: bank-conflict
+// free column access, and the copy-out stays a dwordx4 stream.
+//   phase A  lane per (frame, joint): quaternion straight from HBM (coalesced dwordx4, loads pipelined)
+//            into the first half of the joint's 32-byte output slot;
+//   walk     per joint: compose with the parent (registers when parents[j] == j-1, else its slot), or stay
+//            local when the parent is the root (skeleton.py:236-241); slot <- root-space (q, t, 0);
 //   phase C  lane per (frame, joint): (q, t) -> [q, 0.5 (0,t) (x) q] in place (dual_quat.py:28-36);
 //   out      contiguous dwordx4 streaming stores.
-// Skeleton constants {parent, offset} sit in a small LDS table (one broadcast ds_read_b128 per joint).
+// Skeleton constants {parent, offset} sit in a small LDS table.
 // ---------------------------------------------------------------------------------------------------
 struct ToRootArgs {
     const float *rot;       // [F,J,4]
@@ -30,6 +35,7 @@ struct ToRootArgs {
     float *dq;              // [F,J,8]
     int64_t F;
     int32_t J;
+    int32_t ablate;  // tuning aid (env PM_DQ_ABLATE): 1 = skip the walk, 2 = skip phase C
     Parents parents;
 };
 
@@ -50,9 +56,10 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
     const float invJ = 1.0f / (float)J;
 
     // all global loads first: root position, constants, then the rotations in batches of 4
-    // lanes >= nf shadow frame 0 (same inputs, same values, same addresses): the walk needs no masking
-    const int fc = lane < nf ? lane : 0;
-    const float rp[3] = {a.root_pos[(f0 + fc) * 3], a.root_pos[(f0 + fc) * 3 + 1], a.root_pos[(f0 + fc) * 3 + 2]};
+    // lanes >= 4*FPW shadow lanes 0.. ; frames past a partial tile walk their own (unused) slots: no masking
+    const int wl = lane % (4 * FPW);
+    const int fq = wl >> 2, c = wl & 3;
+    const float rp = (c > 0 && fq < nf) ? a.root_pos[(f0 + fq) * 3 + c - 1] : 0.0f;  // (0, root_pos) component c
     for (int j = lane; j <= J; j += PM_WAVE) {
         const int jc = j < J ? j : J - 1;
         v4f c;
@@ -96,49 +103,55 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
     }
     wave_sync();
 
-    float *fD = sDq + fc * FS;
-    const v4f *cst = reinterpret_cast<const v4f *>(sConst);
-    float gq[4] = {1.0f, 0.0f, 0.0f, 0.0f}, gt[3] = {0.0f, 0.0f, 0.0f};  // joint j-1, root space
-    v4f qn = *reinterpret_cast<const v4f *>(fD);
-    v4f cn = cst[0];
-    for (int j = 0; j < J; ++j) {
-        float q[4] = {qn.x, qn.y, qn.z, qn.w};
-        const v4f c = cn;
-        const int jn = (j + 1 < J) ? j + 1 : j;
-        qn = *reinterpret_cast<const v4f *>(fD + jn * 8);  // slot j+1 still holds its input quaternion
-        cn = cst[j + 1];
-        const int par = __builtin_amdgcn_readfirstlane(__float_as_int(c.x));
-        float t[3];
+    float *fD = sDq + fq * FS;
+    const float *cstf = sConst;
+    // per-lane constants of the component layout
+    const float s1 = (c == 0 || c == 2) ? -1.0f : 1.0f;   // S[c][1]:  - + - +
+    const float s2 = (c == 0 || c == 3) ? -1.0f : 1.0f;   // S[c][2]:  - + + -
+    const float s3 = (c == 0 || c == 1) ? -1.0f : 1.0f;   // S[c][3]:  - - + +
+    const int x1 = c ^ 1, x2 = c ^ 2, x3 = c ^ 3;         // b_{c xor k}
+    const int cn1 = (c == 3) ? 1 : c + 1, cn2 = (c == 2) ? 1 : ((c == 3) ? 2 : c + 2);  // next / next-next of x,y,z
+    const float live = (c == 0) ? 0.0f : 1.0f;            // lane 0 carries the zero scalar part of (0, t)
+    const int toff = (c == 0) ? 7 : 3 + c;                // where component c of (0,t) sits in a slot: t0 t1 t2 0
+
+    float gq = (c == 0) ? 1.0f : 0.0f, gt = 0.0f;  // joint j-1, root space
+    // look-ahead state for joint 0
+    float b0 = fD[c], b1 = fD[x1], b2 = fD[x2], b3 = fD[x3];
+    int par = 0;
+    float vc = 0.0f, vn = 0.0f, vnn = 0.0f;
+    for (int j = (a.ablate & 1) ? J : 0; j < J; ++j) {
+        // joint j+1's inputs do not depend on the chain: request them now (slot j+1 still holds its quaternion)
+        const int jn = j + 1;  // table has J+1 entries; the slot past the last joint is inside the allocation
+        const float nb0 = fD[jn * 8 + c], nb1 = fD[jn * 8 + x1], nb2 = fD[jn * 8 + x2], nb3 = fD[jn * 8 + x3];
+        const int parn = __builtin_amdgcn_readfirstlane(__float_as_int(cstf[jn * 4]));
+        const float nvc = cstf[jn * 4 + c], nvn = cstf[jn * 4 + cn1], nvnn = cstf[jn * 4 + cn2];  // lane 0: unused
+
+        float q, t;
         if (j == 0) {
-            t[0] = rp[0]; t[1] = rp[1]; t[2] = rp[2];  // skeleton.py:232
+            q = b0; t = rp;                       // skeleton.py:232
+        } else if (par == 0) {
+            q = b0; t = vc * live;                // joints hanging off the root stay local (:236-237)
         } else {
-            t[0] = c.y; t[1] = c.z; t[2] = c.w;
-            if (par != 0) {  // skeleton.py:236-241 ; joints hanging off the root stay local
-                float pq[4], pt[3];
-                if (par == j - 1) {
-                    pq[0] = gq[0]; pq[1] = gq[1]; pq[2] = gq[2]; pq[3] = gq[3];
-                    pt[0] = gt[0]; pt[1] = gt[1]; pt[2] = gt[2];
-                } else {  // the parent's slot holds its root-space (q, t) until phase C
-                    float pd[8];
-                    lds_get<8>(fD, par, pd);
-                    pq[0] = pd[0]; pq[1] = pd[1]; pq[2] = pd[2]; pq[3] = pd[3];
-                    pt[0] = pd[4]; pt[1] = pd[5]; pt[2] = pd[6];
-                }
-                float tv[3], qq[4];
-                qmulvec(pq, t, tv);
-                t[0] = tv[0] + pt[0]; t[1] = tv[1] + pt[1]; t[2] = tv[2] + pt[2];
-                qmul(pq, q, qq);
-                q[0] = qq[0]; q[1] = qq[1]; q[2] = qq[2]; q[3] = qq[3];
-            }
+            float pq = gq, pt = gt;
+            if (par != j - 1) { pq = fD[par * 8 + c]; pt = fD[par * 8 + toff]; }  // finished slot: (q, t, 0)
+            const float pw = quad_bcast<0>(pq), px = quad_bcast<1>(pq), py = quad_bcast<2>(pq), pz = quad_bcast<3>(pq);
+            // q = pq (x) q_j   (quat.py:337-361 in component-parallel form)
+            q = pw * b0 + s1 * (px * b1) + s2 * (py * b2) + s3 * (pz * b3);
+            // t = pq . t_j + pt   (quat.py:320-334: tt = 2 (pv x v); v + w tt + pv x tt)
+            const float an = quad_perm<0, 2, 3, 1>(pq), ann = quad_perm<0, 3, 1, 2>(pq);
+            const float tt = 2.0f * (an * vnn - ann * vn);
+            const float ttn = quad_perm<0, 2, 3, 1>(tt), ttnn = quad_perm<0, 3, 1, 2>(tt);
+            t = (vc + pw * tt + (an * ttnn - ann * ttn) + pt) * live;
         }
-        const float d[8] = {q[0], q[1], q[2], q[3], t[0], t[1], t[2], 0.0f};
-        lds_put<8>(fD, j, d);  // root-space (q, t); the dual part is formed lane-parallel in phase C
-        gq[0] = q[0]; gq[1] = q[1]; gq[2] = q[2]; gq[3] = q[3];
-        gt[0] = t[0]; gt[1] = t[1]; gt[2] = t[2];
+        fD[j * 8 + c] = q;
+        fD[j * 8 + toff] = t;
+        gq = q; gt = t;
+        b0 = nb0; b1 = nb1; b2 = nb2; b3 = nb3;
+        par = parn; vc = nvc; vn = nvn; vnn = nvnn;
     }
     wave_sync();
     // phase C, lane per (frame, joint): (q, t) -> [q, 0.5 (0,t) (x) q]  (dual_quat.py:28-36), off the chain
-    for (int e = lane; e < n; e += PM_WAVE) {
+    for (int e = (a.ablate & 2) ? n : lane; e < n; e += PM_WAVE) {
         const int f = (int)(((float)e + 0.5f) * invJ);
         const int j = e - f * J;
         float *slot = sDq + f * FS + j * 8;
@@ -301,18 +314,22 @@ extern "C" int pm_to_root_dq_f32(const float *rot, const float *root_pos, const 
     PM_CHECK_ARGS(rot && root_pos && parents && offsets && dq, "to_root_dq: null pointer");
     ToRootArgs a;
     a.rot = rot; a.root_pos = root_pos; a.offsets = offsets; a.dq = dq; a.F = F; a.J = J;
+    { const char *ab = getenv("PM_DQ_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
     if (int e = pack_parents(parents, J, a.parents)) return e;
     const bool vec = aligned16(rot) && aligned16(dq);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t per_frame = ((size_t)J * 8 + 4) * sizeof(float);
+    const size_t per_frame = ((size_t)J * 8 + 4) * sizeof(float), fixed = 4 * ((size_t)J + 1) * sizeof(float) + 256;
+    int pick = (7 * (16 * per_frame + fixed) <= kMaxLds) ? 16 : 8;  // 4 lanes per frame; keep >= 7 waves per CU if possible
     {
         const char *e = getenv("PM_DQ_FPW");  // tuning aid
-        if (e && atoi(e) == 64 && 64 * per_frame <= kMaxLds / 2) return launch_to_root<64>(a, vec, s);
-        if (e && atoi(e) == 16) return launch_to_root<16>(a, vec, s);
+        if (e && (atoi(e) == 16 || atoi(e) == 8 || atoi(e) == 4)) pick = atoi(e);
     }
-    if (32 * per_frame <= kMaxLds / 4) return launch_to_root<32>(a, vec, s);
-    if (16 * per_frame <= kMaxLds / 2) return launch_to_root<16>(a, vec, s);
-    if (4 * per_frame + 8192 <= kMaxLds) return launch_to_root<4>(a, vec, s);
+    while (pick > 4 && pick * per_frame + fixed > kMaxLds) pick >>= 1;
+    if (pick * per_frame + fixed <= kMaxLds) {
+        if (pick == 16) return launch_to_root<16>(a, vec, s);
+        if (pick == 8) return launch_to_root<8>(a, vec, s);
+        return launch_to_root<4>(a, vec, s);
+    }
     set_error("to_root_dq: J=%d does not fit the LDS tile", J);
     return PM_EUNSUPPORTED;
 }

@@ -124,11 +124,6 @@ __device__ __forceinline__ void tree_walk(float *sRot, float *sPos, const float 
 // The parent row lives in the quad's own registers (previous joint) and is broadcast with DPP quad_perm,
 // so a chain step is 3 FMAs per lane and never goes through LDS; a wave walks only FPW <= 5 frames
 // (4 KiB of LDS at J = 22, 10 KiB at J = 52) and many more waves are resident to hide latency.
-template <int K>
-__device__ __forceinline__ float quad_bcast(const float v) {  // value of lane K of this lane's quad
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), K | (K << 2) | (K << 4) | (K << 6), 0xf, 0xf, true));
-}
-
 template <bool PFO>
 __device__ __forceinline__ void tree_walk_quad(float *sRot, float *sPos, const float *sOff, const float *sConst,
                                                const int J, const int f, const int r, const int c, const float seed) {
