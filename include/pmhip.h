@@ -182,6 +182,10 @@ int pm_dq_unit_flags_f32(const float *dq, int64_t N, float atol, int32_t *flags,
 int pm_stream_ceiling_f32(const float *src, float *dst, int64_t F, int32_t rd_floats,
                           int32_t wr_floats, pm_stream_t stream);
 
+/* LDS-free streaming probe: n4 dwordx4 read, ratio * n4 written, grid-stride with `blocks` 256-thread blocks.
+ * Tells what the memory system sustains for a read:write mix (bench / tuning only). */
+int pm_stream_plain_f32(const float *src, float *dst, int64_t n4, int32_t ratio, int32_t blocks, pm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,7 @@ SIGNATURES = {
     "pm_dq_unit_flags_f32": [_f, _i64, _flt, C.c_void_p, _strm],
     # measurement helper
     "pm_stream_ceiling_f32": [_f, _f, _i64, _i32, _i32, _strm],
+    "pm_stream_plain_f32": [_f, _f, _i64, _i32, _i32, _strm],
 }
 
 _lib = None

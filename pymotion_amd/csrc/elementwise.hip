@@ -320,6 +320,19 @@ __global__ __launch_bounds__(PM_WAVE) void ceiling_kernel(const float *__restric
     for (int i = lane; i < n4; i += PM_WAVE) __builtin_nontemporal_store(l4[i % m4], g4 + i);
 }
 
+// Plain streaming probe without LDS: every thread reads one dwordx4 and writes `ratio` dwordx4 (each store
+// instruction of a wave covers 1 KiB contiguous).  256-thread blocks, grid-stride.  What the memory system
+// sustains for a given read:write mix, independent of any tiling of ours.
+__global__ __launch_bounds__(256) void plain_stream_kernel(const v4f *__restrict__ src, v4f *__restrict__ dst, int64_t n4,
+                                                           int ratio) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const v4f v = __builtin_nontemporal_load(src + i);
+        const int64_t w = i >> 6, l = i & 63;
+        for (int k = 0; k < ratio; ++k) __builtin_nontemporal_store(v, dst + (w * ratio + k) * 64 + l);
+    }
+}
+
 }  // namespace pm
 
 using namespace pm;
@@ -440,4 +453,12 @@ extern "C" int pm_dq_unit_flags_f32(const float *dq, int64_t N, float atol, int3
     if (aligned16(dq)) hipLaunchKernelGGL((dq_norm_kernel<2, true>), dim3((unsigned)grid), dim3(PM_WAVE), lds, s, dq, nullptr, N, atol, flags);
     else hipLaunchKernelGGL((dq_norm_kernel<2, false>), dim3((unsigned)grid), dim3(PM_WAVE), lds, s, dq, nullptr, N, atol, flags);
     return check_hip(hipGetLastError(), "dq_unit_flags");
+}
+
+extern "C" int pm_stream_plain_f32(const float *src, float *dst, int64_t n4, int32_t ratio, int32_t blocks, pm_stream_t stream) {
+    PM_CHECK_ARGS(src && dst && n4 >= 0 && ratio >= 1 && blocks >= 1 && aligned16(src) && aligned16(dst), "stream_plain: bad arguments");
+    if (n4 == 0) return PM_OK;
+    hipLaunchKernelGGL(plain_stream_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const v4f *>(src), reinterpret_cast<v4f *>(dst), n4, (int)ratio);
+    return check_hip(hipGetLastError(), "stream_plain");
 }

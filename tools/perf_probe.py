@@ -100,6 +100,17 @@ def main():
             ms, mn = timeit(lambda: _lib.call("pm_stream_ceiling_f32", p(src), p(dst), Fj, rd, wr, None))
             report(f"ceiling (copy, fk shape) J={J}", ms, mn, Fj * (rd + wr) * 4)
             del dst
+        if want("plain") and J == 22:
+            n4 = Fj * J  # one quaternion per thread in, 3x out = fk's 1:3 read:write mix
+            src = rot.view(-1)
+            dst = torch.empty(n4 * 12, device=dev)
+            for blocks in (2048, 4096, 8192, 16384):
+                ms, mn = timeit(lambda: _lib.call("pm_stream_plain_f32", p(src), p(dst), n4, 3, blocks, None))
+                report(f"plain stream 1:3, {blocks} blocks", ms, mn, n4 * 64)
+            for ratio in (1, 2):
+                ms, mn = timeit(lambda: _lib.call("pm_stream_plain_f32", p(src), p(dst), n4, ratio, 8192, None))
+                report(f"plain stream 1:{ratio}, 8192 blocks", ms, mn, n4 * 16 * (1 + ratio))
+            del dst
         if want("dq"):
             ms, mn = timeit(lambda: _lib.call("pm_to_root_dq_f32", p(rotn), p(root), pp, p(off), Fj, J, p(dq), None))
             report(f"to_root_dq J={J}", ms, mn, Fj * (48 * J + 12))
