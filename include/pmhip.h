@@ -100,6 +100,13 @@ int pm_from_global_rotations_f32(const float *global_quats, const int32_t *paren
 int pm_mirror_rotations_f32(const float *rot, const int32_t *parents /*host*/, const int32_t *mapping /*host*/,
                             int axis, int64_t F, int32_t J, float *out, pm_stream_t stream);
 
+/* ops/skeleton.py:96-170 / skeleton_torch.py:101-176  from_root_positions(positions [F,J,3] root-centred,
+ * parents, offsets [J,3]) -> local rotations [F,J,4]: align each joint's first child direction (from_to),
+ * then correct the roll with every further child (from_to_axis).  One O(J) walk per frame instead of the
+ * reference's fk-per-joint loop. */
+int pm_from_root_positions_f32(const float *positions, const int32_t *parents /*host*/, const float *offsets,
+                               int64_t F, int32_t J, float *rotations, pm_stream_t stream);
+
 /* ---- element-wise conversions: N elements, inputs already broadcast by the caller ------------ */
 
 /* rotations/quat.py:411-423  normalize(q, eps) = q / (|q| + eps) */
@@ -153,6 +160,13 @@ int pm_quat_to_euler_f32(const float *q, const uint8_t *order, int order_per_ele
 /* rotations/quat.py:465-501  slerp(q0, q1, t [N,1], shortest) */
 int pm_quat_slerp_f32(const float *q0, const float *q1, const float *t, int64_t N, int shortest,
                       float *out, pm_stream_t stream);
+
+/* rotations/quat.py:504-576  from_to(v1 [N,3], v2 [N,3], normalize_input) -> [N,4]: parallel -> identity,
+ * anti-parallel -> half turn about an axis orthogonal to v1 (np.isclose thresholds) */
+int pm_quat_from_to_f32(const float *v1, const float *v2, int64_t N, int normalize_input, float *out, pm_stream_t stream);
+/* rotations/quat.py:579-650  from_to_axis(v1, v2, rot_axis [N,3], normalize_input) -> [N,4] */
+int pm_quat_from_to_axis_f32(const float *v1, const float *v2, const float *axis, int64_t N, int normalize_input,
+                             float *out, pm_stream_t stream);
 
 /* rotations/quat.py:426-462  unroll(quaternions, axis): q is [T, S, 4] with the unroll axis FIRST (the
  * front-end moves it there); frame i is negated when the running sign says so: a prefix XOR of

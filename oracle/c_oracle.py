@@ -211,6 +211,31 @@ def quat_to_scaled_angle_axis(q):
     return o
 
 
+def quat_from_to(v1, v2, normalize_input=True):
+    """rotations/quat.py:504-576"""
+    dt, (v1, v2), n, (o,) = _ew("", [v1, v2], [(3,), (3,)], [(4,)])
+    _call("oracle_quat_from_to", dt, v1, v2, _i64(n), (C.c_int, int(bool(normalize_input))), o)
+    return o
+
+
+def quat_from_to_axis(v1, v2, axis, normalize_input=True):
+    """rotations/quat.py:579-650"""
+    dt, (v1, v2, axis), n, (o,) = _ew("", [v1, v2, axis], [(3,), (3,), (3,)], [(4,)])
+    _call("oracle_quat_from_to_axis", dt, v1, v2, axis, _i64(n), (C.c_int, int(bool(normalize_input))), o)
+    return o
+
+
+def from_root_positions(positions, parents, offsets):
+    """ops/skeleton.py:96-170, literal procedure (fk per aligned joint)"""
+    dt = _dt(positions, offsets)
+    P = _prep(positions, dt)
+    lead, J = P.shape[:-2], P.shape[-2]
+    F = int(np.prod(lead, dtype=np.int64))
+    o = np.empty(lead + (J, 4), dtype=dt)
+    _call("oracle_from_root_positions", dt, P, _parents(parents), _prep(offsets, dt), _i64(F), _i32(J), o)
+    return o
+
+
 def quat_unroll(q, axis):
     """rotations/quat.py:426-462"""
     dt = _dt(q)

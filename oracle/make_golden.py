@@ -425,6 +425,42 @@ def gen_mirror():
     np.savez_compressed(os.path.join(OUT, "mirror.npz"), **d)
 
 
+def gen_ik():
+    """tests/golden/ik.npz: quat.from_to / from_to_axis (incl. the parallel / anti-parallel branches),
+    from_root_positions on poses produced by fk, mirror(mode='positions')."""
+    s = Store()
+    rng = np.random.default_rng(31)
+    n = 64
+    v1 = rng.standard_normal((n, 3)).astype(np.float32)
+    v2 = rng.standard_normal((n, 3)).astype(np.float32)
+    v2[0] = v1[0] * 2.5                       # parallel
+    v2[1] = -v1[1] * 0.5                      # anti-parallel, generic v1
+    v1[2] = [3.0, 0.0, 0.0]; v2[2] = [-1.0, 0.0, 0.0]   # anti-parallel along x (other orthogonal helper)
+    v1[3] = [0.0, 2.0, 0.0]; v2[3] = [0.0, 0.0, 5.0]    # 90 degrees
+    ax = rng.standard_normal((n, 3)).astype(np.float32)
+    ax /= np.linalg.norm(ax, axis=-1, keepdims=True)
+    run3(s, "from_to", {"v1": v1, "v2": v2}, qt.from_to, qtt.from_to, ["out"])
+    run3(s, "from_to_nonorm", {"v1": v1 / np.linalg.norm(v1, axis=-1, keepdims=True), "v2": v2 / np.linalg.norm(v2, axis=-1, keepdims=True)},
+         lambda a, b: qt.from_to(a, b, False), lambda a, b: qtt.from_to(a, b, False), ["out"])
+    run3(s, "from_to_axis", {"v1": v1, "v2": v2, "axis": ax}, qt.from_to_axis, qtt.from_to_axis, ["out"])
+    run3(s, "from_to_single", {"v1": v1[5], "v2": v2[5]}, qt.from_to, qtt.from_to, ["out"])
+    for name, parents, F in (("J22", syn.PARENTS_22, 24), ("J52", syn.PARENTS_52, 8), ("topoJ9", syn.random_parents(9, rng), 16),
+                             ("starJ6", np.zeros(6, dtype=np.int32), 12)):
+        J = len(parents)
+        rot = rng.standard_normal((F, J, 4))
+        rot /= np.linalg.norm(rot, axis=-1, keepdims=True)
+        off = syn.make_offsets(J, rng).astype(np.float64)
+        pos, _ = sk.fk(rot, np.zeros((F, 3)), off, parents)
+        pos = np.ascontiguousarray(pos).astype(np.float32)
+        run3(s, f"from_root_positions_{name}", {"pos": pos, "parents": parents, "off": off.astype(np.float32)},
+             sk.from_root_positions, lambda p_, par_, o_: skt.from_root_positions(p_, T(par_), o_), ["rot"], int_keys=("parents",))
+    rot, root, off, par = syn.fk_workload(12, seed=5, normalized=True)
+    r, g, o, e = sk.mirror(rot.astype(np.float64), root.astype(np.float64).copy(), par, off.astype(np.float64), None, None, "positions", "X")
+    s.add("mirror_positions_X", "in", rot=rot, root=root, off=off, parents=par)
+    s.add("mirror_positions_X", "out64", rot=r, gt=g, off=o)
+    s.save("ik.npz")
+
+
 # ---- optional cross-check of oracle/ against the import ------------------------------------------------
 
 def check_oracle():
@@ -478,6 +514,7 @@ if __name__ == "__main__":
     gen_skeleton()
     gen_bvh()
     gen_mirror()
+    gen_ik()
     if args.check:
         check_oracle()
 

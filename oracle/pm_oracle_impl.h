@@ -412,6 +412,96 @@ void FN(oracle_from_global_rotations)(const REAL *gq, const int32_t *parents, in
     }
 }
 
+/* np.isclose(x, target): |x - target| <= 1e-8 + 1e-5 |target| */
+static inline int FN(h_close)(REAL x, REAL target) { return FABS(x - target) <= (REAL)1e-8 + (REAL)1e-5 * FABS(target); }
+/* ops/vector.py:4-19 */
+static inline void FN(h_vnorm)(const REAL *v, REAL *o) {
+    REAL n = SQRT(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) + (REAL)1e-8;
+    o[0] = v[0] / n; o[1] = v[1] / n; o[2] = v[2] / n;
+}
+/* rotations/quat.py:504-576 */
+static inline void FN(h_from_to)(const REAL *v1, const REAL *v2, int normalize_input, REAL *o) {
+    REAL a[3] = {v1[0], v1[1], v1[2]}, b[3] = {v2[0], v2[1], v2[2]}, cr[3], ax[3];
+    if (normalize_input) { FN(h_vnorm)(v1, a); FN(h_vnorm)(v2, b); }
+    FN(h_cross)(a, b, cr);
+    REAL dot = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+    FN(h_vnorm)(cr, ax);
+    REAL w = SQRT(((REAL)1 + dot) * (REAL)0.5), s = SQRT(((REAL)1 - dot) * (REAL)0.5);
+    o[0] = w; o[1] = ax[0] * s; o[2] = ax[1] * s; o[3] = ax[2] * s;
+    if (FN(h_close)(dot, (REAL)1)) { o[0] = 1; o[1] = o[2] = o[3] = 0; }
+    if (FN(h_close)(dot, (REAL)-1)) {
+        int xl = FN(h_close)(FABS(a[0]), (REAL)1);
+        REAL og[3] = {xl ? (REAL)0 : (REAL)1, xl ? (REAL)1 : (REAL)0, (REAL)0}, c2[3], a2[3];
+        FN(h_cross)(a, og, c2);
+        FN(h_vnorm)(c2, a2);
+        o[0] = 0; o[1] = a2[0]; o[2] = a2[1]; o[3] = a2[2];
+    }
+}
+/* rotations/quat.py:579-650 */
+static inline void FN(h_from_to_axis)(const REAL *v1, const REAL *v2, const REAL *axis, int normalize_input, REAL *o) {
+    REAL a[3] = {v1[0], v1[1], v1[2]}, b[3] = {v2[0], v2[1], v2[2]}, cr[3];
+    if (normalize_input) { FN(h_vnorm)(v1, a); FN(h_vnorm)(v2, b); }
+    FN(h_cross)(a, b, cr);
+    REAL dot = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+    REAL w = SQRT(((REAL)1 + dot) * (REAL)0.5), s = SQRT(((REAL)1 - dot) * (REAL)0.5);
+    REAL cda = cr[0] * axis[0] + cr[1] * axis[1] + cr[2] * axis[2];
+    s *= (cda > 0) ? (REAL)1 : ((cda < 0) ? (REAL)-1 : cda);
+    o[0] = w; o[1] = axis[0] * s; o[2] = axis[1] * s; o[3] = axis[2] * s;
+    if (FN(h_close)(dot, (REAL)1)) { o[0] = 1; o[1] = o[2] = o[3] = 0; }
+    if (FN(h_close)(dot, (REAL)-1)) { o[0] = 0; o[1] = axis[0]; o[2] = axis[1]; o[3] = axis[2]; }
+}
+void FN(oracle_quat_from_to)(const REAL *v1, const REAL *v2, int64_t n, int normalize_input, REAL *out) {
+    for (int64_t i = 0; i < n; ++i) FN(h_from_to)(v1 + 3 * i, v2 + 3 * i, normalize_input, out + 4 * i);
+}
+void FN(oracle_quat_from_to_axis)(const REAL *v1, const REAL *v2, const REAL *ax, int64_t n, int normalize_input, REAL *out) {
+    for (int64_t i = 0; i < n; ++i) FN(h_from_to_axis)(v1 + 3 * i, v2 + 3 * i, ax + 3 * i, normalize_input, out + 4 * i);
+}
+
+/* ops/skeleton.py:96-170, followed LITERALLY (an fk + from_matrix per aligned joint and per extra child), one
+ * frame at a time.  The product's O(J) kernel must reproduce this. */
+void FN(oracle_from_root_positions)(const REAL *positions, const int32_t *parents, const REAL *offsets, int64_t F,
+                                    int32_t J, REAL *rotations) {
+    REAL *pos = (REAL *)malloc(sizeof(REAL) * 3 * (size_t)J), *rm = (REAL *)malloc(sizeof(REAL) * 9 * (size_t)J);
+    REAL *gq = (REAL *)malloc(sizeof(REAL) * 4 * (size_t)J);
+    const REAL zero[3] = {0, 0, 0};
+    for (int64_t f = 0; f < F; ++f) {
+        const REAL *P = positions + f * J * 3;
+        REAL *rot = rotations + f * J * 4;
+        for (int32_t j = 0; j < J; ++j) { rot[4 * j] = 1; rot[4 * j + 1] = rot[4 * j + 2] = rot[4 * j + 3] = 0; }
+        for (int32_t j = 0; j < J; ++j) {
+            int first = -1;
+            for (int32_t c = 1; c < J; ++c) {
+                if (parents[c] != j) continue;
+                FN(oracle_fk)(rot, zero, offsets, 0, parents, 1, J, pos, rm);
+                FN(oracle_quat_from_matrix)(rm, J, gq);
+                REAL inv[4] = {gq[4 * j], -gq[4 * j + 1], -gq[4 * j + 2], -gq[4 * j + 3]};
+                if (first < 0) {
+                    first = c;
+                    REAL rd[3] = {pos[3 * c] - pos[3 * j], pos[3 * c + 1] - pos[3 * j + 1], pos[3 * c + 2] - pos[3 * j + 2]};
+                    REAL pd[3] = {P[3 * c] - P[3 * j], P[3 * c + 1] - P[3 * j + 1], P[3 * c + 2] - P[3 * j + 2]};
+                    REAL rdl[3], pdl[3];
+                    FN(h_qmulvec)(inv, rd, rdl);
+                    FN(h_qmulvec)(inv, pd, pdl);
+                    FN(h_from_to)(rdl, pdl, 1, rot + 4 * j);
+                } else {
+                    REAL rd[3] = {pos[3 * c] - pos[3 * j], pos[3 * c + 1] - pos[3 * j + 1], pos[3 * c + 2] - pos[3 * j + 2]};
+                    REAL pd[3] = {P[3 * c] - P[3 * j], P[3 * c + 1] - P[3 * j + 1], P[3 * c + 2] - P[3 * j + 2]};
+                    REAL d0[3] = {P[3 * first] - P[3 * j], P[3 * first + 1] - P[3 * j + 1], P[3 * first + 2] - P[3 * j + 2]};
+                    REAL rdl[3], pdl[3], dn[3], ax[3], roll[4], r2[4];
+                    FN(h_qmulvec)(inv, rd, rdl);
+                    FN(h_qmulvec)(inv, pd, pdl);
+                    FN(h_vnorm)(d0, dn);
+                    FN(h_qmulvec)(inv, dn, ax);
+                    FN(h_from_to_axis)(rdl, pdl, ax, 1, roll);
+                    FN(h_qmul)(rot + 4 * j, roll, r2);
+                    rot[4 * j] = r2[0]; rot[4 * j + 1] = r2[1]; rot[4 * j + 2] = r2[2]; rot[4 * j + 3] = r2[3];
+                }
+            }
+        }
+    }
+    free(pos); free(rm); free(gq);
+}
+
 #undef FN
 #undef FN1
 #undef FN2

@@ -38,6 +38,7 @@ SIGNATURES = {
     "pm_to_root_dq_f32": [_f, _f, C.c_void_p, _f, _i64, _i32, _f, _strm],
     "pm_from_root_dq_f32": [_f, C.c_void_p, _i64, _i32, _f, _f, _strm],
     "pm_from_global_rotations_f32": [_f, C.c_void_p, _i64, _i32, _f, _strm],
+    "pm_from_root_positions_f32": [_f, C.c_void_p, _f, _i64, _i32, _f, _strm],
     "pm_mirror_rotations_f32": [_f, C.c_void_p, C.c_void_p, _int, _i64, _i32, _f, _strm],
     # element-wise
     "pm_quat_normalize_f32": [_f, _i64, _flt, _f, _strm],
@@ -62,6 +63,8 @@ SIGNATURES = {
     "pm_quat_from_euler_f32": [_f, C.c_void_p, _int, _i64, _f, _strm],
     "pm_quat_to_euler_f32": [_f, C.c_void_p, _int, _i64, _f, _strm],
     "pm_quat_slerp_f32": [_f, _f, _f, _i64, _int, _f, _strm],
+    "pm_quat_from_to_f32": [_f, _f, _i64, _int, _f, _strm],
+    "pm_quat_from_to_axis_f32": [_f, _f, _f, _i64, _int, _f, _strm],
     "pm_quat_unroll_workspace_bytes": [_i64, _i32],
     "pm_quat_unroll_f32": [_f, _i64, _i32, _f, C.c_void_p, _strm],
     "pm_dq_unroll_f32": [_f, _i64, _i32, _f, C.c_void_p, _strm],

@@ -155,6 +155,32 @@ def quat_slerp(be, q0, q1, t, shortest=True):
     return ew(be, "pm_quat_slerp_f32", [q0, q1, t], [(4,), (4,), (1,)], [(4,)], [dt], mid=[int(bool(shortest))])
 
 
+def _maybe_1d(be, arrs):
+    """The reference accepts single vectors [3] and returns a single quaternion (quat.py:531-533, 573-574)."""
+    if len(be.shape(arrs[0])) == 1:
+        return [a[None] for a in arrs], True
+    return list(arrs), False
+
+
+def quat_from_to(be, v1, v2, normalize_input=True):
+    assert be.shape(v1)[-1] == 3 and be.shape(v2)[-1] == 3, "Input vectors must have shape [..., 3]"
+    assert be.shape(v1) == be.shape(v2), "Input vectors must have the same shape"
+    (v1, v2), single = _maybe_1d(be, (v1, v2))
+    r = ew(be, "pm_quat_from_to_f32", [v1, v2], [(3,), (3,)], [(4,)], [be.result_dtype(v1, v2)],
+           mid=[int(bool(normalize_input))])
+    return r[0] if single else r
+
+
+def quat_from_to_axis(be, v1, v2, rot_axis, normalize_input=True):
+    assert be.shape(v1)[-1] == 3 and be.shape(v2)[-1] == 3, "Input vectors must have shape [..., 3]"
+    assert be.shape(v1) == be.shape(v2), "Input vectors must have the same shape"
+    assert be.shape(v1) == be.shape(rot_axis), "Input vectors and rotation axis must have the same shape"
+    (v1, v2, rot_axis), single = _maybe_1d(be, (v1, v2, rot_axis))
+    r = ew(be, "pm_quat_from_to_axis_f32", [v1, v2, rot_axis], [(3,), (3,), (3,)], [(4,)],
+           [be.result_dtype(v1, v2, rot_axis)], mid=[int(bool(normalize_input))])
+    return r[0] if single else r
+
+
 def _unroll(be, x, axis, width, fname):
     shp = be.shape(x)
     if len(shp) < 2 or shp[-1] != width:
@@ -409,6 +435,29 @@ def from_global_rotations(be, global_quats, parents):
     return res
 
 
+def from_root_positions(be, positions, parents, offsets):
+    shp = be.shape(positions)
+    if len(shp) < 2 or shp[-1] != 3:
+        raise ValueError(f"positions must be [..., n_joints, 3], got {shp}")
+    lead, J = shp[:-2], shp[-2]
+    p = _parents_host(be, parents, J)
+    if be.shape(offsets) != (J, 3):
+        raise ValueError(f"offsets must be [{J}, 3], got {be.shape(offsets)}")
+    out_dt = be.always64 if be.name == "numpy" else positions.dtype  # skeleton.py:128 builds float64 identities
+    be.begin(positions, offsets)
+    try:
+        F = _prod(lead)
+        pp = be.dev_in(positions)
+        op_ = be.dev_in(offsets)
+        rp, rh = be.dev_out(lead + (J, 4))
+        if F > 0:
+            _lib.call("pm_from_root_positions_f32", pp, p.ctypes.data_as(C.c_void_p), op_, F, J, rp, be.stream())
+        res = be.result(rh, out_dt)
+    finally:
+        be.end()
+    return res
+
+
 _MIRROR_AXIS = {"X": 0, "Y": 1, "Z": 2}
 
 
@@ -419,7 +468,11 @@ def mirror(be, local_rotations, global_translation, parents, offsets, end_sites=
     if axis not in _MIRROR_AXIS:
         raise ValueError("Invalid axis. Choose 'X', 'Y', or 'Z'")
     if mode == "positions":
-        raise NotImplementedError("mirror(mode='positions') needs from_root_positions, which is not part of the GPU hot path yet")
+        # skeleton.py:332-341: true mirror -> fk -> root-centred positions -> IK on the ORIGINAL skeleton
+        m_rots, m_gpos, m_offsets, _ = mirror(be, local_rotations, global_translation, parents, offsets, end_sites, None, "all", axis)
+        pos, _ = fk(be, m_rots, m_gpos, m_offsets, parents)
+        pos = pos - pos[..., 0:1, :]
+        return from_root_positions(be, pos, parents, offsets), m_gpos, offsets, end_sites
     shp = be.shape(local_rotations)
     if len(shp) < 2 or shp[-1] != 4:
         raise ValueError(f"local_rotations must be [..., n_joints, 4], got {shp}")

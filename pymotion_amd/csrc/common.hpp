@@ -222,6 +222,52 @@ __device__ __forceinline__ void dq2rt(const float (&dq)[8], float (&q)[4], float
     t[0] = 2.0f * d[1]; t[1] = 2.0f * d[2]; t[2] = 2.0f * d[3];
 }
 
+// np.isclose(x, target) with the default rtol 1e-5, atol 1e-8 (NaN is never close)
+__device__ __forceinline__ bool isclose_to(float x, float target) { return fabsf(x - target) <= 1e-8f + 1e-5f * fabsf(target); }
+
+// ops/vector.py:4-19 : v / (|v| + eps)
+__device__ __forceinline__ void vnormalize(const float (&v)[3], float eps, float (&o)[3]) {
+    const float inv = 1.0f / (fsqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) + eps);
+    o[0] = v[0] * inv; o[1] = v[1] * inv; o[2] = v[2] * inv;
+}
+
+// rotations/quat.py:504-576 from_to(v1, v2): rotation taking direction v1 to v2.
+__device__ __forceinline__ void from_to(const float (&v1)[3], const float (&v2)[3], bool normalize_input, float (&o)[4]) {
+    float a[3] = {v1[0], v1[1], v1[2]}, b[3] = {v2[0], v2[1], v2[2]};
+    if (normalize_input) { vnormalize(v1, 1e-8f, a); vnormalize(v2, 1e-8f, b); }
+    const float cr[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+    const float dot = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+    float ax[3];
+    vnormalize(cr, 1e-8f, ax);  // quat.normalize on a 3-vector (:545): same formula
+    const float w = fsqrt((1.0f + dot) * 0.5f), s = fsqrt((1.0f - dot) * 0.5f);
+    o[0] = w; o[1] = ax[0] * s; o[2] = ax[1] * s; o[3] = ax[2] * s;
+    if (isclose_to(dot, 1.0f)) { o[0] = 1.0f; o[1] = 0.0f; o[2] = 0.0f; o[3] = 0.0f; }  // parallel (:551-552)
+    if (isclose_to(dot, -1.0f)) {  // anti-parallel (:554-571): half turn about an axis orthogonal to v1
+        const bool xlike = isclose_to(fabsf(a[0]), 1.0f);
+        const float og[3] = {xlike ? 0.0f : 1.0f, xlike ? 1.0f : 0.0f, 0.0f};
+        const float c2[3] = {a[1] * og[2] - a[2] * og[1], a[2] * og[0] - a[0] * og[2], a[0] * og[1] - a[1] * og[0]};
+        float ax2[3];
+        vnormalize(c2, 1e-8f, ax2);
+        o[0] = 0.0f; o[1] = ax2[0]; o[2] = ax2[1]; o[3] = ax2[2];
+    }
+}
+
+// rotations/quat.py:579-650 from_to_axis(v1, v2, rot_axis): same angle, rotation axis fixed.
+__device__ __forceinline__ void from_to_axis(const float (&v1)[3], const float (&v2)[3], const float (&axis)[3],
+                                             bool normalize_input, float (&o)[4]) {
+    float a[3] = {v1[0], v1[1], v1[2]}, b[3] = {v2[0], v2[1], v2[2]};
+    if (normalize_input) { vnormalize(v1, 1e-8f, a); vnormalize(v2, 1e-8f, b); }
+    const float cr[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+    const float dot = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+    const float w = fsqrt((1.0f + dot) * 0.5f);
+    float s = fsqrt((1.0f - dot) * 0.5f);
+    const float cda = cr[0] * axis[0] + cr[1] * axis[1] + cr[2] * axis[2];
+    s *= (cda > 0.0f) ? 1.0f : ((cda < 0.0f) ? -1.0f : cda);  // np.sign (0 -> 0, NaN -> NaN)
+    o[0] = w; o[1] = axis[0] * s; o[2] = axis[1] * s; o[3] = axis[2] * s;
+    if (isclose_to(dot, 1.0f)) { o[0] = 1.0f; o[1] = 0.0f; o[2] = 0.0f; o[3] = 0.0f; }
+    if (isclose_to(dot, -1.0f)) { o[0] = 0.0f; o[1] = axis[0]; o[2] = axis[1]; o[3] = axis[2]; }
+}
+
 // ---- host-side helpers -------------------------------------------------------------------------------
 
 struct Parents {  // passed to kernels BY VALUE (kernarg segment -> s_load_dword, uniform index)

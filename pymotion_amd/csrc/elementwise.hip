@@ -220,6 +220,10 @@ PM_OP(OpSlerp, 4, 4, 1, 4, 0) {
     for (int c = 0; c < 4; ++c) y0[c] = cs * x0[c] + sn * (q2[c] / nn);
 } PM_OP_END
 
+// rotations/quat.py:504-576 / :579-650 (flag = normalize_input)
+PM_OP(OpFromTo, 3, 3, 0, 4, 0) { from_to(x0, x1, a.flag != 0, y0); } PM_OP_END
+PM_OP(OpFromToAxis, 3, 3, 3, 4, 0) { from_to_axis(x0, x1, x2, a.flag != 0, y0); } PM_OP_END
+
 static EwArgs mk(const float *i0, const float *i1, const float *i2, float *o0, float *o1, int64_t N, float eps = 0.0f,
                  int flag = 0, const uint8_t *order = nullptr) {
     EwArgs a;
@@ -461,4 +465,12 @@ extern "C" int pm_stream_plain_f32(const float *src, float *dst, int64_t n4, int
     hipLaunchKernelGGL(plain_stream_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<const v4f *>(src), reinterpret_cast<v4f *>(dst), n4, (int)ratio);
     return check_hip(hipGetLastError(), "stream_plain");
+}
+
+extern "C" int pm_quat_from_to_f32(const float *v1, const float *v2, int64_t N, int normalize_input, float *out, pm_stream_t s) {
+    return launch_ew<OpFromTo>(mk(v1, v2, nullptr, out, nullptr, N, 0.0f, normalize_input), s, "quat_from_to");
+}
+extern "C" int pm_quat_from_to_axis_f32(const float *v1, const float *v2, const float *axis, int64_t N, int normalize_input,
+                                        float *out, pm_stream_t s) {
+    return launch_ew<OpFromToAxis>(mk(v1, v2, axis, out, nullptr, N, 0.0f, normalize_input), s, "quat_from_to_axis");
 }

@@ -72,8 +72,18 @@ def mirror(
     """Mirror a skeleton pose along ``axis``.  ``mode='all'``: perfect mirror, topology mirrored too
     (offsets / end sites change sign); ``mode='symmetry'``: joints swapped through ``joints_mapping``,
     skeleton unchanged.  One fused kernel (fk -> from_matrix -> permute/negate -> from_global_rotations).
-    ``mode='positions'`` (IK through from_root_positions) is not on the GPU path.  Unlike the reference's
+    ``mode='positions'``: positions are mirrored and the rotations recovered by ``from_root_positions``
+    (twist is not preserved).  Unlike the reference's
     'symmetry' mode the caller's ``global_translation`` is not modified in place.
     Returns ``(local_rotations, global_translation, offsets, end_sites)``.
     Reference: ops/skeleton_torch.py:262-359 (and _true_mirror below it)."""
     return _ops.mirror(_be(), local_rotations, global_translation, parents, offsets, end_sites, joints_mapping, mode, axis)
+
+
+def from_root_positions(positions: torch.Tensor, parents, offsets: torch.Tensor) -> torch.Tensor:
+    """Root-centred joint positions ``[..., J, 3]`` -> local rotations ``[..., J, 4]``: every joint with
+    children is turned so that its first child points where the positions say (``quat.from_to``), further
+    children fix the roll (``quat.from_to_axis``); joints without children keep the identity.  One O(J)
+    walk per frame on the GPU instead of the reference's fk-per-joint loop.
+    Reference: ops/skeleton_torch.py:101-176."""
+    return _ops.from_root_positions(_be(), positions, parents, offsets)

@@ -5,7 +5,6 @@ Same function names, positional arguments and conventions as the reference
 ``[..., 3, 3]`` row-major.  Every function launches one hand-written gfx950 kernel from
 ``libpmhip.so`` (fp32 on the GPU); there is no CPU fallback.
 NumPy arrays are copied to the GPU and back; outputs use the dtype the reference would return.
-Not covered here (data-dependent scatter): ``from_to``, ``from_to_axis``.
 """
 import numpy as np
 
@@ -105,3 +104,16 @@ def unroll(quaternions: np.array, axis: int) -> np.array:
     reference's Python loop over frames; returns a new array (the reference flips its argument in
     place through a view).  Reference: quat.py:426-462."""
     return _ops.quat_unroll(_be(), quaternions, axis)
+
+
+def from_to(v1: np.array, v2: np.array, normalize_input: bool = True) -> np.array:
+    """Quaternion rotating direction ``v1`` onto ``v2``; parallel -> identity, anti-parallel -> a half turn
+    about an axis orthogonal to ``v1`` (``isclose`` thresholds of the reference, evaluated per element in
+    the kernel instead of masked scatters).  Reference: quat.py:504-576."""
+    return _ops.quat_from_to(_be(), v1, v2, normalize_input)
+
+
+def from_to_axis(v1: np.array, v2: np.array, rot_axis: np.array, normalize_input: bool = True) -> np.array:
+    """Same angle as ``from_to`` but about the given axis (sign from ``(v1 x v2) . rot_axis``).
+    Reference: quat.py:579-650."""
+    return _ops.quat_from_to_axis(_be(), v1, v2, rot_axis, normalize_input)

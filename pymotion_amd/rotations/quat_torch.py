@@ -5,7 +5,6 @@ Same function names, positional arguments and conventions as the reference
 ``[..., 3, 3]`` row-major.  Every function launches one hand-written gfx950 kernel from
 ``libpmhip.so`` (fp32 on the GPU); there is no CPU fallback.
 Tensors may live on a HIP device (zero-copy, torch's current stream) or on the CPU (copied over and back).
-Not covered here (data-dependent scatter): ``from_to``, ``from_to_axis``.
 """
 import torch
 
@@ -105,3 +104,16 @@ def unroll(quaternions: torch.Tensor, dim: int) -> torch.Tensor:
     reference's Python loop over frames; returns a new array (the reference flips its argument in
     place through a view).  Reference: quat_torch.py:441-477."""
     return _ops.quat_unroll(_be(), quaternions, dim)
+
+
+def from_to(v1: torch.Tensor, v2: torch.Tensor, normalize_input: bool = True) -> torch.Tensor:
+    """Quaternion rotating direction ``v1`` onto ``v2``; parallel -> identity, anti-parallel -> a half turn
+    about an axis orthogonal to ``v1`` (``isclose`` thresholds of the reference, evaluated per element in
+    the kernel instead of masked scatters).  Reference: quat_torch.py:521-601."""
+    return _ops.quat_from_to(_be(), v1, v2, normalize_input)
+
+
+def from_to_axis(v1: torch.Tensor, v2: torch.Tensor, rot_axis: torch.Tensor, normalize_input: bool = True) -> torch.Tensor:
+    """Same angle as ``from_to`` but about the given axis (sign from ``(v1 x v2) . rot_axis``).
+    Reference: quat_torch.py:603-676."""
+    return _ops.quat_from_to_axis(_be(), v1, v2, rot_axis, normalize_input)

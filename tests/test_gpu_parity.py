@@ -402,5 +402,3 @@ def test_mirror_argument_errors():
         sk.mirror(*args, mode="nope")
     with pytest.raises(ValueError):
         sk.mirror(*args, axis="W")
-    with pytest.raises(NotImplementedError):
-        sk.mirror(*args, mode="positions")
