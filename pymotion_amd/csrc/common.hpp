@@ -92,6 +92,40 @@ __device__ __forceinline__ void tile_store(float *__restrict__ g, const float *l
     }
 }
 
+// Stream n 16-byte records (lane-consecutive, dwordx4 each) from HBM through registers, calling
+// fn(e, record) for every element e: two batches of 4 loads per lane (8 KiB per wave) are always in
+// flight -- batch k+2 is requested before batch k is consumed -- so a tile costs one memory latency.
+template <bool VEC, class Fn>
+__device__ __forceinline__ void for_each_record4(const float *__restrict__ gsrc, const int n, const int lane, Fn &&fn) {
+    constexpr int B = 4 * PM_WAVE;
+    auto load = [&](const int e0, v4f (&q)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * PM_WAVE + lane;
+            if (e < n) {
+                if (VEC) q[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(gsrc) + e);
+                else q[u] = v4f{gsrc[4 * e], gsrc[4 * e + 1], gsrc[4 * e + 2], gsrc[4 * e + 3]};
+            }
+        }
+    };
+    auto use = [&](const int e0, const v4f (&q)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * PM_WAVE + lane;
+            if (e < n) fn(e, q[u]);
+        }
+    };
+    v4f qa[4], qb[4];
+    load(0, qa);
+    load(B, qb);
+    for (int e0 = 0; e0 < n; e0 += 2 * B) {
+        use(e0, qa);
+        load(e0 + 2 * B, qa);
+        use(e0 + B, qb);
+        load(e0 + 3 * B, qb);
+    }
+}
+
 // ---- per-lane AoS access to LDS with the widest conflict-free instruction per width -------------
 
 template <int W>

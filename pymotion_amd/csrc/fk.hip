@@ -368,18 +368,12 @@ __global__ __launch_bounds__(PM_WAVE) void mirror_kernel(const MirrorArgs a) {
         reinterpret_cast<v4f *>(sConst)[j] = v4f{__int_as_float(j == 0 ? -1 : a.parents.p[jc]), 0.0f, 0.0f, 0.0f};
         if (j < J) { sTab[j] = (j == 0) ? 0 : a.parents.p[j]; sTab[J + j] = a.mapping.m[j]; }
     }
-    const float *gsrc = a.rot + f0 * J * 4;
-    for (int e = lane; e < n; e += PM_WAVE) {
-        float qi[4], L[9];
-        if (VEC) {
-            const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(gsrc) + e);
-            qi[0] = t.x; qi[1] = t.y; qi[2] = t.z; qi[3] = t.w;
-        } else {
-            qi[0] = gsrc[4 * e]; qi[1] = gsrc[4 * e + 1]; qi[2] = gsrc[4 * e + 2]; qi[3] = gsrc[4 * e + 3];
-        }
+    for_each_record4<VEC>(a.rot + f0 * J * 4, n, lane, [&](const int e, const v4f q) {
+        const float qi[4] = {q.x, q.y, q.z, q.w};
+        float L[9];
         local_from_quat(qi, L);
         lds_put<9>(sRot, e, L);
-    }
+    });
     const int wl = lane % (3 * FPW);
     const int f = wl / 3, r = wl - 3 * f;
     wave_sync();

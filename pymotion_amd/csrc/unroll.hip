@@ -5,7 +5,7 @@
 // prefix product of signs of the ORIGINAL neighbours:  s_i = prod_{k<=i} sgn(dot(q_k, q_{k-1}))  with
 // sgn = -1 iff dot < 0 (the reference's `d0 < d1`), s_0 = +1.  That is a prefix XOR along time per
 // series -- a scan, not a loop:
-//   pass 1  each wave owns a chunk of 1024 consecutive frames of up to 64 series; per 64-frame sub-tile
+//   pass 1  each wave owns a chunk of 256 consecutive frames of up to 64 series; per 64-frame sub-tile
 //           the rows are staged in LDS (coalesced), lane = frame computes its flip bit per series,
 //           one wave ballot per series gives every lane its inclusive prefix parity; the chunk's total
 //           parity per series goes to the workspace;
@@ -19,7 +19,7 @@
 namespace pm {
 
 constexpr int UR_SUB = PM_WAVE;   // frames per sub-tile (lane = frame)
-constexpr int UR_CHUNK = 1024;    // frames per wave
+constexpr int UR_CHUNK = 256;     // frames per wave (4 sub-tiles): 4096 waves at 2^20 frames
 constexpr int UR_SB = 64;         // series per block
 
 struct UnrollArgs {
@@ -56,9 +56,22 @@ __global__ __launch_bounds__(PM_WAVE) void unroll_kernel(const UnrollArgs a) {
         const int nfr = (int)((t1 - ts) < UR_SUB ? (t1 - ts) : UR_SUB);
         // stage rows ts-1 .. ts+nfr-1 (row segments of sb quaternions are contiguous in HBM)
         const int first = (ts == 0) ? 1 : 0;  // no predecessor for the very first frame
-        for (int i = lane + first * sb * V; i < (nfr + 1) * sb * V; i += PM_WAVE) {
-            const int r = i / (sb * V), c = i - r * (sb * V);
-            rows[r * rs * V + c] = *(reinterpret_cast<const v4f *>(a.q) + ((ts - 1 + r) * a.S + s0) * V + c);
+        const int rowlen = sb * V;  // dwordx4 per staged row segment
+        const float inv_rowlen = 1.0f / (float)rowlen;
+        const int i_end = (nfr + 1) * rowlen;
+        for (int i0 = lane + first * rowlen; i0 < i_end; i0 += 4 * PM_WAVE) {  // 4 loads in flight per lane
+            v4f v[4];
+            int dst[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * PM_WAVE;
+                const int r = (int)(((float)i + 0.5f) * inv_rowlen), c = i - r * rowlen;
+                dst[u] = r * rs * V + c;
+                if (i < i_end) v[u] = *(reinterpret_cast<const v4f *>(a.q) + ((ts - 1 + r) * a.S + s0) * V + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u * PM_WAVE < i_end) rows[dst[u]] = v[u];
         }
         wave_sync();
         const bool act = lane < nfr;
@@ -92,15 +105,18 @@ __global__ __launch_bounds__(PM_WAVE) void unroll_kernel(const UnrollArgs a) {
     if (!APPLY && lane < sb) a.ws[(int64_t)chunk * a.S + s0 + lane] = (int)((carry >> lane) & 1ull);
 }
 
-// exclusive prefix XOR over chunks, in place; lane = series
+// exclusive prefix XOR over chunks, in place: one wave per series, lane = chunk (64 at a time), the
+// prefix inside a group of 64 chunks is a ballot + popcount
 __global__ __launch_bounds__(PM_WAVE) void unroll_scan_kernel(int32_t *ws, int nchunks, int S) {
-    const int s = blockIdx.x * PM_WAVE + threadIdx.x;
-    if (s >= S) return;
-    int acc = 0;
-    for (int c = 0; c < nchunks; ++c) {
-        const int v = ws[(int64_t)c * S + s];
-        ws[(int64_t)c * S + s] = acc;
-        acc ^= v & 1;
+    const int s = blockIdx.x, lane = threadIdx.x;
+    int carry = 0;
+    for (int base = 0; base < nchunks; base += PM_WAVE) {
+        const int c = base + lane;
+        const int v = (c < nchunks) ? (ws[(int64_t)c * S + s] & 1) : 0;
+        const unsigned long long m = __ballot(v);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (c < nchunks) ws[(int64_t)c * S + s] = (__popcll(m & below) + carry) & 1;
+        carry ^= __popcll(m) & 1;
     }
 }
 
@@ -130,7 +146,7 @@ static int unroll_launch(const float *q, int64_t T, int32_t S, float *out, void 
     if (int e = allow_lds(unroll_kernel<true, W>, lds)) return e;
     const dim3 grid((unsigned)nchunks, (unsigned)sblocks);
     hipLaunchKernelGGL((unroll_kernel<false, W>), grid, dim3(PM_WAVE), lds, s, a);
-    hipLaunchKernelGGL(unroll_scan_kernel, dim3((unsigned)((S + PM_WAVE - 1) / PM_WAVE)), dim3(PM_WAVE), 0, s, a.ws, (int)nchunks, (int)S);
+    hipLaunchKernelGGL(unroll_scan_kernel, dim3((unsigned)S), dim3(PM_WAVE), 0, s, a.ws, (int)nchunks, (int)S);
     hipLaunchKernelGGL((unroll_kernel<true, W>), grid, dim3(PM_WAVE), lds, s, a);
     return check_hip(hipGetLastError(), "quat_unroll");
 }

@@ -116,6 +116,16 @@ def main():
             report(f"to_root_dq J={J}", ms, mn, Fj * (48 * J + 12))
             ms, mn = timeit(lambda: _lib.call("pm_from_root_dq_f32", p(dq), pp, Fj, J, p(tr), p(qo), None))
             report(f"from_root_dq J={J}", ms, mn, Fj * 60 * J)
+        if want("mirror"):
+            ms, mn = timeit(lambda: _lib.call("pm_mirror_rotations_f32", p(rotn), pp, None, 0, Fj, J, p(qo), None))
+            report(f"mirror (all) J={J}", ms, mn, Fj * 32 * J)
+        if want("ik"):
+            ms, mn = timeit(lambda: _lib.call("pm_from_root_positions_f32", p(pos), pp, p(off), Fj, J, p(qo), None))
+            report(f"from_root_positions J={J}", ms, mn, Fj * 28 * J)
+        if want("unroll"):
+            ws = torch.empty(int(_lib.lib().pm_quat_unroll_workspace_bytes(Fj, J)) + 16, dtype=torch.uint8, device=dev)
+            ms, mn = timeit(lambda: _lib.call("pm_quat_unroll_f32", p(rotn), Fj, J, p(qo), p(ws), None))
+            report(f"quat.unroll axis=0 J={J}", ms, mn, Fj * 48 * J)
         if want("o6d") and J == 52:
             x = torch.randn((Fj, J, 3, 2), device=dev)
             ms, mn = timeit(lambda: _lib.call("pm_fk_from_ortho6d_f32", p(x), p(root), p(off), 0, pp, Fj, J, C.c_float(0.0),
