@@ -42,7 +42,8 @@ def parse():
     ap.add_argument("--joints", type=int, default=22, choices=[22, 52])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=1 << 20)
-    ap.add_argument("--gather", action="store_true", help="also time the RCCL all-gather of (pos, rotmats) (N>1)")
+    ap.add_argument("--no-gather", action="store_true", help="skip the separate timing of the RCCL all-gather of (pos, rotmats) (N>1)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short measurements of BASELINE configs 3 and 4 (N=1)")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
 
@@ -80,6 +81,59 @@ def cpu_baseline(rot, root, off, parents, sample_frames):
         "cpu_model": model,
     }
     return info, pos, rm
+
+
+def secondary_configs(torch, _lib, syn, dev, rot, root, off, parents, sptr):
+    """BASELINE.json configs[2] (dual-quaternion round trip, 22 joints, 2^20 frames) and configs[3] (fused
+    ortho6d.to_quat -> fk, 52 joints, 2^18 frames): same device-resident method as the headline (150 untimed
+    launches, then 100 timed back to back between two HIP events).  Reported, never folded into `value`."""
+    import numpy as np
+
+    F, J = rot.shape[0], rot.shape[1]
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    pp = parents.ctypes.data_as(C.c_void_p)
+    ev = [C.c_void_p(), C.c_void_p()]
+    for e in ev:
+        _lib.call("pm_event_create", C.byref(e))
+
+    def timed(fn, n=100):
+        for _ in range(150):
+            fn()
+        _lib.call("pm_event_record", ev[0], sptr)
+        for _ in range(n):
+            fn()
+        _lib.call("pm_event_record", ev[1], sptr)
+        ms = C.c_float()
+        _lib.call("pm_event_elapsed_ms", ev[0], ev[1], C.byref(ms))
+        return ms.value / n
+
+    out = {}
+    rotn = rot / rot.norm(dim=-1, keepdim=True)
+    dq = torch.empty((F, J, 8), device=dev)
+    tr = torch.empty((F, J, 3), device=dev)
+    qo = torch.empty((F, J, 4), device=dev)
+    t_to = timed(lambda: _lib.call("pm_to_root_dq_f32", p(rotn), p(root), pp, p(off), F, J, p(dq), sptr))
+    t_from = timed(lambda: _lib.call("pm_from_root_dq_f32", p(dq), pp, F, J, p(tr), p(qo), sptr))
+    b_to, b_from = F * (48 * J + 12), F * 60 * J
+    out["dual_quat_round_trip_J22"] = {
+        "frames": F, "to_root_ms": t_to, "from_root_ms": t_from, "frames_per_s": F / ((t_to + t_from) * 1e-3),
+        "hbm_frac": (b_to + b_from) / ((t_to + t_from) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        "round_trip_max_abs_err": {"rot": float((qo - rotn).abs().max()), "offsets": float((tr[:, 1:] - off[1:]).abs().max()),
+                                   "root": float((tr[:, 0] - root).abs().max())},
+    }
+    del dq, tr, qo, rotn
+    F4, par52 = 1 << 18, syn.PARENTS_52
+    x = torch.randn((F4, 52, 3, 2), device=dev)
+    root4 = torch.rand((F4, 3), device=dev) * 4 - 2
+    off4 = torch.from_numpy(syn.make_offsets(52, np.random.default_rng(4), 0.15)).to(dev)
+    pos4 = torch.empty((F4, 52, 3), device=dev)
+    rm4 = torch.empty((F4, 52, 3, 3), device=dev)
+    pp4 = par52.ctypes.data_as(C.c_void_p)
+    t4 = timed(lambda: _lib.call("pm_fk_from_ortho6d_f32", p(x), p(root4), p(off4), 0, pp4, F4, 52, C.c_float(0.0), p(pos4), p(rm4),
+                                 None, sptr))
+    out["fused_ortho6d_fk_J52"] = {"frames": F4, "ms": t4, "frames_per_s": F4 / (t4 * 1e-3),
+                                   "hbm_frac": F4 * (72 * 52 + 12) / (t4 * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    return out
 
 
 def main():
@@ -177,7 +231,7 @@ def main():
         wall, kern_ms = float(tt[0]), float(tt[1])
 
     extra = {}
-    if use_dist and a.gather:
+    if use_dist and world > 1 and not a.no_gather:
         from pymotion_amd.parallel import all_gather_frames
 
         torch.cuda.synchronize()
@@ -193,6 +247,9 @@ def main():
                            "busbw_GBps_per_gpu": shard_bytes * (world - 1) / (g1 - g0) / 1e9,
                            "note": "one all_gather_into_tensor per output; compute-only value excludes it"}
         del gp, gr
+
+    if world == 1 and not a.no_secondary and J == 22:
+        extra["secondary"] = secondary_configs(torch, _lib, syn, dev, rot, root, off, parents, sptr)
 
     if rank == 0:
         bytes_per_frame = 64 * J + 12
