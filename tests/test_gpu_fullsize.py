@@ -130,8 +130,9 @@ def test_config4_fused_ortho6d_fk_256k_frames_52_joints():
     assert float(okf.float().mean()) > 0.4
     assert float((q - q2)[okf].abs().max()) < 1e-5
     assert float((pos - p2)[okf].abs().max()) < 1e-5 and float((rm - r2)[okf].abs().max()) < 1e-5
-    p3, r3 = skt.fk_from_ortho6d(x, root, off, par)  # without the quaternion output: identical transforms
-    assert torch.equal(p3, pos) and torch.equal(r3, rm)
+    p3, r3 = skt.fk_from_ortho6d(x, root, off, par)  # without the quaternion output: Gram-Schmidt matrix used directly
+    assert float((p3 - pos)[okf].abs().max()) < 1e-5 and float((r3 - rm)[okf].abs().max()) < 1e-5
+    assert _ortho_err(r3[okf]) < 2e-5
     # Gram-Schmidt of random gaussians can be ill-conditioned (near-parallel columns): compare with the
     # oracle where the conditioning is sane, and require orthonormal outputs everywhere
     sl = slice(777, 777 + 1024)
