@@ -48,6 +48,15 @@ def parse():
     return ap.parse_args()
 
 
+def _blas_threads():
+    try:
+        from threadpoolctl import threadpool_info
+
+        return {i.get("internal_api", "?"): i.get("num_threads") for i in threadpool_info()}
+    except Exception:
+        return None
+
+
 def cpu_baseline(rot, root, off, parents, sample_frames):
     """Time the NumPy port of the reference fk on a bounded sample; also return its outputs."""
     import numpy as np
@@ -78,6 +87,8 @@ def cpu_baseline(rot, root, off, parents, sample_frames):
         "sample": f"{n} frames x {rot.shape[1]} joints, oracle/numpy_ref.fk_chunked (f64 [F,J,4,4] scratch, "
                   f"per-joint batched matmul, chunks of 2^17), {wall:.1f} s wall",
         "host_cpus_visible": len(os.sched_getaffinity(0)),
+        "os_cpu_count": os.cpu_count(),
+        "blas_threads": _blas_threads(),
         "cpu_model": model,
     }
     return info, pos, rm

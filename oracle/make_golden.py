@@ -320,58 +320,12 @@ def gen_skeleton():
     s.save("skeleton.npz")
 
 
-def write_synthetic_bvh(path, n_frames=48, seed=7):
-    """Deterministic 22-joint BVH (joint names of the reference's README.md:49, topology
-    synthetic.PARENTS_22, metre-scale offsets, End Sites on the leaves).  Angles drift smoothly over
-    several turns so that consecutive quaternions cross the double cover and `unroll` has work to do."""
-    rng = np.random.default_rng(seed)
-    names, parents = syn.JOINT_NAMES_22, syn.PARENTS_22
-    J = len(names)
-    off = syn.make_offsets(J, rng, 0.3).astype(np.float64).round(6)
-    kids = [[] for _ in range(J)]
-    for j in range(1, J):
-        kids[parents[j]].append(j)
-    lines = ["HIERARCHY"]
-
-    def emit(j, depth):
-        tab = "\t" * depth
-        lines.append(f"{tab}{'ROOT' if j == 0 else 'JOINT'} {names[j]}")
-        lines.append(tab + "{")
-        lines.append(f"{tab}\tOFFSET {off[j, 0]:.6f} {off[j, 1]:.6f} {off[j, 2]:.6f}")
-        if j == 0:
-            lines.append(f"{tab}\tCHANNELS 6 Xposition Yposition Zposition Zrotation Xrotation Yrotation")
-        else:
-            lines.append(f"{tab}\tCHANNELS 3 " + ("Zrotation Xrotation Yrotation" if j % 2 else "Yrotation Zrotation Xrotation"))
-        for c in kids[j]:
-            emit(c, depth + 1)
-        if not kids[j]:
-            lines.append(f"{tab}\tEnd Site")
-            lines.append(tab + "\t{")
-            lines.append(f"{tab}\t\tOFFSET 0.000000 0.100000 0.000000")
-            lines.append(tab + "\t}")
-        lines.append(tab + "}")
-
-    emit(0, 0)
-    lines += ["MOTION", f"Frames: {n_frames}", "Frame Time: 0.016667"]
-    t = np.arange(n_frames)[:, None, None]
-    rate = rng.uniform(-25, 25, (1, J, 3))
-    ang = rng.uniform(-180, 180, (1, J, 3)) + rate * t + rng.normal(0, 2, (n_frames, J, 3))
-    root = np.cumsum(rng.normal(0, 0.01, (n_frames, 3)), axis=0) + [0.0, 0.9, 0.0]
-    for f in range(n_frames):
-        vals = list(root[f]) + list(ang[f, 0])
-        for j in range(1, J):
-            vals += list(ang[f, j])
-        lines.append(" ".join(f"{v:.6f}" for v in vals))
-    with open(path, "w") as fh:
-        fh.write("\n".join(lines) + "\n")
-
-
 def gen_bvh():
     from pymotion.io.bvh import BVH
 
     s = Store()
     path = os.path.join(OUT, "synthetic22.bvh")
-    write_synthetic_bvh(path)
+    syn.write_synthetic_bvh(path)
     b = BVH()
     b.load(path)
     d = b.data

@@ -99,3 +99,25 @@ def test_gpu_bvh_get_data_and_fk_match_reference():
     d = np.abs(b.data["rotations"] - g.get("set_data", "out64")["rotations"])
     d = np.minimum(d, 360.0 - d)
     assert d.max() < 0.05  # fp32 atan2 near gimbal configurations, in degrees
+
+
+@pytest.mark.gpu
+def test_config1_bvh_1000_frames_gpu_vs_numpy_cpu_reference(tmp_path):
+    """BASELINE.json configs[0]: NumPy fk on a 22-joint BVH, 1000 frames (CPU) -- the same arrays through the
+    GPU path must agree to 1e-5.  The file is generated on the fly (seeded), read by the build's own loader."""
+    import pymotion_amd.ops.skeleton as sk
+    from oracle import numpy_ref as nr
+    from pymotion_amd import synthetic as syn
+
+    path = str(tmp_path / "clip1000.bvh")
+    syn.write_synthetic_bvh(path, n_frames=1000, seed=123)
+    b = BVH()
+    b.load(path)
+    rots, pos, parents, offsets, _, _ = b.get_data()
+    assert rots.shape == (1000, 22, 4) and rots.dtype == np.float64
+    assert np.abs(np.linalg.norm(rots, axis=-1) - 1).max() < 1e-6
+    assert (np.sum(rots[1:] * rots[:-1], axis=-1) >= 0).all()  # unrolled along frames
+    p_gpu, r_gpu = sk.fk(rots, pos[:, 0, :], offsets, parents)
+    p_cpu, r_cpu = nr.fk(rots, pos[:, 0, :], offsets, parents)  # the reference algorithm, float64
+    assert_close(p_gpu, np.ascontiguousarray(p_cpu), 1e-5, "config 1 positions")
+    assert_close(r_gpu, np.ascontiguousarray(r_cpu), 1e-5, "config 1 rotation matrices")
