@@ -6,6 +6,8 @@
 // tile bases are multiples of 1 KiB) -> registers (per-record read, widest conflict-free DS op), and
 // results go back the same way.  All of these ops are HBM-bound (16-60 B per element, a few dozen
 // flops): the kernel's job is to keep every byte it touches inside full 128-byte lines.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace pm {
@@ -327,13 +329,17 @@ __global__ __launch_bounds__(PM_WAVE) void ceiling_kernel(const float *__restric
 // Plain streaming probe without LDS: every thread reads one dwordx4 and writes `ratio` dwordx4 (each store
 // instruction of a wave covers 1 KiB contiguous).  256-thread blocks, grid-stride.  What the memory system
 // sustains for a given read:write mix, independent of any tiling of ours.
+template <int MODE>  // bit 0: nontemporal loads, bit 1: nontemporal stores
 __global__ __launch_bounds__(256) void plain_stream_kernel(const v4f *__restrict__ src, v4f *__restrict__ dst, int64_t n4,
                                                            int ratio) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        const v4f v = __builtin_nontemporal_load(src + i);
+        const v4f v = (MODE & 1) ? __builtin_nontemporal_load(src + i) : src[i];
         const int64_t w = i >> 6, l = i & 63;
-        for (int k = 0; k < ratio; ++k) __builtin_nontemporal_store(v, dst + (w * ratio + k) * 64 + l);
+        for (int k = 0; k < ratio; ++k) {
+            if (MODE & 2) __builtin_nontemporal_store(v, dst + (w * ratio + k) * 64 + l);
+            else dst[(w * ratio + k) * 64 + l] = v;
+        }
     }
 }
 
@@ -462,8 +468,17 @@ extern "C" int pm_dq_unit_flags_f32(const float *dq, int64_t N, float atol, int3
 extern "C" int pm_stream_plain_f32(const float *src, float *dst, int64_t n4, int32_t ratio, int32_t blocks, pm_stream_t stream) {
     PM_CHECK_ARGS(src && dst && n4 >= 0 && ratio >= 1 && blocks >= 1 && aligned16(src) && aligned16(dst), "stream_plain: bad arguments");
     if (n4 == 0) return PM_OK;
-    hipLaunchKernelGGL(plain_stream_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<const v4f *>(src), reinterpret_cast<v4f *>(dst), n4, (int)ratio);
+    const char *m = getenv("PM_PLAIN_MODE");  // tuning aid: 0..3 = nontemporal {none, loads, stores, both}
+    const int mode = m ? atoi(m) : 3;
+    auto *s4 = reinterpret_cast<const v4f *>(src);
+    auto *d4 = reinterpret_cast<v4f *>(dst);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (mode & 3) {
+        case 0: hipLaunchKernelGGL(plain_stream_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, s4, d4, n4, (int)ratio); break;
+        case 1: hipLaunchKernelGGL(plain_stream_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, s4, d4, n4, (int)ratio); break;
+        case 2: hipLaunchKernelGGL(plain_stream_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, s4, d4, n4, (int)ratio); break;
+        default: hipLaunchKernelGGL(plain_stream_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, st, s4, d4, n4, (int)ratio); break;
+    }
     return check_hip(hipGetLastError(), "stream_plain");
 }
 

@@ -366,8 +366,8 @@ __global__ __launch_bounds__(PM_WAVE) void mirror_kernel(const MirrorArgs a) {
     const int FJ = FPW * J;
     const int n = nf * J;
     float *sRot = smem;                 // [FJ*9]  world rotations; reused as the output staging [FJ*4]
-    float *sPos = sRot + FJ * 9;        // [FJ*3]  (the walk writes positions too; unused here)
-    float *sQ = sPos + FJ * 3;          // [FJ*4]  world quaternions
+    float *sQ = sRot + FJ * 9;          // [FJ*4]  world quaternions (phase C on)
+    float *sPos = sQ;                   //         the walk's positions are not needed: they land here and are overwritten
     float *sConst = sQ + FJ * 4;        // [(J+1)*4]
     int *sTab = reinterpret_cast<int *>(sConst + 4 * (J + 1));  // [2J] parent | mapping
 
@@ -382,10 +382,14 @@ __global__ __launch_bounds__(PM_WAVE) void mirror_kernel(const MirrorArgs a) {
         local_from_quat(qi, L);
         lds_put<9>(sRot, e, L);
     });
-    const int wl = lane % (3 * FPW);
-    const int f = wl / 3, r = wl - 3 * f;
+    constexpr bool QUAD = FPW <= 5;  // as in fk_tile: twelve lanes per frame for big skeletons
+    const int wl = lane % ((QUAD ? 12 : 3) * FPW);
+    const int f = QUAD ? wl / 12 : wl / 3;
+    const int r = QUAD ? (wl - 12 * f) / 4 : wl - 3 * f;
+    const int c = wl & 3;
     wave_sync();
-    tree_walk<false>(sRot, sPos, nullptr, sConst, J, f, r, 0.0f, false);
+    if constexpr (QUAD) tree_walk_quad<false>(sRot, sPos, nullptr, sConst, J, f, r, c, (c == r) ? 1.0f : 0.0f);
+    else tree_walk<false>(sRot, sPos, nullptr, sConst, J, f, r, 0.0f, false);
     wave_sync();
     for (int e = lane; e < n; e += PM_WAVE) {  // world rotation -> quaternion
         float m[9], q[4];
@@ -498,7 +502,7 @@ static int fk_common(int src_kind, const float *src, const float *root_pos, cons
 
 template <int FPW>
 static int launch_mirror(const MirrorArgs &a, bool vec, hipStream_t s) {
-    const size_t lds = ((size_t)FPW * a.J * 16 + 4 * (a.J + 1) + 2 * a.J) * sizeof(float);
+    const size_t lds = ((size_t)FPW * a.J * 13 + 4 * (a.J + 1) + 2 * a.J) * sizeof(float);
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
     const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
     if (grid > 0x7fffffffLL) { set_error("mirror: grid too large"); return PM_EUNSUPPORTED; }
@@ -535,18 +539,9 @@ extern "C" int pm_mirror_rotations_f32(const float *rot, const int32_t *parents,
     }
     const bool vec = aligned16(rot) && aligned16(out);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t per_frame = (size_t)J * 16 * sizeof(float), fixed = (6 * (size_t)J + 4) * sizeof(float) + 256;
-    static const int cand[] = {20, 12, 8, 4};
-    for (int want = 5; want >= 1; want -= 2)
-        for (int c : cand)
-            if ((size_t)want * (c * per_frame + fixed) <= kMaxLds) {
-                switch (c) {
-                    case 20: return launch_mirror<20>(a, vec, s);
-                    case 12: return launch_mirror<12>(a, vec, s);
-                    case 8: return launch_mirror<8>(a, vec, s);
-                    default: return launch_mirror<4>(a, vec, s);
-                }
-            }
+    const size_t per_frame = (size_t)J * 13 * sizeof(float), fixed = (6 * (size_t)J + 4) * sizeof(float) + 256;
+    if (7 * (20 * per_frame + fixed) <= kMaxLds) return launch_mirror<20>(a, vec, s);
+    if (4 * per_frame + fixed <= kMaxLds) return launch_mirror<4>(a, vec, s);
     set_error("mirror: J=%d does not fit the LDS tile", J);
     return PM_EUNSUPPORTED;
 }

@@ -405,3 +405,28 @@ def test_mirror_argument_errors():
         sk.mirror(*args, mode="nope")
     with pytest.raises(ValueError):
         sk.mirror(*args, axis="W")
+
+
+@pytest.mark.parametrize("J", [52, 31, 130])
+def test_mirror_big_skeletons_vs_oracle_composition(J):
+    """Skeletons too big for 20 frames per wave take the twelve-lanes-per-frame walk: check against the
+    reference's chain rebuilt from oracle pieces (fk -> from_matrix -> negate -> from_global_rotations)."""
+    from pymotion_amd import synthetic as syn
+
+    rng = np.random.default_rng(J)
+    parents = syn.PARENTS_52 if J == 52 else syn.random_parents(J, rng)
+    F = 257
+    rot = rng.standard_normal((F, J, 4)).astype(np.float32)
+    rot /= np.linalg.norm(rot, axis=-1, keepdims=True)
+    root = rng.uniform(-1, 1, (F, 3)).astype(np.float32)
+    off = syn.make_offsets(J, rng, 0.1)
+    got, gt, o2, _ = sk.mirror(rot, root, parents, off, None, None, "all", "Y")
+    _, rm = co.fk(rot.astype(np.float64), np.zeros((F, 3)), off.astype(np.float64), parents)
+    g = co.quat_from_matrix(rm)
+    g[..., 1] *= -1  # axis Y -> components (1, 3)  (skeleton.py:313-315)
+    g[..., 3] *= -1
+    want = co.from_global_rotations(g, parents)
+    err = np.minimum(np.abs(got - want).max(-1), np.abs(got + want).max(-1)).max()
+    assert err <= ATOL, err
+    assert_close(gt, root * np.array([1, -1, 1], np.float32), 0, "translation")
+    assert_close(o2, off * np.array([1, -1, 1], np.float32), 0, "offsets")
