@@ -430,3 +430,41 @@ def test_mirror_big_skeletons_vs_oracle_composition(J):
     assert err <= ATOL, err
     assert_close(gt, root * np.array([1, -1, 1], np.float32), 0, "translation")
     assert_close(o2, off * np.array([1, -1, 1], np.float32), 0, "offsets")
+
+
+def test_fk_is_hip_graph_capturable_and_stream_ordered():
+    """The C ABI does no allocation / synchronisation of its own: a call on torch's capturing stream lands in
+    a HIP graph and replays with new inputs in the same buffers."""
+    import ctypes as C
+
+    from pymotion_amd import _lib
+    from pymotion_amd import synthetic as syn
+
+    torch = _torch_mods()[0]
+    rot, root, off, parents = syn.fk_workload(2000, seed=21)
+    d_rot, d_root, d_off = (torch.from_numpy(x).cuda() for x in (rot, root, off))
+    pos = torch.zeros((2000, 22, 3), device="cuda")
+    rm = torch.zeros((2000, 22, 3, 3), device="cuda")
+    pp = parents.ctypes.data_as(C.c_void_p)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+
+    def launch():
+        _lib.call("pm_fk_f32", p(d_rot), p(d_root), p(d_off), 0, pp, 2000, 22, p(pos), p(rm),
+                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        launch()  # warm-up outside capture (module load)
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        launch()
+    rot2, root2, _, _ = syn.fk_workload(2000, seed=22)
+    d_rot.copy_(torch.from_numpy(rot2))
+    d_root.copy_(torch.from_numpy(root2))
+    pos.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    p_o, r_o = co.fk(rot2.astype(np.float64), root2.astype(np.float64), off.astype(np.float64), parents)
+    assert_close(pos.cpu().numpy(), p_o, ATOL, "graph replay pos")
+    assert_close(rm.cpu().numpy(), r_o, ATOL, "graph replay rotmats")
