@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""End-to-end time of the NumPy front door (host arrays in, host arrays out: H2D + kernel + D2H + float64
+cast), next to the device-resident kernel time.  For the PCIe-inclusive note in DESIGN.md §6."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import pymotion_amd.ops.skeleton as sk
+from pymotion_amd import synthetic as syn
+
+for F in (1000, 1 << 17, 1 << 20):
+    rot, root, off, par = syn.fk_workload(F, seed=1)
+    sk.fk(rot[:64], root[:64], off, par)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        pos, rm = sk.fk(rot, root, off, par)
+        ts.append(time.perf_counter() - t0)
+    t = min(ts)
+    moved = F * (64 * 22 + 12)
+    print(f"NumPy door fk F={F}: {t * 1e3:.2f} ms  {F / t:.3e} frames/s  ({moved / t / 1e9:.1f} GB/s of fp32 payload over PCIe, output cast to float64)")
