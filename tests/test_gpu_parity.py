@@ -300,6 +300,12 @@ def test_fk_and_dq_vs_oracle_sizes(F, J):
     gpos = rng.uniform(-2, 2, (F, 3)).astype(np.float32)
     off = syn.make_offsets(J, rng, 0.3 if J <= 52 else 0.05)
     f64 = lambda a: a.astype(np.float64)  # noqa: E731
+    rot_z = rot.copy()
+    rot_z[::5, ::3] = 0  # zero quaternions -> identity local rotation (quat.py:423), on every kernel shape
+    pz, rz = sk.fk(rot_z, gpos, off, parents)
+    pz_o, rz_o = co.fk(f64(rot_z), f64(gpos), f64(off), parents)
+    assert_close(pz, pz_o, ATOL, "fk pos with zero quats")
+    assert_close(rz, rz_o, ATOL, "fk rotmats with zero quats")
     pos, rm = sk.fk(rot, gpos, off, parents)
     p_o, r_o = co.fk(f64(rot), f64(gpos), f64(off), parents)
     assert_close(pos, p_o, ATOL, "fk pos")
