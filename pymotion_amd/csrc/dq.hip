@@ -281,11 +281,17 @@ __global__ __launch_bounds__(PM_WAVE) void gather_parent_kernel(const GatherArgs
 
 template <int MODE>
 static int launch_gather(const GatherArgs &a, bool vec, hipStream_t s) {
-    // frames per wave: multiple of 4 (16-byte tile bases), ~256 (frame,joint) items per wave
+    // Frames per wave: a multiple of 4 (16-byte tile bases) giving ~160-210 (frame,joint) items per wave.
+    // Small tiles win here -- there is no chain to amortise and many resident waves hide the load latency
+    // (measured at 2^20 x 22: 8/12/16/20 frames per wave -> 250/266/312/314 us; at 2^18 x 52: 4/8 -> 174/192).
     const size_t per_frame = (size_t)a.J * gather_lds_w<MODE>() * sizeof(float);
     const size_t extra = (size_t)a.J * sizeof(int);  // parents table
-    int fpw = (int)((256 + a.J - 1) / a.J);
-    fpw = (fpw + 3) & ~3;
+    int fpw = ((160 + a.J - 1) / a.J + 3) & ~3;
+    if (fpw < 4) fpw = 4;
+    {
+        const char *e = getenv("PM_GATHER_FPW");  // tuning aid
+        if (e && atoi(e) >= 4) fpw = atoi(e) & ~3;
+    }
     while (fpw > 4 && fpw * per_frame + extra > kMaxLds / 4) fpw -= 4;
     if (fpw * per_frame + extra > kMaxLds) { set_error("gather: J too large for LDS"); return PM_EUNSUPPORTED; }
     const size_t lds = fpw * per_frame + extra;
