@@ -1,6 +1,7 @@
 // elementwise.hip -- quaternion / dual-quaternion / ortho6d element-wise conversions for gfx950.
 //
-// One templated streaming kernel: a wave owns a tile of 256 elements (4 per lane).  Each operand is
+// One templated streaming kernel: a wave owns a tile of 128 elements (2 per lane; measured 64/128/256: small
+// tiles = more resident waves win by 5-12 % on the narrow records, 128 is the best overall).  Each operand is
 // an AoS record of W floats (W in {1,3,4,6,8,9}); records of odd width cannot be moved with aligned
 // dwordx4 per lane directly, so every operand goes HBM -> LDS (contiguous dwordx4, perfectly coalesced,
 // tile bases are multiples of 1 KiB) -> registers (per-record read, widest conflict-free DS op), and
@@ -12,7 +13,7 @@
 
 namespace pm {
 
-constexpr int EW_TILE = 256;  // elements per wave
+constexpr int EW_TILE = 128;  // elements per wave
 constexpr int EW_PER_LANE = EW_TILE / PM_WAVE;
 
 struct EwArgs {
