@@ -261,7 +261,7 @@ __device__ __forceinline__ bool isclose_to(float x, float target) { return fabsf
 
 // ops/vector.py:4-19 : v / (|v| + eps)
 __device__ __forceinline__ void vnormalize(const float (&v)[3], float eps, float (&o)[3]) {
-    const float inv = 1.0f / (fsqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) + eps);
+    const float inv = frcp(fsqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) + eps);
     o[0] = v[0] * inv; o[1] = v[1] * inv; o[2] = v[2] * inv;
 }
 
@@ -276,7 +276,8 @@ __device__ __forceinline__ void from_to(const float (&v1)[3], const float (&v2)[
     const float w = fsqrt((1.0f + dot) * 0.5f), s = fsqrt((1.0f - dot) * 0.5f);
     o[0] = w; o[1] = ax[0] * s; o[2] = ax[1] * s; o[3] = ax[2] * s;
     if (isclose_to(dot, 1.0f)) { o[0] = 1.0f; o[1] = 0.0f; o[2] = 0.0f; o[3] = 0.0f; }  // parallel (:551-552)
-    if (isclose_to(dot, -1.0f)) {  // anti-parallel (:554-571): half turn about an axis orthogonal to v1
+    const bool anti = isclose_to(dot, -1.0f);
+    if (__builtin_amdgcn_ballot_w64(anti) != 0 && anti) {  // anti-parallel (:554-571), rare: skipped by the whole wave otherwise
         const bool xlike = isclose_to(fabsf(a[0]), 1.0f);
         const float og[3] = {xlike ? 0.0f : 1.0f, xlike ? 1.0f : 0.0f, 0.0f};
         const float c2[3] = {a[1] * og[2] - a[2] * og[1], a[2] * og[0] - a[0] * og[2], a[0] * og[1] - a[1] * og[0]};

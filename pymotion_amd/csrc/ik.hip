@@ -14,6 +14,8 @@
 //     G_j = G_pre (x) rot_j/(|rot_j| + 1e-8)  (fk normalises its inputs, skeleton.py:45; from_to's axis is only
 //     unit up to its own eps);  joints without children keep the identity (:126-130).
 // HBM traffic: 12 J B/frame in, 16 J out.  Positions are staged in LDS (coalesced), results leave coalesced.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace pm {
@@ -152,6 +154,14 @@ extern "C" int pm_from_root_positions_f32(const float *positions, const int32_t 
     const bool vec = aligned16(positions) && aligned16(rotations);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t per_frame = (size_t)(2 * (4 * J + 4) + 3 * J) * sizeof(float), fixed = (size_t)(6 * J + 2) * sizeof(float) + 256;
+    {
+        const char *e = getenv("PM_IK_FPW");  // tuning aid
+        const int v = e ? atoi(e) : 0;
+        if (v == 64 && 64 * per_frame + fixed <= kMaxLds) return launch_ik<64>(a, vec, s);
+        if (v == 32 && 32 * per_frame + fixed <= kMaxLds) return launch_ik<32>(a, vec, s);
+        if (v == 16) return launch_ik<16>(a, vec, s);
+        if (v == 8) return launch_ik<8>(a, vec, s);
+    }
     if (5 * (32 * per_frame + fixed) <= kMaxLds) return launch_ik<32>(a, vec, s);
     if (2 * (16 * per_frame + fixed) <= kMaxLds) return launch_ik<16>(a, vec, s);
     if (4 * per_frame + fixed <= kMaxLds) return launch_ik<4>(a, vec, s);
