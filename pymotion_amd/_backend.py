@@ -115,7 +115,11 @@ class NumpyBackend:
         dt = np.result_type(*[np.asarray(x).dtype for x in xs])
         return dt if dt.kind == "f" else np.dtype(np.float64)
 
-    always64 = np.dtype(np.float64)  # what the reference hard-codes for some outputs
+    @property
+    def always64(self):  # what the reference hard-codes for some outputs (opt-out: config.numpy_float64_outputs)
+        from . import config
+
+        return np.dtype(np.float64) if config.numpy_float64_outputs else np.dtype(np.float32)
 
     def stream(self):
         return None

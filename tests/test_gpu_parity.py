@@ -501,3 +501,19 @@ def test_maximum_joint_count_everywhere():
     assert np.minimum(np.abs(r_ik - r_or).max(-1), np.abs(r_ik + r_or).max(-1)).max() <= 1e-3
     with pytest.raises(ValueError):
         sk.fk(np.zeros((2, 513, 4), np.float32), np.zeros((2, 3), np.float32), np.zeros((513, 3), np.float32), np.maximum(np.arange(513) - 1, 0))
+
+
+def test_numpy_float64_output_opt_out():
+    from pymotion_amd import config
+    from pymotion_amd import synthetic as syn
+
+    rot, root, off, par = syn.fk_workload(100, seed=2)
+    assert sk.fk(rot, root, off, par)[0].dtype == np.float64
+    config.numpy_float64_outputs = False
+    try:
+        p32, r32 = sk.fk(rot, root, off, par)
+        assert p32.dtype == np.float32 and r32.dtype == np.float32
+        assert quat.to_matrix(rot[0]).dtype == np.float32
+    finally:
+        config.numpy_float64_outputs = True
+    assert_close(p32, sk.fk(rot, root, off, par)[0], 0, "same values, only the dtype differs")
