@@ -121,39 +121,77 @@ __device__ __forceinline__ void tree_walk(float *sRot, float *sPos, const float 
 // lanes per frame a wave needs 8-20 frames to be worth its instructions.  Here a QUAD (4 consecutive
 // lanes) owns row r of a frame and each lane ONE element of it (c < 3: R[r][c], c = 3: p[r]):
 //     G[r][c] = sum_k Gp[r][k] * [L | t][k][c]  (+ Gp[r][3] for c = 3)
-// The parent row lives in the quad's own registers (previous joint) and is broadcast with DPP quad_perm,
-// so a chain step is 3 FMAs per lane and never goes through LDS; a wave walks only FPW <= 5 frames
-// (4 KiB of LDS at J = 22, 10 KiB at J = 52) and many more waves are resident to hide latency.
+// The parent row lives in the quad's own registers (previous joint) and is broadcast by the DPP operand
+// of the multiply itself, so a chain step is 4 VALU instructions per lane and never goes through LDS;
+// a wave walks only FPW <= 5 frames (10 KiB of LDS at J = 52) and many more waves are resident.
+// These kernels sit close to the VALU issue limit (one wave64 instruction = 4 cycles of a SIMD), so
+// the step is kept to ~10 instructions:
+//   * phase A leaves L TRANSPOSED in the slot, so the three coefficients of a lane (column c of L, or
+//     the offset t for the position lane) are contiguous: one pointer, immediate offsets;
+//   * the parent indices ride in a VGPR across the lanes (lane i = joint base + i), one v_readlane per
+//     step instead of an LDS read + readfirstlane behind an lgkmcnt wait.
+
+// sum_k bcast_k(e) * a_k over the quad (k = 0..2), DPP folded into the multiplies.
+__device__ __forceinline__ float quad_dot3(const float e, const float a0, const float a1, const float a2) {
+    float acc;
+    // s_nop 1: a VGPR written by VALU needs two wait states before a DPP read (the assembler does not
+    // pad inside inline asm)
+    asm("s_nop 1\n\t"
+        "v_mul_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %3 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %4 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf"
+        : "=&v"(acc)
+        : "v"(e), "v"(a0), "v"(a1), "v"(a2));
+    return acc;
+}
+
 template <bool PFO>
 __device__ __forceinline__ void tree_walk_quad(float *sRot, float *sPos, const float *sOff, const float *sConst,
-                                               const int J, const int f, const int r, const int c, const float seed) {
+                                               const int J, const int f, const int r, const int c, const float seed,
+                                               const int lane) {
     float *fL = sRot + f * J * 9;
-    float *fPos = sPos + f * J * 3;
-    // what this lane multiplies the parent row with at joint j: column c of L_j (stride 3 in the slot) or,
-    // for the position lane, the offset t_j (from the constant table, or the per-frame offsets tile)
-    const float *coef0 = (c < 3) ? (fL + c) : (PFO ? sOff + f * J * 3 : sConst + 1);
-    const int cstep = (c < 3) ? 9 : (PFO ? 3 : 4), kstep = (c < 3) ? 3 : 1;
-    // where this lane's element of joint j lives in the image
-    float *own0 = (c < 3) ? (fL + r * 3 + c) : (fPos + r);
+    // what this lane multiplies the parent row with at joint j: column c of L_j = row c of the transposed
+    // slot, or, for the position lane, the offset t_j (constant table, or the per-frame offsets tile)
+    const float *coef = (c < 3) ? (fL + 3 * c) : (PFO ? sOff + f * J * 3 : sConst + 1);
+    const int cstep = (c < 3) ? 9 : (PFO ? 3 : 4);
+    // where this lane's element of joint j lives in the image (row-major G, positions)
+    float *own0 = (c < 3) ? (fL + r * 3 + c) : (sPos + f * J * 3 + r);
     const int ostep = (c < 3) ? 9 : 3;
-    const v4f *cst = reinterpret_cast<const v4f *>(sConst);
+    const float m3 = (c == 3) ? 1.0f : 0.0f;
 
     float g = seed;  // element (r, c) of joint j-1: joint 0 multiplies the seed row e_r | root_pos[r] (exact)
-    float a0 = coef0[0], a1 = coef0[kstep], a2 = coef0[2 * kstep];
-    if (c == 3) { a0 = 0.0f; a1 = 0.0f; a2 = 0.0f; }  // root: translation = the seed itself (offsets[0] ignored)
+    float *own = own0;
     int par = -1;
-    for (int j = 0; j < J; ++j) {
-        // look-ahead (independent of the chain): coefficients and parent of joint j+1; slot j+1 still holds L
-        const int jn = j + 1;  // the table has J+1 entries and the image one slot of slack past the last joint
-        const float n0 = coef0[jn * cstep], n1 = coef0[jn * cstep + kstep], n2 = coef0[jn * cstep + 2 * kstep];
-        const int parn = __builtin_amdgcn_readfirstlane(__float_as_int(cst[jn].x));
-        float e = g;
-        if (par != j - 1) e = own0[par * ostep];  // wave-uniform: parent is not the previous joint
-        const float p0 = quad_bcast<0>(e), p1 = quad_bcast<1>(e), p2 = quad_bcast<2>(e), pt = quad_bcast<3>(e);
-        g = p0 * a0 + p1 * a1 + p2 * a2 + ((c == 3) ? pt : 0.0f);
-        own0[j * ostep] = g;
-        a0 = n0; a1 = n1; a2 = n2;
+    // One step, straight-line (no branch, so every LDS wait is a counted one):
+    //   * `a` = this joint's coefficients, requested two steps ago; once used the same registers are
+    //     refilled with joint j+2's (slots j+1, j+2 still hold L^T; the image and the table have two
+    //     entries of slack past the last joint);
+    //   * `pe` = the parent's element read from the image one step ago -- used when the parent is not
+    //     joint j-1 (then it was finished, and written, before step j-1); otherwise the register chain;
+    //   * first thing, the same read is issued for joint j+1 (`pen`).
+    auto step = [&](const int j, const int parn, float (&a)[3], const float pe, float &pen, const bool last_may_be_dummy) {
+        pen = own0[__umul24(parn, ostep)];
+        const float e = (par == j - 1) ? g : pe;  // wave-uniform
+        g = __builtin_fmaf(m3, e, quad_dot3(e, a[0], a[1], a[2]));  // + Gp[r][3] on the position lane
+        if (!last_may_be_dummy || j < J) *own = g;
+        own += ostep;
+        a[0] = coef[2 * cstep]; a[1] = coef[2 * cstep + 1]; a[2] = coef[2 * cstep + 2];
+        coef += cstep;
         par = parn;
+    };
+    float A[3] = {coef[0], coef[1], coef[2]}, B[3] = {coef[cstep], coef[cstep + 1], coef[cstep + 2]};
+    if (c == 3) { A[0] = 0.0f; A[1] = 0.0f; A[2] = 0.0f; }  // root: translation = the seed itself (offsets[0] ignored)
+    float peA = 0.0f, peB = 0.0f;
+    for (int jb = 0; jb < J; jb += PM_WAVE) {
+        // parents of joints jb+1 .. jb+64 across the lanes (the table repeats its last entry past J)
+        const int i0 = jb + 1 + lane;
+        const int pv = __float_as_int(sConst[4 * (i0 < J ? i0 : J)]);
+        const int jend = (J - jb) < PM_WAVE ? (J - jb) : PM_WAVE;
+        asm volatile("" ::"v"(pv));  // settle the window load here, not as an lgkmcnt(0) inside the loop
+        for (int jj = 0; jj < jend; jj += 2) {  // pairs; for odd J the very last step is a dummy that stores nothing
+            step(jb + jj, __builtin_amdgcn_readlane(pv, jj), A, peA, peB, false);
+            step(jb + jj + 1, __builtin_amdgcn_readlane(pv, jj + 1), B, peB, peA, true);
+        }
     }
 }
 
@@ -169,11 +207,23 @@ __device__ __forceinline__ v4f load_joint_const(const Parents &parents, const fl
     return c;
 }
 
+// local rotation -> its slot of the image: as is for the three-lane walk, transposed for tree_walk_quad
+template <bool TRANSPOSED>
+__device__ __forceinline__ void put_local(float *sRot, const int e, const float (&L)[9]) {
+    if (TRANSPOSED) {
+        const float T[9] = {L[0], L[3], L[6], L[1], L[4], L[7], L[2], L[5], L[8]};
+        lds_put<9>(sRot, e, T);
+    } else {
+        lds_put<9>(sRot, e, L);
+    }
+}
+
 template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT>
 __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int64_t f0, const int nf, const int lane) {
     const int J = a.J;
     const int FJ = FPW * J;
     const int n = nf * J;  // (frame, joint) elements in this tile
+    constexpr bool QUAD = FPW <= 5;  // few frames per wave (big J): 12 lanes per frame, see tree_walk_quad
 
     float *sRot = smem;                                // [FPW*J*9]  FPW % 4 == 0 keeps every carve 16 B aligned
     float *sPos = sRot + FJ * 9;                       // [FPW*J*3]
@@ -185,7 +235,6 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
     // latency: root position (used first by phase B), skeleton constants, then the rotations.
     // Lanes >= 3*FPW shadow lanes 0.. (same frame, same row, same values, same addresses) and frames
     // past the end of a partial tile walk uninitialised slots of their own: phase B needs no masking.
-    constexpr bool QUAD = FPW <= 5;  // few frames per wave (big J): 12 lanes per frame, see tree_walk_quad
     const int wl = lane % ((QUAD ? 12 : 3) * FPW);
     const int f = QUAD ? wl / 12 : wl / 3;
     const int r = QUAD ? (wl - 12 * f) / 4 : wl - 3 * f;
@@ -227,7 +276,7 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
                     } else {
                         local_from_quat(qi[u], L);
                     }
-                    lds_put<9>(sRot, e, L);
+                    put_local<QUAD>(sRot, e, L);
                 }
             }
         };
@@ -282,12 +331,12 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
                         m2q(m, qi);
                         lds_put<4>(sQo, e, qi);
                         local_from_quat(qi, L);
-                        lds_put<9>(sRot, e, L);
+                        put_local<QUAD>(sRot, e, L);
                     } else {
                         // Without the quaternion output the trip matrix -> quaternion -> normalise -> matrix is the
                         // identity on an orthonormal matrix up to fp32 rounding (~2e-7, two orders inside the parity
                         // budget): the Gram-Schmidt result IS the local rotation.  Saves ~80 VALU ops per joint.
-                        lds_put<9>(sRot, e, m);
+                        put_local<QUAD>(sRot, e, m);
                     }
                 }
             }
@@ -312,7 +361,7 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
 
     if constexpr (QUAD) {
         const float seed = (c == 3) ? gp : ((c == r) ? 1.0f : 0.0f);
-        if (!(a.ablate & 2)) tree_walk_quad<PFO>(sRot, sPos, sOff, sConst, J, f, r, c, seed);
+        if (!(a.ablate & 2)) tree_walk_quad<PFO>(sRot, sPos, sOff, sConst, J, f, r, c, seed, lane);
     } else {
         tree_walk<PFO>(sRot, sPos, sOff, sConst, J, f, r, gp, (a.ablate & 2) != 0);
     }
@@ -365,11 +414,12 @@ __global__ __launch_bounds__(PM_WAVE) void mirror_kernel(const MirrorArgs a) {
     const int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
     const int FJ = FPW * J;
     const int n = nf * J;
+    constexpr bool QUAD = FPW <= 5;     // as in fk_tile: twelve lanes per frame for big skeletons
     float *sRot = smem;                 // [FJ*9]  world rotations; reused as the output staging [FJ*4]
     float *sQ = sRot + FJ * 9;          // [FJ*4]  world quaternions (phase C on)
     float *sPos = sQ;                   //         the walk's positions are not needed: they land here and are overwritten
     float *sConst = sQ + FJ * 4;        // [(J+1)*4]
-    int *sTab = reinterpret_cast<int *>(sConst + 4 * (J + 1));  // [2J] parent | mapping
+    int *sTab = reinterpret_cast<int *>(sConst + 4 * (J + 4));  // [2J] parent | mapping
 
     for (int j = lane; j <= J; j += PM_WAVE) {
         const int jc = j < J ? j : J - 1;
@@ -380,15 +430,14 @@ __global__ __launch_bounds__(PM_WAVE) void mirror_kernel(const MirrorArgs a) {
         const float qi[4] = {q.x, q.y, q.z, q.w};
         float L[9];
         local_from_quat(qi, L);
-        lds_put<9>(sRot, e, L);
+        put_local<QUAD>(sRot, e, L);
     });
-    constexpr bool QUAD = FPW <= 5;  // as in fk_tile: twelve lanes per frame for big skeletons
     const int wl = lane % ((QUAD ? 12 : 3) * FPW);
     const int f = QUAD ? wl / 12 : wl / 3;
     const int r = QUAD ? (wl - 12 * f) / 4 : wl - 3 * f;
     const int c = wl & 3;
     wave_sync();
-    if constexpr (QUAD) tree_walk_quad<false>(sRot, sPos, nullptr, sConst, J, f, r, c, (c == r) ? 1.0f : 0.0f);
+    if constexpr (QUAD) tree_walk_quad<false>(sRot, sPos, nullptr, sConst, J, f, r, c, (c == r) ? 1.0f : 0.0f, lane);
     else tree_walk<false>(sRot, sPos, nullptr, sConst, J, f, r, 0.0f, false);
     wave_sync();
     for (int e = lane; e < n; e += PM_WAVE) {  // world rotation -> quaternion
@@ -423,7 +472,7 @@ __global__ __launch_bounds__(PM_WAVE) void mirror_kernel(const MirrorArgs a) {
 
 template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT>
 static int launch_fk(const FkArgs &a, hipStream_t s) {
-    const size_t lds = ((size_t)FPW * a.J * fk_lds_floats<SRC, PFO, QOUT>() + 4 * (a.J + 1)) * sizeof(float);
+    const size_t lds = ((size_t)FPW * a.J * fk_lds_floats<SRC, PFO, QOUT>() + 4 * (a.J + 4)) * sizeof(float);
     auto k = fk_kernel<FPW, VEC, PFO, SRC, QOUT>;
     if (int e = allow_lds(k, lds)) return e;
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
@@ -465,7 +514,7 @@ static int dispatch_fk2(const FkArgs &a, bool vec, bool pfo, hipStream_t s) {
 template <int SRC>
 static int dispatch_fk(const FkArgs &a, bool vec, bool pfo, hipStream_t s) {
     const size_t per_frame = (size_t)a.J * (12 + (pfo ? 3 : 0) + (a.quat_out ? 4 : 0)) * sizeof(float);
-    const size_t fixed = 4 * ((size_t)a.J + 1) * sizeof(float) + 256;
+    const size_t fixed = 4 * ((size_t)a.J + 4) * sizeof(float) + 256;
     int pick = (7 * (20 * per_frame + fixed) <= kMaxLds) ? 20 : 4;
     const char *ov = getenv("PM_FK_FPW");  // tuning aid: 20, 8 or 4
     if (ov && atoi(ov) > 0) pick = atoi(ov);
@@ -502,7 +551,7 @@ static int fk_common(int src_kind, const float *src, const float *root_pos, cons
 
 template <int FPW>
 static int launch_mirror(const MirrorArgs &a, bool vec, hipStream_t s) {
-    const size_t lds = ((size_t)FPW * a.J * 13 + 4 * (a.J + 1) + 2 * a.J) * sizeof(float);
+    const size_t lds = ((size_t)FPW * a.J * 13 + 4 * (a.J + 4) + 2 * a.J) * sizeof(float);
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
     const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
     if (grid > 0x7fffffffLL) { set_error("mirror: grid too large"); return PM_EUNSUPPORTED; }
@@ -539,7 +588,7 @@ extern "C" int pm_mirror_rotations_f32(const float *rot, const int32_t *parents,
     }
     const bool vec = aligned16(rot) && aligned16(out);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t per_frame = (size_t)J * 13 * sizeof(float), fixed = (6 * (size_t)J + 4) * sizeof(float) + 256;
+    const size_t per_frame = (size_t)J * 13 * sizeof(float), fixed = (6 * (size_t)J + 16) * sizeof(float) + 256;
     if (7 * (20 * per_frame + fixed) <= kMaxLds) return launch_mirror<20>(a, vec, s);
     if (4 * per_frame + fixed <= kMaxLds) return launch_mirror<4>(a, vec, s);
     set_error("mirror: J=%d does not fit the LDS tile", J);

@@ -496,8 +496,13 @@ def test_maximum_joint_count_everywhere():
     want = co.from_global_rotations(g, parents)
     assert np.minimum(np.abs(got - want).max(-1), np.abs(got + want).max(-1)).max() <= 5e-5  # depth up to ~20 levels of fp32 products
     pos, _ = sk.fk(rot, np.zeros_like(root), off, parents)
-    r_ik = sk.from_root_positions(pos.astype(np.float32), parents, off)
-    r_or = co.from_root_positions(f64(pos.astype(np.float32)), parents, f64(off))
+    pos_or = co.fk(f64(rot), np.zeros((F, 3)), f64(off), parents)[0]
+    assert_close(pos, pos_or, ATOL)
+    # the inverse problem is ill-conditioned on some of these 512 random bones: feed both sides the SAME
+    # (oracle) positions so that the comparison does not depend on the last bit of the fk kernel
+    pos32 = pos_or.astype(np.float32)
+    r_ik = sk.from_root_positions(pos32, parents, off)
+    r_or = co.from_root_positions(f64(pos32), parents, f64(off))
     assert np.minimum(np.abs(r_ik - r_or).max(-1), np.abs(r_ik + r_or).max(-1)).max() <= 1e-3
     with pytest.raises(ValueError):
         sk.fk(np.zeros((2, 513, 4), np.float32), np.zeros((2, 3), np.float32), np.zeros((513, 3), np.float32), np.maximum(np.arange(513) - 1, 0))
