@@ -14,20 +14,25 @@ namespace pm {
 // frame, lane c holding component c of the running root-space quaternion and of the translation written
 // as the pure quaternion (0, t).  Products with a distributed left operand use
 //     (a (x) b)_c = sum_k S[c][k] a_k b_{c xor k}          (Klein-group structure of the Hamilton product)
-// with a_k a DPP quad broadcast and the b's read from LDS at per-lane permuted addresses; cross products
-// of the rotate-a-vector formula (quat.py:320-334) use DPP rotations of lanes 1..3.  A chain step is ~40
-// instructions for 16 frames, never waits on LDS, and a wave needs only 16 frames of LDS image (11.5 KiB
-// at J = 22 -> 13 waves per CU).
-// The LDS image is the tile's OUTPUT (32 J B per frame) with one 16-byte pad per frame: bank-conflict
-// free column access, and the copy-out stays a dwordx4 stream.
+// with a_k a quad broadcast and b_{c xor k} a quad permutation, both folded into the DPP operand of the
+// multiply-adds; the cross products of the rotate-a-vector formula (quat.py:320-334) are DPP rotations of
+// lanes 1..3.  A step is 12 chained VALU instructions (dq_step_math) plus ~20 of bookkeeping for 16
+// frames, straight-line: no branch, and every LDS wait is a counted one.
+// The LDS image is the tile's OUTPUT (32 J B per frame) plus, per frame, one IDENTITY slot and a 16-byte
+// pad (bank-conflict free column access; the copy-out stays a dwordx4 stream):
 //   phase A  lane per (frame, joint): quaternion straight from HBM (coalesced dwordx4, loads pipelined)
 //            into the first half of the joint's 32-byte output slot;
-//   walk     per joint: compose with the parent (registers when parents[j] == j-1, else its slot), or stay
-//            local when the parent is the root (skeleton.py:236-241); slot <- root-space (q, t, 0);
+//   walk     per joint: compose with the parent -- the register chain when parents[j] == j-1, else the
+//            parent's finished slot, read one step ahead; joints whose parent is the root stay local
+//            (skeleton.py:236-241), which here means "parent = the identity slot", and the root itself
+//            (:232) is the same step with the frame's root position as its offset; slot <- (q, t, 0);
 //   phase C  lane per (frame, joint): (q, t) -> [q, 0.5 (0,t) (x) q] in place (dual_quat.py:28-36);
 //   out      contiguous dwordx4 streaming stores.
-// Skeleton constants {parent, offset} sit in a small LDS table.
+// Per-joint constants sit in LDS in the form the lanes consume them: {v_c, 2 v_next-next, 2 v_next} per
+// lane column, and the effective parent index (one v_readlane per step, 64 joints per VGPR).
 // ---------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int to_root_frame_stride(const int J) { return 8 * J + 12; }
+
 struct ToRootArgs {
     const float *rot;       // [F,J,4]
     const float *root_pos;  // [F,3]
@@ -38,6 +43,46 @@ struct ToRootArgs {
     int32_t ablate;  // tuning aid (env PM_DQ_ABLATE): 1 = skip the walk, 2 = skip phase C
     Parents parents;
 };
+
+// One step of the quad walk for the lane holding component c, as ONE block of 12 VALU instructions
+// with the quad exchanges folded into the DPP operand of the multiplies (these kernels sit near the
+// VALU issue limit: one wave64 instruction = 4 cycles of a SIMD):
+//   q = pq (x) b                                        quat.py:337-361, component-parallel:
+//       q_c = sum_k S[c][k] pq_k b_{c xor k},  sb_k = S[c][k] b_{c xor k} prepared off the chain
+//   t = live * (pv x tt + pw tt) + s,  tt = 2 (pv x v), s = live v_c + pt      quat.py:320-334
+//       w1 = 2 v_nextnext, w2 = 2 v_next (from the joint table), `next` = quad_perm [0,2,3,1]
+// pq must have been written at least two instructions earlier by VALU (the leading s_nop covers it;
+// inside the block the instruction order keeps every VALU write two slots away from its DPP read).
+__device__ __forceinline__ void dq_step_math(const float pq, const float s, const float b0, const float sb1,
+                                             const float sb2, const float sb3, const float w1, const float w2,
+                                             const float live, float &q, float &t) {
+    float tt, an, ann, x;
+    asm("s_nop 1\n\t"
+        "v_mul_f32_dpp %0, %6, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %2, %6, %12 quad_perm:[0,2,3,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %6, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, -%6, %13 quad_perm:[0,3,1,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %6, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %3, %6 quad_perm:[0,2,3,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %6, %11 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %4, %6 quad_perm:[0,3,1,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %5, %2, %3 quad_perm:[0,3,1,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, -%2, %4 quad_perm:[0,2,3,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %6, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fma_f32 %1, %14, %5, %7"
+        : "=&v"(q), "=&v"(t), "=&v"(tt), "=&v"(an), "=&v"(ann), "=&v"(x)
+        : "v"(pq), "v"(s), "v"(b0), "v"(sb1), "v"(sb2), "v"(sb3), "v"(w1), "v"(w2), "v"(live));
+}
+
+// S[c][k] * b_{c xor k} in one instruction (b was loaded from LDS: no VALU -> DPP hazard)
+template <int P0, int P1, int P2, int P3>
+__device__ __forceinline__ float quad_perm_mul(const float b, const float sign) {
+    float r;
+    asm("v_mul_f32_dpp %0, %1, %2 quad_perm:[%3,%4,%5,%6] row_mask:0xf bank_mask:0xf"
+        : "=&v"(r)
+        : "v"(b), "v"(sign), "n"(P0), "n"(P1), "n"(P2), "n"(P3));
+    return r;
+}
 
 template <int FPW, bool VEC>
 __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a) {
@@ -50,9 +95,10 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
     const int64_t f0 = tile * FPW;
     const int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
     const int n = nf * J;
-    const int FS = 8 * J + 4;           // padded frame stride in floats
-    float *sDq = smem;                  // [FPW * FS]
-    float *sConst = sDq + FPW * FS;     // [(J+1)*4]
+    const int FS = to_root_frame_stride(J);  // J slots + the identity slot + one 16-byte pad (odd FS/4: conflict-free columns)
+    float *sDq = smem;                                        // [FPW * FS]
+    float *sTab = sDq + FPW * FS;                             // [(J+3) * 12]  joint j, lane column c: {live v_c, 2 v_nn, 2 v_n}
+    int *sPar = reinterpret_cast<int *>(sTab + 12 * (J + 3));  // [J+1]  effective parent (J = identity slot); entry J repeats J-1
     const float invJ = 1.0f / (float)J;
 
     // all global loads first: root position, constants, then the rotations in batches of 4
@@ -60,12 +106,21 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
     const int wl = lane % (4 * FPW);
     const int fq = wl >> 2, c = wl & 3;
     const float rp = (c > 0 && fq < nf) ? a.root_pos[(f0 + fq) * 3 + c - 1] : 0.0f;  // (0, root_pos) component c
+    for (int i = lane; i < 4 * (J + 3); i += PM_WAVE) {  // the joint table: offsets in the form each lane column consumes
+        const int j = i >> 2, cc = i & 3, jc = j < J ? j : J - 1;
+        const float o[3] = {a.offsets[3 * jc], a.offsets[3 * jc + 1], a.offsets[3 * jc + 2]};
+        float vc = 0.0f, w1 = 0.0f, w2 = 0.0f;  // column 0 carries the zero scalar part of (0, t)
+        if (cc > 0) {
+            const int cur = cc - 1, nx = cur == 2 ? 0 : cur + 1, nn = nx == 2 ? 0 : nx + 1;
+            vc = o[cur]; w1 = 2.0f * o[nn]; w2 = 2.0f * o[nx];
+        }
+        sTab[3 * i] = vc; sTab[3 * i + 1] = w1; sTab[3 * i + 2] = w2;
+    }
     for (int j = lane; j <= J; j += PM_WAVE) {
-        const int jc = j < J ? j : J - 1;
-        v4f c;
-        c.x = __int_as_float(a.parents.p[jc]);
-        c.y = a.offsets[3 * jc]; c.z = a.offsets[3 * jc + 1]; c.w = a.offsets[3 * jc + 2];
-        reinterpret_cast<v4f *>(sConst)[j] = c;
+        // joints hanging off the root stay local (skeleton.py:236-237) = composed with the identity slot;
+        // so does the root itself (:232), whose "offset" is the frame's root position
+        const int p = a.parents.p[j < J ? j : J - 1];
+        sPar[j] = (p == 0) ? J : p;
     }
     const float *gsrc = a.rot + f0 * J * 4;
     auto load_batch = [&](const int e0, v4f (&q)[4]) {
@@ -101,53 +156,57 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
             load_batch(e0 + 3 * B, qb);
         }
     }
+    float *fD = sDq + fq * FS;
+    fD[J * 8 + c] = (c == 0) ? 1.0f : 0.0f;  // the identity slot: (1,0,0,0 | 0,0,0,0)
+    fD[J * 8 + 4 + c] = 0.0f;
     wave_sync();
 
-    float *fD = sDq + fq * FS;
-    const float *cstf = sConst;
-    // per-lane constants of the component layout
+    // ---- the walk: four lanes per frame, lane c owns component c of (q_j, (0, t_j)) -----------------------
+    // Straight-line steps (no branch, every LDS wait a counted one).  Per step: the parent's (q, t) was
+    // read from the image one step ago (`pe*`), unless the parent is the previous joint (register chain);
+    // the joint's own quaternion component and its table row were requested two steps ago into the
+    // register set the step consumes (A / B ping-pong) and are re-requested for joint j+2 once used.
     const float s1 = (c == 0 || c == 2) ? -1.0f : 1.0f;   // S[c][1]:  - + - +
     const float s2 = (c == 0 || c == 3) ? -1.0f : 1.0f;   // S[c][2]:  - + + -
     const float s3 = (c == 0 || c == 1) ? -1.0f : 1.0f;   // S[c][3]:  - - + +
-    const int x1 = c ^ 1, x2 = c ^ 2, x3 = c ^ 3;         // b_{c xor k}
-    const int cn1 = (c == 3) ? 1 : c + 1, cn2 = (c == 2) ? 1 : ((c == 3) ? 2 : c + 2);  // next / next-next of x,y,z
     const float live = (c == 0) ? 0.0f : 1.0f;            // lane 0 carries the zero scalar part of (0, t)
     const int toff = (c == 0) ? 7 : 3 + c;                // where component c of (0,t) sits in a slot: t0 t1 t2 0
-
-    float gq = (c == 0) ? 1.0f : 0.0f, gt = 0.0f;  // joint j-1, root space
-    // look-ahead state for joint 0
-    float b0 = fD[c], b1 = fD[x1], b2 = fD[x2], b3 = fD[x3];
-    int par = 0;
-    float vc = 0.0f, vn = 0.0f, vnn = 0.0f;
-    for (int j = (a.ablate & 1) ? J : 0; j < J; ++j) {
-        // joint j+1's inputs do not depend on the chain: request them now (slot j+1 still holds its quaternion)
-        const int jn = j + 1;  // table has J+1 entries; the slot past the last joint is inside the allocation
-        const float nb0 = fD[jn * 8 + c], nb1 = fD[jn * 8 + x1], nb2 = fD[jn * 8 + x2], nb3 = fD[jn * 8 + x3];
-        const int parn = __builtin_amdgcn_readfirstlane(__float_as_int(cstf[jn * 4]));
-        const float nvc = cstf[jn * 4 + c], nvn = cstf[jn * 4 + cn1], nvnn = cstf[jn * 4 + cn2];  // lane 0: unused
-
+    const float *fDq = fD + c, *fDt = fD + toff;          // parent reads
+    float *oq = fD + c, *ot = fD + toff;                  // slot of the current pair's first joint
+    const float *tb = sTab + 3 * c;                       // table row of the current pair's first joint
+    struct Regs { float b, vc, w1, w2; };
+    Regs A = {oq[0], rp, 0.0f, 0.0f};                     // the root: "offset" = root position (skeleton.py:232)
+    Regs B = {oq[8], tb[12], tb[13], tb[14]};
+    float gq = 0.0f, gt = 0.0f;                           // previous joint, root space
+    float peqA = (c == 0) ? 1.0f : 0.0f, petA = 0.0f, peqB = 0.0f, petB = 0.0f;  // the root composes with the identity
+    int par = J;
+    auto step = [&](const int j, const int o, const int parn, Regs &S, const float peq, const float pet, float &peqn,
+                    float &petn, const bool may_be_dummy) {
+        peqn = fDq[parn * 8];  // parent of joint j+1, if it is not joint j itself (then: a stale value, unused)
+        petn = fDt[parn * 8];
+        const float sb1 = quad_perm_mul<1, 0, 3, 2>(S.b, s1), sb2 = quad_perm_mul<2, 3, 0, 1>(S.b, s2),
+                    sb3 = quad_perm_mul<3, 2, 1, 0>(S.b, s3);
+        const bool chain = (par == j - 1);  // wave-uniform
+        const float pq = chain ? gq : peq, pt = chain ? gt : pet;
+        const float s = S.vc + pt;
         float q, t;
-        if (j == 0) {
-            q = b0; t = rp;                       // skeleton.py:232
-        } else if (par == 0) {
-            q = b0; t = vc * live;                // joints hanging off the root stay local (:236-237)
-        } else {
-            float pq = gq, pt = gt;
-            if (par != j - 1) { pq = fD[par * 8 + c]; pt = fD[par * 8 + toff]; }  // finished slot: (q, t, 0)
-            const float pw = quad_bcast<0>(pq), px = quad_bcast<1>(pq), py = quad_bcast<2>(pq), pz = quad_bcast<3>(pq);
-            // q = pq (x) q_j   (quat.py:337-361 in component-parallel form)
-            q = pw * b0 + s1 * (px * b1) + s2 * (py * b2) + s3 * (pz * b3);
-            // t = pq . t_j + pt   (quat.py:320-334: tt = 2 (pv x v); v + w tt + pv x tt)
-            const float an = quad_perm<0, 2, 3, 1>(pq), ann = quad_perm<0, 3, 1, 2>(pq);
-            const float tt = 2.0f * (an * vnn - ann * vn);
-            const float ttn = quad_perm<0, 2, 3, 1>(tt), ttnn = quad_perm<0, 3, 1, 2>(tt);
-            t = (vc + pw * tt + (an * ttnn - ann * ttn) + pt) * live;
+        dq_step_math(pq, s, S.b, sb1, sb2, sb3, S.w1, S.w2, live, q, t);
+        if (!may_be_dummy || j < J) { oq[o] = q; ot[o] = t; }  // slot <- root-space (q, t, 0)
+        S.b = oq[o + 16];                                      // joint j+2: its slot still holds the input quaternion
+        S.vc = tb[(o >> 3) * 12 + 24]; S.w1 = tb[(o >> 3) * 12 + 25]; S.w2 = tb[(o >> 3) * 12 + 26];
+        gq = q; gt = t; par = parn;
+    };
+    for (int jb = (a.ablate & 1) ? J : 0; jb < J; jb += PM_WAVE) {
+        // effective parents of joints jb+1 .. jb+64 across the lanes: one v_readlane per step
+        const int i0 = jb + 1 + lane;
+        const int pv = sPar[i0 < J ? i0 : J];
+        const int jend = (J - jb) < PM_WAVE ? (J - jb) : PM_WAVE;
+        asm volatile("" ::"v"(pv));  // settle the window load here, not as an lgkmcnt(0) inside the loop
+        for (int jj = 0; jj < jend; jj += 2) {  // pairs; for odd J the very last step is a dummy that stores nothing
+            step(jb + jj, 0, __builtin_amdgcn_readlane(pv, jj), A, peqA, petA, peqB, petB, false);
+            step(jb + jj + 1, 8, __builtin_amdgcn_readlane(pv, jj + 1), B, peqB, petB, peqA, petA, true);
+            oq += 16; ot += 16; tb += 24;
         }
-        fD[j * 8 + c] = q;
-        fD[j * 8 + toff] = t;
-        gq = q; gt = t;
-        b0 = nb0; b1 = nb1; b2 = nb2; b3 = nb3;
-        par = parn; vc = nvc; vn = nvn; vnn = nvnn;
     }
     wave_sync();
     // phase C, lane per (frame, joint): (q, t) -> [q, 0.5 (0,t) (x) q]  (dual_quat.py:28-36), off the chain
@@ -177,7 +236,7 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
 
 template <int FPW>
 static int launch_to_root(const ToRootArgs &a, bool vec, hipStream_t s) {
-    const size_t lds = ((size_t)FPW * (8 * a.J + 4) + 4 * (a.J + 1)) * sizeof(float);
+    const size_t lds = ((size_t)FPW * to_root_frame_stride(a.J) + 12 * (a.J + 3) + (a.J + 1)) * sizeof(float);
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
     const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
     if (grid > 0x7fffffffLL) { set_error("to_root_dq: grid too large"); return PM_EUNSUPPORTED; }
@@ -324,7 +383,7 @@ extern "C" int pm_to_root_dq_f32(const float *rot, const float *root_pos, const 
     if (int e = pack_parents(parents, J, a.parents)) return e;
     const bool vec = aligned16(rot) && aligned16(dq);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t per_frame = ((size_t)J * 8 + 4) * sizeof(float), fixed = 4 * ((size_t)J + 1) * sizeof(float) + 256;
+    const size_t per_frame = (size_t)to_root_frame_stride(J) * sizeof(float), fixed = (13 * (size_t)J + 37) * sizeof(float) + 256;
     int pick = (7 * (16 * per_frame + fixed) <= kMaxLds) ? 16 : 8;  // 4 lanes per frame; keep >= 7 waves per CU if possible
     {
         const char *e = getenv("PM_DQ_FPW");  // tuning aid
