@@ -383,6 +383,131 @@ __global__ __launch_bounds__(PM_WAVE) void fk_kernel(const FkArgs a) {
     fk_tile<FPW, VEC, PFO, SRC, QOUT>(a, smem, f0, nf, threadIdx.x);
 }
 
+// ---- pipelined form for mid-size skeletons (tree_walk_quad shape: FPW = 4, J <= 64, shared offsets) ---
+// With ~50 joints the serial walk is a third of a tile's life and a wave that walks has nothing in
+// flight; 15 resident waves then cannot keep HBM busy (measured: 53 % of peak for the fused ortho6d
+// config against 71 % with the walk ablated).  Here a workgroup owns `nt` consecutive tiles and keeps
+// the memory system fed from inside the walk:
+//     loads(i+1) are issued BEFORE walk(i) into registers (<= 4 records per lane),
+//     after the walk:  math(i+1) from those registers -> copy-out(i) -> park L(i+1) in LDS -> loads(i+2)
+// so loads overlap the walk and the stores overlap the next tile's math and walk.  The vmcnt wait in
+// front of math(i+1) only ever covers loads that are a whole walk old (the stores of tile i are issued
+// after it).  The skeleton table is staged once per workgroup.
+template <int FPW, int EPL, bool VEC, int SRC, bool QOUT>
+__global__ __launch_bounds__(PM_WAVE) void fk_pipe_kernel(const FkArgs a, const int nt) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr bool QUAD = FPW <= 5;  // records per lane: FPW * J <= 64 * EPL
+    const int lane = threadIdx.x;
+    const int J = a.J;
+    const int FJ = FPW * J;
+    const int64_t ntiles = (a.F + FPW - 1) / FPW;
+    const int64_t group = xcd_tile((ntiles + nt - 1) / nt);
+    if (group < 0) return;
+    const int64_t t0 = group * nt;
+    const int cnt = (int)((ntiles - t0) < nt ? (ntiles - t0) : nt);
+
+    float *sRot = smem;                          // [FJ*9]
+    float *sPos = sRot + FJ * 9;                 // [FJ*3]
+    float *sQo = sPos + FJ * 3;                  // [FJ*4]  (QOUT)
+    float *sConst = sQo + (QOUT ? FJ * 4 : 0);   // [(J+4)*4]
+    for (int j = lane; j <= J; j += PM_WAVE) reinterpret_cast<v4f *>(sConst)[j] = load_joint_const<false>(a.parents, a.offsets, J, j);
+
+    const int wl = lane % ((QUAD ? 12 : 3) * FPW);
+    const int f = QUAD ? wl / 12 : wl / 3;
+    const int r = QUAD ? (wl - 12 * f) / 4 : wl - 3 * f;
+    const int c = wl & 3;  // QUAD only: column of [R | p]
+
+    v4f in4[EPL];       // SRC_QUAT: one quaternion per record
+    v2f in2[EPL][3];    // SRC_O6D: 24-byte records as three dwordx2 (see fk_tile)
+    float gp = 0.0f;
+    auto issue = [&](const int64_t f0, const int nf) {
+        const int n = nf * J;
+        gp = (f < nf) ? a.root_pos[(f0 + f) * 3 + r] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < EPL; ++u) {
+            const int e = u * PM_WAVE + lane;
+            if constexpr (SRC == SRC_QUAT) {
+                const float *g = a.src + f0 * J * 4;
+                in4[u] = v4f{1.0f, 0.0f, 0.0f, 0.0f};
+                if (e < n) {
+                    if (VEC) in4[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(g) + e);
+                    else in4[u] = v4f{g[4 * e], g[4 * e + 1], g[4 * e + 2], g[4 * e + 3]};
+                }
+            } else {
+                const float *g = a.src + f0 * J * 6;
+                in2[u][0] = v2f{1.0f, 0.0f}; in2[u][1] = v2f{0.0f, 1.0f}; in2[u][2] = v2f{0.0f, 0.0f};
+                if (e < n) {
+                    if (VEC) {
+                        const v2f *p = reinterpret_cast<const v2f *>(g) + 3 * e;
+                        in2[u][0] = __builtin_nontemporal_load(p);
+                        in2[u][1] = __builtin_nontemporal_load(p + 1);
+                        in2[u][2] = __builtin_nontemporal_load(p + 2);
+                    } else {
+                        const float *p = g + 6 * e;
+                        in2[u][0] = v2f{p[0], p[1]}; in2[u][1] = v2f{p[2], p[3]}; in2[u][2] = v2f{p[4], p[5]};
+                    }
+                }
+            }
+        }
+    };
+    auto copy_out = [&](const int64_t f0, const int n) {
+        tile_store<VEC>(a.rotmats + f0 * J * 9, sRot, n * 9, lane);
+        tile_store<VEC>(a.pos + f0 * J * 3, sPos, n * 3, lane);
+        if (QOUT) tile_store<VEC>(a.quat_out + f0 * J * 4, sQo, n * 4, lane);
+    };
+
+    int64_t f0 = t0 * FPW, f0_prev = 0;
+    int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW), n_prev = 0;
+    issue(f0, nf);
+    for (int i = 0; i < cnt; ++i) {
+        const int n = nf * J;
+        // math of tile i, in registers (phase A of fk_tile)
+        float L[EPL][9], Q[EPL][4];
+#pragma unroll
+        for (int u = 0; u < EPL; ++u) {
+            if constexpr (SRC == SRC_QUAT) {
+                const float qi[4] = {in4[u].x, in4[u].y, in4[u].z, in4[u].w};
+                local_from_quat(qi, L[u]);
+            } else {
+                const float xx[6] = {in2[u][0].x, in2[u][0].y, in2[u][1].x, in2[u][1].y, in2[u][2].x, in2[u][2].y};
+                if constexpr (QOUT) {
+                    float m[9];
+                    o6d2m(xx, a.eps, m);
+                    m2q(m, Q[u]);
+                    local_from_quat(Q[u], L[u]);
+                } else {
+                    o6d2m(xx, a.eps, L[u]);  // the Gram-Schmidt result IS the local rotation (see fk_tile)
+                }
+            }
+        }
+        const float gp_i = gp;
+        if (i > 0) copy_out(f0_prev, n_prev);  // the image of tile i-1 leaves ...
+#pragma unroll
+        for (int u = 0; u < EPL; ++u) {        // ... and tile i's local rotations take its place (in-order DS)
+            const int e = u * PM_WAVE + lane;
+            if (e < n) {
+                put_local<QUAD>(sRot, e, L[u]);
+                if (QOUT) lds_put<4>(sQo, e, Q[u]);
+            }
+        }
+        f0_prev = f0; n_prev = n;
+        if (i + 1 < cnt) {
+            f0 += FPW;
+            nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
+            issue(f0, nf);                      // in flight during the walk below
+        }
+        wave_sync();
+        if constexpr (QUAD) {
+            const float seed = (c == 3) ? gp_i : ((c == r) ? 1.0f : 0.0f);
+            if (!(a.ablate & 2)) tree_walk_quad<false>(sRot, sPos, nullptr, sConst, J, f, r, c, seed, lane);
+        } else {
+            tree_walk<false>(sRot, sPos, nullptr, sConst, J, f, r, gp_i, (a.ablate & 2) != 0);
+        }
+        wave_sync();
+    }
+    copy_out(f0_prev, n_prev);
+}
+
 
 // ---- mirror (ops/skeleton.py:247-344 modes 'all' / 'symmetry', :347-418 _true_mirror), fused -----------
 // The reference chains  fk -> quat.from_matrix -> [joint permutation] -> negate two components ->
@@ -485,6 +610,27 @@ static int launch_fk(const FkArgs &a, hipStream_t s) {
     return check_hip(hipGetLastError(), "fk launch");
 }
 
+template <int FPW, int EPL, bool VEC, int SRC, bool QOUT>
+static int launch_fk_pipe(const FkArgs &a, const int nt, hipStream_t s) {
+    const size_t lds = ((size_t)FPW * a.J * (12 + (QOUT ? 4 : 0)) + 4 * (a.J + 4)) * sizeof(float);
+    auto k = fk_pipe_kernel<FPW, EPL, VEC, SRC, QOUT>;
+    if (int e = allow_lds(k, lds)) return e;
+    const int64_t ntiles = (a.F + FPW - 1) / FPW, ngroups = (ntiles + nt - 1) / nt;
+    const int64_t grid = ((ngroups + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
+    if (grid > 0x7fffffffLL) { set_error("fk: grid too large"); return PM_EUNSUPPORTED; }
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a, nt);
+    return check_hip(hipGetLastError(), "fk launch");
+}
+
+template <int FPW, int EPL, int SRC>
+static int dispatch_fk_pipe(const FkArgs &a, bool vec, const int nt, hipStream_t s) {
+    const bool qout = a.quat_out != nullptr;
+    if constexpr (SRC == SRC_O6D) {
+        if (qout) return vec ? launch_fk_pipe<FPW, EPL, true, SRC, true>(a, nt, s) : launch_fk_pipe<FPW, EPL, false, SRC, true>(a, nt, s);
+    }
+    return vec ? launch_fk_pipe<FPW, EPL, true, SRC, false>(a, nt, s) : launch_fk_pipe<FPW, EPL, false, SRC, false>(a, nt, s);
+}
+
 template <int FPW, int SRC>
 static int dispatch_fk2(const FkArgs &a, bool vec, bool pfo, hipStream_t s) {
     const bool qout = a.quat_out != nullptr;
@@ -508,7 +654,7 @@ static int dispatch_fk2(const FkArgs &a, bool vec, bool pfo, hipStream_t s) {
 // Frames per wave (FPW, a multiple of 4 so that every tile base stays 16-byte aligned for any J).
 // The LDS image (48 J B per frame) bounds residency, and with fewer than ~7 waves per CU nothing hides
 // the walk's latency.  Two shapes cover the range (measured, 2^18 frames x 52 joints: FPW 20/16/12/8 with
-// three lanes per frame 376/311/307/253 us, FPW 4 with twelve lanes per frame 203 us):
+// three lanes per frame 376/311/307/253 us, FPW 4 with twelve lanes per frame 178 us; FPW 2 / 5: 227 / 176 us):
 //   FPW 20, 3 lanes per frame  while 7 tiles fit a CU's LDS (J <= 23 without extras),
 //   FPW 4, 12 lanes per frame (tree_walk_quad) beyond that.
 template <int SRC>
@@ -519,6 +665,15 @@ static int dispatch_fk(const FkArgs &a, bool vec, bool pfo, hipStream_t s) {
     const char *ov = getenv("PM_FK_FPW");  // tuning aid: 20, 8 or 4
     if (ov && atoi(ov) > 0) pick = atoi(ov);
     if ((size_t)pick * per_frame + fixed > kMaxLds) pick = 4;
+    if (pick == 4 && !pfo && a.J <= 64) {
+        // mid-size skeletons: registers-first phase A and tiles pipelined inside a workgroup (fk_pipe_kernel).
+        // Measured at 2^18 x 52: fused ortho6d 224 us (fk_kernel) -> 188 / 183 / 187 / 198 us with 1 / 2 / 4 / 8
+        // tiles per workgroup; the same structure on the 20-frame tile of J = 22 is slower (293 vs 270 us).
+        int nt = ((a.F + 3) / 4 >= 16384) ? 2 : 1;
+        const char *e = getenv("PM_FK_NT");  // tuning aid: tiles per workgroup, 0 = fk_kernel
+        if (e) nt = atoi(e);
+        if (nt > 0) return dispatch_fk_pipe<4, 4, SRC>(a, vec, nt, s);
+    }
     switch (pick) {
         case 20: return dispatch_fk2<20, SRC>(a, vec, pfo, s);
         case 8: return dispatch_fk2<8, SRC>(a, vec, pfo, s);

@@ -320,6 +320,35 @@ def test_fk_and_dq_vs_oracle_sizes(F, J):
     assert_close(q, q_o, ATOL, "from_root_dq rot")
 
 
+@pytest.mark.parametrize("nt", ["0", "1", "2", "3", "7"])
+@pytest.mark.parametrize("F,J", [(4 * 7 + 1, 52), (4 * 6, 24), (3, 64), (4 * 13 + 2, 33)])
+def test_fk_pipelined_tiles_ragged_groups(monkeypatch, nt, F, J):
+    """24 <= J <= 64 runs fk_pipe_kernel: `nt` tiles per workgroup (PM_FK_NT; 0 = the one-tile kernel).
+    Odd tile counts, a partial last tile and a partial last group must all come out identical."""
+    from pymotion_amd import synthetic as syn
+
+    monkeypatch.setenv("PM_FK_NT", nt)
+    rng = np.random.default_rng(F * 100 + J)
+    parents = syn.PARENTS_52 if J == 52 else syn.random_parents(J, rng)
+    rot = rng.standard_normal((F, J, 4)).astype(np.float32)
+    gpos = rng.uniform(-2, 2, (F, 3)).astype(np.float32)
+    off = syn.make_offsets(J, rng, 0.15)
+    f64 = lambda a: a.astype(np.float64)  # noqa: E731
+    pos, rm = sk.fk(rot, gpos, off, parents)
+    p_o, r_o = co.fk(f64(rot), f64(gpos), f64(off), parents)
+    assert_close(pos, p_o, ATOL, "fk pos")
+    assert_close(rm, r_o, ATOL, "fk rotmats")
+    x = rng.standard_normal((F, J, 3, 2)).astype(np.float32)
+    q_o = co.o6d_to_quat(f64(x))
+    p_o, r_o = co.fk(q_o, f64(gpos), f64(off), parents)
+    for want_q in (False, True):
+        out = sk.fk_from_ortho6d(x, gpos, off, parents, return_quat=want_q)
+        assert_close(out[0], p_o, 2e-5, "fused pos")
+        assert_close(out[1], r_o, 2e-5, "fused rotmats")
+        if want_q:
+            assert_close(out[2], q_o, ATOL, "fused quats")
+
+
 def test_fk_per_frame_offsets_and_unaligned_views():
     from pymotion_amd import synthetic as syn
 
