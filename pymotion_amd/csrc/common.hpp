@@ -93,26 +93,29 @@ __device__ __forceinline__ void tile_store(float *__restrict__ g, const float *l
 }
 
 // Stream n 16-byte records (lane-consecutive, dwordx4 each) from HBM through registers, calling
-// fn(e, record) for every element e: two batches of 4 loads per lane (8 KiB per wave) are always in
-// flight -- batch k+2 is requested before batch k is consumed -- so a tile costs one memory latency.
+// fn(e, record, valid) for every element slot e: two batches of 4 loads per lane (8 KiB per wave) are
+// always in flight -- batch k+2 is requested before batch k is consumed -- so a tile costs one memory
+// latency.  Loads are unconditional inside a batch (a slot past the end re-reads the last record, and fn
+// is told so through `valid`): fn should compute unconditionally and guard only its stores, so that the
+// four records of a batch are scheduled together with no exec-mask branch between them.
 template <bool VEC, class Fn>
 __device__ __forceinline__ void for_each_record4(const float *__restrict__ gsrc, const int n, const int lane, Fn &&fn) {
     constexpr int B = 4 * PM_WAVE;
     auto load = [&](const int e0, v4f (&q)[4]) {
+        if (e0 >= n) return;  // wave-uniform
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int e = e0 + u * PM_WAVE + lane;
-            if (e < n) {
-                if (VEC) q[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(gsrc) + e);
-                else q[u] = v4f{gsrc[4 * e], gsrc[4 * e + 1], gsrc[4 * e + 2], gsrc[4 * e + 3]};
-            }
+            const int e = e0 + u * PM_WAVE + lane, ec = e < n ? e : n - 1;
+            if (VEC) q[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(gsrc) + ec);
+            else q[u] = v4f{gsrc[4 * ec], gsrc[4 * ec + 1], gsrc[4 * ec + 2], gsrc[4 * ec + 3]};
         }
     };
     auto use = [&](const int e0, const v4f (&q)[4]) {
+        if (e0 >= n) return;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = e0 + u * PM_WAVE + lane;
-            if (e < n) fn(e, q[u]);
+            fn(e, q[u], e < n);
         }
     };
     v4f qa[4], qb[4];
@@ -123,6 +126,20 @@ __device__ __forceinline__ void for_each_record4(const float *__restrict__ gsrc,
         load(e0 + 2 * B, qa);
         use(e0 + B, qb);
         load(e0 + 3 * B, qb);
+    }
+}
+
+// fn(slot, valid) over the n element slots of an LDS tile, U slots per lane and trip.  A slot index past
+// the end is clamped to the last element and flagged invalid: fn computes unconditionally and guards only
+// its stores, so the U elements of a trip are scheduled together with no exec-mask branch between them.
+template <int U, class Fn>
+__device__ __forceinline__ void for_each_slot(const int n, const int lane, Fn &&fn) {
+    for (int e0 = 0; e0 < n; e0 += U * PM_WAVE) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * PM_WAVE + lane;
+            fn(e < n ? e : n - 1, e < n);
+        }
     }
 }
 

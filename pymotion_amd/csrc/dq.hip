@@ -124,24 +124,22 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
     }
     const float *gsrc = a.rot + f0 * J * 4;
     auto load_batch = [&](const int e0, v4f (&q)[4]) {
+        if (e0 >= n) return;  // wave-uniform; inside a batch the loads are unconditional (clamped): no exec branches
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int e = e0 + u * PM_WAVE + lane;
-            if (e < n) {
-                if (VEC) q[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(gsrc) + e);
-                else q[u] = v4f{gsrc[4 * e], gsrc[4 * e + 1], gsrc[4 * e + 2], gsrc[4 * e + 3]};
-            }
+            const int e = e0 + u * PM_WAVE + lane, ec = e < n ? e : n - 1;
+            if (VEC) q[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(gsrc) + ec);
+            else q[u] = v4f{gsrc[4 * ec], gsrc[4 * ec + 1], gsrc[4 * ec + 2], gsrc[4 * ec + 3]};
         }
     };
     auto park_batch = [&](const int e0, const v4f (&q)[4]) {
+        if (e0 >= n) return;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = e0 + u * PM_WAVE + lane;
-            if (e < n) {
-                const int f = (int)(((float)e + 0.5f) * invJ);  // e / J, exact for e < 2^22
-                const int j = e - f * J;
-                *reinterpret_cast<v4f *>(sDq + f * FS + j * 8) = q[u];
-            }
+            const int f = (int)(((float)e + 0.5f) * invJ);  // e / J, exact for e < 2^22
+            const int j = e - f * J;
+            if (e < n) *reinterpret_cast<v4f *>(sDq + f * FS + j * 8) = q[u];
         }
     };
     {   // two batches (8 KiB per wave) in flight, batch k+2 requested before batch k is consumed
@@ -210,7 +208,7 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
     }
     wave_sync();
     // phase C, lane per (frame, joint): (q, t) -> [q, 0.5 (0,t) (x) q]  (dual_quat.py:28-36), off the chain
-    for (int e = (a.ablate & 2) ? n : lane; e < n; e += PM_WAVE) {
+    for_each_slot<2>((a.ablate & 2) ? 0 : n, lane, [&](const int e, const bool valid) {
         const int f = (int)(((float)e + 0.5f) * invJ);
         const int j = e - f * J;
         float *slot = sDq + f * FS + j * 8;
@@ -218,8 +216,8 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
         lds_get<8>(slot, 0, qt);
         const float q[4] = {qt[0], qt[1], qt[2], qt[3]}, t[3] = {qt[4], qt[5], qt[6]};
         rt2dq(q, t, d);
-        *reinterpret_cast<v4f *>(slot + 4) = v4f{d[4], d[5], d[6], d[7]};
-    }
+        if (valid) *reinterpret_cast<v4f *>(slot + 4) = v4f{d[4], d[5], d[6], d[7]};
+    });
     wave_sync();
     // copy-out: dwordx4 i of the tile lives at frame i / 2J, chunk i % 2J of the padded image
     float *gout = a.dq + f0 * J * 8;
@@ -294,41 +292,43 @@ __global__ __launch_bounds__(PM_WAVE) void gather_parent_kernel(const GatherArgs
     wave_sync();
     const int n = nf * J;
     const float invJ = 1.0f / (float)J;
-    for (int e = lane; e < n; e += PM_WAVE) {
+    // Branch-free per element: every lane composes with its parent's record and a joint that stays as it is
+    // (the root; in MODE 0 also the root's children, skeleton.py:194-203) selects its own value afterwards
+    // -- no lane divergence, and two elements per trip in flight.
+    for_each_slot<2>(n, lane, [&](const int e, const bool valid) {
         const int f = (int)(((float)e + 0.5f) * invJ);  // e / J without an integer divide (exact for e < 2^22)
         const int j = e - f * J;
         const int par = sPar[j];
         if constexpr (MODE == 0) {
-            float d[8], q[4], t[3];
+            float d[8], q[4], t[3], pd[8], pq[4], pt[3], qq[4], tt[3];
             lds_get<8>(sIn, e, d);
+            lds_get<8>(sIn, f * J + par, pd);
             dq2rt(d, q, t);  // dual_quat.py:75-83
-            if (j != 0 && par != 0) {  // skeleton.py:194-203, parent still in root space
-                float pd[8], pq[4], pt[3];
-                lds_get<8>(sIn, f * J + par, pd);
-                dq2rt(pd, pq, pt);
-                const float inv[4] = {pq[0], -pq[1], -pq[2], -pq[3]};
-                const float dv[3] = {t[0] - pt[0], t[1] - pt[1], t[2] - pt[2]};
-                float qq[4];
-                qmulvec(inv, dv, t);
-                qmul(inv, q, qq);
-                q[0] = qq[0]; q[1] = qq[1]; q[2] = qq[2]; q[3] = qq[3];
+            dq2rt(pd, pq, pt);
+            const float inv[4] = {pq[0], -pq[1], -pq[2], -pq[3]};
+            const float dv[3] = {t[0] - pt[0], t[1] - pt[1], t[2] - pt[2]};
+            qmulvec(inv, dv, tt);
+            qmul(inv, q, qq);
+            const bool keep = (j == 0) || (par == 0);  // parent still in root space otherwise
+#pragma unroll
+            for (int k = 0; k < 3; ++k) tt[k] = keep ? t[k] : tt[k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) qq[k] = keep ? q[k] : qq[k];
+            if (valid) {
+                lds_put<3>(sO0, e, tt);
+                lds_put<4>(sO1, e, qq);
             }
-            lds_put<3>(sO0, e, t);
-            lds_put<4>(sO1, e, q);
         } else {
-            float g[4], o[4];
+            float g[4], pg[4], o[4];
             lds_get<4>(sIn, e, g);
-            if (j == 0) {
-                o[0] = g[0]; o[1] = g[1]; o[2] = g[2]; o[3] = g[3];
-            } else {  // skeleton.py:85-91 : conj(global_parent) (x) global_child
-                float pg[4];
-                lds_get<4>(sIn, f * J + par, pg);
-                const float inv[4] = {pg[0], -pg[1], -pg[2], -pg[3]};
-                qmul(inv, g, o);
-            }
-            lds_put<4>(sO0, e, o);
+            lds_get<4>(sIn, f * J + par, pg);
+            const float inv[4] = {pg[0], -pg[1], -pg[2], -pg[3]};
+            qmul(inv, g, o);  // skeleton.py:85-91 : conj(global_parent) (x) global_child
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (j == 0) ? g[k] : o[k];
+            if (valid) lds_put<4>(sO0, e, o);
         }
-    }
+    });
     wave_sync();
     if constexpr (MODE == 0) {
         tile_store<VEC>(a.out0 + f0 * J * 3, sO0, n * 3, lane);

@@ -58,15 +58,18 @@ __global__ __launch_bounds__(PM_WAVE) void ew_kernel(const EwArgs a) {
     ew_stage_in<I1, VEC>(a.in1, s1, e0, n, lane);
     ew_stage_in<I2, VEC>(a.in2, s2, e0, n, lane);
     wave_sync();
+    // Reads and arithmetic are unconditional (slots past a partial tile hold stale LDS: harmless), so that the
+    // elements of a lane are scheduled and packed together with no exec-mask branch between them; only the
+    // LDS write-back is guarded.
 #pragma unroll
     for (int m = 0; m < EW_PER_LANE; ++m) {
         const int idx = m * PM_WAVE + lane;
+        float x0[I0 ? I0 : 1], x1[I1 ? I1 : 1], x2[I2 ? I2 : 1], y0[O0 ? O0 : 1], y1[O1 ? O1 : 1];
+        if constexpr (I0 > 0) lds_get<I0>(s0, idx, reinterpret_cast<float(&)[I0]>(x0));
+        if constexpr (I1 > 0) lds_get<I1>(s1, idx, reinterpret_cast<float(&)[I1]>(x1));
+        if constexpr (I2 > 0) lds_get<I2>(s2, idx, reinterpret_cast<float(&)[I2]>(x2));
+        Op::apply(x0, x1, x2, y0, y1, a, e0 + (idx < n ? idx : n - 1));  // (ops that index global side tables stay in bounds)
         if (idx < n) {
-            float x0[I0 ? I0 : 1], x1[I1 ? I1 : 1], x2[I2 ? I2 : 1], y0[O0 ? O0 : 1], y1[O1 ? O1 : 1];
-            if constexpr (I0 > 0) lds_get<I0>(s0, idx, reinterpret_cast<float(&)[I0]>(x0));
-            if constexpr (I1 > 0) lds_get<I1>(s1, idx, reinterpret_cast<float(&)[I1]>(x1));
-            if constexpr (I2 > 0) lds_get<I2>(s2, idx, reinterpret_cast<float(&)[I2]>(x2));
-            Op::apply(x0, x1, x2, y0, y1, a, e0 + idx);
             if constexpr (O0 > 0) lds_put<O0>(t0, idx, reinterpret_cast<float(&)[O0]>(y0));
             if constexpr (O1 > 0) lds_put<O1>(t1, idx, reinterpret_cast<float(&)[O1]>(y1));
         }

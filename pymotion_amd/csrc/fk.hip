@@ -250,34 +250,31 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
     // ---- phase A -------------------------------------------------------------------------------------
     if constexpr (SRC == SRC_QUAT) {
         const float *gsrc = a.src + f0 * J * 4;
+        // Loads and math are unconditional (a record past the tile's end re-reads the last one): no exec-mask
+        // branches between the four records of a batch, so the compiler schedules and packs them together;
+        // only the LDS write is guarded.
         auto load_batch = [&](const int e0, float (&qi)[4][4]) {
+            if (e0 >= n) return;  // wave-uniform
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * PM_WAVE + lane;
-                if (e < n) {
-                    if (VEC) {
-                        const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(gsrc) + e);
-                        qi[u][0] = t.x; qi[u][1] = t.y; qi[u][2] = t.z; qi[u][3] = t.w;
-                    } else {
-                        qi[u][0] = gsrc[4 * e]; qi[u][1] = gsrc[4 * e + 1]; qi[u][2] = gsrc[4 * e + 2]; qi[u][3] = gsrc[4 * e + 3];
-                    }
+                const int e = e0 + u * PM_WAVE + lane, ec = e < n ? e : n - 1;
+                if (VEC) {
+                    const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(gsrc) + ec);
+                    qi[u][0] = t.x; qi[u][1] = t.y; qi[u][2] = t.z; qi[u][3] = t.w;
+                } else {
+                    qi[u][0] = gsrc[4 * ec]; qi[u][1] = gsrc[4 * ec + 1]; qi[u][2] = gsrc[4 * ec + 2]; qi[u][3] = gsrc[4 * ec + 3];
                 }
             }
         };
         auto do_batch = [&](const int e0, const float (&qi)[4][4]) {
+            if (e0 >= n) return;  // wave-uniform
+            float L[4][9];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) local_from_quat(qi[u], L[u]);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int e = e0 + u * PM_WAVE + lane;
-                if (e < n) {
-                    float L[9];
-                    if (a.ablate & 1) {
-#pragma unroll
-                        for (int c = 0; c < 9; ++c) L[c] = qi[u][c & 3];
-                    } else {
-                        local_from_quat(qi[u], L);
-                    }
-                    put_local<QUAD>(sRot, e, L);
-                }
+                if (e < n) put_local<QUAD>(sRot, e, L[u]);
             }
         };
         // two batches (8 x 16 B per lane = 8 KiB per wave) in flight before the first use, then
@@ -302,42 +299,45 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
         // staging of the input, which at J = 52 is what buys a third resident wave per CU.
         const float *gsrc = a.src + f0 * J * 6;
         auto load_batch = [&](const int e0, v2f (&x)[2][3]) {
+            if (e0 >= n) return;  // wave-uniform; inside a batch loads and math are unconditional, as above
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int e = e0 + u * PM_WAVE + lane;
-                if (e < n) {
-                    if (VEC) {
-                        const v2f *p = reinterpret_cast<const v2f *>(gsrc) + 3 * e;
-                        x[u][0] = __builtin_nontemporal_load(p);
-                        x[u][1] = __builtin_nontemporal_load(p + 1);
-                        x[u][2] = __builtin_nontemporal_load(p + 2);
-                    } else {
-                        const float *p = gsrc + 6 * e;
-                        x[u][0] = v2f{p[0], p[1]}; x[u][1] = v2f{p[2], p[3]}; x[u][2] = v2f{p[4], p[5]};
-                    }
+                const int e = e0 + u * PM_WAVE + lane, ec = e < n ? e : n - 1;
+                if (VEC) {
+                    const v2f *p = reinterpret_cast<const v2f *>(gsrc) + 3 * ec;
+                    x[u][0] = __builtin_nontemporal_load(p);
+                    x[u][1] = __builtin_nontemporal_load(p + 1);
+                    x[u][2] = __builtin_nontemporal_load(p + 2);
+                } else {
+                    const float *p = gsrc + 6 * ec;
+                    x[u][0] = v2f{p[0], p[1]}; x[u][1] = v2f{p[2], p[3]}; x[u][2] = v2f{p[4], p[5]};
                 }
             }
         };
         auto do_batch = [&](const int e0, const v2f (&x)[2][3]) {
+            if (e0 >= n) return;
+            float L[2][9], Q[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float xx[6] = {x[u][0].x, x[u][0].y, x[u][1].x, x[u][1].y, x[u][2].x, x[u][2].y};
+                if constexpr (QOUT) {
+                    float m[9];
+                    o6d2m(xx, a.eps, m);
+                    m2q(m, Q[u]);
+                    local_from_quat(Q[u], L[u]);
+                } else {
+                    // Without the quaternion output the trip matrix -> quaternion -> normalise -> matrix is the
+                    // identity on an orthonormal matrix up to fp32 rounding (~2e-7, two orders inside the parity
+                    // budget): the Gram-Schmidt result IS the local rotation.  Saves ~80 VALU ops per joint.
+                    o6d2m(xx, a.eps, L[u]);
+                }
+            }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int e = e0 + u * PM_WAVE + lane;
                 if (e < n) {
-                    const float xx[6] = {x[u][0].x, x[u][0].y, x[u][1].x, x[u][1].y, x[u][2].x, x[u][2].y};
-                    float m[9];
-                    o6d2m(xx, a.eps, m);
-                    if constexpr (QOUT) {
-                        float qi[4], L[9];
-                        m2q(m, qi);
-                        lds_put<4>(sQo, e, qi);
-                        local_from_quat(qi, L);
-                        put_local<QUAD>(sRot, e, L);
-                    } else {
-                        // Without the quaternion output the trip matrix -> quaternion -> normalise -> matrix is the
-                        // identity on an orthonormal matrix up to fp32 rounding (~2e-7, two orders inside the parity
-                        // budget): the Gram-Schmidt result IS the local rotation.  Saves ~80 VALU ops per joint.
-                        put_local<QUAD>(sRot, e, m);
-                    }
+                    put_local<QUAD>(sRot, e, L[u]);
+                    if (QOUT) lds_put<4>(sQo, e, Q[u]);
                 }
             }
         };
@@ -551,11 +551,11 @@ __global__ __launch_bounds__(PM_WAVE) void mirror_kernel(const MirrorArgs a) {
         reinterpret_cast<v4f *>(sConst)[j] = v4f{__int_as_float(j == 0 ? -1 : a.parents.p[jc]), 0.0f, 0.0f, 0.0f};
         if (j < J) { sTab[j] = (j == 0) ? 0 : a.parents.p[j]; sTab[J + j] = a.mapping.m[j]; }
     }
-    for_each_record4<VEC>(a.rot + f0 * J * 4, n, lane, [&](const int e, const v4f q) {
+    for_each_record4<VEC>(a.rot + f0 * J * 4, n, lane, [&](const int e, const v4f q, const bool valid) {
         const float qi[4] = {q.x, q.y, q.z, q.w};
         float L[9];
         local_from_quat(qi, L);
-        put_local<QUAD>(sRot, e, L);
+        if (valid) put_local<QUAD>(sRot, e, L);
     });
     const int wl = lane % ((QUAD ? 12 : 3) * FPW);
     const int f = QUAD ? wl / 12 : wl / 3;
@@ -565,32 +565,29 @@ __global__ __launch_bounds__(PM_WAVE) void mirror_kernel(const MirrorArgs a) {
     if constexpr (QUAD) tree_walk_quad<false>(sRot, sPos, nullptr, sConst, J, f, r, c, (c == r) ? 1.0f : 0.0f, lane);
     else tree_walk<false>(sRot, sPos, nullptr, sConst, J, f, r, 0.0f, false);
     wave_sync();
-    for (int e = lane; e < n; e += PM_WAVE) {  // world rotation -> quaternion
+    for_each_slot<2>(n, lane, [&](const int e, const bool valid) {  // world rotation -> quaternion
         float m[9], q[4];
         lds_get<9>(sRot, e, m);
         m2q(m, q);
-        lds_put<4>(sQ, e, q);
-    }
+        if (valid) lds_put<4>(sQ, e, q);
+    });
     wave_sync();
     const float invJ = 1.0f / (float)J;
     const float s1 = (a.c0 == 1 || a.c1 == 1) ? -1.0f : 1.0f, s2 = (a.c0 == 2 || a.c1 == 2) ? -1.0f : 1.0f,
                 s3 = (a.c0 == 3 || a.c1 == 3) ? -1.0f : 1.0f;
-    for (int e = lane; e < n; e += PM_WAVE) {
+    for_each_slot<2>(n, lane, [&](const int e, const bool valid) {
         const int fr = (int)(((float)e + 0.5f) * invJ);
         const int j = e - fr * J;
-        float g[4], o[4];
+        float g[4], pg[4], o[4];
         lds_get<4>(sQ, fr * J + sTab[J + j], g);
+        lds_get<4>(sQ, fr * J + sTab[J + sTab[j]], pg);
         g[1] *= s1; g[2] *= s2; g[3] *= s3;
-        if (j == 0) {
-            o[0] = g[0]; o[1] = g[1]; o[2] = g[2]; o[3] = g[3];
-        } else {
-            float pg[4];
-            lds_get<4>(sQ, fr * J + sTab[J + sTab[j]], pg);
-            const float inv[4] = {pg[0], -pg[1] * s1, -pg[2] * s2, -pg[3] * s3};
-            qmul(inv, g, o);
-        }
-        lds_put<4>(sRot, e, o);
-    }
+        const float inv[4] = {pg[0], -pg[1] * s1, -pg[2] * s2, -pg[3] * s3};
+        qmul(inv, g, o);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (j == 0) ? g[k] : o[k];  // the root has no parent (select, not branch)
+        if (valid) lds_put<4>(sRot, e, o);
+    });
     wave_sync();
     tile_store<VEC>(a.out + f0 * J * 4, sRot, n * 4, lane);
 }
