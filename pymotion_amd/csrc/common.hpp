@@ -21,6 +21,7 @@ namespace pm {
 
 typedef float v4f __attribute__((ext_vector_type(4)));  // native vectors: nontemporal builtins need them
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v3f_a4 __attribute__((ext_vector_type(3), aligned(4)));  // 12-byte record at 4-byte alignment (global dwordx3)
 
 // Compiler-level ordering of LDS traffic inside one wave (hardware already executes a wave's
 // DS instructions in order).  Emits no instruction beyond the waitcnt the compiler needs.

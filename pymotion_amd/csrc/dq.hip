@@ -27,7 +27,8 @@ namespace pm {
 //            (skeleton.py:236-241), which here means "parent = the identity slot", and the root itself
 //            (:232) is the same step with the frame's root position as its offset; slot <- (q, t, 0);
 //   phase C  lane per (frame, joint): (q, t) -> [q, 0.5 (0,t) (x) q] in place (dual_quat.py:28-36);
-//   out      contiguous dwordx4 streaming stores.
+//   out      contiguous dwordx4 streaming stores (measured: storing the 32-byte records straight from the
+//            phase-C registers, two dwordx4 per lane at a 32-byte stride, is 5 % slower at J = 22).
 // Per-joint constants sit in LDS in the form the lanes consume them: {v_c, 2 v_next-next, 2 v_next} per
 // lane column, and the effective parent index (one v_readlane per step, 64 joints per VGPR).
 // ---------------------------------------------------------------------------------------------------
@@ -268,7 +269,7 @@ struct GatherArgs {
 template <int MODE>
 constexpr int gather_in_w() { return MODE == 0 ? 8 : 4; }
 template <int MODE>
-constexpr int gather_lds_w() { return MODE == 0 ? 8 + 3 + 4 : 4 + 4; }
+constexpr int gather_lds_w() { return gather_in_w<MODE>(); }  // only the input tile is staged; outputs leave from registers
 
 template <int MODE, bool VEC>
 __global__ __launch_bounds__(PM_WAVE) void gather_parent_kernel(const GatherArgs a, const int fpw) {
@@ -283,11 +284,17 @@ __global__ __launch_bounds__(PM_WAVE) void gather_parent_kernel(const GatherArgs
     const int nf = (int)((a.F - f0) < fpw ? (a.F - f0) : fpw);
     const int FJ = fpw * J;
     float *sIn = smem;             // [fpw*J*IW]
-    float *sO0 = sIn + FJ * IW;    // [fpw*J*3] or [fpw*J*4]
-    float *sO1 = sO0 + FJ * (MODE == 0 ? 3 : 4);
 
     tile_load<VEC>(a.in + f0 * J * IW, sIn, nf * J * IW, lane);
-    int *sPar = reinterpret_cast<int *>(sO1 + FJ * (MODE == 0 ? 4 : 0));  // [J] parents, staged once
+    int *sPar = reinterpret_cast<int *>(sIn + FJ * IW);  // [J] parents, staged once
+    // Outputs are one record per lane with consecutive lanes on consecutive records: a dwordx4 (rotation) or
+    // dwordx3 (translation) store per lane is already a contiguous, fully coalesced stream -- no LDS staging.
+    float *g0 = a.out0 + f0 * J * (MODE == 0 ? 3 : 4);
+    float *g1 = (MODE == 0) ? a.out1 + f0 * J * 4 : nullptr;
+    auto store4 = [&](float *g, const int e, const float (&v)[4]) {
+        if (VEC) __builtin_nontemporal_store(v4f{v[0], v[1], v[2], v[3]}, reinterpret_cast<v4f *>(g) + e);
+        else { g[4 * e] = v[0]; g[4 * e + 1] = v[1]; g[4 * e + 2] = v[2]; g[4 * e + 3] = v[3]; }
+    };
     for (int j = lane; j < J; j += PM_WAVE) sPar[j] = (j == 0) ? 0 : a.parents.p[j];
     wave_sync();
     const int n = nf * J;
@@ -315,8 +322,8 @@ __global__ __launch_bounds__(PM_WAVE) void gather_parent_kernel(const GatherArgs
 #pragma unroll
             for (int k = 0; k < 4; ++k) qq[k] = keep ? q[k] : qq[k];
             if (valid) {
-                lds_put<3>(sO0, e, tt);
-                lds_put<4>(sO1, e, qq);
+                __builtin_nontemporal_store(v3f_a4{tt[0], tt[1], tt[2]}, reinterpret_cast<v3f_a4 *>(g0 + 3 * e));
+                store4(g1, e, qq);
             }
         } else {
             float g[4], pg[4], o[4];
@@ -326,16 +333,9 @@ __global__ __launch_bounds__(PM_WAVE) void gather_parent_kernel(const GatherArgs
             qmul(inv, g, o);  // skeleton.py:85-91 : conj(global_parent) (x) global_child
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k] = (j == 0) ? g[k] : o[k];
-            if (valid) lds_put<4>(sO0, e, o);
+            if (valid) store4(g0, e, o);
         }
     });
-    wave_sync();
-    if constexpr (MODE == 0) {
-        tile_store<VEC>(a.out0 + f0 * J * 3, sO0, n * 3, lane);
-        tile_store<VEC>(a.out1 + f0 * J * 4, sO1, n * 4, lane);
-    } else {
-        tile_store<VEC>(a.out0 + f0 * J * 4, sO0, n * 4, lane);
-    }
 }
 
 template <int MODE>

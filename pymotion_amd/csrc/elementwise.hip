@@ -2,11 +2,11 @@
 //
 // One templated streaming kernel: a wave owns a tile of 128 elements (2 per lane; measured 64/128/256: small
 // tiles = more resident waves win by 5-12 % on the narrow records, 128 is the best overall).  Each operand is
-// an AoS record of W floats (W in {1,3,4,6,8,9}); records of odd width cannot be moved with aligned
-// dwordx4 per lane directly, so every operand goes HBM -> LDS (contiguous dwordx4, perfectly coalesced,
-// tile bases are multiples of 1 KiB) -> registers (per-record read, widest conflict-free DS op), and
-// results go back the same way.  All of these ops are HBM-bound (16-60 B per element, a few dozen
-// flops): the kernel's job is to keep every byte it touches inside full 128-byte lines.
+// an AoS record of W floats (W in {1,3,4,6,8,9}).  Records of 1, 3 or 4 floats move straight between HBM and
+// registers (one record per lane = a contiguous stream); the wider / odd ones go HBM -> LDS (contiguous
+// dwordx4, perfectly coalesced, tile bases are multiples of 1 KiB) -> registers (per-record read, widest
+// conflict-free DS op) and back the same way.  All of these ops are HBM-bound (16-60 B per element, a few
+// dozen flops): the kernel's job is to keep every byte it touches inside full 128-byte lines.
 #include <stdlib.h>
 
 #include "common.hpp"
@@ -25,13 +25,56 @@ struct EwArgs {
     int flag;  // slerp: shortest; euler: order_per_element
 };
 
+// Records of 4 (dwordx4), 3 (dwordx3) or 1 float: one record per lane with consecutive lanes on consecutive
+// records is already a contiguous, fully coalesced stream -- straight between HBM and registers.  The other
+// widths (6, 8, 9) go through an LDS tile so that HBM only ever sees contiguous dwordx4 (measured on the
+// 32-byte records of to_root_dual_quat: two dwordx4 per lane at a 32-byte stride are 5 % slower than the
+// staged copy).
+__host__ __device__ constexpr bool ew_direct_out(const int W) { return W == 1 || W == 3 || W == 4; }
+__host__ __device__ constexpr bool ew_direct_in(const int W) { return false && ew_direct_out(W); }
+__host__ __device__ constexpr int ew_lds_in(const int W) { return ew_direct_in(W) ? 0 : W; }
+__host__ __device__ constexpr int ew_lds_out(const int W) { return ew_direct_out(W) ? 0 : W; }
+
 template <int W, bool VEC>
 __device__ __forceinline__ void ew_stage_in(const float *g, float *s, int64_t e0, int n, int lane) {
-    if constexpr (W > 0) tile_load<VEC>(g + e0 * W, s, n * W, lane);
+    if constexpr (W > 0 && !ew_direct_in(W)) tile_load<VEC>(g + e0 * W, s, n * W, lane);
 }
 template <int W, bool VEC>
 __device__ __forceinline__ void ew_stage_out(float *g, const float *s, int64_t e0, int n, int lane) {
-    if constexpr (W > 0) tile_store<VEC>(g + e0 * W, s, n * W, lane);
+    if constexpr (W > 0 && !ew_direct_out(W)) tile_store<VEC>(g + e0 * W, s, n * W, lane);
+}
+// record `idx` of the tile -> registers (idx already clamped into the tile)
+template <int W, bool VEC>
+__device__ __forceinline__ void ew_get(const float *g, const float *s, const int64_t e0, const int idx, float (&x)[W ? W : 1]) {
+    if constexpr (W == 0) {
+    } else if constexpr (!ew_direct_in(W)) {
+        lds_get<W>(s, idx, reinterpret_cast<float(&)[W]>(x));
+    } else if constexpr (W == 4) {
+        const float *p = g + (e0 + idx) * 4;
+        if (VEC) { const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p)); x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w; }
+        else { x[0] = p[0]; x[1] = p[1]; x[2] = p[2]; x[3] = p[3]; }
+    } else if constexpr (W == 3) {
+        const v3f_a4 t = __builtin_nontemporal_load(reinterpret_cast<const v3f_a4 *>(g + (e0 + idx) * 3));
+        x[0] = t.x; x[1] = t.y; x[2] = t.z;
+    } else {
+        x[0] = __builtin_nontemporal_load(g + e0 + idx);
+    }
+}
+// registers -> record `idx` (valid slots only): straight to HBM, or into the LDS tile for the staged widths
+template <int W, bool VEC>
+__device__ __forceinline__ void ew_put(float *g, float *s, const int64_t e0, const int idx, const float (&y)[W ? W : 1]) {
+    if constexpr (W == 0) {
+    } else if constexpr (!ew_direct_out(W)) {
+        lds_put<W>(s, idx, reinterpret_cast<const float(&)[W]>(y));
+    } else if constexpr (W == 4) {
+        float *p = g + (e0 + idx) * 4;
+        if (VEC) __builtin_nontemporal_store(v4f{y[0], y[1], y[2], y[3]}, reinterpret_cast<v4f *>(p));
+        else { p[0] = y[0]; p[1] = y[1]; p[2] = y[2]; p[3] = y[3]; }
+    } else if constexpr (W == 3) {
+        __builtin_nontemporal_store(v3f_a4{y[0], y[1], y[2]}, reinterpret_cast<v3f_a4 *>(g + (e0 + idx) * 3));
+    } else {
+        __builtin_nontemporal_store(y[0], g + e0 + idx);
+    }
 }
 
 // Op concept: static constexpr int I0,I1,I2,O0,O1 (0 = absent);
@@ -48,30 +91,35 @@ __global__ __launch_bounds__(PM_WAVE) void ew_kernel(const EwArgs a) {
     const int64_t e0 = tile * EW_TILE;
     const int n = (int)((a.N - e0) < EW_TILE ? (a.N - e0) : EW_TILE);
 
-    float *s0 = smem;
-    float *s1 = s0 + EW_TILE * I0;
-    float *s2 = s1 + EW_TILE * I1;
-    float *t0 = s2 + EW_TILE * I2;
-    float *t1 = t0 + EW_TILE * O0;
+    float *s0 = smem;  // tiles of the staged operands only
+    float *s1 = s0 + EW_TILE * ew_lds_in(I0);
+    float *s2 = s1 + EW_TILE * ew_lds_in(I1);
+    float *t0 = s2 + EW_TILE * ew_lds_in(I2);
+    float *t1 = t0 + EW_TILE * ew_lds_out(O0);
 
     ew_stage_in<I0, VEC>(a.in0, s0, e0, n, lane);
     ew_stage_in<I1, VEC>(a.in1, s1, e0, n, lane);
     ew_stage_in<I2, VEC>(a.in2, s2, e0, n, lane);
     wave_sync();
-    // Reads and arithmetic are unconditional (slots past a partial tile hold stale LDS: harmless), so that the
-    // elements of a lane are scheduled and packed together with no exec-mask branch between them; only the
-    // LDS write-back is guarded.
+    // Reads and arithmetic are unconditional (a slot past a partial tile re-reads the tile's last record), so
+    // that the elements of a lane are scheduled and packed together with no exec-mask branch between them;
+    // only the write-back is guarded.
+    float x0[EW_PER_LANE][I0 ? I0 : 1], x1[EW_PER_LANE][I1 ? I1 : 1], x2[EW_PER_LANE][I2 ? I2 : 1];
 #pragma unroll
     for (int m = 0; m < EW_PER_LANE; ++m) {
-        const int idx = m * PM_WAVE + lane;
-        float x0[I0 ? I0 : 1], x1[I1 ? I1 : 1], x2[I2 ? I2 : 1], y0[O0 ? O0 : 1], y1[O1 ? O1 : 1];
-        if constexpr (I0 > 0) lds_get<I0>(s0, idx, reinterpret_cast<float(&)[I0]>(x0));
-        if constexpr (I1 > 0) lds_get<I1>(s1, idx, reinterpret_cast<float(&)[I1]>(x1));
-        if constexpr (I2 > 0) lds_get<I2>(s2, idx, reinterpret_cast<float(&)[I2]>(x2));
-        Op::apply(x0, x1, x2, y0, y1, a, e0 + (idx < n ? idx : n - 1));  // (ops that index global side tables stay in bounds)
+        const int idx = m * PM_WAVE + lane, ic = idx < n ? idx : n - 1;
+        ew_get<I0, VEC>(a.in0, s0, e0, ic, x0[m]);
+        ew_get<I1, VEC>(a.in1, s1, e0, ic, x1[m]);
+        ew_get<I2, VEC>(a.in2, s2, e0, ic, x2[m]);
+    }
+#pragma unroll
+    for (int m = 0; m < EW_PER_LANE; ++m) {
+        const int idx = m * PM_WAVE + lane, ic = idx < n ? idx : n - 1;
+        float y0[O0 ? O0 : 1], y1[O1 ? O1 : 1];
+        Op::apply(x0[m], x1[m], x2[m], y0, y1, a, e0 + ic);  // (ops that index global side tables stay in bounds)
         if (idx < n) {
-            if constexpr (O0 > 0) lds_put<O0>(t0, idx, reinterpret_cast<float(&)[O0]>(y0));
-            if constexpr (O1 > 0) lds_put<O1>(t1, idx, reinterpret_cast<float(&)[O1]>(y1));
+            ew_put<O0, VEC>(a.out0, t0, e0, idx, y0);
+            ew_put<O1, VEC>(a.out1, t1, e0, idx, y1);
         }
     }
     wave_sync();
@@ -87,7 +135,7 @@ static int launch_ew(const EwArgs &a, pm_stream_t stream, const char *name) {
         set_error("%s: null pointer", name);
         return PM_EINVAL;
     }
-    constexpr size_t lds = (size_t)EW_TILE * (Op::I0 + Op::I1 + Op::I2 + Op::O0 + Op::O1) * sizeof(float);
+    constexpr size_t lds = (size_t)EW_TILE * (ew_lds_in(Op::I0) + ew_lds_in(Op::I1) + ew_lds_in(Op::I2) + ew_lds_out(Op::O0) + ew_lds_out(Op::O1)) * sizeof(float);
     const int64_t ntiles = (a.N + EW_TILE - 1) / EW_TILE;
     const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
     if (grid > 0x7fffffffLL) { set_error("%s: grid too large", name); return PM_EUNSUPPORTED; }

@@ -586,10 +586,12 @@ __global__ __launch_bounds__(PM_WAVE) void mirror_kernel(const MirrorArgs a) {
         qmul(inv, g, o);
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = (j == 0) ? g[k] : o[k];  // the root has no parent (select, not branch)
-        if (valid) lds_put<4>(sRot, e, o);
+        if (valid) {  // one record per lane, consecutive lanes on consecutive records: stored from registers
+            float *g = a.out + f0 * J * 4;
+            if (VEC) __builtin_nontemporal_store(v4f{o[0], o[1], o[2], o[3]}, reinterpret_cast<v4f *>(g) + e);
+            else { g[4 * e] = o[0]; g[4 * e + 1] = o[1]; g[4 * e + 2] = o[2]; g[4 * e + 3] = o[3]; }
+        }
     });
-    wave_sync();
-    tile_store<VEC>(a.out + f0 * J * 4, sRot, n * 4, lane);
 }
 
 template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT>

@@ -134,12 +134,13 @@ def main():
         if want("ew") and J == 22:
             N = Fj * J
             q = rotn.view(N, 4)
+            q2 = torch.randn((N, 4), device=dev)
             m = rm.view(N, 9)
             ms, mn = timeit(lambda: _lib.call("pm_quat_to_matrix_f32", p(q), N, p(m), None))
             report("quat.to_matrix", ms, mn, N * 52)
             ms, mn = timeit(lambda: _lib.call("pm_quat_from_matrix_f32", p(m), N, p(qo), None))
             report("quat.from_matrix", ms, mn, N * 52)
-            ms, mn = timeit(lambda: _lib.call("pm_quat_mul_f32", p(q), p(q), N, p(qo), None))
+            ms, mn = timeit(lambda: _lib.call("pm_quat_mul_f32", p(q), p(q2), N, p(qo), None))
             report("quat.mul", ms, mn, N * 48)
             ms, mn = timeit(lambda: _lib.call("pm_quat_normalize_f32", p(q), N, C.c_float(1e-8), p(qo), None))
             report("quat.normalize", ms, mn, N * 32)
