@@ -1,0 +1,20 @@
+#!/bin/bash
+# Re-collect everything under profiles/ for one round (run on the MI355X box from the repo root):
+#     bash tools/collect_profiles.sh 01        -> gpurun_out/profiles_r01/*  (copy into profiles/ afterwards)
+# Separate rocprofv3 passes for the kernel trace and for each PMC counter, as the MI355X guide prescribes.
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+RN=${1:-01}
+OUT=$R/gpurun_out/profiles_r$RN
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+python $R/bench.py > $OUT/bench.log 2>&1
+tail -1 $OUT/bench.log > $OUT/r${RN}_bench_1gpu.json
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- python $R/bench.py --no-cpu-baseline > $OUT/trace.log 2>&1
+cp $(find $OUT/trace -name '*kernel_stats.csv' | head -1) $OUT/r${RN}_bench_kernel_stats.csv
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f --output-format csv -- python $R/tools/perf_probe.py --only fk,ceiling,dq,o6d --sustained 20 > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o w --output-format csv -- python $R/tools/perf_probe.py --only fk,ceiling,dq,o6d --sustained 20 > $OUT/pmc_write.log 2>&1
+python $R/tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $((10#$RN)) > $OUT/r${RN}_fk_hbm_traffic.json
+python $R/tools/perf_probe.py --sustained 100 > $OUT/r${RN}_kernel_probe.txt 2>&1
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write
+ls -la $OUT
