@@ -188,6 +188,16 @@ int pm_dq_normalize_f32(const float *dq, int64_t N, int orthogonalize, float ato
                         pm_stream_t stream);
 int pm_dq_unit_flags_f32(const float *dq, int64_t N, float atol, int32_t *flags, pm_stream_t stream);
 
+/* ---- resampling along the time axis ------------------------------------------------------------------ */
+
+/* ops/time.py:4-66 interpolate_positions (method "linear"), torch twin ops/time_torch.py.
+ * positions viewed as [A, T, B] (A = product of the axes before the time axis, B = product of those after),
+ * out [A, S, B]:  out[a, s, :] = (1 - weights[s]) * positions[a, idx[s], :] + weights[s] * positions[a, idx[s] + 1, :]
+ * idx (int32, 0 <= idx <= T - 2) and weights (fp32) are DEVICE arrays of S entries: the caller derives them
+ * from the two 1-D time arrays exactly as time.py:49-54 does (searchsorted, clamp, divide).  T >= 2. */
+int pm_interpolate_linear_f32(const float *positions, const int32_t *idx, const float *weights, int64_t A,
+                              int64_t T, int64_t S, int64_t B, float *out, pm_stream_t stream);
+
 /* ---- measurement helper --------------------------------------------------------------------------- */
 
 /* Streaming ceiling with fk's traffic shape: per frame read rd_floats and write wr_floats

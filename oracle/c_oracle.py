@@ -247,6 +247,22 @@ def quat_unroll(q, axis):
     return np.moveaxis(o.reshape(shp), 0, axis)
 
 
+def interpolate_positions(sample_times, original_times, positions, axis):
+    """ops/time.py:4-66 (any time axis; the reference's own broadcast needs it second to last)"""
+    pos = np.asarray(positions)
+    dt = np.float32 if (pos.dtype == np.float32 and np.asarray(sample_times).dtype == np.float32) else np.float64
+    pos = np.ascontiguousarray(pos, dtype=dt)
+    st = np.ascontiguousarray(sample_times, dtype=dt)
+    ot = np.ascontiguousarray(original_times, dtype=dt)
+    ax = axis % pos.ndim
+    A = int(np.prod(pos.shape[:ax], dtype=np.int64))
+    T = pos.shape[ax]
+    B = int(np.prod(pos.shape[ax + 1:], dtype=np.int64))
+    o = np.empty(pos.shape[:ax] + (len(st),) + pos.shape[ax + 1:], dtype=dt)
+    _call("oracle_interpolate_positions", dt, st, ot, pos, _i64(A), _i64(T), _i64(len(st)), _i64(B), o)
+    return o
+
+
 _AX = {"x": 0, "y": 1, "z": 2}
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate tests/golden/*.npz by IMPORTING the reference (this container only).
 
-    python oracle/make_golden.py            # writes tests/golden/{elementwise,trig,skeleton,bvh,mirror}.npz + synthetic22.bvh
+    python oracle/make_golden.py            # writes tests/golden/{elementwise,trig,skeleton,bvh,mirror,ik,time}.npz + synthetic22.bvh
     python oracle/make_golden.py --check    # also cross-checks oracle/ (C + NumPy) against the import
 
 The reference (UPC-ViRVIG/pymotion v0.2.3, pure Python) lives at /root/reference and
@@ -415,6 +415,33 @@ def gen_ik():
     s.save("ik.npz")
 
 
+def gen_time():
+    """tests/golden/time.npz: ops/time.py interpolate_positions -- the literal of the reference's own test
+    (ops/tests/test_time.py:12-66) and seeded clips with non-uniform times, exact hits and extrapolation on
+    both sides.  The time axis is the second to last one (the only layout the reference's broadcast supports)."""
+    import pymotion.ops.time as tm
+    import pymotion.ops.time_torch as tmt
+
+    s = Store()
+    pos = np.array([[[0, 0, 0], [1, 1, 0], [2, 0, 0], [8, 0, 1], [20, 0, 0]],
+                    [[1, 1, 1], [1, 1, 0], [2, 0, 0], [8, 0, 1], [20, 0, 0]]], dtype=np.float32)[np.newaxis, np.newaxis, ...]
+    x = np.array([0, 2, 3, 4, 5], dtype=np.float32)
+    new_x = np.array([0.5, 1.75, 2.25, 3.75, 4, 5, 6, 7, 8], dtype=np.float32)
+    run3(s, "interp_lit", {"sample": new_x, "orig": x, "pos": pos}, lambda a, b, c: tm.interpolate_positions(a, b, c, 3),
+         lambda a, b, c: tmt.interpolate_positions(a, b, c, 3), ["out"])
+    rng = np.random.default_rng(77)
+    for name, lead, Tn, Sn in (("clip", (22,), 40, 97), ("lead", (2, 3), 17, 33), ("two", (5,), 2, 9)):
+        orig = np.cumsum(rng.uniform(0.01, 0.1, Tn)).astype(np.float32)
+        sample = np.sort(rng.uniform(orig[0] - 0.2, orig[-1] + 0.2, Sn)).astype(np.float32)
+        sample[1] = orig[0]; sample[2] = orig[-1]; sample[3] = orig[Tn // 2]   # exact hits (searchsorted side='left')
+        sample = rng.permutation(sample)                                          # sample times need not be sorted
+        p = rng.uniform(-2, 2, lead + (Tn, 3)).astype(np.float32)
+        ax = len(lead)
+        run3(s, f"interp_{name}", {"sample": sample, "orig": orig, "pos": p},
+             lambda a, b, c, ax=ax: tm.interpolate_positions(a, b, c, ax), lambda a, b, c, ax=ax: tmt.interpolate_positions(a, b, c, ax), ["out"])
+    s.save("time.npz")
+
+
 # ---- optional cross-check of oracle/ against the import ------------------------------------------------
 
 def check_oracle():
@@ -462,13 +489,13 @@ def check_oracle():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true", help="also cross-check oracle/ against the imported reference")
+    ap.add_argument("--only", default="", help="comma-separated subset of: elementwise,trig,skeleton,bvh,mirror,ik,time")
     args = ap.parse_args()
-    gen_elementwise()
-    gen_trig()
-    gen_skeleton()
-    gen_bvh()
-    gen_mirror()
-    gen_ik()
+    gens = {"elementwise": gen_elementwise, "trig": gen_trig, "skeleton": gen_skeleton, "bvh": gen_bvh, "mirror": gen_mirror,
+            "ik": gen_ik, "time": gen_time}
+    for name, gen in gens.items():
+        if not args.only or name in args.only.split(","):
+            gen()
     if args.check:
         check_oracle()
 

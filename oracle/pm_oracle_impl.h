@@ -502,6 +502,30 @@ void FN(oracle_from_root_positions)(const REAL *positions, const int32_t *parent
     free(pos); free(rm); free(gq);
 }
 
+/* ---- time axis ------------------------------------------------------------------------ */
+
+/* ops/time.py:4-66 interpolate_positions (linear), positions viewed as [A,T,B] with the time axis in the
+ * middle, out [A,S,B].  idx = clamp(searchsorted(original, sample, side='left') - 1, 0, T-2) (:49-52),
+ * w = (sample - original[idx]) / (original[idx+1] - original[idx]) (:53-54),
+ * out = (1 - w) * p[idx] + w * p[idx+1] (:61-64): samples outside the original range extrapolate. */
+void FN(oracle_interpolate_positions)(const REAL *sample_times, const REAL *original_times, const REAL *positions,
+                                      int64_t A, int64_t T, int64_t S, int64_t B, REAL *out) {
+    for (int64_t s = 0; s < S; ++s) {
+        const REAL v = sample_times[s];
+        int64_t lo = 0, hi = T;  /* first i with original[i] >= v */
+        while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (original_times[mid] < v) lo = mid + 1; else hi = mid; }
+        int64_t i = lo - 1;
+        if (i < 0) i = 0;
+        if (i > T - 2) i = T - 2;
+        const REAL w = (v - original_times[i]) / (original_times[i + 1] - original_times[i]);
+        for (int64_t a = 0; a < A; ++a) {
+            const REAL *p0 = positions + (a * T + i) * B, *p1 = p0 + B;
+            REAL *o = out + (a * S + s) * B;
+            for (int64_t b = 0; b < B; ++b) o[b] = ((REAL)1 - w) * p0[b] + w * p1[b];
+        }
+    }
+}
+
 #undef FN
 #undef FN1
 #undef FN2

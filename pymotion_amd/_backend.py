@@ -184,6 +184,16 @@ class NumpyBackend:
     def host_ints(x):
         return np.ascontiguousarray(np.asarray(x), dtype=np.int32)
 
+    @staticmethod
+    def interp_coefficients(sample_times, original_times):
+        """ops/time.py:49-54 on the host (two 1-D arrays): -> (idx int32[S], weights [S] in the times' dtype)."""
+        st, ot = np.asarray(sample_times), np.asarray(original_times)
+        idxs = np.minimum(np.maximum(np.searchsorted(ot, st) - 1, 0), ot.shape[0] - 2)
+        weights = (st - ot[idxs]) / (ot[idxs + 1] - ot[idxs])
+        return idxs.astype(np.int32), weights
+
+    i32 = np.int32
+
 
 # ---------------------------------------------------------------------------------------------
 # torch front door
@@ -283,6 +293,19 @@ class TorchBackend:
         if isinstance(x, torch.Tensor):
             x = x.detach().cpu().numpy()  # J integers; on a HIP tensor this is the only sync of the call
         return np.ascontiguousarray(np.asarray(x), dtype=np.int32)
+
+    def interp_coefficients(self, sample_times, original_times):
+        """ops/time_torch.py:49-54 with torch ops, wherever the two 1-D tensors live (no host sync)."""
+        torch = self.torch
+        st, ot = torch.as_tensor(sample_times), torch.as_tensor(original_times)
+        ot = ot.to(st.device)
+        idxs = torch.clamp(torch.searchsorted(ot, st) - 1, min=0, max=ot.shape[0] - 2)
+        weights = (st - ot[idxs]) / (ot[idxs + 1] - ot[idxs])
+        return idxs.to(torch.int32), weights
+
+    @property
+    def i32(self):
+        return self.torch.int32
 
 
 def numpy_backend():

@@ -70,6 +70,7 @@ SIGNATURES = {
     "pm_dq_unroll_f32": [_f, _i64, _i32, _f, C.c_void_p, _strm],
     "pm_dq_normalize_f32": [_f, _i64, _int, _flt, _f, C.c_void_p, _strm],
     "pm_dq_unit_flags_f32": [_f, _i64, _flt, C.c_void_p, _strm],
+    "pm_interpolate_linear_f32": [_f, C.c_void_p, _f, _i64, _i64, _i64, _i64, _f, _strm],
     # measurement helper
     "pm_stream_ceiling_f32": [_f, _f, _i64, _i32, _i32, _strm],
     "pm_stream_plain_f32": [_f, _f, _i64, _i32, _i32, _strm],

@@ -215,6 +215,43 @@ def dq_unroll(be, dq, axis):
     return _unroll(be, dq, axis, 8, "pm_dq_unroll_f32")
 
 
+# ---- resampling along the time axis (ops/time.py) -------------------------------------------------------
+
+def interpolate_positions(be, sample_times, original_times, positions, axis, method="linear"):
+    """ops/time.py:4-66 / ops/time_torch.py.  The reference's final broadcast (time.py:61-64) is only
+    well-formed when the time axis is the second to last one; here any axis works (same values there)."""
+    if method != "linear":
+        raise ValueError("Only linear interpolation is supported yet.")
+    shp = be.shape(positions)
+    nd = len(shp)
+    if nd < 1:
+        raise ValueError("positions needs a time axis")
+    ax = axis % nd
+    T = shp[ax]
+    if be.shape(original_times) != (T,):
+        raise ValueError("Wrong shape of data. Positions along the axis dimension must be equal to the length of original_times.")
+    if len(be.shape(sample_times)) != 1:
+        raise ValueError("sample_times must be a 1D array")
+    if T < 2:
+        raise ValueError("linear interpolation needs at least two original times")
+    S = be.shape(sample_times)[0]
+    A, B = _prod(shp[:ax]), _prod(shp[ax + 1:])
+    be.begin(positions)
+    try:
+        idx, w = be.interp_coefficients(sample_times, original_times)
+        dt = be.result_dtype(w, positions)  # what (1 - weights) * positions promotes to
+        pp = be.dev_in(positions)
+        ip = be.dev_in(idx, dtype=be.i32)
+        wp = be.dev_in(w)
+        op, oh = be.dev_out(shp[:ax] + (S,) + shp[ax + 1:])
+        if A * S * B > 0:
+            _lib.call("pm_interpolate_linear_f32", pp, ip, wp, A, T, S, B, op, be.stream())
+        res = be.result(oh, dt)
+    finally:
+        be.end()
+    return res
+
+
 # ---- dual quaternions ----------------------------------------------------------------------------
 
 def dq_from_rt(be, q, t):

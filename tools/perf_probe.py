@@ -126,6 +126,15 @@ def main():
             ws = torch.empty(int(_lib.lib().pm_quat_unroll_workspace_bytes(Fj, J)) + 16, dtype=torch.uint8, device=dev)
             ms, mn = timeit(lambda: _lib.call("pm_quat_unroll_f32", p(rotn), Fj, J, p(qo), p(ws), None))
             report(f"quat.unroll axis=0 J={J}", ms, mn, Fj * 48 * J)
+        if want("interp") and J == 22:
+            Tn, Sn = Fj // 4, Fj // 2                      # 2x up-sampling of a [T, J, 3] clip
+            idx = (torch.arange(Sn, device=dev) // 2).clamp(max=Tn - 2).to(torch.int32)
+            w = torch.rand(Sn, device=dev)
+            src = torch.randn((Tn, J * 3), device=dev)
+            dst = torch.empty((Sn, J * 3), device=dev)
+            ms, mn = timeit(lambda: _lib.call("pm_interpolate_linear_f32", p(src), p(idx), p(w), 1, Tn, Sn, J * 3, p(dst), None))
+            report("interpolate_positions 2x up J=22", ms, mn, (Tn + Sn) * J * 12)
+            del src, dst
         if want("o6d") and J == 52:
             x = torch.randn((Fj, J, 3, 2), device=dev)
             ms, mn = timeit(lambda: _lib.call("pm_fk_from_ortho6d_f32", p(x), p(root), p(off), 0, pp, Fj, J, C.c_float(0.0),
