@@ -4,8 +4,8 @@
 // blends them with (1 - w), w (time.py:49-64); idx / w come from a searchsorted over the two 1-D time
 // arrays (S and T entries -- tiny next to the payload, computed by the caller and passed as device arrays).
 // Viewed as [A, T, B] -> [A, S, B] (A = product of the axes before the time axis, B = after) the op is a
-// streaming row gather: every output row of B floats reads two input rows.  One lane per dwordx4 of the
-// output (B % 4 == 0 and 16-byte aligned pointers: a vector never straddles a row) or per float; consecutive
+// streaming row gather: every output row of B floats reads two input rows.  One lane per dwordx4 / dwordx2 of
+// the output (row length a multiple of 4 / 2 floats: a vector never straddles a row) or per float; consecutive
 // lanes are consecutive in memory on both sides, so loads and stores are fully coalesced; neighbouring
 // samples that fall between the same two frames re-read the same rows out of L2.
 #include "common.hpp"
@@ -20,26 +20,63 @@ struct InterpArgs {
     int64_t A, T, S, B;
 };
 
-template <bool VEC>
+constexpr int IP_PER_THREAD = 4;                       // lane-elements per thread
+constexpr int IP_BLOCK = 256 * IP_PER_THREAD;          // per workgroup: a contiguous run of the flattened output
+
+template <int VW>  // floats per lane-element: 4 / 2 when the row length allows (a vector never straddles a row), else 1
 __global__ __launch_bounds__(256) void interp_linear_kernel(const InterpArgs a) {
-    constexpr int VW = VEC ? 4 : 1;
     const int64_t Bv = a.B / VW;                       // row length in lane-elements
     const int64_t nv = a.A * a.S * Bv;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nv) return;
-    const int64_t row = i / Bv, b = i - row * Bv;      // output row (a, s), position inside the row
-    const int64_t aa = row / a.S, s = row - aa * a.S;
-    const int32_t i0 = a.idx[s];
-    const float w = a.w[s], u = 1.0f - w;              // time.py:61-64: (1 - w) * p[idx] + w * p[idx + 1]
-    const float *p0 = a.pos + ((aa * a.T + i0) * a.B) + b * VW;
-    const float *p1 = p0 + a.B;
-    float *o = a.out + row * a.B + b * VW;
-    if (VEC) {
-        const v4f x = *reinterpret_cast<const v4f *>(p0), y = *reinterpret_cast<const v4f *>(p1);
-        const v4f r = {u * x.x + w * y.x, u * x.y + w * y.y, u * x.z + w * y.z, u * x.w + w * y.w};
-        __builtin_nontemporal_store(r, reinterpret_cast<v4f *>(o));
-    } else {
-        o[0] = u * p0[0] + w * p1[0];
+    const int64_t base = (int64_t)blockIdx.x * IP_BLOCK;
+    // Where the block's run starts: one 64-bit divide per wave (uniform), then every lane-element is a small
+    // offset from it and finds its row with a float-reciprocal divide (exact: offsets stay below 2^22).
+    const int64_t row0 = base / Bv;
+    const int b0 = (int)(base - row0 * Bv);
+    const int64_t a0 = row0 / a.S;
+    const int64_t s0 = row0 - a0 * a.S;
+    const float invB = 1.0f / (float)Bv, invS = 1.0f / (float)a.S;
+    const bool narrow = Bv < (1 << 21);                // otherwise a block never leaves its first two rows
+    const bool short_s = a.S < (1 << 21);              // likewise for the sample axis
+#pragma unroll
+    for (int k = 0; k < IP_PER_THREAD; ++k) {
+        const int o = k * 256 + threadIdx.x;
+        if (base + o >= nv) break;
+        int dr;                                        // rows past row0 (<= 1024)
+        int64_t b;
+        if (narrow) {
+            const int e = b0 + o;                      // < Bv + 1024
+            dr = (int)(((float)e + 0.5f) * invB);
+            b = e - dr * (int)Bv;
+        } else {
+            const int64_t e = (int64_t)b0 + o;
+            dr = e >= Bv ? 1 : 0;
+            b = e >= Bv ? e - Bv : e;
+        }
+        const int64_t row = row0 + dr;
+        int64_t aa, s;
+        if (short_s) {
+            const int t = (int)s0 + dr, q = (int)(((float)t + 0.5f) * invS);
+            aa = a0 + q; s = t - q * (int)a.S;
+        } else {
+            const int64_t t = s0 + dr;
+            aa = a0 + (t >= a.S ? 1 : 0); s = t >= a.S ? t - a.S : t;
+        }
+        const int32_t i0 = a.idx[s];
+        const float w = a.w[s], u = 1.0f - w;          // time.py:61-64: (1 - w) * p[idx] + w * p[idx + 1]
+        const float *p0 = a.pos + ((aa * a.T + i0) * a.B) + b * VW;
+        const float *p1 = p0 + a.B;
+        float *o_ = a.out + row * a.B + b * VW;
+        if constexpr (VW == 4) {
+            const v4f x = *reinterpret_cast<const v4f *>(p0), y = *reinterpret_cast<const v4f *>(p1);
+            const v4f r = {u * x.x + w * y.x, u * x.y + w * y.y, u * x.z + w * y.z, u * x.w + w * y.w};
+            __builtin_nontemporal_store(r, reinterpret_cast<v4f *>(o_));
+        } else if constexpr (VW == 2) {
+            const v2f x = *reinterpret_cast<const v2f *>(p0), y = *reinterpret_cast<const v2f *>(p1);
+            const v2f r = {u * x.x + w * y.x, u * x.y + w * y.y};
+            __builtin_nontemporal_store(r, reinterpret_cast<v2f *>(o_));
+        } else {
+            __builtin_nontemporal_store(u * p0[0] + w * p1[0], o_);
+        }
     }
 }
 
@@ -53,12 +90,14 @@ extern "C" int pm_interpolate_linear_f32(const float *positions, const int32_t *
     PM_CHECK_ARGS(positions && idx && weights && out, "interpolate_linear: null pointer");
     InterpArgs a;
     a.pos = positions; a.idx = idx; a.w = weights; a.out = out; a.A = A; a.T = T; a.S = S; a.B = B;
-    const bool vec = (B % 4 == 0) && aligned16(positions) && aligned16(out);
-    const int64_t nv = A * S * (vec ? B / 4 : B);
-    const int64_t grid = (nv + 255) / 256;
+    const int vw = ((B % 4 == 0) && aligned16(positions) && aligned16(out)) ? 4
+                   : ((B % 2 == 0) && ((uintptr_t)positions % 8 == 0) && ((uintptr_t)out % 8 == 0)) ? 2 : 1;
+    const int64_t nv = A * S * (B / vw);
+    const int64_t grid = (nv + IP_BLOCK - 1) / IP_BLOCK;
     if (grid > 0x7fffffffLL) { set_error("interpolate_linear: grid too large"); return PM_EUNSUPPORTED; }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (vec) hipLaunchKernelGGL(interp_linear_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(interp_linear_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, a);
+    if (vw == 4) hipLaunchKernelGGL(interp_linear_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, a);
+    else if (vw == 2) hipLaunchKernelGGL(interp_linear_kernel<2>, dim3((unsigned)grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(interp_linear_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, a);
     return check_hip(hipGetLastError(), "interpolate_linear launch");
 }
