@@ -51,6 +51,32 @@ __device__ __forceinline__ float quad_perm(const float v) {
 template <int K>
 __device__ __forceinline__ float quad_bcast(const float v) { return quad_perm<K, K, K, K>(v); }  // value of quad lane K
 
+// S[c][k] * b_{c xor k} in one instruction (b was loaded from LDS: no VALU -> DPP hazard)
+template <int P0, int P1, int P2, int P3>
+__device__ __forceinline__ float quad_perm_mul(const float b, const float sign) {
+    float r;
+    asm("v_mul_f32_dpp %0, %1, %2 quad_perm:[%3,%4,%5,%6] row_mask:0xf bank_mask:0xf"
+        : "=&v"(r)
+        : "v"(b), "v"(sign), "n"(P0), "n"(P1), "n"(P2), "n"(P3));
+    return r;
+}
+
+// Component c of the Hamilton product pq (x) b held across a quad (lane c = component c of every operand):
+//     q_c = sum_k S[c][k] pq_k b_{c xor k}      (quat.py:337-361; Klein-group structure of the product)
+// with pq_k a quad broadcast folded into the DPP operand and sb_k = S[c][k] b_{c xor k} prepared by the
+// caller (quad_perm_mul).  pq must not have been written by the VALU instruction right before (s_nop covers it).
+__device__ __forceinline__ float quad_qmul(const float pq, const float b0, const float sb1, const float sb2, const float sb3) {
+    float q;
+    asm("s_nop 1\n\t"
+        "v_mul_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %3 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %4 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %5 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"
+        : "=&v"(q)
+        : "v"(pq), "v"(b0), "v"(sb1), "v"(sb2), "v"(sb3));
+    return q;
+}
+
 // ---- wave-private linear tile copies ------------------------------------------------------------
 
 // global -> LDS, n floats, contiguous.  VEC: g is 16-byte aligned -> dwordx4 per lane, loads

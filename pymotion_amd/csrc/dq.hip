@@ -75,16 +75,6 @@ __device__ __forceinline__ void dq_step_math(const float pq, const float s, cons
         : "v"(pq), "v"(s), "v"(b0), "v"(sb1), "v"(sb2), "v"(sb3), "v"(w1), "v"(w2), "v"(live));
 }
 
-// S[c][k] * b_{c xor k} in one instruction (b was loaded from LDS: no VALU -> DPP hazard)
-template <int P0, int P1, int P2, int P3>
-__device__ __forceinline__ float quad_perm_mul(const float b, const float sign) {
-    float r;
-    asm("v_mul_f32_dpp %0, %1, %2 quad_perm:[%3,%4,%5,%6] row_mask:0xf bank_mask:0xf"
-        : "=&v"(r)
-        : "v"(b), "v"(sign), "n"(P0), "n"(P1), "n"(P2), "n"(P3));
-    return r;
-}
-
 template <int FPW, bool VEC>
 __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];

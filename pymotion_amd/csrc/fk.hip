@@ -509,91 +509,6 @@ __global__ __launch_bounds__(PM_WAVE) void fk_pipe_kernel(const FkArgs a, const 
 }
 
 
-// ---- mirror (ops/skeleton.py:247-344 modes 'all' / 'symmetry', :347-418 _true_mirror), fused -----------
-// The reference chains  fk -> quat.from_matrix -> [joint permutation] -> negate two components ->
-// from_global_rotations  through four full-size arrays.  World ROTATIONS do not depend on offsets or
-// the root position, so one kernel does it per tile: phase A and the tree walk of fk give the world
-// rotation matrices in LDS, then lane-parallel  R -> quaternion (quat.py:85-156), and finally
-// local'_j = conj(g'_parent(j)) (x) g'_j  with  g'_j = flip(g_map[j])  (skeleton.py:322-331 / :410-416).
-struct Map16 { int16_t m[PM_MAX_JOINTS]; };
-
-struct MirrorArgs {
-    const float *rot;   // [F,J,4] local rotations
-    float *out;         // [F,J,4] mirrored local rotations
-    int64_t F;
-    int32_t J;
-    int32_t c0, c1;     // quaternion components to negate (X: 2,3  Y: 1,3  Z: 1,2)
-    Parents parents;
-    Map16 mapping;      // identity for mode 'all'
-};
-
-template <int FPW, bool VEC>
-__global__ __launch_bounds__(PM_WAVE) void mirror_kernel(const MirrorArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x;
-    const int J = a.J;
-    const int64_t ntiles = (a.F + FPW - 1) / FPW;
-    const int64_t tile = xcd_tile(ntiles);
-    if (tile < 0) return;
-    const int64_t f0 = tile * FPW;
-    const int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
-    const int FJ = FPW * J;
-    const int n = nf * J;
-    constexpr bool QUAD = FPW <= 5;     // as in fk_tile: twelve lanes per frame for big skeletons
-    float *sRot = smem;                 // [FJ*9]  world rotations; reused as the output staging [FJ*4]
-    float *sQ = sRot + FJ * 9;          // [FJ*4]  world quaternions (phase C on)
-    float *sPos = sQ;                   //         the walk's positions are not needed: they land here and are overwritten
-    float *sConst = sQ + FJ * 4;        // [(J+1)*4]
-    int *sTab = reinterpret_cast<int *>(sConst + 4 * (J + 4));  // [2J] parent | mapping
-
-    for (int j = lane; j <= J; j += PM_WAVE) {
-        const int jc = j < J ? j : J - 1;
-        reinterpret_cast<v4f *>(sConst)[j] = v4f{__int_as_float(j == 0 ? -1 : a.parents.p[jc]), 0.0f, 0.0f, 0.0f};
-        if (j < J) { sTab[j] = (j == 0) ? 0 : a.parents.p[j]; sTab[J + j] = a.mapping.m[j]; }
-    }
-    for_each_record4<VEC>(a.rot + f0 * J * 4, n, lane, [&](const int e, const v4f q, const bool valid) {
-        const float qi[4] = {q.x, q.y, q.z, q.w};
-        float L[9];
-        local_from_quat(qi, L);
-        if (valid) put_local<QUAD>(sRot, e, L);
-    });
-    const int wl = lane % ((QUAD ? 12 : 3) * FPW);
-    const int f = QUAD ? wl / 12 : wl / 3;
-    const int r = QUAD ? (wl - 12 * f) / 4 : wl - 3 * f;
-    const int c = wl & 3;
-    wave_sync();
-    if constexpr (QUAD) tree_walk_quad<false>(sRot, sPos, nullptr, sConst, J, f, r, c, (c == r) ? 1.0f : 0.0f, lane);
-    else tree_walk<false>(sRot, sPos, nullptr, sConst, J, f, r, 0.0f, false);
-    wave_sync();
-    for_each_slot<2>(n, lane, [&](const int e, const bool valid) {  // world rotation -> quaternion
-        float m[9], q[4];
-        lds_get<9>(sRot, e, m);
-        m2q(m, q);
-        if (valid) lds_put<4>(sQ, e, q);
-    });
-    wave_sync();
-    const float invJ = 1.0f / (float)J;
-    const float s1 = (a.c0 == 1 || a.c1 == 1) ? -1.0f : 1.0f, s2 = (a.c0 == 2 || a.c1 == 2) ? -1.0f : 1.0f,
-                s3 = (a.c0 == 3 || a.c1 == 3) ? -1.0f : 1.0f;
-    for_each_slot<2>(n, lane, [&](const int e, const bool valid) {
-        const int fr = (int)(((float)e + 0.5f) * invJ);
-        const int j = e - fr * J;
-        float g[4], pg[4], o[4];
-        lds_get<4>(sQ, fr * J + sTab[J + j], g);
-        lds_get<4>(sQ, fr * J + sTab[J + sTab[j]], pg);
-        g[1] *= s1; g[2] *= s2; g[3] *= s3;
-        const float inv[4] = {pg[0], -pg[1] * s1, -pg[2] * s2, -pg[3] * s3};
-        qmul(inv, g, o);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = (j == 0) ? g[k] : o[k];  // the root has no parent (select, not branch)
-        if (valid) {  // one record per lane, consecutive lanes on consecutive records: stored from registers
-            float *g = a.out + f0 * J * 4;
-            if (VEC) __builtin_nontemporal_store(v4f{o[0], o[1], o[2], o[3]}, reinterpret_cast<v4f *>(g) + e);
-            else { g[4 * e] = o[0]; g[4 * e + 1] = o[1]; g[4 * e + 2] = o[2]; g[4 * e + 3] = o[3]; }
-        }
-    });
-}
-
 template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT>
 static int launch_fk(const FkArgs &a, hipStream_t s) {
     const size_t lds = ((size_t)FPW * a.J * fk_lds_floats<SRC, PFO, QOUT>() + 4 * (a.J + 4)) * sizeof(float);
@@ -703,51 +618,7 @@ static int fk_common(int src_kind, const float *src, const float *root_pos, cons
     return dispatch_fk<SRC_O6D>(a, vec, offsets_per_frame != 0, s);
 }
 
-template <int FPW>
-static int launch_mirror(const MirrorArgs &a, bool vec, hipStream_t s) {
-    const size_t lds = ((size_t)FPW * a.J * 13 + 4 * (a.J + 4) + 2 * a.J) * sizeof(float);
-    const int64_t ntiles = (a.F + FPW - 1) / FPW;
-    const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
-    if (grid > 0x7fffffffLL) { set_error("mirror: grid too large"); return PM_EUNSUPPORTED; }
-    if (vec) {
-        auto k = mirror_kernel<FPW, true>;
-        if (int e = allow_lds(k, lds)) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
-    } else {
-        auto k = mirror_kernel<FPW, false>;
-        if (int e = allow_lds(k, lds)) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
-    }
-    return check_hip(hipGetLastError(), "mirror launch");
-}
-
 }  // namespace pm
-
-extern "C" int pm_mirror_rotations_f32(const float *rot, const int32_t *parents, const int32_t *mapping, int axis,
-                                       int64_t F, int32_t J, float *out, pm_stream_t stream) {
-    using namespace pm;
-    PM_CHECK_ARGS(F >= 0 && J >= 1 && J <= PM_MAX_JOINTS, "mirror: need F >= 0 and 1 <= J <= PM_MAX_JOINTS");
-    PM_CHECK_ARGS(axis >= 0 && axis <= 2, "mirror: axis must be 0 (X), 1 (Y) or 2 (Z)");
-    if (F == 0) return PM_OK;
-    PM_CHECK_ARGS(rot && parents && out, "mirror: null pointer");
-    MirrorArgs a;
-    a.rot = rot; a.out = out; a.F = F; a.J = J;
-    a.c0 = (axis == 0) ? 2 : 1;  // skeleton.py:310-318: X -> (2,3), Y -> (1,3), Z -> (1,2)
-    a.c1 = (axis == 2) ? 2 : 3;
-    if (int e = pack_parents(parents, J, a.parents)) return e;
-    for (int32_t j = 0; j < J; ++j) {
-        const int32_t m = mapping ? mapping[j] : j;
-        if (m < 0 || m >= J) { set_error("mirror: joints_mapping[%d] = %d out of range", j, m); return PM_EINVAL; }
-        a.mapping.m[j] = (int16_t)m;
-    }
-    const bool vec = aligned16(rot) && aligned16(out);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t per_frame = (size_t)J * 13 * sizeof(float), fixed = (6 * (size_t)J + 16) * sizeof(float) + 256;
-    if (7 * (20 * per_frame + fixed) <= kMaxLds) return launch_mirror<20>(a, vec, s);
-    if (4 * per_frame + fixed <= kMaxLds) return launch_mirror<4>(a, vec, s);
-    set_error("mirror: J=%d does not fit the LDS tile", J);
-    return PM_EUNSUPPORTED;
-}
 
 extern "C" int pm_fk_f32(const float *rot, const float *root_pos, const float *offsets, int offsets_per_frame,
                          const int32_t *parents, int64_t F, int32_t J, float *pos, float *rotmats,

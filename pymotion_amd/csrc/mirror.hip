@@ -1,0 +1,195 @@
+// mirror.hip -- skeleton mirroring, rotation part, for gfx950.
+//   ops/skeleton.py:247-344 `mirror` (modes 'all' / 'symmetry'), :347-418 `_true_mirror`
+// The reference chains  fk -> quat.from_matrix -> [joint permutation] -> negate two components ->
+// from_global_rotations  through four full-size arrays.  World ROTATIONS depend neither on offsets nor on
+// the root position, and  from_matrix(to_matrix(g)) = sign(g[dom]) g / |g|  where `dom` is the component
+// its four-way branch (quat.py:85-156) makes dominant -- so no matrix is ever formed here:
+//   phase A  lane per (frame, joint): quaternion straight from HBM, normalised like fk does (skeleton.py:45),
+//            parked in a 16-byte slot of the frame's LDS image (16 J B per frame: 27 waves per CU at J = 22);
+//   walk     four lanes per frame compose world quaternions down the tree, g_j = g_parent (x) q_j, with the
+//            quad exchanges folded into DPP operands (quad_qmul): ~12 instructions a step for 16 frames, branch
+//            free, the parent read one step ahead unless it is the previous joint (register chain);
+//   finish   lane per (frame, joint): the reference's sign (the from_matrix branch, decided from the matrix
+//            diagonal the quaternion implies) and normalisation, the joint permutation, the two negated
+//            components, local'_j = conj(g'_parent(j)) (x) g'_j (skeleton.py:322-331 / :410-416), stored
+//            straight from registers (one record per lane = a contiguous dwordx4 stream).
+#include <stdlib.h>
+
+#include "common.hpp"
+
+namespace pm {
+
+struct Map16 { int16_t m[PM_MAX_JOINTS]; };
+
+struct MirrorArgs {
+    const float *rot;   // [F,J,4] local rotations
+    float *out;         // [F,J,4] mirrored local rotations
+    int64_t F;
+    int32_t J;
+    int32_t c0, c1;     // quaternion components to negate (X: 2,3  Y: 1,3  Z: 1,2)
+    Parents parents;
+    Map16 mapping;      // identity for mode 'all'
+};
+
+// J slots + the identity slot, padded so that (stride / 4) is odd: the quads of 8 frames hit 8 distinct bank groups
+__host__ __device__ constexpr int mirror_frame_stride(const int J) { return 4 * ((J + 1) | 1); }
+
+// from_matrix(to_matrix(g)) without the matrices: quat.py:276-317 gives the diagonal, quat.py:85-156 the branch,
+// and each branch's candidate is 4 g[dom] g; then its normalize (:155, quat.py:411-423).
+__device__ __forceinline__ void canonical_sign(const float (&g)[4], float (&o)[4]) {
+    const float x2 = g[1] + g[1], y2 = g[2] + g[2], z2 = g[3] + g[3];
+    const float xx = g[1] * x2, yy = g[2] * y2, zz = g[3] * z2;
+    const float r00 = 1.0f - (yy + zz), r11 = 1.0f - (xx + zz), r22 = 1.0f - (xx + yy);
+    const float dom = (r22 < 0.0f) ? ((r00 > r11) ? g[1] : g[2]) : ((r00 < -r11) ? g[3] : g[0]);
+    const float sg = (dom < 0.0f) ? -1.0f : 1.0f;
+    const float c[4] = {sg * g[0], sg * g[1], sg * g[2], sg * g[3]};
+    qnormalize(c, 1e-8f, o);
+}
+
+template <int FPW, bool VEC>
+__global__ __launch_bounds__(PM_WAVE) void mirror_kernel(const MirrorArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int J = a.J;
+    const int64_t ntiles = (a.F + FPW - 1) / FPW;
+    const int64_t tile = xcd_tile(ntiles);
+    if (tile < 0) return;
+    const int64_t f0 = tile * FPW;
+    const int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
+    const int n = nf * J;
+    const int FS = mirror_frame_stride(J);
+    float *sQ = smem;                                          // [FPW * FS]
+    int *sPar = reinterpret_cast<int *>(sQ + FPW * FS);        // [J+1]  walk parent (the root: the identity slot J); entry J repeats
+    int *sMap = sPar + (J + 1);                                // [2J]   {mapping[j], mapping[parents[j]]}
+    const float invJ = 1.0f / (float)J;
+
+    for (int j = lane; j <= J; j += PM_WAVE) {
+        const int jc = j < J ? j : J - 1;
+        sPar[j] = (jc == 0) ? J : a.parents.p[jc];
+        if (j < J) { sMap[2 * j] = a.mapping.m[j]; sMap[2 * j + 1] = a.mapping.m[j == 0 ? 0 : a.parents.p[j]]; }
+    }
+    for_each_record4<VEC>(a.rot + f0 * J * 4, n, lane, [&](const int e, const v4f q, const bool valid) {
+        const float qi[4] = {q.x, q.y, q.z, q.w};
+        float u[4];
+        qnormalize(qi, 1e-8f, u);  // skeleton.py:45
+        const int f = (int)(((float)e + 0.5f) * invJ);  // e / J, exact for e < 2^22
+        const int j = e - f * J;
+        if (valid) *reinterpret_cast<v4f *>(sQ + f * FS + j * 4) = v4f{u[0], u[1], u[2], u[3]};
+    });
+    const int wl = lane % (4 * FPW);  // lanes >= 4*FPW shadow lanes 0..; frames past a partial tile walk their own slots
+    const int fq = wl >> 2, c = wl & 3;
+    float *fD = sQ + fq * FS;
+    fD[J * 4 + c] = (c == 0) ? 1.0f : 0.0f;  // the identity slot
+    wave_sync();
+
+    // ---- the walk (see to_root_dq_kernel for the same scheme with a translation on top) ------------------
+    const float s1 = (c == 0 || c == 2) ? -1.0f : 1.0f;   // S[c][1]:  - + - +
+    const float s2 = (c == 0 || c == 3) ? -1.0f : 1.0f;   // S[c][2]:  - + + -
+    const float s3 = (c == 0 || c == 1) ? -1.0f : 1.0f;   // S[c][3]:  - - + +
+    const float *fDq = fD + c;
+    float *oq = fD + c;                                   // slot of the current pair's first joint
+    float bA = oq[0], bB = oq[4];                         // own component of joints j, j+1 (requested two steps ahead)
+    float gq = 0.0f;                                      // previous joint's world quaternion (component c)
+    float peA = (c == 0) ? 1.0f : 0.0f, peB = 0.0f;       // parent read one step ahead; the root composes with the identity
+    int par = J;
+    auto step = [&](const int j, const int o, const int parn, float &b, const float pe, float &pen, const bool may_be_dummy) {
+        pen = fDq[parn * 4];  // parent of joint j+1, if it is not joint j itself (then: a stale value, unused)
+        const float sb1 = quad_perm_mul<1, 0, 3, 2>(b, s1), sb2 = quad_perm_mul<2, 3, 0, 1>(b, s2), sb3 = quad_perm_mul<3, 2, 1, 0>(b, s3);
+        const float pq = (par == j - 1) ? gq : pe;  // wave-uniform
+        const float q = quad_qmul(pq, b, sb1, sb2, sb3);
+        if (!may_be_dummy || j < J) oq[o] = q;
+        b = oq[o + 8];                              // joint j+2: its slot still holds the local quaternion
+        gq = q; par = parn;
+    };
+    for (int jb = 0; jb < J; jb += PM_WAVE) {
+        const int i0 = jb + 1 + lane;
+        const int pv = sPar[i0 < J ? i0 : J];       // parents of joints jb+1 .. jb+64 across the lanes
+        const int jend = (J - jb) < PM_WAVE ? (J - jb) : PM_WAVE;
+        asm volatile("" ::"v"(pv));                 // settle the window load here, not as an lgkmcnt(0) inside the loop
+        for (int jj = 0; jj < jend; jj += 2) {      // pairs; for odd J the very last step is a dummy that stores nothing
+            step(jb + jj, 0, __builtin_amdgcn_readlane(pv, jj), bA, peA, peB, false);
+            step(jb + jj + 1, 4, __builtin_amdgcn_readlane(pv, jj + 1), bB, peB, peA, true);
+            oq += 8;
+        }
+    }
+    wave_sync();
+
+    // ---- finish, lane per (frame, joint) --------------------------------------------------------------------
+    const float f1 = (a.c0 == 1 || a.c1 == 1) ? -1.0f : 1.0f, f2 = (a.c0 == 2 || a.c1 == 2) ? -1.0f : 1.0f,
+                f3 = (a.c0 == 3 || a.c1 == 3) ? -1.0f : 1.0f;
+    float *gout = a.out + f0 * J * 4;
+    for_each_slot<2>(n, lane, [&](const int e, const bool valid) {
+        const int fr = (int)(((float)e + 0.5f) * invJ);
+        const int j = e - fr * J;
+        const float *fq_ = sQ + fr * FS;
+        float g[4], pg[4], cg[4], cp[4], o[4];
+        lds_get<4>(fq_, sMap[2 * j], g);
+        lds_get<4>(fq_, sMap[2 * j + 1], pg);
+        canonical_sign(g, cg);
+        canonical_sign(pg, cp);
+        cg[1] *= f1; cg[2] *= f2; cg[3] *= f3;  // skeleton.py:310-318
+        const float inv[4] = {cp[0], -cp[1] * f1, -cp[2] * f2, -cp[3] * f3};
+        qmul(inv, cg, o);                       // skeleton.py:85-91 on the mirrored world rotations
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (j == 0) ? cg[k] : o[k];  // the root has no parent (select, not branch)
+        if (valid) {
+            if (VEC) __builtin_nontemporal_store(v4f{o[0], o[1], o[2], o[3]}, reinterpret_cast<v4f *>(gout) + e);
+            else { gout[4 * e] = o[0]; gout[4 * e + 1] = o[1]; gout[4 * e + 2] = o[2]; gout[4 * e + 3] = o[3]; }
+        }
+    });
+}
+
+template <int FPW>
+static int launch_mirror(const MirrorArgs &a, bool vec, hipStream_t s) {
+    const size_t lds = ((size_t)FPW * mirror_frame_stride(a.J) + 3 * (size_t)a.J + 1 + 8) * sizeof(float);  // + slack for the walk's look-ahead
+    const int64_t ntiles = (a.F + FPW - 1) / FPW;
+    const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
+    if (grid > 0x7fffffffLL) { set_error("mirror: grid too large"); return PM_EUNSUPPORTED; }
+    if (vec) {
+        auto k = mirror_kernel<FPW, true>;
+        if (int e = allow_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
+    } else {
+        auto k = mirror_kernel<FPW, false>;
+        if (int e = allow_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
+    }
+    return check_hip(hipGetLastError(), "mirror launch");
+}
+
+}  // namespace pm
+
+extern "C" int pm_mirror_rotations_f32(const float *rot, const int32_t *parents, const int32_t *mapping, int axis,
+                                       int64_t F, int32_t J, float *out, pm_stream_t stream) {
+    using namespace pm;
+    PM_CHECK_ARGS(F >= 0 && J >= 1 && J <= PM_MAX_JOINTS, "mirror: need F >= 0 and 1 <= J <= PM_MAX_JOINTS");
+    PM_CHECK_ARGS(axis >= 0 && axis <= 2, "mirror: axis must be 0 (X), 1 (Y) or 2 (Z)");
+    if (F == 0) return PM_OK;
+    PM_CHECK_ARGS(rot && parents && out, "mirror: null pointer");
+    MirrorArgs a;
+    a.rot = rot; a.out = out; a.F = F; a.J = J;
+    a.c0 = (axis == 0) ? 2 : 1;  // skeleton.py:310-318: X -> (2,3), Y -> (1,3), Z -> (1,2)
+    a.c1 = (axis == 2) ? 2 : 3;
+    if (int e = pack_parents(parents, J, a.parents)) return e;
+    for (int32_t j = 0; j < J; ++j) {
+        const int32_t m = mapping ? mapping[j] : j;
+        if (m < 0 || m >= J) { set_error("mirror: joints_mapping[%d] = %d out of range", j, m); return PM_EINVAL; }
+        a.mapping.m[j] = (int16_t)m;
+    }
+    const bool vec = aligned16(rot) && aligned16(out);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t per_frame = (size_t)mirror_frame_stride(J) * sizeof(float), fixed = (3 * (size_t)J + 9) * sizeof(float) + 256;
+    int pick = (7 * (16 * per_frame + fixed) <= kMaxLds) ? 16 : 8;  // 4 lanes per frame; keep >= 7 waves per CU if possible
+    {
+        const char *e = getenv("PM_MIRROR_FPW");  // tuning aid
+        if (e && (atoi(e) == 16 || atoi(e) == 8 || atoi(e) == 4)) pick = atoi(e);
+    }
+    while (pick > 4 && pick * per_frame + fixed > kMaxLds) pick >>= 1;
+    if (pick * per_frame + fixed <= kMaxLds) {
+        if (pick == 16) return launch_mirror<16>(a, vec, s);
+        if (pick == 8) return launch_mirror<8>(a, vec, s);
+        return launch_mirror<4>(a, vec, s);
+    }
+    set_error("mirror: J=%d does not fit the LDS tile", J);
+    return PM_EUNSUPPORTED;
+}
