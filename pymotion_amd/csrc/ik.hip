@@ -13,7 +13,7 @@
 //         rot_j = rot_j (x) from_to_axis(offsets[gc], inv(G_j)(P_gc - P_j), inv(G_j) normalize(P_c0 - P_j))   (:147-168)
 //     G_j = G_pre (x) rot_j/(|rot_j| + 1e-8)  (fk normalises its inputs, skeleton.py:45; from_to's axis is only
 //     unit up to its own eps);  joints without children keep the identity (:126-130).
-// HBM traffic: 12 J B/frame in, 16 J out.  Positions are staged in LDS (coalesced), results leave coalesced.
+// HBM traffic: 12 J B/frame in, 16 J out, both as coalesced one-record-per-lane streams.
 #include <stdlib.h>
 
 #include "common.hpp"
@@ -35,6 +35,16 @@ struct IkArgs {
     Topo16 topo;
 };
 
+// LDS image: ONE 16-byte slot per (frame, joint).  It holds the joint's position until the joint has been
+// aligned (positions are only read while processing the joint itself or its parent, and parents come first)
+// and the joint's world quaternion G_j afterwards -- 16 J + 16 B per frame, so 64 frames (every lane of the
+// wave) fit in 23 KiB at J = 22 and six such waves share a CU.  The local rotations are not staged at all:
+// G_j = G_pre (x) rot_j/(|rot_j| + 1e-8), so the final lane-per-(frame, joint) pass recovers
+// rot_j = conj(G_parent) (x) G_j (the from_global_rotations gather; equal to the reference's value up to the
+// ~1e-7 by which from_to's output misses unit length) and stores it straight from registers, coalesced.
+// Joints without children keep the exact identity (:126-130).
+__host__ __device__ constexpr int ik_frame_stride(const int J) { return 4 * J + 4; }  // (stride / 4) odd for even J: conflict-free
+
 template <int FPW, bool VEC>
 __global__ __launch_bounds__(PM_WAVE) void from_root_positions_kernel(const IkArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -46,14 +56,32 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_kernel(const IkAr
     const int64_t f0 = tile * FPW;
     const int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
     const int n = nf * J;
-    const int FS = 4 * J + 4;                 // padded frame stride of the quaternion images (see dq.hip)
-    float *sOut = smem;                       // [FPW * FS]   local rotations (output image)
-    float *sG = sOut + FPW * FS;              // [FPW * FS]   world quaternions of finished joints
-    float *sP = sG + FPW * FS;                // [FPW * J * 3] positions tile (linear)
-    float *sOff = sP + FPW * J * 3;           // [J * 3]
+    const int FS = ik_frame_stride(J);
+    float *sS = smem;                         // [FPW * FS]  slot (f, j): position, then world quaternion
+    float *sOff = sS + FPW * FS;              // [J * 3]
     int *sTopo = reinterpret_cast<int *>(sOff + 3 * J);  // [J] parent | [J+1] cstart | [J] clist
+    const float invJ = 1.0f / (float)J;
 
-    tile_load<VEC>(a.pos + f0 * J * 3, sP, n * 3, lane);
+    // positions: one 12-byte record per lane, consecutive lanes on consecutive records (coalesced dwordx3),
+    // four loads per lane in flight, re-packed into the 16-byte slots
+    {
+        const float *g = a.pos + f0 * J * 3;
+        for (int e0 = 0; e0 < n; e0 += 4 * PM_WAVE) {
+            v3f_a4 p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * PM_WAVE + lane, ec = e < n ? e : n - 1;
+                p[u] = __builtin_nontemporal_load(reinterpret_cast<const v3f_a4 *>(g + 3 * ec));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * PM_WAVE + lane;
+                const int f = (int)(((float)e + 0.5f) * invJ);  // e / J, exact for e < 2^22
+                const int j = e - f * J;
+                if (e < n) { float *sl = sS + f * FS + 4 * j; sl[0] = p[u].x; sl[1] = p[u].y; sl[2] = p[u].z; }
+            }
+        }
+    }
     for (int i = lane; i < 3 * J; i += PM_WAVE) sOff[i] = a.offsets[i];
     for (int j = lane; j <= J; j += PM_WAVE) {
         if (j < J) { sTopo[j] = a.topo.parent[j]; sTopo[2 * J + 1 + j] = a.topo.clist[j]; }
@@ -61,18 +89,23 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_kernel(const IkAr
     }
     wave_sync();
 
+    // ---- the walk: one lane per frame ------------------------------------------------------------------------
     const int f = lane % FPW;  // lanes >= FPW shadow lanes 0.. ; frames past a partial tile use their own slots
-    const float *fP = sP + f * J * 3;
-    float *fOut = sOut + f * FS, *fG = sG + f * FS;
+    float *fS = sS + f * FS;
+    float g[4] = {1.0f, 0.0f, 0.0f, 0.0f};  // world quaternion of the previous joint
     for (int j = 0; j < J; ++j) {
-        float gpre[4] = {1.0f, 0.0f, 0.0f, 0.0f};
-        if (j > 0) lds_get<4>(fG, sTopo[j], gpre);
+        const int par = sTopo[j];
+        float gpre[4] = {g[0], g[1], g[2], g[3]};
+        if (j == 0) { gpre[0] = 1.0f; gpre[1] = 0.0f; gpre[2] = 0.0f; gpre[3] = 0.0f; }
+        else if (par != j - 1) lds_get<4>(fS, par, gpre);  // wave-uniform: a finished joint's slot holds its G
         const int cs = sTopo[J + j], ce = sTopo[J + j + 1];  // wave-uniform
         float rot[4] = {1.0f, 0.0f, 0.0f, 0.0f};
         if (ce > cs) {
             const int c0 = sTopo[2 * J + 1 + cs];
-            const float pj[3] = {fP[3 * j], fP[3 * j + 1], fP[3 * j + 2]};
-            const float d[3] = {fP[3 * c0] - pj[0], fP[3 * c0 + 1] - pj[1], fP[3 * c0 + 2] - pj[2]};
+            float pj[4], pc[4];
+            lds_get<4>(fS, j, pj);
+            lds_get<4>(fS, c0, pc);  // children come later: their slots still hold positions
+            const float d[3] = {pc[0] - pj[0], pc[1] - pj[1], pc[2] - pj[2]};
             const float inv[4] = {gpre[0], -gpre[1], -gpre[2], -gpre[3]};
             float pred[3];
             qmulvec(inv, d, pred);
@@ -80,11 +113,12 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_kernel(const IkAr
             from_to(rest, pred, true, rot);
             for (int k = cs + 1; k < ce; ++k) {  // roll correction from every further child
                 const int gc = sTopo[2 * J + 1 + k];
-                float gj[4], rn[4];
+                float gj[4], rn[4], pg[4];
                 qnormalize(rot, 1e-8f, rn);  // the reference's fk normalises local rotations (skeleton.py:45)
                 qmul(gpre, rn, gj);
                 const float ginv[4] = {gj[0], -gj[1], -gj[2], -gj[3]};
-                const float dg[3] = {fP[3 * gc] - pj[0], fP[3 * gc + 1] - pj[1], fP[3 * gc + 2] - pj[2]};
+                lds_get<4>(fS, gc, pg);
+                const float dg[3] = {pg[0] - pj[0], pg[1] - pj[1], pg[2] - pj[2]};
                 float predg[3], dn[3], axis[3], roll[4], r2[4];
                 qmulvec(ginv, dg, predg);
                 vnormalize(d, 1e-8f, dn);
@@ -95,27 +129,37 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_kernel(const IkAr
                 rot[0] = r2[0]; rot[1] = r2[1]; rot[2] = r2[2]; rot[3] = r2[3];
             }
         }
-        float g[4], rn[4];
+        float rn[4];
         qnormalize(rot, 1e-8f, rn);
         qmul(gpre, rn, g);
-        lds_put<4>(fOut, j, rot);
-        lds_put<4>(fG, j, g);
+        lds_put<4>(fS, j, g);  // P_j is dead from here on
     }
     wave_sync();
+
+    // ---- local rotations back out of the world quaternions, lane per (frame, joint), straight to HBM -----------
     float *gout = a.out + f0 * J * 4;
-    const float invJ = 1.0f / (float)J;
-    for (int i = lane; i < n; i += PM_WAVE) {  // dwordx4 i = (frame i / J, joint i % J) of the padded image
-        const int fr = (int)(((float)i + 0.5f) * invJ);
-        const int j = i - fr * J;
-        const v4f v = *reinterpret_cast<const v4f *>(sOut + fr * FS + j * 4);
-        if (VEC) __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(gout) + i);
-        else { gout[4 * i] = v.x; gout[4 * i + 1] = v.y; gout[4 * i + 2] = v.z; gout[4 * i + 3] = v.w; }
-    }
+    for_each_slot<2>(n, lane, [&](const int e, const bool valid) {
+        const int fr = (int)(((float)e + 0.5f) * invJ);
+        const int j = e - fr * J;
+        const float *fq = sS + fr * FS;
+        float gj[4], gp[4], o[4];
+        lds_get<4>(fq, j, gj);
+        lds_get<4>(fq, sTopo[j], gp);
+        const float inv[4] = {gp[0], -gp[1], -gp[2], -gp[3]};
+        qmul(inv, gj, o);
+        const bool leaf = sTopo[J + j + 1] == sTopo[J + j];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = leaf ? (k == 0 ? 1.0f : 0.0f) : ((j == 0) ? gj[k] : o[k]);
+        if (valid) {
+            if (VEC) __builtin_nontemporal_store(v4f{o[0], o[1], o[2], o[3]}, reinterpret_cast<v4f *>(gout) + e);
+            else { gout[4 * e] = o[0]; gout[4 * e + 1] = o[1]; gout[4 * e + 2] = o[2]; gout[4 * e + 3] = o[3]; }
+        }
+    });
 }
 
 template <int FPW>
 static int launch_ik(const IkArgs &a, bool vec, hipStream_t s) {
-    const size_t lds = ((size_t)FPW * (2 * (4 * a.J + 4) + 3 * a.J) + 3 * a.J + 3 * a.J + 2) * sizeof(float);
+    const size_t lds = ((size_t)FPW * ik_frame_stride(a.J) + 3 * a.J + 3 * a.J + 2) * sizeof(float);
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
     const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
     if (grid > 0x7fffffffLL) { set_error("from_root_positions: grid too large"); return PM_EUNSUPPORTED; }
@@ -153,7 +197,7 @@ extern "C" int pm_from_root_positions_f32(const float *positions, const int32_t 
     for (int32_t j = 1; j < J; ++j) a.topo.clist[fill[p.p[j]]++] = (int16_t)j;
     const bool vec = aligned16(positions) && aligned16(rotations);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t per_frame = (size_t)(2 * (4 * J + 4) + 3 * J) * sizeof(float), fixed = (size_t)(6 * J + 2) * sizeof(float) + 256;
+    const size_t per_frame = (size_t)ik_frame_stride(J) * sizeof(float), fixed = (size_t)(6 * J + 2) * sizeof(float) + 256;
     {
         const char *e = getenv("PM_IK_FPW");  // tuning aid
         const int v = e ? atoi(e) : 0;
@@ -162,7 +206,8 @@ extern "C" int pm_from_root_positions_f32(const float *positions, const int32_t 
         if (v == 16) return launch_ik<16>(a, vec, s);
         if (v == 8) return launch_ik<8>(a, vec, s);
     }
-    if (5 * (32 * per_frame + fixed) <= kMaxLds) return launch_ik<32>(a, vec, s);
+    if (4 * (64 * per_frame + fixed) <= kMaxLds) return launch_ik<64>(a, vec, s);  // every lane busy, >= 4 waves per CU
+    if (4 * (32 * per_frame + fixed) <= kMaxLds) return launch_ik<32>(a, vec, s);
     if (2 * (16 * per_frame + fixed) <= kMaxLds) return launch_ik<16>(a, vec, s);
     if (4 * per_frame + fixed <= kMaxLds) return launch_ik<4>(a, vec, s);
     set_error("from_root_positions: J=%d does not fit the LDS tile", J);
