@@ -10,7 +10,8 @@
 //           one wave ballot per series gives every lane its inclusive prefix parity; the chunk's total
 //           parity per series goes to the workspace;
 //   pass 2  exclusive prefix XOR over chunks (lane = series; a few thousand independent loads);
-//   pass 3  pass 1 again with the carry-in, writing +-q.
+//   pass 3  pass 1 again with the carry-in; the corrected records go back into the LDS rows and leave as
+//           contiguous dwordx4 streams.
 // (LDS: 65 rows x 65 records x 16|32 B = 66|132 KiB at most.)
 // Layout: q [T, S, 4] (unroll axis first; the front-end moves it there), out same.
 // Algorithmic HBM bytes: 16 (pass 1) + 16 + 16 (pass 3) = 48 B per quaternion.
@@ -88,16 +89,27 @@ __global__ __launch_bounds__(PM_WAVE) void unroll_kernel(const UnrollArgs a) {
                 const unsigned long long upto = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);
                 const int par = (__popcll(m & upto) + (int)((carry >> j) & 1ull)) & 1;
                 if (act) {
+                    // corrected record back into its row, in place: every lane has read this series' `cur` and
+                    // `prv` above (in-order DS), and the flip bits only ever use ORIGINAL neighbours
                     const float sg = par ? -1.0f : 1.0f;
-                    v4f *o = reinterpret_cast<v4f *>(a.out) + ((ts + lane) * a.S + s0 + j) * V;
-                    o[0] = v4f{cur.x * sg, cur.y * sg, cur.z * sg, cur.w * sg};
+                    rows[((lane + 1) * rs + j) * V] = v4f{cur.x * sg, cur.y * sg, cur.z * sg, cur.w * sg};
                     if constexpr (V == 2) {
                         const v4f du = rows[((lane + 1) * rs + j) * V + 1];
-                        o[1] = v4f{du.x * sg, du.y * sg, du.z * sg, du.w * sg};
+                        rows[((lane + 1) * rs + j) * V + 1] = v4f{du.x * sg, du.y * sg, du.z * sg, du.w * sg};
                     }
                 }
             }
             if (__popcll(m) & 1) newcarry ^= (1ull << j);
+        }
+        if (APPLY) {
+            // rows 1..nfr leave the way they came: contiguous dwordx4, 4 stores in flight per lane
+            wave_sync();
+            const int o_end = nfr * rowlen;
+            for (int i = lane; i < o_end; i += PM_WAVE) {
+                const int r = (int)(((float)i + 0.5f) * inv_rowlen), c = i - r * rowlen;
+                const v4f v = rows[(r + 1) * rs * V + c];
+                __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(a.out) + ((ts + r) * a.S + s0) * V + c);
+            }
         }
         carry = newcarry;
         wave_sync();
