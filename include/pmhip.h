@@ -94,8 +94,9 @@ int pm_from_global_rotations_f32(const float *global_quats, const int32_t *paren
                                  int64_t F, int32_t J, float *local_quats, pm_stream_t stream);
 
 /* ops/skeleton.py:247-344 mirror (modes 'all', 'symmetry') / :347-418 _true_mirror -- the rotation part,
- * fused: fk -> quat.from_matrix -> gather joints_mapping -> negate two quaternion components ->
- * from_global_rotations in one kernel.  mapping is a HOST int32[J] (NULL = identity, mode 'all');
+ * fused: the result of fk -> quat.from_matrix -> gather joints_mapping -> negate two quaternion components ->
+ * from_global_rotations from one kernel (world rotations are composed as quaternions and given the sign
+ * from_matrix would pick; no matrix is formed).  mapping is a HOST int32[J] (NULL = identity, mode 'all');
  * axis 0/1/2 = X/Y/Z.  Translations / offsets / end sites are sign flips the front-end does. */
 int pm_mirror_rotations_f32(const float *rot, const int32_t *parents /*host*/, const int32_t *mapping /*host*/,
                             int axis, int64_t F, int32_t J, float *out, pm_stream_t stream);

@@ -71,7 +71,8 @@ def mirror(
 ):
     """Mirror a skeleton pose along ``axis``.  ``mode='all'``: perfect mirror, topology mirrored too
     (offsets / end sites change sign); ``mode='symmetry'``: joints swapped through ``joints_mapping``,
-    skeleton unchanged.  One fused kernel (fk -> from_matrix -> permute/negate -> from_global_rotations).
+    skeleton unchanged.  One fused kernel (a quaternion tree walk with the sign convention of
+    fk -> from_matrix, then permute / negate / from_global_rotations; csrc/mirror.hip).
     ``mode='positions'``: positions are mirrored and the rotations recovered by ``from_root_positions``
     (twist is not preserved).  Unlike the reference's
     'symmetry' mode the caller's ``global_translation`` is not modified in place.

@@ -444,8 +444,8 @@ def test_mirror_argument_errors():
 
 @pytest.mark.parametrize("J", [52, 31, 130])
 def test_mirror_big_skeletons_vs_oracle_composition(J):
-    """Skeletons too big for 20 frames per wave take the twelve-lanes-per-frame walk: check against the
-    reference's chain rebuilt from oracle pieces (fk -> from_matrix -> negate -> from_global_rotations)."""
+    """Bigger skeletons (8 / 4 frames per wave, odd joint counts, several 64-joint windows of the walk):
+    check against the reference's chain rebuilt from oracle pieces (fk -> from_matrix -> negate -> from_global_rotations)."""
     from pymotion_amd import synthetic as syn
 
     rng = np.random.default_rng(J)
