@@ -405,6 +405,24 @@ def fk_from_ortho6d(be, o6d, global_pos, offsets, parents, return_quat=False):
     return res
 
 
+_ROOT_OFFSET_CHECKED = {}
+
+
+def _assert_root_offset_is_zero(be, offsets):
+    """The reference's ``assert (offsets[0] == 0).all()`` (skeleton.py:227 / skeleton_torch.py:242).  On a HIP
+    tensor that comparison is a device->host synchronisation per call; the verdict is remembered per tensor
+    (storage pointer + torch's in-place version counter), so a loop over clips of one skeleton pays it once."""
+    if be.name != "torch" or not getattr(offsets, "is_cuda", False):
+        off0 = np.asarray(offsets[0].detach().cpu() if be.name == "torch" else offsets[0])
+        assert (off0 == 0).all()
+        return
+    key = (offsets.data_ptr(), offsets._version, tuple(offsets.shape), offsets.dtype, offsets.device)
+    if _ROOT_OFFSET_CHECKED.get("key") == key:
+        return
+    assert bool((offsets[0] == 0).all())
+    _ROOT_OFFSET_CHECKED["key"] = key
+
+
 def to_root_dual_quat(be, rotations, global_pos, parents, offsets):
     shp = be.shape(rotations)
     if len(shp) < 2 or shp[-1] != 4:
@@ -413,8 +431,7 @@ def to_root_dual_quat(be, rotations, global_pos, parents, offsets):
     p = _parents_host(be, parents, J)
     if be.shape(offsets) != (J, 3):
         raise ValueError(f"offsets must be [{J}, 3], got {be.shape(offsets)}")
-    off0 = np.asarray(offsets[0].detach().cpu() if be.name == "torch" else offsets[0])
-    assert (off0 == 0).all()  # skeleton.py:227
+    _assert_root_offset_is_zero(be, offsets)  # skeleton.py:227
     out_dt = be.always64 if be.name == "numpy" else rotations.dtype
     be.begin(rotations, global_pos, offsets)
     try:
