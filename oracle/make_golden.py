@@ -415,6 +415,26 @@ def gen_ik():
     s.save("ik.npz")
 
 
+def gen_skeleton_extra():
+    """tests/golden/skeleton_extra.npz: cases added after skeleton.npz was frozen.  fk with a NON-ZERO offsets[0]
+    (ignored by the reference: positions[..., 0, :] is overwritten by global_pos, skeleton.py:49), shared and
+    per-frame offsets, on both walk shapes (J <= 23 / J >= 24) and the single-joint skeleton."""
+    s = Store()
+    rng = np.random.default_rng(4049)
+    for name, parents, F in (("J1", np.zeros(1, dtype=np.int32), 5), ("J2", np.zeros(2, dtype=np.int32), 7),
+                             ("J22", syn.PARENTS_22, 33), ("J24", syn.random_parents(24, rng), 9), ("J52", syn.PARENTS_52, 6)):
+        J = len(parents)
+        rot = rng.standard_normal((F, J, 4)).astype(np.float32)
+        gpos = rng.uniform(-2, 2, (F, 3)).astype(np.float32)
+        off = rng.uniform(-0.3, 0.3, (J, 3)).astype(np.float32)  # row 0 deliberately not zero
+        run3(s, f"fk_off0_{name}", {"rot": rot, "gpos": gpos, "off": off, "parents": parents}, sk.fk,
+             lambda r, g, o, p: skt.fk(r, g, o, T(p)), ["pos", "rotmats"], int_keys=("parents",))
+        offf = rng.uniform(-0.3, 0.3, (F, J, 3)).astype(np.float32)
+        run3(s, f"fk_off0_pf_{name}", {"rot": rot, "gpos": gpos, "off": offf, "parents": parents}, sk.fk,
+             lambda r, g, o, p: skt.fk(r, g, o, T(p)), ["pos", "rotmats"], int_keys=("parents",))
+    s.save("skeleton_extra.npz")
+
+
 def gen_time():
     """tests/golden/time.npz: ops/time.py interpolate_positions -- the literal of the reference's own test
     (ops/tests/test_time.py:12-66) and seeded clips with non-uniform times, exact hits and extrapolation on
@@ -489,10 +509,10 @@ def check_oracle():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true", help="also cross-check oracle/ against the imported reference")
-    ap.add_argument("--only", default="", help="comma-separated subset of: elementwise,trig,skeleton,bvh,mirror,ik,time")
+    ap.add_argument("--only", default="", help="comma-separated subset of: elementwise,trig,skeleton,bvh,mirror,ik,time,skeleton_extra")
     args = ap.parse_args()
     gens = {"elementwise": gen_elementwise, "trig": gen_trig, "skeleton": gen_skeleton, "bvh": gen_bvh, "mirror": gen_mirror,
-            "ik": gen_ik, "time": gen_time}
+            "ik": gen_ik, "time": gen_time, "skeleton_extra": gen_skeleton_extra}
     for name, gen in gens.items():
         if not args.only or name in args.only.split(","):
             gen()

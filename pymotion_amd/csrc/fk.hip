@@ -201,9 +201,10 @@ __device__ __forceinline__ v4f load_joint_const(const Parents &parents, const fl
     const int jc = j < J ? j : J - 1;
     v4f c;
     c.x = __int_as_float(j == 0 ? -1 : parents.p[jc]);
-    c.y = PFO ? 0.0f : offsets[3 * jc];
-    c.z = PFO ? 0.0f : offsets[3 * jc + 1];
-    c.w = PFO ? 0.0f : offsets[3 * jc + 2];
+    const bool none = PFO || j == 0;  // per-frame offsets come from their own tile; offsets[0] is ignored (skeleton.py:49)
+    c.y = none ? 0.0f : offsets[3 * jc];
+    c.z = none ? 0.0f : offsets[3 * jc + 1];
+    c.w = none ? 0.0f : offsets[3 * jc + 2];
     return c;
 }
 

@@ -223,6 +223,20 @@ def test_fk_numpy_and_torch_vs_reference_golden(case):
     assert_close(tr.cpu().numpy(), want["rotmats"], ATOL, case + " torch rotmats")
 
 
+@pytest.mark.parametrize("case", golden("skeleton_extra.npz").names("fk_off0_"))
+def test_fk_ignores_a_nonzero_root_offset_like_the_reference(case):
+    """regression (found by tests/test_gpu_fuzz.py): the three-lane walk used to add offsets[0] to the root"""
+    g = golden("skeleton_extra.npz")
+    i, want = g.get(case, "in"), g.get(case, "out64")
+    pos, rm = sk.fk(i["rot"], i["gpos"], i["off"], i["parents"])
+    assert_close(pos, want["pos"], ATOL, case + " pos")
+    assert_close(rm, want["rotmats"], ATOL, case + " rotmats")
+    assert_close(pos[:, 0], i["gpos"], 0, case + " root position is global_pos, bit for bit")
+    torch, skt = _torch_mods()[:2]
+    tp, tr = skt.fk(*[torch.from_numpy(i[k]).cuda() for k in ("rot", "gpos", "off")], torch.from_numpy(i["parents"]))
+    assert_close(tp.cpu().numpy(), want["pos"], ATOL, case + " torch pos")
+
+
 def test_fk_from_ortho6d_vs_reference_golden():
     g = golden("skeleton.npz")
     case = "fk_from_o6d_J52"

@@ -105,6 +105,19 @@ def test_oracles_fk(case):
     assert_close(rm, want["rotmats"], TIGHT, case + " rotmats")
 
 
+@pytest.mark.parametrize("case", golden("skeleton_extra.npz").names("fk_off0_"))
+def test_oracles_fk_ignore_a_nonzero_root_offset(case):
+    """offsets[0] is overwritten by global_pos in the reference (skeleton.py:49), shared or per-frame"""
+    g = golden("skeleton_extra.npz")
+    i, want = up64(g.get(case, "in")), g.get(case, "out64")
+    pos, rm = co.fk(i["rot"], i["gpos"], i["off"], i["parents"])
+    assert_close(pos, want["pos"], TIGHT, case + " pos")
+    assert_close(rm, want["rotmats"], TIGHT, case + " rotmats")
+    assert_close(pos[:, 0], i["gpos"], 0, case + " root")
+    p2, r2 = nr.fk(i["rot"], i["gpos"], i["off"], i["parents"])
+    assert_close(p2, want["pos"], TIGHT, case + " numpy_ref pos")
+
+
 @pytest.mark.parametrize("case", _skel_cases("to_root_dq_"))
 def test_oracles_to_root_dq(case):
     g = golden("skeleton.npz")
