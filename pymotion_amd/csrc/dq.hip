@@ -47,7 +47,7 @@ struct ToRootArgs {
 
 // One step of the quad walk for the lane holding component c, as ONE block of 12 VALU instructions
 // with the quad exchanges folded into the DPP operand of the multiplies (these kernels sit near the
-// VALU issue limit: one wave64 instruction = 4 cycles of a SIMD):
+// VALU issue limit):
 //   q = pq (x) b                                        quat.py:337-361, component-parallel:
 //       q_c = sum_k S[c][k] pq_k b_{c xor k},  sb_k = S[c][k] b_{c xor k} prepared off the chain
 //   t = live * (pv x tt + pw tt) + s,  tt = 2 (pv x v), s = live v_c + pt      quat.py:320-334

@@ -124,7 +124,7 @@ __device__ __forceinline__ void tree_walk(float *sRot, float *sPos, const float 
 // The parent row lives in the quad's own registers (previous joint) and is broadcast by the DPP operand
 // of the multiply itself, so a chain step is 4 VALU instructions per lane and never goes through LDS;
 // a wave walks only FPW <= 5 frames (10 KiB of LDS at J = 52) and many more waves are resident.
-// These kernels sit close to the VALU issue limit (one wave64 instruction = 4 cycles of a SIMD), so
+// These kernels sit close to the VALU issue limit (SQ_ACTIVE_INST_VALU covers ~2/3 of the SIMD cycles), so
 // the step is kept to ~10 instructions:
 //   * phase A leaves L TRANSPOSED in the slot, so the three coefficients of a lane (column c of L, or
 //     the offset t for the position lane) are contiguous: one pointer, immediate offsets;

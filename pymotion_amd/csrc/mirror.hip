@@ -115,6 +115,18 @@ __global__ __launch_bounds__(PM_WAVE) void mirror_kernel(const MirrorArgs a) {
     wave_sync();
 
     // ---- finish, lane per (frame, joint) --------------------------------------------------------------------
+    // (this kernel is VALU-bound -- SQ_ACTIVE_INST_VALU accounts for every SIMD cycle -- so each world quaternion
+    // gets the reference's sign and normalisation ONCE, in place, not once as a child and once per child it has)
+    for_each_slot<2>(n, lane, [&](const int e, const bool valid) {
+        const int fr = (int)(((float)e + 0.5f) * invJ);
+        const int j = e - fr * J;
+        float *slot = sQ + fr * FS + 4 * j;
+        float g[4], cg[4];
+        lds_get<4>(slot, 0, g);
+        canonical_sign(g, cg);
+        if (valid) *reinterpret_cast<v4f *>(slot) = v4f{cg[0], cg[1], cg[2], cg[3]};
+    });
+    wave_sync();
     const float f1 = (a.c0 == 1 || a.c1 == 1) ? -1.0f : 1.0f, f2 = (a.c0 == 2 || a.c1 == 2) ? -1.0f : 1.0f,
                 f3 = (a.c0 == 3 || a.c1 == 3) ? -1.0f : 1.0f;
     float *gout = a.out + f0 * J * 4;
@@ -122,11 +134,9 @@ __global__ __launch_bounds__(PM_WAVE) void mirror_kernel(const MirrorArgs a) {
         const int fr = (int)(((float)e + 0.5f) * invJ);
         const int j = e - fr * J;
         const float *fq_ = sQ + fr * FS;
-        float g[4], pg[4], cg[4], cp[4], o[4];
-        lds_get<4>(fq_, sMap[2 * j], g);
-        lds_get<4>(fq_, sMap[2 * j + 1], pg);
-        canonical_sign(g, cg);
-        canonical_sign(pg, cp);
+        float cg[4], cp[4], o[4];
+        lds_get<4>(fq_, sMap[2 * j], cg);
+        lds_get<4>(fq_, sMap[2 * j + 1], cp);
         cg[1] *= f1; cg[2] *= f2; cg[3] *= f3;  // skeleton.py:310-318
         const float inv[4] = {cp[0], -cp[1] * f1, -cp[2] * f2, -cp[3] * f3};
         qmul(inv, cg, o);                       // skeleton.py:85-91 on the mirrored world rotations
