@@ -5,14 +5,14 @@
 // prefix product of signs of the ORIGINAL neighbours:  s_i = prod_{k<=i} sgn(dot(q_k, q_{k-1}))  with
 // sgn = -1 iff dot < 0 (the reference's `d0 < d1`), s_0 = +1.  That is a prefix XOR along time per
 // series -- a scan, not a loop:
-//   pass 1  each wave owns a chunk of 256 consecutive frames of up to 64 series; per 64-frame sub-tile
+//   pass 1  each wave owns a chunk of 256 consecutive frames of up to 24 series; per 64-frame sub-tile
 //           the rows are staged in LDS (coalesced), lane = frame computes its flip bit per series,
 //           one wave ballot per series gives every lane its inclusive prefix parity; the chunk's total
 //           parity per series goes to the workspace;
 //   pass 2  exclusive prefix XOR over chunks (lane = series; a few thousand independent loads);
 //   pass 3  pass 1 again with the carry-in; the corrected records go back into the LDS rows and leave as
 //           contiguous dwordx4 streams.
-// (LDS: 65 rows x 65 records x 16|32 B = 66|132 KiB at most.)
+// (LDS: 65 rows x 25 records x 16|32 B = 26|52 KiB at most.)
 // Layout: q [T, S, 4] (unroll axis first; the front-end moves it there), out same.
 // Algorithmic HBM bytes: 16 (pass 1) + 16 + 16 (pass 3) = 48 B per quaternion.
 #include "common.hpp"
@@ -21,7 +21,7 @@ namespace pm {
 
 constexpr int UR_SUB = PM_WAVE;   // frames per sub-tile (lane = frame)
 constexpr int UR_CHUNK = 256;     // frames per wave (4 sub-tiles): 4096 waves at 2^20 frames
-constexpr int UR_SB = 64;         // series per block
+constexpr int UR_SB_MAX = 24;     // series per block at most: 65 rows x 25 x 16 B = 26 KiB of LDS -> 6 waves per CU
 
 struct UnrollArgs {
     const float *q;
@@ -30,6 +30,7 @@ struct UnrollArgs {
     int64_t T;
     int32_t S;
     int32_t nchunks;
+    int32_t sbsize;   // series per block (<= UR_SB_MAX, balanced over the blocks)
 };
 
 // W = 4: quaternions; W = 8: dual quaternions (sign decided by the real part, applied to all 8 floats,
@@ -40,8 +41,8 @@ __global__ __launch_bounds__(PM_WAVE) void unroll_kernel(const UnrollArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
     const int chunk = blockIdx.x;
-    const int s0 = blockIdx.y * UR_SB;
-    const int sb = (a.S - s0) < UR_SB ? (a.S - s0) : UR_SB;  // series in this block
+    const int s0 = blockIdx.y * a.sbsize;
+    const int sb = (a.S - s0) < a.sbsize ? (a.S - s0) : a.sbsize;  // series in this block
     const int64_t t0 = (int64_t)chunk * UR_CHUNK;
     const int64_t t1 = (t0 + UR_CHUNK) < a.T ? (t0 + UR_CHUNK) : a.T;
     const int rs = sb | 1;  // row stride in quaternions, odd: per-lane ds_read_b128 down a column is conflict-free
@@ -60,18 +61,19 @@ __global__ __launch_bounds__(PM_WAVE) void unroll_kernel(const UnrollArgs a) {
         const int rowlen = sb * V;  // dwordx4 per staged row segment
         const float inv_rowlen = 1.0f / (float)rowlen;
         const int i_end = (nfr + 1) * rowlen;
-        for (int i0 = lane + first * rowlen; i0 < i_end; i0 += 4 * PM_WAVE) {  // 4 loads in flight per lane
-            v4f v[4];
-            int dst[4];
+        constexpr int UR_DEPTH = 8;  // loads in flight per lane (8 KiB per wave: with 6 resident waves, 4 starved HBM)
+        for (int i0 = lane + first * rowlen; i0 < i_end; i0 += UR_DEPTH * PM_WAVE) {
+            v4f v[UR_DEPTH];
+            int dst[UR_DEPTH];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * PM_WAVE;
-                const int r = (int)(((float)i + 0.5f) * inv_rowlen), c = i - r * rowlen;
+            for (int u = 0; u < UR_DEPTH; ++u) {
+                const int i = i0 + u * PM_WAVE, ic = i < i_end ? i : i_end - 1;  // clamped: loads are unconditional
+                const int r = (int)(((float)ic + 0.5f) * inv_rowlen), c = ic - r * rowlen;
                 dst[u] = r * rs * V + c;
-                if (i < i_end) v[u] = *(reinterpret_cast<const v4f *>(a.q) + ((ts - 1 + r) * a.S + s0) * V + c);
+                v[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(a.q) + ((ts - 1 + r) * a.S + s0) * V + c);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < UR_DEPTH; ++u)
                 if (i0 + u * PM_WAVE < i_end) rows[dst[u]] = v[u];
         }
         wave_sync();
@@ -148,11 +150,13 @@ static int unroll_launch(const float *q, int64_t T, int32_t S, float *out, void 
     PM_CHECK_ARGS(q && out && workspace, "quat_unroll: null pointer");
     PM_CHECK_ARGS(aligned16(q) && aligned16(out), "quat_unroll: q and out must be 16-byte aligned");
     const int64_t nchunks = (T + UR_CHUNK - 1) / UR_CHUNK;
-    const int sblocks = (S + UR_SB - 1) / UR_SB;
+    const int nsb = (S + UR_SB_MAX - 1) / UR_SB_MAX;
+    const int sbsize = (S + nsb - 1) / nsb;
+    const int sblocks = (S + sbsize - 1) / sbsize;
     if (nchunks > 0x7fffffffLL || sblocks > 65535) { set_error("quat_unroll: problem too large"); return PM_EUNSUPPORTED; }
     UnrollArgs a;
-    a.q = q; a.out = out; a.ws = static_cast<int32_t *>(workspace); a.T = T; a.S = S; a.nchunks = (int)nchunks;
-    const size_t lds = (size_t)(UR_SUB + 1) * ((S < UR_SB ? S : UR_SB) | 1) * 4 * W;
+    a.q = q; a.out = out; a.ws = static_cast<int32_t *>(workspace); a.T = T; a.S = S; a.nchunks = (int)nchunks; a.sbsize = sbsize;
+    const size_t lds = (size_t)(UR_SUB + 1) * (sbsize | 1) * 4 * W;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int e = allow_lds(unroll_kernel<false, W>, lds)) return e;
     if (int e = allow_lds(unroll_kernel<true, W>, lds)) return e;
