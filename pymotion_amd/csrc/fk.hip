@@ -43,7 +43,7 @@ struct FkArgs {
     int64_t F;
     int32_t J;
     float eps;              // ortho6d Gram-Schmidt floor
-    int32_t ablate;         // tuning aid (env PM_FK_ABLATE): 1 = no local math, 2 = no tree walk; 0 in production
+    int32_t ablate;         // tuning aid (env PM_FK_ABLATE): 2 = no tree walk; 0 in production
     Parents parents;
 };
 

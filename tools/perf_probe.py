@@ -153,6 +153,17 @@ def main():
             report("quat.mul", ms, mn, N * 48)
             ms, mn = timeit(lambda: _lib.call("pm_quat_normalize_f32", p(q), N, C.c_float(1e-8), p(qo), None))
             report("quat.normalize", ms, mn, N * 32)
+            eul = torch.rand((N, 3), device=dev) * 6.0 - 3.0
+            order = torch.tensor([2, 0, 1], dtype=torch.uint8, device=dev)  # 'zxy' for every element
+            ms, mn = timeit(lambda: _lib.call("pm_quat_from_euler_f32", p(eul), p(order), 0, N, p(qo), None))
+            report("quat.from_euler (one order)", ms, mn, N * 28)
+            eo = torch.empty((N, 3), device=dev)
+            ms, mn = timeit(lambda: _lib.call("pm_quat_to_euler_f32", p(q), p(order), 0, N, p(eo), None))
+            report("quat.to_euler (one order)", ms, mn, N * 28)
+            tt = torch.rand((N,), device=dev)
+            ms, mn = timeit(lambda: _lib.call("pm_quat_slerp_f32", p(q), p(q2), p(tt), N, 1, p(qo), None))
+            report("quat.slerp", ms, mn, N * 52)
+            del eul, eo, tt
             qo2 = qo.view(N, 4)
             ms, mn = timeit(lambda: qo2.copy_(q))
             report("torch copy_ (16 B/elem r+w)", ms, mn, N * 32)
