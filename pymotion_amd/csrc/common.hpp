@@ -42,14 +42,10 @@ __device__ __forceinline__ int64_t xcd_tile(int64_t ntiles) {
     return t < ntiles ? t : -1;
 }
 
-// ---- DPP moves inside a quad (4 consecutive lanes): register-to-register, no LDS -------------------
-// quad_perm<a,b,c,d>: lane i of every quad receives the value of lane {a,b,c,d}[i] of the same quad.
-template <int P0, int P1, int P2, int P3>
-__device__ __forceinline__ float quad_perm(const float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), P0 | (P1 << 2) | (P2 << 4) | (P3 << 6), 0xf, 0xf, true));
-}
-template <int K>
-__device__ __forceinline__ float quad_bcast(const float v) { return quad_perm<K, K, K, K>(v); }  // value of quad lane K
+// ---- DPP arithmetic inside a quad (4 consecutive lanes): register-to-register, no LDS ---------------
+// quad_perm:[a,b,c,d] = lane i of every quad reads the operand of lane {a,b,c,d}[i] of the same quad.  The
+// exchange rides on the DPP operand of the multiply(-add) itself (inline asm: the compiler would emit a
+// v_mov_dpp plus the arithmetic instruction), which is what keeps the tree-walk steps short.
 
 // S[c][k] * b_{c xor k} in one instruction (b was loaded from LDS: no VALU -> DPP hazard)
 template <int P0, int P1, int P2, int P3>

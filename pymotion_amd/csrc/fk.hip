@@ -47,9 +47,6 @@ struct FkArgs {
     Parents parents;
 };
 
-template <int SRC>
-constexpr int src_width() { return SRC == SRC_QUAT ? 4 : 6; }
-
 // LDS floats per frame-joint: rot 9 + pos 3 (+ per-frame offsets 3) (+ quat_out 4)
 template <int SRC, bool PFO, bool QOUT>
 constexpr int fk_lds_floats() { return 12 + (PFO ? 3 : 0) + (QOUT ? 4 : 0); }
