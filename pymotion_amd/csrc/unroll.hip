@@ -5,13 +5,13 @@
 // prefix product of signs of the ORIGINAL neighbours:  s_i = prod_{k<=i} sgn(dot(q_k, q_{k-1}))  with
 // sgn = -1 iff dot < 0 (the reference's `d0 < d1`), s_0 = +1.  That is a prefix XOR along time per
 // series -- a scan, not a loop:
-//   pass 1  each wave owns a chunk of 256 consecutive frames of up to 24 series; per 64-frame sub-tile
-//           the rows are staged in LDS (coalesced), lane = frame computes its flip bit per series,
-//           one wave ballot per series gives every lane its inclusive prefix parity; the chunk's total
-//           parity per series goes to the workspace;
+//   pass 1  each wave streams a chunk of 256 consecutive frames (one record per lane, the predecessor row an
+//           L1 / L2 hit) and XORs the flip bits into per-series parities (LDS atomics) -> workspace;
 //   pass 2  exclusive prefix XOR over chunks (lane = series; a few thousand independent loads);
-//   pass 3  pass 1 again with the carry-in; the corrected records go back into the LDS rows and leave as
-//           contiguous dwordx4 streams.
+//   pass 3  each wave owns a chunk of up to 24 series; per 64-frame sub-tile the rows are staged in LDS
+//           (coalesced), lane = frame computes its flip bit per series, one wave ballot per series gives every
+//           lane its inclusive prefix parity (+ the chunk's carry-in); the corrected records go back into the
+//           LDS rows and leave as contiguous dwordx4 streams.
 // (LDS: 65 rows x 25 records x 16|32 B = 26|52 KiB at most.)
 // Layout: q [T, S, 4] (unroll axis first; the front-end moves it there), out same.
 // Algorithmic HBM bytes: 16 (pass 1) + 16 + 16 (pass 3) = 48 B per quaternion.
@@ -35,8 +35,8 @@ struct UnrollArgs {
 
 // W = 4: quaternions; W = 8: dual quaternions (sign decided by the real part, applied to all 8 floats,
 // rotations/dual_quat.py:139-167).
-template <bool APPLY, int W>
-__global__ __launch_bounds__(PM_WAVE) void unroll_kernel(const UnrollArgs a) {
+template <int W>
+__global__ __launch_bounds__(PM_WAVE) void unroll_apply_kernel(const UnrollArgs a) {
     constexpr int V = W / 4;  // dwordx4 per record
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
@@ -48,9 +48,9 @@ __global__ __launch_bounds__(PM_WAVE) void unroll_kernel(const UnrollArgs a) {
     const int rs = sb | 1;  // row stride in quaternions, odd: per-lane ds_read_b128 down a column is conflict-free
     v4f *rows = reinterpret_cast<v4f *>(smem);  // [(UR_SUB + 1)][rs][V]: row 0 = the frame before the sub-tile
 
-    // carry-in parity per series (lane = series): exclusive prefix over earlier chunks (pass 3 only)
+    // carry-in parity per series (lane = series): exclusive prefix over earlier chunks
     unsigned long long carry = 0;  // bit j = parity of series s0 + j
-    if (APPLY) {
+    {
         const int c = (lane < sb) ? a.ws[(int64_t)chunk * a.S + s0 + lane] : 0;
         carry = __ballot(c & 1);
     }
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(PM_WAVE) void unroll_kernel(const UnrollArgs a) {
                 flip = (cur.x * prv.x + cur.y * prv.y + cur.z * prv.z + cur.w * prv.w) < 0.0f;
             }
             const unsigned long long m = __ballot(flip);
-            if (APPLY) {
+            {
                 const unsigned long long upto = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);
                 const int par = (__popcll(m & upto) + (int)((carry >> j) & 1ull)) & 1;
                 if (act) {
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(PM_WAVE) void unroll_kernel(const UnrollArgs a) {
             }
             if (__popcll(m) & 1) newcarry ^= (1ull << j);
         }
-        if (APPLY) {
+        {
             // rows 1..nfr leave the way they came: contiguous dwordx4, 4 stores in flight per lane
             wave_sync();
             const int o_end = nfr * rowlen;
@@ -116,7 +116,52 @@ __global__ __launch_bounds__(PM_WAVE) void unroll_kernel(const UnrollArgs a) {
         carry = newcarry;
         wave_sync();
     }
-    if (!APPLY && lane < sb) a.ws[(int64_t)chunk * a.S + s0 + lane] = (int)((carry >> lane) & 1ull);
+}
+
+// pass 1 as a plain stream (no LDS tile, one record per lane, consecutive lanes on consecutive records): the
+// flip bit of record (t, s) needs record (t-1, s), which the same wave fetched S records earlier (an L1 / L2
+// hit), and the chunk's parity per series is an LDS atomic XOR.  Series are taken in blocks of UR_P1_SB.
+constexpr int UR_P1_SB = 8192;
+
+template <int W>
+__global__ __launch_bounds__(PM_WAVE) void unroll_parity_kernel(const UnrollArgs a) {
+    constexpr int V = W / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int *par = reinterpret_cast<int *>(smem);
+    const int lane = threadIdx.x;
+    const int chunk = blockIdx.x;
+    const int s0 = blockIdx.y * UR_P1_SB;
+    const int sb = (a.S - s0) < UR_P1_SB ? (a.S - s0) : UR_P1_SB;
+    const int64_t t0 = (int64_t)chunk * UR_CHUNK;
+    const int64_t t1 = (t0 + UR_CHUNK) < a.T ? (t0 + UR_CHUNK) : a.T;
+    for (int i = lane; i < sb; i += PM_WAVE) par[i] = 0;
+    wave_sync();
+    const int n = (int)(t1 - t0) * sb;  // records of this chunk x series block (< 2^22: UR_CHUNK * UR_P1_SB = 2^21)
+    const float inv_sb = 1.0f / (float)sb;
+    const v4f *q = reinterpret_cast<const v4f *>(a.q);
+    for (int i0 = 0; i0 < n; i0 += 4 * PM_WAVE) {
+        v4f cur[4], prv[4];
+        int ser[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * PM_WAVE + lane, ic = i < n ? i : n - 1;
+            const int r = (int)(((float)ic + 0.5f) * inv_sb), c = ic - r * sb;
+            const int64_t t = t0 + r;
+            ser[u] = c;
+            ok[u] = (i < n) && (t > 0);
+            const int64_t e = (t * a.S + s0 + c) * V;
+            cur[u] = __builtin_nontemporal_load(q + e);
+            prv[u] = q[t > 0 ? e - (int64_t)a.S * V : e];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool flip = ok[u] && (cur[u].x * prv[u].x + cur[u].y * prv[u].y + cur[u].z * prv[u].z + cur[u].w * prv[u].w) < 0.0f;
+            if (flip) __hip_atomic_fetch_xor(par + ser[u], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    wave_sync();
+    for (int i = lane; i < sb; i += PM_WAVE) a.ws[(int64_t)chunk * a.S + s0 + i] = par[i] & 1;
 }
 
 // exclusive prefix XOR over chunks, in place: one wave per series, lane = chunk (64 at a time), the
@@ -158,12 +203,15 @@ static int unroll_launch(const float *q, int64_t T, int32_t S, float *out, void 
     a.q = q; a.out = out; a.ws = static_cast<int32_t *>(workspace); a.T = T; a.S = S; a.nchunks = (int)nchunks; a.sbsize = sbsize;
     const size_t lds = (size_t)(UR_SUB + 1) * (sbsize | 1) * 4 * W;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (int e = allow_lds(unroll_kernel<false, W>, lds)) return e;
-    if (int e = allow_lds(unroll_kernel<true, W>, lds)) return e;
+    if (int e = allow_lds(unroll_apply_kernel<W>, lds)) return e;
     const dim3 grid((unsigned)nchunks, (unsigned)sblocks);
-    hipLaunchKernelGGL((unroll_kernel<false, W>), grid, dim3(PM_WAVE), lds, s, a);
+    {   // pass 1: chunk parities
+        const int p1_blocks = (S + UR_P1_SB - 1) / UR_P1_SB;
+        const size_t p1_lds = (size_t)(S < UR_P1_SB ? S : UR_P1_SB) * sizeof(int);
+        hipLaunchKernelGGL((unroll_parity_kernel<W>), dim3((unsigned)nchunks, (unsigned)p1_blocks), dim3(PM_WAVE), p1_lds, s, a);
+    }
     hipLaunchKernelGGL(unroll_scan_kernel, dim3((unsigned)S), dim3(PM_WAVE), 0, s, a.ws, (int)nchunks, (int)S);
-    hipLaunchKernelGGL((unroll_kernel<true, W>), grid, dim3(PM_WAVE), lds, s, a);
+    hipLaunchKernelGGL((unroll_apply_kernel<W>), grid, dim3(PM_WAVE), lds, s, a);
     return check_hip(hipGetLastError(), "quat_unroll");
 }
 

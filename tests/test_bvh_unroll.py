@@ -67,7 +67,8 @@ def test_gpu_dq_unroll_and_long_sequences():
     assert_close(dq.unroll(i["dq"], 0), want, 1e-7, "dq unroll")
     # many chunks (T > 1024), more series than one block (S > 64), ragged tail: against the sequential oracle
     rng = np.random.default_rng(3)
-    for T, S in ((5000, 22), (1025, 70), (1, 3), (2, 1), (64, 64), (4097, 130)):
+    # (S > 8192: more than one series block in the parity pass; 24 < S: several series blocks in the apply pass)
+    for T, S in ((5000, 22), (1025, 70), (1, 3), (2, 1), (64, 64), (4097, 130), (300, 8200), (257, 25)):
         base = np.cumsum(rng.normal(0, 0.08, (T, S, 4)), axis=0) + rng.normal(0, 1, (1, S, 4))
         q = (base * rng.choice([-1.0, 1.0], (T, S, 1))).astype(np.float32)
         got = quat.unroll(q, 0)
@@ -75,6 +76,13 @@ def test_gpu_dq_unroll_and_long_sequences():
         assert_close(got, ref, 1e-7, f"T={T} S={S}")
         d = np.sum(got[1:] * got[:-1], axis=-1)
         assert (d >= 0).all()  # the defining property: neighbours never sit on opposite covers
+    # dual quaternions on long, wide clips: the sign of the real part decides, all 8 floats follow
+    for T, S in ((1500, 22), (260, 30)):
+        base = np.cumsum(rng.normal(0, 0.08, (T, S, 8)), axis=0) + rng.normal(0, 1, (1, S, 8))
+        d8 = (base * rng.choice([-1.0, 1.0], (T, S, 1))).astype(np.float32)
+        got = dq.unroll(d8, 0)
+        sign = co.quat_unroll(d8[..., :4].astype(np.float64), 0)[..., :1] / d8[..., :1]
+        assert_close(got, d8 * np.sign(sign), 1e-7, f"dq T={T} S={S}")
 
 
 @pytest.mark.gpu
