@@ -191,12 +191,33 @@ PM_OP(OpO6dFromMatrix, 9, 0, 0, 6, 0) {
     y0[0] = x0[0]; y0[1] = x0[1]; y0[2] = x0[3]; y0[3] = x0[4]; y0[4] = x0[6]; y0[5] = x0[7];
 } PM_OP_END
 
-// ---- second wave: trig-heavy conversions (accurate libm-grade sin/cos/acos/atan2: parity first) ----
+// ---- second wave: trig-heavy conversions (libm-grade accuracy: parity first) ----------------------------
+// These are VALU-bound, not HBM-bound (SQ_INSTS_VALU: ~480 per 128 elements for from_euler with libm's sincosf,
+// every SIMD cycle busy), so sin/cos use a lean path of the same accuracy class: k = rint(x 2/pi) and the
+// reduction r = x - k pi/2 in double precision (three full-rate f64 instructions, exact to 2^-53 |x|: valid for
+// any |x| < 1e8 with no Cody-Waite constant juggling and no Payne-Hanek), then the Cephes minimax polynomials
+// on [-pi/4, pi/4] (|error| < 2^-24) and the quadrant fix-up.  Beyond 1e8 rad (nobody's Euler angle) libm takes over.
+__device__ __forceinline__ void sincos_rr(const float x, float &s, float &c) {
+    const double xd = (double)x, kd = rint(xd * 0.6366197723675814);
+    const float r = (float)fma(kd, -1.5707963267948966, xd);
+    const int k = (int)kd;
+    const float r2 = r * r;
+    const float sp = r + r * r2 * (-1.6666654611e-1f + r2 * (8.3321608736e-3f + r2 * -1.9515295891e-4f));
+    const float cp = 1.0f - 0.5f * r2 + r2 * r2 * (4.166664568298827e-2f + r2 * (-1.388731625493765e-3f + r2 * 2.443315711809948e-5f));
+    const bool swap = (k & 1) != 0;  // x = r + k pi/2:  k mod 4 = 0: (s, c)   1: (c, -s)   2: (-s, -c)   3: (-c, s)
+    float ss = swap ? cp : sp, cc = swap ? sp : cp;
+    ss = (k & 2) ? -ss : ss;
+    cc = ((k + 1) & 2) ? -cc : cc;
+    if (!(fabsf(x) < 1e8f)) { ss = sinf(x); cc = cosf(x); }  // huge, inf, NaN
+    s = ss; c = cc;
+}
+
 
 // rotations/quat.py:24-40
 __device__ __forceinline__ void aa2q(float angle, float ax, float ay, float az, float (&o)[4]) {
     const float h = angle / 2.0f;
-    const float c = cosf(h), s = sinf(h);
+    float s, c;
+    sincos_rr(h, s, c);
     o[0] = c; o[1] = s * ax; o[2] = s * ay; o[3] = s * az;
 }
 PM_OP(OpFromAngleAxis, 1, 3, 0, 4, 0) { aa2q(x0[0], x1[0], x1[1], x1[2], y0); } PM_OP_END
@@ -247,13 +268,16 @@ PM_OP(OpToEuler, 4, 0, 0, 3, 0) {
     const float aa = x0[0] - qj, bb = qi + qk * sg, cc = qj + x0[0], dd = qk * sg - qi;
     const float two_pi = 6.283185307179586f;
     float e[3];
-    e[1] = 2.0f * atan2f(hypotf(cc, dd), hypotf(aa, bb)) - 1.5707963267948966f;
+    // (np.hypot on quaternion-sized operands: no overflow to guard against, plain sqrt of the sum of squares)
+    e[1] = 2.0f * atan2f(__fsqrt_rn(cc * cc + dd * dd), __fsqrt_rn(aa * aa + bb * bb)) - 1.5707963267948966f;
     const float hs = atan2f(bb, aa), hd = atan2f(dd, cc);
     e[2] = hs - hd;
     e[0] = (hs + hd) * sg;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {  // np.mod(e, 2pi): result carries the divisor's sign
-        float r = fmodf(e[c], two_pi);
+    for (int c = 0; c < 3; ++c) {  // np.mod(e, 2pi): result carries the divisor's sign.  |e| < 4 pi here, so fmod is
+        float r = e[c];            // at most one exact subtraction (Sterbenz), no division loop
+        r = (r >= two_pi) ? r - two_pi : r;
+        r = (r <= -two_pi) ? r + two_pi : r;
         if (r < 0.0f) r += two_pi;
         y0[c] = r;
     }
@@ -269,7 +293,8 @@ PM_OP(OpSlerp, 4, 4, 1, 4, 0) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) { q2[c] = b[c] - x0[c] * dot; const float u = q2[c] + 0.000001f; nn += u * u; }
     nn = __fsqrt_rn(nn);
-    const float cs = cosf(th), sn = sinf(th);
+    float cs, sn;
+    sincos_rr(th, sn, cs);
 #pragma unroll
     for (int c = 0; c < 4; ++c) y0[c] = cs * x0[c] + sn * (q2[c] / nn);
 } PM_OP_END

@@ -124,6 +124,23 @@ def test_trig_vs_reference_golden(case):
     _check(case, names, tuple(t.cpu().numpy() for t in _tup(fn_t(m, ins))), g, atol)
 
 
+def test_sin_cos_of_the_trig_ops_over_a_wide_angle_range():
+    """from_angle_axis uses the library's own sin/cos (one double-precision FMA for the range reduction +
+    minimax polynomials): libm-grade over every range a caller can produce, libm itself beyond 1e8 rad."""
+    rng = np.random.default_rng(12)
+    ax = np.tile(np.array([[0.0, 0.0, 1.0]], np.float32), (4096, 1))
+    for scale, tol in ((3.2, 2e-7), (100.0, 2e-7), (2e4, 2e-7), (5e7, 2e-7), (3e9, 2e-7)):
+        ang = (rng.uniform(-scale, scale, (4096, 1))).astype(np.float32)
+        got = quat.from_angle_axis(ang, ax)
+        h = ang.astype(np.float64)[:, 0] / 2
+        assert_close(got[:, 0], np.cos(h), tol, f"cos up to {scale}")
+        assert_close(got[:, 3], np.sin(h), tol, f"sin up to {scale}")
+    exact = quat.from_angle_axis(np.array([[0.0], [np.pi], [-np.pi], [2 * np.pi]], np.float32), ax[:4])
+    assert_close(exact[:, 0], [1.0, np.cos(np.float32(np.pi) / 2), np.cos(np.float32(np.pi) / 2), -1.0], 2e-7)
+    bad = quat.from_angle_axis(np.array([[np.inf], [np.nan]], np.float32), ax[:2])
+    assert np.isnan(bad[:, 0]).all()
+
+
 def _order_strings(codes):
     return np.array(list("xyz"))[codes]
 
