@@ -213,6 +213,25 @@ __device__ __forceinline__ void sincos_rr(const float x, float &s, float &c) {
 }
 
 
+// atan2 of the same class (Cephes atanf: reduction at tan(pi/8) + degree-4 polynomial in z = u^2, |error| < 2^-23
+// relative), with np.arctan2's quadrant / signed-zero conventions; 0/0, inf and NaN operands go to libm (a branch
+// the wave skips when no lane needs it -- a select would drag libm's code along for every element).
+__device__ __forceinline__ float atan2_rr(const float y, const float x) {
+    const float ay = fabsf(y), ax = fabsf(x);
+    const float hi = fmaxf(ay, ax), lo = fminf(ay, ax);
+    const float t = lo * frcp(hi);                         // in [0, 1]
+    const bool mid = t > 0.4142135623730950f;
+    const float u = mid ? (t - 1.0f) * frcp(t + 1.0f) : t;
+    const float z = u * u;
+    float a = (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * u + u;
+    a += mid ? 0.7853981633974483f : 0.0f;
+    a = (ay > ax) ? 1.5707963267948966f - a : a;           // atan(ay / ax) in [0, pi/2]
+    a = (x < 0.0f) ? 3.141592653589793f - a : a;           // left half plane
+    a = copysignf(a, y);
+    if (!((hi > 0.0f) && (hi < 3.0e38f) && (lo == lo))) a = atan2f(y, x);
+    return a;
+}
+
 // rotations/quat.py:24-40
 __device__ __forceinline__ void aa2q(float angle, float ax, float ay, float az, float (&o)[4]) {
     const float h = angle / 2.0f;
@@ -269,8 +288,8 @@ PM_OP(OpToEuler, 4, 0, 0, 3, 0) {
     const float two_pi = 6.283185307179586f;
     float e[3];
     // (np.hypot on quaternion-sized operands: no overflow to guard against, plain sqrt of the sum of squares)
-    e[1] = 2.0f * atan2f(__fsqrt_rn(cc * cc + dd * dd), __fsqrt_rn(aa * aa + bb * bb)) - 1.5707963267948966f;
-    const float hs = atan2f(bb, aa), hd = atan2f(dd, cc);
+    e[1] = 2.0f * atan2_rr(__fsqrt_rn(cc * cc + dd * dd), __fsqrt_rn(aa * aa + bb * bb)) - 1.5707963267948966f;
+    const float hs = atan2_rr(bb, aa), hd = atan2_rr(dd, cc);
     e[2] = hs - hd;
     e[0] = (hs + hd) * sg;
 #pragma unroll
