@@ -165,6 +165,28 @@ def test_euler_vs_reference_golden():
     assert np.minimum(d, 2 * np.pi - d).max() < 5e-4
 
 
+def test_to_euler_on_quadrant_boundaries_and_identity():
+    """the library's own atan2 must keep np.arctan2's conventions where they matter: axis-aligned rotations
+    (operands exactly 0), the identity (atan2(0, 0) family) and every quadrant"""
+    ang = np.array([0.0, np.pi / 2, -np.pi / 2, np.pi, 0.3, -2.8, 1.0e-7, -1.0e-7], np.float64)
+    grid = np.stack(np.meshgrid(ang, ang, ang, indexing="ij"), -1).reshape(-1, 3)
+    for order in (["z", "x", "y"], ["x", "y", "z"], ["y", "z", "x"]):
+        o = np.tile(np.array(order), (len(grid), 1))
+        q = co.quat_from_euler(grid, o)
+        got = quat.to_euler(q.astype(np.float32), o)
+        want = co.quat_to_euler(q.astype(np.float32).astype(np.float64), o)
+        d = np.abs(got - want)
+        d = np.minimum(d, 2 * np.pi - d)
+        # gimbal-locked poses (middle angle +-pi/2) split the remaining rotation between the outer angles
+        # arbitrarily: judge those through the rotation they encode
+        lock = np.isclose(np.abs(np.sin(grid[:, 1])), 1.0, atol=1e-6)
+        assert d[~lock].max() < 2e-3, (order, d[~lock].max())
+        back = co.quat_from_euler(got.astype(np.float64), o)
+        err = np.minimum(np.abs(back - q).max(-1), np.abs(back + q).max(-1))
+        assert err.max() < 2e-3, (order, err.max())
+        assert np.isfinite(got).all() and (got >= 0).all() and (got <= 2 * np.pi + 1e-6).all()
+
+
 def test_o6d_zero_column_matches_each_front_door():
     g = golden("elementwise.npz")
     x = g.get("o6d_to_matrix_zero_col", "in")["x"]
