@@ -376,10 +376,22 @@ class TorchBackend:
         self._keep = []
         self._guard.__exit__(None, None, None)
 
+    _ints_memo = {}
+
     def host_ints(self, x):
         torch = self.torch
         if isinstance(x, torch.Tensor):
-            x = x.detach().cpu().numpy()  # J integers; on a HIP tensor this is the only sync of the call
+            if x.is_cuda:
+                # J integers living on the device: the copy is a synchronisation, so remember it per tensor version
+                # (a loop over clips with one `parents` tensor pays once)
+                key = (x.data_ptr(), x._version, tuple(x.shape), x.dtype, x.device)
+                hit = TorchBackend._ints_memo.get("key")
+                if hit is not None and hit[0] == key:
+                    return hit[1]
+                arr = np.ascontiguousarray(x.detach().cpu().numpy(), dtype=np.int32)
+                TorchBackend._ints_memo["key"] = (key, arr)
+                return arr
+            x = x.detach().numpy()
         return np.ascontiguousarray(np.asarray(x), dtype=np.int32)
 
     def interp_coefficients(self, sample_times, original_times):

@@ -421,6 +421,32 @@ def test_fk_per_frame_offsets_and_unaligned_views():
     assert_close(tr.cpu().numpy(), r1, ATOL, "unaligned rotmats")
 
 
+def test_device_resident_parents_and_offsets_are_rechecked_when_they_change():
+    """parents / offsets living on the GPU cost a host sync to inspect; the verdict is remembered per tensor
+    VERSION, so an in-place edit must be seen"""
+    torch, skt = _torch_mods()[:2]
+    from pymotion_amd import synthetic as syn
+
+    rot, root, off, par = syn.fk_workload(33, seed=4, normalized=True)
+    tr, tg, to = (torch.from_numpy(a).cuda() for a in (rot, root, off))
+    tp = torch.from_numpy(par.astype(np.int64)).cuda()
+    for _ in range(3):
+        pos, _ = skt.fk(tr, tg, to, tp)
+        assert_close(pos.cpu().numpy(), co.fk(rot.astype(np.float64), root.astype(np.float64), off.astype(np.float64), par)[0], ATOL)
+        skt.to_root_dual_quat(tr, tg, tp, to)
+    tp[5] = 2  # re-parent joint 5 in place (was 0)
+    par2 = par.copy()
+    par2[5] = 2
+    pos, _ = skt.fk(tr, tg, to, tp)
+    assert_close(pos.cpu().numpy(), co.fk(rot.astype(np.float64), root.astype(np.float64), off.astype(np.float64), par2)[0], ATOL)
+    to[0, 1] = 0.5  # offsets[0] != 0 now: to_root_dual_quat must assert like the reference (skeleton_torch.py:242)
+    with pytest.raises(AssertionError):
+        skt.to_root_dual_quat(tr, tg, tp, to)
+    tp[3] = 7  # not topological any more
+    with pytest.raises(ValueError):
+        skt.fk(tr, tg, to, tp)
+
+
 def test_bad_topology_raises_value_error():
     rot = np.zeros((2, 3, 4), np.float32)
     with pytest.raises(ValueError, match="topological"):
