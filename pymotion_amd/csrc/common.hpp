@@ -305,10 +305,9 @@ __device__ __forceinline__ void vnormalize(const float (&v)[3], float eps, float
     o[0] = v[0] * inv; o[1] = v[1] * inv; o[2] = v[2] * inv;
 }
 
-// rotations/quat.py:504-576 from_to(v1, v2): rotation taking direction v1 to v2.
-__device__ __forceinline__ void from_to(const float (&v1)[3], const float (&v2)[3], bool normalize_input, float (&o)[4]) {
-    float a[3] = {v1[0], v1[1], v1[2]}, b[3] = {v2[0], v2[1], v2[2]};
-    if (normalize_input) { vnormalize(v1, 1e-8f, a); vnormalize(v2, 1e-8f, b); }
+// rotations/quat.py:504-576 from_to(v1, v2): rotation taking direction v1 to v2.  `a`, `b` are the directions AFTER
+// the optional normalisation (:541-543), so that a caller with a constant v1 can normalise it once.
+__device__ __forceinline__ void from_to_unit(const float (&a)[3], const float (&b)[3], float (&o)[4]) {
     const float cr[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
     const float dot = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
     float ax[3];
@@ -326,12 +325,14 @@ __device__ __forceinline__ void from_to(const float (&v1)[3], const float (&v2)[
         o[0] = 0.0f; o[1] = ax2[0]; o[2] = ax2[1]; o[3] = ax2[2];
     }
 }
-
-// rotations/quat.py:579-650 from_to_axis(v1, v2, rot_axis): same angle, rotation axis fixed.
-__device__ __forceinline__ void from_to_axis(const float (&v1)[3], const float (&v2)[3], const float (&axis)[3],
-                                             bool normalize_input, float (&o)[4]) {
+__device__ __forceinline__ void from_to(const float (&v1)[3], const float (&v2)[3], bool normalize_input, float (&o)[4]) {
     float a[3] = {v1[0], v1[1], v1[2]}, b[3] = {v2[0], v2[1], v2[2]};
     if (normalize_input) { vnormalize(v1, 1e-8f, a); vnormalize(v2, 1e-8f, b); }
+    from_to_unit(a, b, o);
+}
+
+// rotations/quat.py:579-650 from_to_axis(v1, v2, rot_axis): same angle, rotation axis fixed (a, b as above).
+__device__ __forceinline__ void from_to_axis_unit(const float (&a)[3], const float (&b)[3], const float (&axis)[3], float (&o)[4]) {
     const float cr[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
     const float dot = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
     const float w = fsqrt((1.0f + dot) * 0.5f);
@@ -341,6 +342,12 @@ __device__ __forceinline__ void from_to_axis(const float (&v1)[3], const float (
     o[0] = w; o[1] = axis[0] * s; o[2] = axis[1] * s; o[3] = axis[2] * s;
     if (isclose_to(dot, 1.0f)) { o[0] = 1.0f; o[1] = 0.0f; o[2] = 0.0f; o[3] = 0.0f; }
     if (isclose_to(dot, -1.0f)) { o[0] = 0.0f; o[1] = axis[0]; o[2] = axis[1]; o[3] = axis[2]; }
+}
+__device__ __forceinline__ void from_to_axis(const float (&v1)[3], const float (&v2)[3], const float (&axis)[3],
+                                             bool normalize_input, float (&o)[4]) {
+    float a[3] = {v1[0], v1[1], v1[2]}, b[3] = {v2[0], v2[1], v2[2]};
+    if (normalize_input) { vnormalize(v1, 1e-8f, a); vnormalize(v2, 1e-8f, b); }
+    from_to_axis_unit(a, b, axis, o);
 }
 
 // ---- host-side helpers -------------------------------------------------------------------------------

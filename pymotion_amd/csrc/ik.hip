@@ -82,7 +82,12 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_kernel(const IkAr
             }
         }
     }
-    for (int i = lane; i < 3 * J; i += PM_WAVE) sOff[i] = a.offsets[i];
+    for (int j = lane; j < J; j += PM_WAVE) {  // rest directions, normalised once (from_to would do it per frame: quat.py:541)
+        const float o[3] = {a.offsets[3 * j], a.offsets[3 * j + 1], a.offsets[3 * j + 2]};
+        float u[3];
+        vnormalize(o, 1e-8f, u);
+        sOff[3 * j] = u[0]; sOff[3 * j + 1] = u[1]; sOff[3 * j + 2] = u[2];
+    }
     for (int j = lane; j <= J; j += PM_WAVE) {
         if (j < J) { sTopo[j] = a.topo.parent[j]; sTopo[2 * J + 1 + j] = a.topo.clist[j]; }
         sTopo[J + j] = a.topo.cstart[j];
@@ -109,8 +114,10 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_kernel(const IkAr
             const float inv[4] = {gpre[0], -gpre[1], -gpre[2], -gpre[3]};
             float pred[3];
             qmulvec(inv, d, pred);
-            const float rest[3] = {sOff[3 * c0], sOff[3 * c0 + 1], sOff[3 * c0 + 2]};
-            from_to(rest, pred, true, rot);
+            const float rest[3] = {sOff[3 * c0], sOff[3 * c0 + 1], sOff[3 * c0 + 2]};  // already unit
+            float predn[3];
+            vnormalize(pred, 1e-8f, predn);
+            from_to_unit(rest, predn, rot);
             for (int k = cs + 1; k < ce; ++k) {  // roll correction from every further child
                 const int gc = sTopo[2 * J + 1 + k];
                 float gj[4], rn[4], pg[4];
@@ -123,16 +130,20 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_kernel(const IkAr
                 qmulvec(ginv, dg, predg);
                 vnormalize(d, 1e-8f, dn);
                 qmulvec(ginv, dn, axis);
-                const float restg[3] = {sOff[3 * gc], sOff[3 * gc + 1], sOff[3 * gc + 2]};
-                from_to_axis(restg, predg, axis, true, roll);
+                const float restg[3] = {sOff[3 * gc], sOff[3 * gc + 1], sOff[3 * gc + 2]};  // already unit
+                float predgn[3];
+                vnormalize(predg, 1e-8f, predgn);
+                from_to_axis_unit(restg, predgn, axis, roll);
                 qmul(rot, roll, r2);
                 rot[0] = r2[0]; rot[1] = r2[1]; rot[2] = r2[2]; rot[3] = r2[3];
             }
         }
-        float rn[4];
-        qnormalize(rot, 1e-8f, rn);
-        qmul(gpre, rn, g);
-        lds_put<4>(fS, j, g);  // P_j is dead from here on
+        if (ce > cs) {  // (a childless joint keeps the identity, nobody reads its G: nothing to do)
+            float rn[4];
+            qnormalize(rot, 1e-8f, rn);
+            qmul(gpre, rn, g);
+            lds_put<4>(fS, j, g);  // P_j is dead from here on
+        }
     }
     wave_sync();
 
