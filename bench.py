@@ -246,13 +246,16 @@ def main():
     extra = {}
     if use_dist:
         # every rank checks a slice of ITS shard against the CPU oracle (the checker, not the measured path)
-        from oracle import c_oracle as co
-
         n_chk = min(F, 1 << 12)
         sl = slice(F // 2, F // 2 + n_chk) if F >= 2 * n_chk else slice(0, n_chk)
-        p_o, r_o = co.fk(rot[sl].cpu().numpy().astype(np.float64), root[sl].cpu().numpy().astype(np.float64),
-                         off_np.astype(np.float64), parents)
-        err = max(float(np.abs(pos[sl].cpu().numpy() - p_o).max()), float(np.abs(rm[sl].cpu().numpy() - r_o).max()))
+        try:
+            from oracle import c_oracle as co
+
+            p_o, r_o = co.fk(rot[sl].cpu().numpy().astype(np.float64), root[sl].cpu().numpy().astype(np.float64),
+                             off_np.astype(np.float64), parents)
+            err = max(float(np.abs(pos[sl].cpu().numpy() - p_o).max()), float(np.abs(rm[sl].cpu().numpy() - r_o).max()))
+        except Exception:  # noqa: BLE001  (checker unavailable on this box: report it, keep every rank in the collective)
+            err = float("inf")
         et = torch.tensor([err], device=dev, dtype=torch.float64)
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
         extra["max_abs_err_vs_oracle_slice"] = {"value": float(et[0]), "frames_per_rank": n_chk}
