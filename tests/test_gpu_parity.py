@@ -447,6 +447,26 @@ def test_device_resident_parents_and_offsets_are_rechecked_when_they_change():
         skt.fk(tr, tg, to, tp)
 
 
+def test_numpy_door_large_inputs_take_the_threaded_staging_path():
+    """>= 4 MB arrays that need a cast or a gather (float64, strided, Fortran order) are converted by several
+    threads into reused staging memory; the results must be bit-identical to the plain fp32 contiguous call"""
+    from pymotion_amd import synthetic as syn
+
+    rot, root, off, par = syn.fk_workload(60_000, seed=9)
+    p0, r0 = sk.fk(rot, root, off, par)
+    wide = np.zeros(rot.shape[:-1] + (8,), np.float64)
+    wide[..., ::2] = rot
+    for variant in (rot.astype(np.float64), wide[..., ::2], np.asfortranarray(rot)):
+        assert not (variant.dtype == np.float32 and variant.flags.c_contiguous)
+        p1, r1 = sk.fk(variant, root.astype(np.float64), off, par)
+        np.testing.assert_array_equal(p1, p0)
+        np.testing.assert_array_equal(r1, r0)
+    for _ in range(3):  # staging buffers are recycled between calls: results stay independent arrays
+        p2, r2 = sk.fk(rot, root, off, par)
+        assert p2 is not p0 and not np.shares_memory(p2, p0)
+        np.testing.assert_array_equal(p2, p0)
+
+
 def test_bad_topology_raises_value_error():
     rot = np.zeros((2, 3, 4), np.float32)
     with pytest.raises(ValueError, match="topological"):
