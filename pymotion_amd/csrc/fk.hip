@@ -44,8 +44,17 @@ struct FkArgs {
     int32_t J;
     float eps;              // ortho6d Gram-Schmidt floor
     int32_t ablate;         // tuning aid (env PM_FK_ABLATE): 2 = no tree walk; 0 in production
+    int32_t pad;            // floats of padding per frame in each per-frame LDS region (0 or 4), set by dispatch_fk
     Parents parents;
 };
+
+// LDS bank conflicts of the walks: lanes of DIFFERENT frames touch the same joint slot in the same instruction, so the
+// distance between frames in the image must not be a multiple of 8 floats (three-lane walk, 20 frames) resp. 16 floats
+// (quad walk, 4 frames) -- which 9 J (rotations) and 3 J (positions, per-frame offsets) are exactly when J is a multiple
+// of 8 resp. 16 (24-joint SMPL, 32, 64...: measured 46 % of peak at J = 32 against 60-65 % at J = 28 / 40 before,
+// 62 % after).  Those skeletons get `pad` = 4 floats between frames (keeps 16-byte alignment: 9 J and 3 J are multiples
+// of 4 then); the image is then no longer the HBM layout verbatim and phase A / copy-out address it per frame
+// (image_slot / image_store).  Every other J keeps the linear image.  The choice is made in dispatch_fk.
 
 // LDS floats per frame-joint: rot 9 + pos 3 (+ per-frame offsets 3) (+ quat_out 4)
 template <int SRC, bool PFO, bool QOUT>
@@ -65,11 +74,11 @@ __device__ __forceinline__ void local_from_quat(const float (&qi)[4], float (&L)
 // Lane (f, r) owns row r of frame f; `gp` = root_pos[f][r].
 template <bool PFO>
 __device__ __forceinline__ void tree_walk(float *sRot, float *sPos, const float *sOff, const float *sConst,
-                                          const int J, const int f, const int r, const float gp, const bool skip) {
-    float *fL = sRot + f * J * 9;         // this frame's slots (L before, G after)
-    float *fRot = fL + r * 3;             // this lane's row inside a slot
-    float *fPos = sPos + f * J * 3 + r;
-    const float *fOff = sOff + f * J * 3;
+                                          const int J, const int pad, const int f, const int r, const float gp, const bool skip) {
+    float *fL = sRot + f * (J * 9 + pad);  // this frame's slots (L before, G after)
+    float *fRot = fL + r * 3;              // this lane's row inside a slot
+    float *fPos = sPos + f * (J * 3 + pad) + r;
+    const float *fOff = sOff + f * (J * 3 + pad);
 
     // Row r of joint j-1's transform, seeded so that joint 0 falls out of the same formula:
     // e_r . L = row r of L (exact: 1*x + 0*y + 0*z) and translation = root_pos[r] (offsets[0] ignored).
@@ -144,15 +153,15 @@ __device__ __forceinline__ float quad_dot3(const float e, const float a0, const 
 
 template <bool PFO>
 __device__ __forceinline__ void tree_walk_quad(float *sRot, float *sPos, const float *sOff, const float *sConst,
-                                               const int J, const int f, const int r, const int c, const float seed,
+                                               const int J, const int pad, const int f, const int r, const int c, const float seed,
                                                const int lane) {
-    float *fL = sRot + f * J * 9;
+    float *fL = sRot + f * (J * 9 + pad);
     // what this lane multiplies the parent row with at joint j: column c of L_j = row c of the transposed
     // slot, or, for the position lane, the offset t_j (constant table, or the per-frame offsets tile)
-    const float *coef = (c < 3) ? (fL + 3 * c) : (PFO ? sOff + f * J * 3 : sConst + 1);
+    const float *coef = (c < 3) ? (fL + 3 * c) : (PFO ? sOff + f * (J * 3 + pad) : sConst + 1);
     const int cstep = (c < 3) ? 9 : (PFO ? 3 : 4);
     // where this lane's element of joint j lives in the image (row-major G, positions)
-    float *own0 = (c < 3) ? (fL + r * 3 + c) : (sPos + f * J * 3 + r);
+    float *own0 = (c < 3) ? (fL + r * 3 + c) : (sPos + f * (J * 3 + pad) + r);
     const int ostep = (c < 3) ? 9 : 3;
     const float m3 = (c == 3) ? 1.0f : 0.0f;
 
@@ -207,27 +216,72 @@ __device__ __forceinline__ v4f load_joint_const(const Parents &parents, const fl
 
 // local rotation -> its slot of the image: as is for the three-lane walk, transposed for tree_walk_quad
 template <bool TRANSPOSED>
-__device__ __forceinline__ void put_local(float *sRot, const int e, const float (&L)[9]) {
+__device__ __forceinline__ void put_local(float *slot, const float (&L)[9]) {
     if (TRANSPOSED) {
         const float T[9] = {L[0], L[3], L[6], L[1], L[4], L[7], L[2], L[5], L[8]};
-        lds_put<9>(sRot, e, T);
+        lds_put<9>(slot, 0, T);
     } else {
-        lds_put<9>(sRot, e, L);
+        lds_put<9>(slot, 0, L);
     }
 }
 
-template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT>
+// where element e = (frame f, joint j) of a tile starts in a per-frame image region: `w` floats per joint,
+// frames J * w + pad floats apart.  pad == 0: the region is linear (e * w), no division.
+template <bool PAD>
+__device__ __forceinline__ int image_slot(const int e, const int J, const float invJ, const int w, const int pad) {
+    if (!PAD) return e * w;  // compile time: the linear image must not carry a branch between the records of a batch
+    const int f = (int)(((float)e + 0.5f) * invJ);  // e / J, exact for e < 2^22
+    return e * w + f * pad;
+}
+
+// LDS image region (nf frames of `per_frame` floats, `pad` floats between frames) <-> its contiguous HBM tile.
+template <bool VEC>
+__device__ __forceinline__ void image_store(float *__restrict__ g, const float *lds, const int nf, const int per_frame,
+                                            const int pad, const int lane) {
+    if (pad == 0) { tile_store<VEC>(g, lds, nf * per_frame, lane); return; }
+    if (VEC) {  // per_frame and pad are multiples of 4 floats whenever pad != 0
+        const int V4 = per_frame >> 2, S4 = (per_frame + pad) >> 2, n4 = nf * V4;
+        const float inv = 1.0f / (float)V4;
+        for (int i = lane; i < n4; i += PM_WAVE) {
+            const int f = (int)(((float)i + 0.5f) * inv);
+            __builtin_nontemporal_store(reinterpret_cast<const v4f *>(lds)[i + f * (S4 - V4)], reinterpret_cast<v4f *>(g) + i);
+        }
+    } else {
+        const float inv = 1.0f / (float)per_frame;
+        for (int k = lane; k < nf * per_frame; k += PM_WAVE) g[k] = lds[k + (int)(((float)k + 0.5f) * inv) * pad];
+    }
+}
+template <bool VEC>
+__device__ __forceinline__ void image_load(const float *__restrict__ g, float *lds, const int nf, const int per_frame,
+                                           const int pad, const int lane) {
+    if (pad == 0) { tile_load<VEC>(g, lds, nf * per_frame, lane); return; }
+    if (VEC) {
+        const int V4 = per_frame >> 2, S4 = (per_frame + pad) >> 2, n4 = nf * V4;
+        const float inv = 1.0f / (float)V4;
+        for (int i = lane; i < n4; i += PM_WAVE) {
+            const int f = (int)(((float)i + 0.5f) * inv);
+            reinterpret_cast<v4f *>(lds)[i + f * (S4 - V4)] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(g) + i);
+        }
+    } else {
+        const float inv = 1.0f / (float)per_frame;
+        for (int k = lane; k < nf * per_frame; k += PM_WAVE) lds[k + (int)(((float)k + 0.5f) * inv) * pad] = g[k];
+    }
+}
+
+template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT, bool PAD>
 __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int64_t f0, const int nf, const int lane) {
     const int J = a.J;
     const int FJ = FPW * J;
     const int n = nf * J;  // (frame, joint) elements in this tile
     constexpr bool QUAD = FPW <= 5;  // few frames per wave (big J): 12 lanes per frame, see tree_walk_quad
 
-    float *sRot = smem;                                // [FPW*J*9]  FPW % 4 == 0 keeps every carve 16 B aligned
-    float *sPos = sRot + FJ * 9;                       // [FPW*J*3]
-    float *sOff = sPos + FJ * 3;                       // [FPW*J*3]  (PFO)
-    float *sQo = sOff + (PFO ? FJ * 3 : 0);            // [FPW*J*4]  (QOUT)
-    float *sConst = sQo + (QOUT ? FJ * 4 : 0);         // [(J+1)*4]  per joint {parent (int bits), t0, t1, t2}
+    const int pad = PAD ? a.pad : 0;                   // floats between frames in the per-frame regions (see FkArgs::pad)
+    const float invJ = 1.0f / (float)J;
+    float *sRot = smem;                                // [FPW*(J*9+pad)]  FPW % 4 == 0 keeps every carve 16 B aligned
+    float *sPos = sRot + FJ * 9 + FPW * pad;           // [FPW*(J*3+pad)]
+    float *sOff = sPos + FJ * 3 + FPW * pad;           // [FPW*(J*3+pad)]  (PFO)
+    float *sQo = sOff + (PFO ? FJ * 3 + FPW * pad : 0);  // [FPW*J*4]  (QOUT; lane-per-record access only: linear)
+    float *sConst = sQo + (QOUT ? FJ * 4 : 0);         // [(J+4)*4]  per joint {parent (int bits), t0, t1, t2}
 
     // Every global load of the tile is issued up front, back to back, so the wave pays ONE memory
     // latency: root position (used first by phase B), skeleton constants, then the rotations.
@@ -272,7 +326,7 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int e = e0 + u * PM_WAVE + lane;
-                if (e < n) put_local<QUAD>(sRot, e, L[u]);
+                if (e < n) put_local<QUAD>(sRot + image_slot<PAD>(e, J, invJ, 9, pad), L[u]);
             }
         };
         // two batches (8 x 16 B per lane = 8 KiB per wave) in flight before the first use, then
@@ -334,7 +388,7 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
             for (int u = 0; u < 2; ++u) {
                 const int e = e0 + u * PM_WAVE + lane;
                 if (e < n) {
-                    put_local<QUAD>(sRot, e, L[u]);
+                    put_local<QUAD>(sRot + image_slot<PAD>(e, J, invJ, 9, pad), L[u]);
                     if (QOUT) lds_put<4>(sQo, e, Q[u]);
                 }
             }
@@ -352,25 +406,25 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
             load_batch(e0 + 3 * B, xb);
         }
     }
-    if (PFO) tile_load<VEC>(a.offsets + f0 * J * 3, sOff, n * 3, lane);
+    if (PFO) image_load<VEC>(a.offsets + f0 * J * 3, sOff, nf, J * 3, pad, lane);
 
     // ---- phase B -------------------------------------------------------------------------------------
     wave_sync();
 
     if constexpr (QUAD) {
         const float seed = (c == 3) ? gp : ((c == r) ? 1.0f : 0.0f);
-        if (!(a.ablate & 2)) tree_walk_quad<PFO>(sRot, sPos, sOff, sConst, J, f, r, c, seed, lane);
+        if (!(a.ablate & 2)) tree_walk_quad<PFO>(sRot, sPos, sOff, sConst, J, pad, f, r, c, seed, lane);
     } else {
-        tree_walk<PFO>(sRot, sPos, sOff, sConst, J, f, r, gp, (a.ablate & 2) != 0);
+        tree_walk<PFO>(sRot, sPos, sOff, sConst, J, pad, f, r, gp, (a.ablate & 2) != 0);
     }
     wave_sync();
-    tile_store<VEC>(a.rotmats + f0 * J * 9, sRot, n * 9, lane);
-    tile_store<VEC>(a.pos + f0 * J * 3, sPos, n * 3, lane);
+    image_store<VEC>(a.rotmats + f0 * J * 9, sRot, nf, J * 9, pad, lane);
+    image_store<VEC>(a.pos + f0 * J * 3, sPos, nf, J * 3, pad, lane);
     if (QOUT) tile_store<VEC>(a.quat_out + f0 * J * 4, sQo, n * 4, lane);
 }
 
 // One tile (FPW frames) per single-wave workgroup; XCD-aware tile order (common.hpp).
-template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT>
+template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT, bool PAD>
 __global__ __launch_bounds__(PM_WAVE) void fk_kernel(const FkArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
@@ -378,7 +432,7 @@ __global__ __launch_bounds__(PM_WAVE) void fk_kernel(const FkArgs a) {
     if (tile < 0) return;
     const int64_t f0 = tile * FPW;
     const int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
-    fk_tile<FPW, VEC, PFO, SRC, QOUT>(a, smem, f0, nf, threadIdx.x);
+    fk_tile<FPW, VEC, PFO, SRC, QOUT, PAD>(a, smem, f0, nf, threadIdx.x);
 }
 
 // ---- pipelined form for mid-size skeletons (tree_walk_quad shape: FPW = 4, J <= 64, shared offsets) ---
@@ -391,7 +445,7 @@ __global__ __launch_bounds__(PM_WAVE) void fk_kernel(const FkArgs a) {
 // so loads overlap the walk and the stores overlap the next tile's math and walk.  The vmcnt wait in
 // front of math(i+1) only ever covers loads that are a whole walk old (the stores of tile i are issued
 // after it).  The skeleton table is staged once per workgroup.
-template <int FPW, int EPL, bool VEC, int SRC, bool QOUT>
+template <int FPW, int EPL, bool VEC, int SRC, bool QOUT, bool PAD>
 __global__ __launch_bounds__(PM_WAVE) void fk_pipe_kernel(const FkArgs a, const int nt) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool QUAD = FPW <= 5;  // records per lane: FPW * J <= 64 * EPL
@@ -404,9 +458,11 @@ __global__ __launch_bounds__(PM_WAVE) void fk_pipe_kernel(const FkArgs a, const 
     const int64_t t0 = group * nt;
     const int cnt = (int)((ntiles - t0) < nt ? (ntiles - t0) : nt);
 
-    float *sRot = smem;                          // [FJ*9]
-    float *sPos = sRot + FJ * 9;                 // [FJ*3]
-    float *sQo = sPos + FJ * 3;                  // [FJ*4]  (QOUT)
+    const int pad = PAD ? a.pad : 0;             // see FkArgs::pad
+    const float invJ = 1.0f / (float)J;
+    float *sRot = smem;                          // [FPW*(J*9+pad)]
+    float *sPos = sRot + FJ * 9 + FPW * pad;     // [FPW*(J*3+pad)]
+    float *sQo = sPos + FJ * 3 + FPW * pad;      // [FJ*4]  (QOUT)
     float *sConst = sQo + (QOUT ? FJ * 4 : 0);   // [(J+4)*4]
     for (int j = lane; j <= J; j += PM_WAVE) reinterpret_cast<v4f *>(sConst)[j] = load_joint_const<false>(a.parents, a.offsets, J, j);
 
@@ -448,14 +504,14 @@ __global__ __launch_bounds__(PM_WAVE) void fk_pipe_kernel(const FkArgs a, const 
             }
         }
     };
-    auto copy_out = [&](const int64_t f0, const int n) {
-        tile_store<VEC>(a.rotmats + f0 * J * 9, sRot, n * 9, lane);
-        tile_store<VEC>(a.pos + f0 * J * 3, sPos, n * 3, lane);
-        if (QOUT) tile_store<VEC>(a.quat_out + f0 * J * 4, sQo, n * 4, lane);
+    auto copy_out = [&](const int64_t f0, const int nfr) {
+        image_store<VEC>(a.rotmats + f0 * J * 9, sRot, nfr, J * 9, pad, lane);
+        image_store<VEC>(a.pos + f0 * J * 3, sPos, nfr, J * 3, pad, lane);
+        if (QOUT) tile_store<VEC>(a.quat_out + f0 * J * 4, sQo, nfr * J * 4, lane);
     };
 
     int64_t f0 = t0 * FPW, f0_prev = 0;
-    int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW), n_prev = 0;
+    int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW), nf_prev = 0;
     issue(f0, nf);
     for (int i = 0; i < cnt; ++i) {
         const int n = nf * J;
@@ -479,16 +535,16 @@ __global__ __launch_bounds__(PM_WAVE) void fk_pipe_kernel(const FkArgs a, const 
             }
         }
         const float gp_i = gp;
-        if (i > 0) copy_out(f0_prev, n_prev);  // the image of tile i-1 leaves ...
+        if (i > 0) copy_out(f0_prev, nf_prev);  // the image of tile i-1 leaves ...
 #pragma unroll
         for (int u = 0; u < EPL; ++u) {        // ... and tile i's local rotations take its place (in-order DS)
             const int e = u * PM_WAVE + lane;
             if (e < n) {
-                put_local<QUAD>(sRot, e, L[u]);
+                put_local<QUAD>(sRot + image_slot<PAD>(e, J, invJ, 9, pad), L[u]);
                 if (QOUT) lds_put<4>(sQo, e, Q[u]);
             }
         }
-        f0_prev = f0; n_prev = n;
+        f0_prev = f0; nf_prev = nf;
         if (i + 1 < cnt) {
             f0 += FPW;
             nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
@@ -497,20 +553,20 @@ __global__ __launch_bounds__(PM_WAVE) void fk_pipe_kernel(const FkArgs a, const 
         wave_sync();
         if constexpr (QUAD) {
             const float seed = (c == 3) ? gp_i : ((c == r) ? 1.0f : 0.0f);
-            if (!(a.ablate & 2)) tree_walk_quad<false>(sRot, sPos, nullptr, sConst, J, f, r, c, seed, lane);
+            if (!(a.ablate & 2)) tree_walk_quad<false>(sRot, sPos, nullptr, sConst, J, pad, f, r, c, seed, lane);
         } else {
-            tree_walk<false>(sRot, sPos, nullptr, sConst, J, f, r, gp_i, (a.ablate & 2) != 0);
+            tree_walk<false>(sRot, sPos, nullptr, sConst, J, pad, f, r, gp_i, (a.ablate & 2) != 0);
         }
         wave_sync();
     }
-    copy_out(f0_prev, n_prev);
+    copy_out(f0_prev, nf_prev);
 }
 
 
-template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT>
-static int launch_fk(const FkArgs &a, hipStream_t s) {
-    const size_t lds = ((size_t)FPW * a.J * fk_lds_floats<SRC, PFO, QOUT>() + 4 * (a.J + 4)) * sizeof(float);
-    auto k = fk_kernel<FPW, VEC, PFO, SRC, QOUT>;
+template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT, bool PAD>
+static int launch_fk_p(const FkArgs &a, hipStream_t s) {
+    const size_t lds = ((size_t)FPW * (a.J * fk_lds_floats<SRC, PFO, QOUT>() + a.pad * (PFO ? 3 : 2)) + 4 * (a.J + 4)) * sizeof(float);
+    auto k = fk_kernel<FPW, VEC, PFO, SRC, QOUT, PAD>;
     if (int e = allow_lds(k, lds)) return e;
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
     const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
@@ -522,16 +578,21 @@ static int launch_fk(const FkArgs &a, hipStream_t s) {
     return check_hip(hipGetLastError(), "fk launch");
 }
 
-template <int FPW, int EPL, bool VEC, int SRC, bool QOUT>
-static int launch_fk_pipe(const FkArgs &a, const int nt, hipStream_t s) {
-    const size_t lds = ((size_t)FPW * a.J * (12 + (QOUT ? 4 : 0)) + 4 * (a.J + 4)) * sizeof(float);
-    auto k = fk_pipe_kernel<FPW, EPL, VEC, SRC, QOUT>;
+template <int FPW, int EPL, bool VEC, int SRC, bool QOUT, bool PAD>
+static int launch_fk_pipe_p(const FkArgs &a, const int nt, hipStream_t s) {
+    const size_t lds = ((size_t)FPW * (a.J * (12 + (QOUT ? 4 : 0)) + 2 * a.pad) + 4 * (a.J + 4)) * sizeof(float);
+    auto k = fk_pipe_kernel<FPW, EPL, VEC, SRC, QOUT, PAD>;
     if (int e = allow_lds(k, lds)) return e;
     const int64_t ntiles = (a.F + FPW - 1) / FPW, ngroups = (ntiles + nt - 1) / nt;
     const int64_t grid = ((ngroups + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
     if (grid > 0x7fffffffLL) { set_error("fk: grid too large"); return PM_EUNSUPPORTED; }
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a, nt);
     return check_hip(hipGetLastError(), "fk launch");
+}
+
+template <int FPW, int EPL, bool VEC, int SRC, bool QOUT>
+static int launch_fk_pipe(const FkArgs &a, const int nt, hipStream_t s) {
+    return a.pad ? launch_fk_pipe_p<FPW, EPL, VEC, SRC, QOUT, true>(a, nt, s) : launch_fk_pipe_p<FPW, EPL, VEC, SRC, QOUT, false>(a, nt, s);
 }
 
 template <int FPW, int EPL, int SRC>
@@ -541,6 +602,11 @@ static int dispatch_fk_pipe(const FkArgs &a, bool vec, const int nt, hipStream_t
         if (qout) return vec ? launch_fk_pipe<FPW, EPL, true, SRC, true>(a, nt, s) : launch_fk_pipe<FPW, EPL, false, SRC, true>(a, nt, s);
     }
     return vec ? launch_fk_pipe<FPW, EPL, true, SRC, false>(a, nt, s) : launch_fk_pipe<FPW, EPL, false, SRC, false>(a, nt, s);
+}
+
+template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT>
+static int launch_fk(const FkArgs &a, hipStream_t s) {
+    return a.pad ? launch_fk_p<FPW, VEC, PFO, SRC, QOUT, true>(a, s) : launch_fk_p<FPW, VEC, PFO, SRC, QOUT, false>(a, s);
 }
 
 template <int FPW, int SRC>
@@ -564,19 +630,28 @@ static int dispatch_fk2(const FkArgs &a, bool vec, bool pfo, hipStream_t s) {
 }
 
 // Frames per wave (FPW, a multiple of 4 so that every tile base stays 16-byte aligned for any J).
-// The LDS image (48 J B per frame) bounds residency, and with fewer than ~7 waves per CU nothing hides
-// the walk's latency.  Two shapes cover the range (measured, 2^18 frames x 52 joints: FPW 20/16/12/8 with
-// three lanes per frame 376/311/307/253 us, FPW 4 with twelve lanes per frame 178 us; FPW 2 / 5: 227 / 176 us):
-//   FPW 20, 3 lanes per frame  while 7 tiles fit a CU's LDS (J <= 23 without extras),
+// The LDS image (48 J B per frame) bounds residency, and with too few waves per CU nothing hides the walk's
+// latency.  Two shapes cover the range (measured, 2^18 frames x 52 joints: FPW 20/16/12/8 with three lanes per
+// frame 376/311/307/253 us, FPW 4 with twelve lanes per frame 178 us; FPW 2 / 5: 227 / 176 us):
+//   FPW 20, 3 lanes per frame  while 6 tiles fit a CU's LDS (J <= 27 without extras; measured at 2^19 frames,
+//           J = 24..28: three lanes 166/161/175/179/209 us, twelve lanes 183/190/184/195/195 us),
 //   FPW 4, 12 lanes per frame (tree_walk_quad) beyond that.
+// Frame padding against LDS bank aliasing (FkArgs::pad) depends on the shape: the 20 frames of the three-lane walk
+// alias when 9 J is a multiple of 8 floats (J % 8 == 0), the 4 frames of the quad walk sit 8 banks apart then and only
+// alias when it is a multiple of 16 (J % 16 == 0; J = 40: 261 us without, 272 us with the padding).
 template <int SRC>
-static int dispatch_fk(const FkArgs &a, bool vec, bool pfo, hipStream_t s) {
-    const size_t per_frame = (size_t)a.J * (12 + (pfo ? 3 : 0) + (a.quat_out ? 4 : 0)) * sizeof(float);
+static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
+    FkArgs a = a_in;
+    const int extras = (pfo ? 3 : 0) + (a.quat_out ? 4 : 0), nreg = pfo ? 3 : 2;
+    auto frame_bytes = [&](const int pad) { return ((size_t)a.J * (12 + extras) + (size_t)pad * nreg) * sizeof(float); };
     const size_t fixed = 4 * ((size_t)a.J + 4) * sizeof(float) + 256;
-    int pick = (7 * (20 * per_frame + fixed) <= kMaxLds) ? 20 : 4;
+    const int pad3 = (a.J % 8 == 0) ? 4 : 0, pad12 = (a.J % 16 == 0) ? 4 : 0;
+    int pick = (6 * (20 * frame_bytes(pad3) + fixed) <= kMaxLds) ? 20 : 4;
     const char *ov = getenv("PM_FK_FPW");  // tuning aid: 20, 8 or 4
     if (ov && atoi(ov) > 0) pick = atoi(ov);
-    if ((size_t)pick * per_frame + fixed > kMaxLds) pick = 4;
+    if ((size_t)pick * frame_bytes(pad3) + fixed > kMaxLds) pick = 4;
+    a.pad = (pick == 4) ? pad12 : pad3;
+    const size_t per_frame = frame_bytes(a.pad);
     if (pick == 4 && !pfo && a.J <= 64) {
         // mid-size skeletons: registers-first phase A and tiles pipelined inside a workgroup (fk_pipe_kernel).
         // Measured at 2^18 x 52: fused ortho6d 224 us (fk_kernel) -> 188 / 183 / 187 / 198 us with 1 / 2 / 4 / 8
@@ -603,7 +678,7 @@ static int fk_common(int src_kind, const float *src, const float *root_pos, cons
     PM_CHECK_ARGS(src && root_pos && offsets && parents && pos && rotmats, "fk: null pointer");
     FkArgs a;
     a.src = src; a.root_pos = root_pos; a.offsets = offsets; a.pos = pos; a.rotmats = rotmats;
-    a.quat_out = quat_out; a.F = F; a.J = J; a.eps = eps;
+    a.quat_out = quat_out; a.F = F; a.J = J; a.eps = eps; a.pad = 0;  // set by dispatch_fk, per walk shape
     {
         const char *ab = getenv("PM_FK_ABLATE");
         a.ablate = ab ? atoi(ab) : 0;

@@ -43,7 +43,7 @@ struct IkArgs {
 // rot_j = conj(G_parent) (x) G_j (the from_global_rotations gather; equal to the reference's value up to the
 // ~1e-7 by which from_to's output misses unit length) and stores it straight from registers, coalesced.
 // Joints without children keep the exact identity (:126-130).
-__host__ __device__ constexpr int ik_frame_stride(const int J) { return 4 * J + 4; }  // (stride / 4) odd for even J: conflict-free
+__host__ __device__ constexpr int ik_frame_stride(const int J) { return 4 * ((J + 1) | 1); }  // (stride / 4) odd: the lanes (= frames) of a ds_read_b128 spread over all banks
 
 template <int FPW, bool VEC>
 __global__ __launch_bounds__(PM_WAVE) void from_root_positions_kernel(const IkArgs a) {

@@ -341,7 +341,9 @@ def test_reference_style_dq_round_trip():
 
 
 @pytest.mark.parametrize("F,J", [(1, 1), (1, 22), (19, 22), (20, 22), (21, 22), (1000, 22), (100_003, 22), (777, 52),
-                                 (50, 3), (333, 128), (7, 300), (9, 512)])
+                                 (50, 3), (333, 128), (7, 300), (9, 512),
+                                 # joint counts that are multiples of 8 / 16: the fk image is padded per frame there
+                                 (77, 8), (130, 16), (61, 24), (2049, 24), (45, 32), (33, 48), (21, 64), (19, 80)])
 def test_fk_and_dq_vs_oracle_sizes(F, J):
     from pymotion_amd import synthetic as syn
 
