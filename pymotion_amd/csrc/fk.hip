@@ -652,14 +652,15 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
     if ((size_t)pick * frame_bytes(pad3) + fixed > kMaxLds) pick = 4;
     a.pad = (pick == 4) ? pad12 : pad3;
     const size_t per_frame = frame_bytes(a.pad);
-    if (pick == 4 && !pfo && a.J <= 64) {
-        // mid-size skeletons: registers-first phase A and tiles pipelined inside a workgroup (fk_pipe_kernel).
-        // Measured at 2^18 x 52: fused ortho6d 224 us (fk_kernel) -> 188 / 183 / 187 / 198 us with 1 / 2 / 4 / 8
-        // tiles per workgroup; the same structure on the 20-frame tile of J = 22 is slower (293 vs 270 us).
+    if (pick == 4 && !pfo && a.J <= 128) {
+        // mid-size skeletons: registers-first phase A and tiles pipelined inside a workgroup (fk_pipe_kernel; 4 records
+        // per lane up to 64 joints, 8 up to 128).  Measured at 2^18 x 52: fused ortho6d 224 us (fk_kernel) -> 188 / 183 /
+        // 187 / 198 us with 1 / 2 / 4 / 8 tiles per workgroup; the same structure on the 20-frame tile of J = 22 is
+        // slower (293 vs 270 us).
         int nt = ((a.F + 3) / 4 >= 16384) ? 2 : 1;
         const char *e = getenv("PM_FK_NT");  // tuning aid: tiles per workgroup, 0 = fk_kernel
         if (e) nt = atoi(e);
-        if (nt > 0) return dispatch_fk_pipe<4, 4, SRC>(a, vec, nt, s);
+        if (nt > 0) return a.J <= 64 ? dispatch_fk_pipe<4, 4, SRC>(a, vec, nt, s) : dispatch_fk_pipe<4, 8, SRC>(a, vec, nt, s);
     }
     switch (pick) {
         case 20: return dispatch_fk2<20, SRC>(a, vec, pfo, s);

@@ -376,9 +376,9 @@ def test_fk_and_dq_vs_oracle_sizes(F, J):
 
 
 @pytest.mark.parametrize("nt", ["0", "1", "2", "3", "7"])
-@pytest.mark.parametrize("F,J", [(4 * 7 + 1, 52), (4 * 6, 24), (3, 64), (4 * 13 + 2, 33)])
+@pytest.mark.parametrize("F,J", [(4 * 7 + 1, 52), (4 * 6, 28), (3, 64), (4 * 13 + 2, 33), (4 * 5 + 3, 65), (9, 128), (6, 96)])
 def test_fk_pipelined_tiles_ragged_groups(monkeypatch, nt, F, J):
-    """24 <= J <= 64 runs fk_pipe_kernel: `nt` tiles per workgroup (PM_FK_NT; 0 = the one-tile kernel).
+    """28 <= J <= 128 runs fk_pipe_kernel (4 records per lane up to 64 joints, 8 beyond): `nt` tiles per workgroup (PM_FK_NT; 0 = the one-tile kernel).
     Odd tile counts, a partial last tile and a partial last group must all come out identical."""
     from pymotion_amd import synthetic as syn
 

@@ -24,7 +24,23 @@ for J in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "8,1
     off = torch.randn((J, 3), device="cuda")
     pos = torch.empty((F, J, 3), device="cuda")
     rm = torch.empty((F, J, 3, 3), device="cuda")
-    ms, _ = pp.timeit(lambda: _lib.call("pm_fk_f32", P(rot), P(root), P(off), 0, par.ctypes.data_as(C.c_void_p), F, J, P(pos), P(rm), None))
+    pp_ = par.ctypes.data_as(C.c_void_p)
+    ms, _ = pp.timeit(lambda: _lib.call("pm_fk_f32", P(rot), P(root), P(off), 0, pp_, F, J, P(pos), P(rm), None))
     gb = F * (64 * J + 12) / ms / 1e6
-    print(f"FPW={os.environ.get('PM_FK_FPW', 'auto'):>4} J={J:3d}: {ms * 1e3:7.1f} us  {gb:6.0f} GB/s ({gb / 80:.1f}% of 8 TB/s)", flush=True)
+    line = f"FPW={os.environ.get('PM_FK_FPW', 'auto'):>4} J={J:3d}: fk {ms * 1e3:7.1f} us {gb / 80:5.1f}%"
+    if os.environ.get("PM_SWEEP_ALL"):
+        off[0] = 0
+        dq = torch.empty((F, J, 8), device="cuda")
+        tr = torch.empty((F, J, 3), device="cuda")
+        qo = torch.empty((F, J, 4), device="cuda")
+        for name, fn, nb in (
+            ("to_root", lambda: _lib.call("pm_to_root_dq_f32", P(rot), P(root), pp_, P(off), F, J, P(dq), None), 48 * J + 12),
+            ("from_root", lambda: _lib.call("pm_from_root_dq_f32", P(dq), pp_, F, J, P(tr), P(qo), None), 60 * J),
+            ("mirror", lambda: _lib.call("pm_mirror_rotations_f32", P(rot), pp_, None, 0, F, J, P(qo), None), 32 * J),
+            ("ik", lambda: _lib.call("pm_from_root_positions_f32", P(pos), pp_, P(off), F, J, P(qo), None), 28 * J),
+        ):
+            ms, _ = pp.timeit(fn)
+            line += f" | {name} {ms * 1e3:7.1f} us {F * nb / ms / 1e6 / 80:5.1f}%"
+        del dq, tr, qo
+    print(line, flush=True)
     del rot, pos, rm
