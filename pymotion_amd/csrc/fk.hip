@@ -335,6 +335,8 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
         float qa[4][4], qb[4][4];
         load_batch(0, qa);
         load_batch(B, qb);
+        // per-frame offsets: requested while the rotations are still in flight (one memory latency for both)
+        if (PFO) image_load<VEC>(a.offsets + f0 * J * 3, sOff, nf, J * 3, pad, lane);
         if (lane <= J) reinterpret_cast<v4f *>(sConst)[lane] = c_first;
         for (int j = lane + PM_WAVE; j <= J; j += PM_WAVE) reinterpret_cast<v4f *>(sConst)[j] = load_const(j);
         for (int e0 = 0; e0 < n; e0 += 2 * B) {
@@ -397,6 +399,7 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
         v2f xa[2][3], xb[2][3];
         load_batch(0, xa);
         load_batch(B, xb);
+        if (PFO) image_load<VEC>(a.offsets + f0 * J * 3, sOff, nf, J * 3, pad, lane);
         if (lane <= J) reinterpret_cast<v4f *>(sConst)[lane] = c_first;
         for (int j = lane + PM_WAVE; j <= J; j += PM_WAVE) reinterpret_cast<v4f *>(sConst)[j] = load_const(j);
         for (int e0 = 0; e0 < n; e0 += 2 * B) {
@@ -406,8 +409,6 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
             load_batch(e0 + 3 * B, xb);
         }
     }
-    if (PFO) image_load<VEC>(a.offsets + f0 * J * 3, sOff, nf, J * 3, pad, lane);
-
     // ---- phase B -------------------------------------------------------------------------------------
     wave_sync();
 
@@ -647,6 +648,9 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
     const size_t fixed = 4 * ((size_t)a.J + 4) * sizeof(float) + 256;
     const int pad3 = (a.J % 8 == 0) ? 4 : 0, pad12 = (a.J % 16 == 0) ? 4 : 0;
     int pick = (6 * (20 * frame_bytes(pad3) + fixed) <= kMaxLds) ? 20 : 4;
+    // The variants with a bigger image or a heavier phase A do better on the quad shape earlier (2^20 x 22: per-frame
+    // offsets 422 us three-lane vs 358 us quad; ortho6d source 371 vs 350 us, at J = 24 226 vs 181 us, at J = 16 130 vs 139 us).
+    if (pfo || (SRC == SRC_O6D && a.J >= 20)) pick = 4;
     const char *ov = getenv("PM_FK_FPW");  // tuning aid: 20, 8 or 4
     if (ov && atoi(ov) > 0) pick = atoi(ov);
     if ((size_t)pick * frame_bytes(pad3) + fixed > kMaxLds) pick = 4;
