@@ -446,7 +446,7 @@ __global__ __launch_bounds__(PM_WAVE) void fk_kernel(const FkArgs a) {
 // so loads overlap the walk and the stores overlap the next tile's math and walk.  The vmcnt wait in
 // front of math(i+1) only ever covers loads that are a whole walk old (the stores of tile i are issued
 // after it).  The skeleton table is staged once per workgroup.
-template <int FPW, int EPL, bool VEC, int SRC, bool QOUT, bool PAD>
+template <int FPW, int EPL, bool VEC, int SRC, bool QOUT, bool PAD, bool PFO>
 __global__ __launch_bounds__(PM_WAVE) void fk_pipe_kernel(const FkArgs a, const int nt) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool QUAD = FPW <= 5;  // records per lane: FPW * J <= 64 * EPL
@@ -463,9 +463,10 @@ __global__ __launch_bounds__(PM_WAVE) void fk_pipe_kernel(const FkArgs a, const 
     const float invJ = 1.0f / (float)J;
     float *sRot = smem;                          // [FPW*(J*9+pad)]
     float *sPos = sRot + FJ * 9 + FPW * pad;     // [FPW*(J*3+pad)]
-    float *sQo = sPos + FJ * 3 + FPW * pad;      // [FJ*4]  (QOUT)
+    float *sOff = sPos + FJ * 3 + FPW * pad;     // [FPW*(J*3+pad)]  (PFO: per-frame offsets)
+    float *sQo = sOff + (PFO ? FJ * 3 + FPW * pad : 0);  // [FJ*4]  (QOUT)
     float *sConst = sQo + (QOUT ? FJ * 4 : 0);   // [(J+4)*4]
-    for (int j = lane; j <= J; j += PM_WAVE) reinterpret_cast<v4f *>(sConst)[j] = load_joint_const<false>(a.parents, a.offsets, J, j);
+    for (int j = lane; j <= J; j += PM_WAVE) reinterpret_cast<v4f *>(sConst)[j] = load_joint_const<PFO>(a.parents, a.offsets, J, j);
 
     const int wl = lane % ((QUAD ? 12 : 3) * FPW);
     const int f = QUAD ? wl / 12 : wl / 3;
@@ -474,6 +475,7 @@ __global__ __launch_bounds__(PM_WAVE) void fk_pipe_kernel(const FkArgs a, const 
 
     v4f in4[EPL];       // SRC_QUAT: one quaternion per record
     v2f in2[EPL][3];    // SRC_O6D: 24-byte records as three dwordx2 (see fk_tile)
+    v3f_a4 inO[EPL];    // PFO: the record's offset (12-byte records, consecutive lanes on consecutive records)
     float gp = 0.0f;
     auto issue = [&](const int64_t f0, const int nf) {
         const int n = nf * J;
@@ -481,6 +483,10 @@ __global__ __launch_bounds__(PM_WAVE) void fk_pipe_kernel(const FkArgs a, const 
 #pragma unroll
         for (int u = 0; u < EPL; ++u) {
             const int e = u * PM_WAVE + lane;
+            if constexpr (PFO) {
+                inO[u] = v3f_a4{0.0f, 0.0f, 0.0f};
+                if (e < n) inO[u] = __builtin_nontemporal_load(reinterpret_cast<const v3f_a4 *>(a.offsets + (f0 * J + e) * 3));
+            }
             if constexpr (SRC == SRC_QUAT) {
                 const float *g = a.src + f0 * J * 4;
                 in4[u] = v4f{1.0f, 0.0f, 0.0f, 0.0f};
@@ -543,6 +549,10 @@ __global__ __launch_bounds__(PM_WAVE) void fk_pipe_kernel(const FkArgs a, const 
             if (e < n) {
                 put_local<QUAD>(sRot + image_slot<PAD>(e, J, invJ, 9, pad), L[u]);
                 if (QOUT) lds_put<4>(sQo, e, Q[u]);
+                if constexpr (PFO) {
+                    float *o = sOff + image_slot<PAD>(e, J, invJ, 3, pad);
+                    o[0] = inO[u].x; o[1] = inO[u].y; o[2] = inO[u].z;
+                }
             }
         }
         f0_prev = f0; nf_prev = nf;
@@ -554,9 +564,9 @@ __global__ __launch_bounds__(PM_WAVE) void fk_pipe_kernel(const FkArgs a, const 
         wave_sync();
         if constexpr (QUAD) {
             const float seed = (c == 3) ? gp_i : ((c == r) ? 1.0f : 0.0f);
-            if (!(a.ablate & 2)) tree_walk_quad<false>(sRot, sPos, nullptr, sConst, J, pad, f, r, c, seed, lane);
+            if (!(a.ablate & 2)) tree_walk_quad<PFO>(sRot, sPos, sOff, sConst, J, pad, f, r, c, seed, lane);
         } else {
-            tree_walk<false>(sRot, sPos, nullptr, sConst, J, pad, f, r, gp_i, (a.ablate & 2) != 0);
+            tree_walk<PFO>(sRot, sPos, sOff, sConst, J, pad, f, r, gp_i, (a.ablate & 2) != 0);
         }
         wave_sync();
     }
@@ -579,10 +589,10 @@ static int launch_fk_p(const FkArgs &a, hipStream_t s) {
     return check_hip(hipGetLastError(), "fk launch");
 }
 
-template <int FPW, int EPL, bool VEC, int SRC, bool QOUT, bool PAD>
+template <int FPW, int EPL, bool VEC, int SRC, bool QOUT, bool PAD, bool PFO>
 static int launch_fk_pipe_p(const FkArgs &a, const int nt, hipStream_t s) {
-    const size_t lds = ((size_t)FPW * (a.J * (12 + (QOUT ? 4 : 0)) + 2 * a.pad) + 4 * (a.J + 4)) * sizeof(float);
-    auto k = fk_pipe_kernel<FPW, EPL, VEC, SRC, QOUT, PAD>;
+    const size_t lds = ((size_t)FPW * (a.J * (12 + (PFO ? 3 : 0) + (QOUT ? 4 : 0)) + (PFO ? 3 : 2) * a.pad) + 4 * (a.J + 4)) * sizeof(float);
+    auto k = fk_pipe_kernel<FPW, EPL, VEC, SRC, QOUT, PAD, PFO>;
     if (int e = allow_lds(k, lds)) return e;
     const int64_t ntiles = (a.F + FPW - 1) / FPW, ngroups = (ntiles + nt - 1) / nt;
     const int64_t grid = ((ngroups + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
@@ -592,17 +602,18 @@ static int launch_fk_pipe_p(const FkArgs &a, const int nt, hipStream_t s) {
 }
 
 template <int FPW, int EPL, bool VEC, int SRC, bool QOUT>
-static int launch_fk_pipe(const FkArgs &a, const int nt, hipStream_t s) {
-    return a.pad ? launch_fk_pipe_p<FPW, EPL, VEC, SRC, QOUT, true>(a, nt, s) : launch_fk_pipe_p<FPW, EPL, VEC, SRC, QOUT, false>(a, nt, s);
+static int launch_fk_pipe(const FkArgs &a, const bool pfo, const int nt, hipStream_t s) {
+    if (pfo) return a.pad ? launch_fk_pipe_p<FPW, EPL, VEC, SRC, QOUT, true, true>(a, nt, s) : launch_fk_pipe_p<FPW, EPL, VEC, SRC, QOUT, false, true>(a, nt, s);
+    return a.pad ? launch_fk_pipe_p<FPW, EPL, VEC, SRC, QOUT, true, false>(a, nt, s) : launch_fk_pipe_p<FPW, EPL, VEC, SRC, QOUT, false, false>(a, nt, s);
 }
 
 template <int FPW, int EPL, int SRC>
-static int dispatch_fk_pipe(const FkArgs &a, bool vec, const int nt, hipStream_t s) {
+static int dispatch_fk_pipe(const FkArgs &a, bool vec, bool pfo, const int nt, hipStream_t s) {
     const bool qout = a.quat_out != nullptr;
     if constexpr (SRC == SRC_O6D) {
-        if (qout) return vec ? launch_fk_pipe<FPW, EPL, true, SRC, true>(a, nt, s) : launch_fk_pipe<FPW, EPL, false, SRC, true>(a, nt, s);
+        if (qout) return vec ? launch_fk_pipe<FPW, EPL, true, SRC, true>(a, pfo, nt, s) : launch_fk_pipe<FPW, EPL, false, SRC, true>(a, pfo, nt, s);
     }
-    return vec ? launch_fk_pipe<FPW, EPL, true, SRC, false>(a, nt, s) : launch_fk_pipe<FPW, EPL, false, SRC, false>(a, nt, s);
+    return vec ? launch_fk_pipe<FPW, EPL, true, SRC, false>(a, pfo, nt, s) : launch_fk_pipe<FPW, EPL, false, SRC, false>(a, pfo, nt, s);
 }
 
 template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT>
@@ -656,7 +667,7 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
     if ((size_t)pick * frame_bytes(pad3) + fixed > kMaxLds) pick = 4;
     a.pad = (pick == 4) ? pad12 : pad3;
     const size_t per_frame = frame_bytes(a.pad);
-    if (pick == 4 && !pfo && a.J <= 128) {
+    if (pick == 4 && a.J <= 128) {
         // mid-size skeletons: registers-first phase A and tiles pipelined inside a workgroup (fk_pipe_kernel; 4 records
         // per lane up to 64 joints, 8 up to 128).  Measured at 2^18 x 52: fused ortho6d 224 us (fk_kernel) -> 188 / 183 /
         // 187 / 198 us with 1 / 2 / 4 / 8 tiles per workgroup; the same structure on the 20-frame tile of J = 22 is
@@ -664,7 +675,7 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
         int nt = ((a.F + 3) / 4 >= 16384) ? 2 : 1;
         const char *e = getenv("PM_FK_NT");  // tuning aid: tiles per workgroup, 0 = fk_kernel
         if (e) nt = atoi(e);
-        if (nt > 0) return a.J <= 64 ? dispatch_fk_pipe<4, 4, SRC>(a, vec, nt, s) : dispatch_fk_pipe<4, 8, SRC>(a, vec, nt, s);
+        if (nt > 0) return a.J <= 64 ? dispatch_fk_pipe<4, 4, SRC>(a, vec, pfo, nt, s) : dispatch_fk_pipe<4, 8, SRC>(a, vec, pfo, nt, s);
     }
     switch (pick) {
         case 20: return dispatch_fk2<20, SRC>(a, vec, pfo, s);

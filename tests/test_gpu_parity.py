@@ -402,6 +402,16 @@ def test_fk_pipelined_tiles_ragged_groups(monkeypatch, nt, F, J):
         assert_close(out[1], r_o, 2e-5, "fused rotmats")
         if want_q:
             assert_close(out[2], q_o, ATOL, "fused quats")
+    # per-frame offsets ride in the same pipelined kernel (their records are prefetched like the rotations)
+    offf = rng.uniform(-0.2, 0.2, (F, J, 3)).astype(np.float32)
+    pos, rm = sk.fk(rot, gpos, offf, parents)
+    p_o, r_o = co.fk(f64(rot), f64(gpos), f64(offf), parents)
+    assert_close(pos, p_o, ATOL, "fk pos, per-frame offsets")
+    assert_close(rm, r_o, ATOL, "fk rotmats, per-frame offsets")
+    out = sk.fk_from_ortho6d(x, gpos, offf, parents, return_quat=True)
+    p_o, r_o = co.fk(q_o, f64(gpos), f64(offf), parents)
+    assert_close(out[0], p_o, 2e-5, "fused pos, per-frame offsets")
+    assert_close(out[1], r_o, 2e-5, "fused rotmats, per-frame offsets")
 
 
 def test_fk_per_frame_offsets_and_unaligned_views():
