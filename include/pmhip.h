@@ -179,9 +179,9 @@ int pm_quat_unroll_f32(const float *q, int64_t T, int32_t S, float *out, void *w
 int pm_dq_unroll_f32(const float *dq, int64_t T, int32_t S, float *out, void *workspace, pm_stream_t stream);
 
 /* rotations/dual_quat.py:86-136  normalize / is_unit.  The reference picks ONE branch for the whole batch
- * from global `.all()` reductions; the kernels add violation counts to three DEVICE ints that the caller
- * zeroes first (pm_memset) and reads back:  flags[0] += #(|qr|^2 !~ 0), flags[1] += #(|qr|^2 !~ 1),
- * flags[2] += #(qr.qd !~ 0 within atol)  (np.isclose rules, NaN never close).
+ * from global `.all()` reductions; the kernels raise three DEVICE ints that the caller zeroes first (pm_memset)
+ * and reads back:  flags[0] != 0 iff some |qr|^2 !~ 0, flags[1] != 0 iff some |qr|^2 !~ 1, flags[2] != 0 iff some
+ * qr.qd !~ 0 within atol  (np.isclose rules, NaN never close; the values are lower bounds of the violation counts).
  * pm_dq_normalize_f32: orthogonalize == 0 -> out = dq / |qr| and flags describe THAT result (:102-106);
  *                      orthogonalize != 0 -> the branch of :107-113 (flags may be NULL).
  * pm_dq_unit_flags_f32: flags of the input itself (is_unit, :118-136). */

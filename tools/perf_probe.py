@@ -164,6 +164,23 @@ def main():
             ms, mn = timeit(lambda: _lib.call("pm_quat_slerp_f32", p(q), p(q2), p(tt), N, 1, p(qo), None))
             report("quat.slerp", ms, mn, N * 52)
             del eul, eo, tt
+            v3 = torch.randn((N, 3), device=dev)
+            v3b = torch.randn((N, 3), device=dev)
+            d8 = torch.randn((N, 8), device=dev)
+            d8o = torch.empty((N, 8), device=dev)
+            x6 = torch.randn((N, 6), device=dev)
+            flags = torch.zeros(3, dtype=torch.int32, device=dev)
+            for name, fn, nb in (
+                ("quat.mul_vec", lambda: _lib.call("pm_quat_mul_vec_f32", p(q), p(v3), N, p(v3b), None), 40),
+                ("quat.from_to", lambda: _lib.call("pm_quat_from_to_f32", p(v3), p(v3b), N, 1, p(qo), None), 40),
+                ("dq.from_rotation_translation", lambda: _lib.call("pm_dq_from_rt_f32", p(q), p(v3), N, p(d8o), None), 60),
+                ("dq.normalize", lambda: _lib.call("pm_dq_normalize_f32", p(d8), N, 0, C.c_float(1e-3), p(d8o), p(flags), None), 64),
+                ("dq.is_unit (flags)", lambda: _lib.call("pm_dq_unit_flags_f32", p(d8), N, C.c_float(1e-3), p(flags), None), 32),
+                ("ortho6d.to_matrix", lambda: _lib.call("pm_o6d_to_matrix_f32", p(x6), N, C.c_float(0.0), p(m), None), 60),
+            ):
+                ms, mn = timeit(fn)
+                report(name, ms, mn, N * nb)
+            del v3, v3b, d8, d8o, x6
             qo2 = qo.view(N, 4)
             ms, mn = timeit(lambda: qo2.copy_(q))
             report("torch copy_ (16 B/elem r+w)", ms, mn, N * 32)
