@@ -170,6 +170,7 @@ def main():
             d8o = torch.empty((N, 8), device=dev)
             x6 = torch.randn((N, 6), device=dev)
             flags = torch.zeros(3, dtype=torch.int32, device=dev)
+            ws = torch.empty(int(_lib.lib().pm_quat_unroll_workspace_bytes(Fj, J)), dtype=torch.uint8, device=dev)
             for name, fn, nb in (
                 ("quat.mul_vec", lambda: _lib.call("pm_quat_mul_vec_f32", p(q), p(v3), N, p(v3b), None), 40),
                 ("quat.from_to", lambda: _lib.call("pm_quat_from_to_f32", p(v3), p(v3b), N, 1, p(qo), None), 40),
@@ -177,6 +178,20 @@ def main():
                 ("dq.normalize", lambda: _lib.call("pm_dq_normalize_f32", p(d8), N, 0, C.c_float(1e-3), p(d8o), p(flags), None), 64),
                 ("dq.is_unit (flags)", lambda: _lib.call("pm_dq_unit_flags_f32", p(d8), N, C.c_float(1e-3), p(flags), None), 32),
                 ("ortho6d.to_matrix", lambda: _lib.call("pm_o6d_to_matrix_f32", p(x6), N, C.c_float(0.0), p(m), None), 60),
+                ("ortho6d.to_quat", lambda: _lib.call("pm_o6d_to_quat_f32", p(x6), N, C.c_float(0.0), p(qo), None), 40),
+                ("ortho6d.from_quat", lambda: _lib.call("pm_o6d_from_quat_f32", p(q), N, p(x6), None), 40),
+                ("ortho6d.from_matrix", lambda: _lib.call("pm_o6d_from_matrix_f32", p(m), N, p(x6), None), 60),
+                ("quat.conjugate", lambda: _lib.call("pm_quat_conjugate_f32", p(q), N, p(qo), None), 32),
+                ("quat.length", lambda: _lib.call("pm_quat_length_f32", p(q), N, p(v3), None), 20),
+                ("dq.to_rotation_translation", lambda: _lib.call("pm_dq_to_rt_f32", p(d8), N, p(qo), p(v3b), None), 60),
+                ("dq.from_translation", lambda: _lib.call("pm_dq_from_t_f32", p(v3), N, p(d8o), None), 44),
+                ("quat.from_angle_axis", lambda: _lib.call("pm_quat_from_angle_axis_f32", p(x6), p(v3), N, p(qo), None), 32),
+                ("quat.from_scaled_angle_axis", lambda: _lib.call("pm_quat_from_scaled_angle_axis_f32", p(v3), N, p(qo), None), 28),
+                ("quat.to_angle_axis", lambda: _lib.call("pm_quat_to_angle_axis_f32", p(q), N, p(x6), p(v3b), None), 32),
+                ("quat.to_scaled_angle_axis", lambda: _lib.call("pm_quat_to_scaled_angle_axis_f32", p(q), N, p(v3b), None), 28),
+                ("quat.from_to_axis", lambda: _lib.call("pm_quat_from_to_axis_f32", p(v3), p(v3b), p(v3), N, 1, p(qo), None), 52),
+                ("from_global_rotations", lambda: _lib.call("pm_from_global_rotations_f32", p(q), pp, Fj, J, p(qo), None), 32),
+                ("dq.unroll axis=0", lambda: _lib.call("pm_dq_unroll_f32", p(d8), Fj, J, p(d8o), p(ws), None), 96),
             ):
                 ms, mn = timeit(fn)
                 report(name, ms, mn, N * nb)
