@@ -8,6 +8,9 @@ parsed on the host by a small tokenizer; the numeric work of ``get_data`` -- Eul
 GPU kernels instead of ``np.apply_along_axis`` over strings and a Python loop over frames.
 Writing files (``save``), joint removal / reordering and scaling stay with the reference.
 """
+import re
+import warnings
+
 import numpy as np
 
 from ..rotations import quat
@@ -83,13 +86,21 @@ class BVH:
             else:
                 i += 1  # HIERARCHY and anything unknown
 
-        mt = motion.split()
-        n_frames = int(mt[mt.index("Frames:") + 1])
-        k = mt.index("Time:")
-        frame_time = float(mt[k + 1])
+        # "Frames: N" / "Frame Time: dt" (io/bvh.py:133-147 of the reference), then N rows of numbers.  The header is
+        # tokenised in Python; the numbers -- almost all of the file -- go through NumPy's C text parser.
+        m = re.search(r"Frames:\s*(\d+)\s+Frame\s+Time:\s*(\S+)", motion)
+        if m is None:
+            raise ValueError(f"{filename}: malformed MOTION header")
+        n_frames = int(m.group(1))
+        frame_time = float(m.group(2))
         J = len(names)
         width = sum(nchan)
-        vals = np.array(mt[k + 2:k + 2 + n_frames * width], dtype=np.float64).reshape(n_frames, width)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", DeprecationWarning)  # text-mode fromstring: not deprecated, but some NumPy builds warn
+            flat = np.fromstring(motion[m.end():], dtype=np.float64, sep=" ")
+        if flat.size < n_frames * width:
+            raise ValueError(f"{filename}: {flat.size} motion values, expected {n_frames} x {width}")
+        vals = flat[:n_frames * width].reshape(n_frames, width)
 
         offsets = np.array(offsets, dtype=np.float64)
         positions = np.tile(offsets, (n_frames, 1)).reshape(n_frames, J, 3)
