@@ -30,7 +30,9 @@ struct UnrollArgs {
     int64_t T;
     int32_t S;
     int32_t nchunks;
-    int32_t sbsize;   // series per block (<= UR_SB_MAX, balanced over the blocks)
+    int32_t sbsize;   // series per block of the apply pass (<= UR_SB_MAX, balanced over the blocks)
+    int32_t sblocks;  // number of such blocks; the grid is 1-D: block = chunk * sblocks + series block
+    int32_t p1_sb, p1_blocks;  // the same for the parity pass (series per block chosen so that the grid fills the chip)
 };
 
 // W = 4: quaternions; W = 8: dual quaternions (sign decided by the real part, applied to all 8 floats,
@@ -40,8 +42,8 @@ __global__ __launch_bounds__(PM_WAVE) void unroll_apply_kernel(const UnrollArgs 
     constexpr int V = W / 4;  // dwordx4 per record
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
-    const int chunk = blockIdx.x;
-    const int s0 = blockIdx.y * a.sbsize;
+    const int chunk = blockIdx.x / a.sblocks;
+    const int s0 = (blockIdx.x - chunk * a.sblocks) * a.sbsize;
     const int sb = (a.S - s0) < a.sbsize ? (a.S - s0) : a.sbsize;  // series in this block
     const int64_t t0 = (int64_t)chunk * UR_CHUNK;
     const int64_t t1 = (t0 + UR_CHUNK) < a.T ? (t0 + UR_CHUNK) : a.T;
@@ -120,7 +122,8 @@ __global__ __launch_bounds__(PM_WAVE) void unroll_apply_kernel(const UnrollArgs 
 
 // pass 1 as a plain stream (no LDS tile, one record per lane, consecutive lanes on consecutive records): the
 // flip bit of record (t, s) needs record (t-1, s), which the same wave fetched S records earlier (an L1 / L2
-// hit), and the chunk's parity per series is an LDS atomic XOR.  Series are taken in blocks of UR_P1_SB.
+// hit), and the chunk's parity per series is an LDS atomic XOR.  Series are taken in blocks of at most UR_P1_SB,
+// fewer when the clip is short and wide, so that chunks x series blocks still fill the chip.
 constexpr int UR_P1_SB = 8192;
 
 template <int W>
@@ -129,9 +132,9 @@ __global__ __launch_bounds__(PM_WAVE) void unroll_parity_kernel(const UnrollArgs
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int *par = reinterpret_cast<int *>(smem);
     const int lane = threadIdx.x;
-    const int chunk = blockIdx.x;
-    const int s0 = blockIdx.y * UR_P1_SB;
-    const int sb = (a.S - s0) < UR_P1_SB ? (a.S - s0) : UR_P1_SB;
+    const int chunk = blockIdx.x / a.p1_blocks;
+    const int s0 = (blockIdx.x - chunk * a.p1_blocks) * a.p1_sb;
+    const int sb = (a.S - s0) < a.p1_sb ? (a.S - s0) : a.p1_sb;
     const int64_t t0 = (int64_t)chunk * UR_CHUNK;
     const int64_t t1 = (t0 + UR_CHUNK) < a.T ? (t0 + UR_CHUNK) : a.T;
     for (int i = lane; i < sb; i += PM_WAVE) par[i] = 0;
@@ -179,6 +182,19 @@ __global__ __launch_bounds__(PM_WAVE) void unroll_scan_kernel(int32_t *ws, int n
     }
 }
 
+// the same for short, wide clips (few chunks, many series): one THREAD per series walks the chunks; consecutive
+// threads touch consecutive words of a chunk's row
+__global__ __launch_bounds__(256) void unroll_scan_wide_kernel(int32_t *ws, int nchunks, int S) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    int carry = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        const int v = ws[(int64_t)c * S + s] & 1;
+        ws[(int64_t)c * S + s] = carry;
+        carry ^= v;
+    }
+}
+
 }  // namespace pm
 
 using namespace pm;
@@ -198,19 +214,23 @@ static int unroll_launch(const float *q, int64_t T, int32_t S, float *out, void 
     const int nsb = (S + UR_SB_MAX - 1) / UR_SB_MAX;
     const int sbsize = (S + nsb - 1) / nsb;
     const int sblocks = (S + sbsize - 1) / sbsize;
-    if (nchunks > 0x7fffffffLL || sblocks > 65535) { set_error("quat_unroll: problem too large"); return PM_EUNSUPPORTED; }
+    // parity pass: series per block from the size of the grid it leaves (>= ~8 K waves if the problem has them)
+    int p1_sb = UR_P1_SB;
+    while (p1_sb > 64 && nchunks * ((S + p1_sb - 1) / p1_sb) < 8192) p1_sb >>= 1;
+    const int64_t p1_blocks = (S + p1_sb - 1) / p1_sb;
+    if (nchunks * sblocks > 0x7fffffffLL || nchunks * p1_blocks > 0x7fffffffLL) { set_error("quat_unroll: problem too large"); return PM_EUNSUPPORTED; }
     UnrollArgs a;
-    a.q = q; a.out = out; a.ws = static_cast<int32_t *>(workspace); a.T = T; a.S = S; a.nchunks = (int)nchunks; a.sbsize = sbsize;
+    a.q = q; a.out = out; a.ws = static_cast<int32_t *>(workspace); a.T = T; a.S = S; a.nchunks = (int)nchunks; a.sbsize = sbsize; a.sblocks = sblocks; a.p1_sb = p1_sb; a.p1_blocks = (int)p1_blocks;
     const size_t lds = (size_t)(UR_SUB + 1) * (sbsize | 1) * 4 * W;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int e = allow_lds(unroll_apply_kernel<W>, lds)) return e;
-    const dim3 grid((unsigned)nchunks, (unsigned)sblocks);
+    const dim3 grid((unsigned)(nchunks * sblocks));
     {   // pass 1: chunk parities
-        const int p1_blocks = (S + UR_P1_SB - 1) / UR_P1_SB;
-        const size_t p1_lds = (size_t)(S < UR_P1_SB ? S : UR_P1_SB) * sizeof(int);
-        hipLaunchKernelGGL((unroll_parity_kernel<W>), dim3((unsigned)nchunks, (unsigned)p1_blocks), dim3(PM_WAVE), p1_lds, s, a);
+        const size_t p1_lds = (size_t)(S < p1_sb ? S : p1_sb) * sizeof(int);
+        hipLaunchKernelGGL((unroll_parity_kernel<W>), dim3((unsigned)(nchunks * p1_blocks)), dim3(PM_WAVE), p1_lds, s, a);
     }
-    hipLaunchKernelGGL(unroll_scan_kernel, dim3((unsigned)S), dim3(PM_WAVE), 0, s, a.ws, (int)nchunks, (int)S);
+    if (nchunks <= 256) hipLaunchKernelGGL(unroll_scan_wide_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, s, a.ws, (int)nchunks, (int)S);
+    else hipLaunchKernelGGL(unroll_scan_kernel, dim3((unsigned)S), dim3(PM_WAVE), 0, s, a.ws, (int)nchunks, (int)S);
     hipLaunchKernelGGL((unroll_apply_kernel<W>), grid, dim3(PM_WAVE), lds, s, a);
     return check_hip(hipGetLastError(), "quat_unroll");
 }

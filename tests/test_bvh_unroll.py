@@ -68,7 +68,8 @@ def test_gpu_dq_unroll_and_long_sequences():
     # many chunks (T > 1024), more series than one block (S > 64), ragged tail: against the sequential oracle
     rng = np.random.default_rng(3)
     # (S > 8192: more than one series block in the parity pass; 24 < S: several series blocks in the apply pass)
-    for T, S in ((5000, 22), (1025, 70), (1, 3), (2, 1), (64, 64), (4097, 130), (300, 8200), (257, 25)):
+    for T, S in ((5000, 22), (1025, 70), (1, 3), (2, 1), (64, 64), (4097, 130), (300, 8200), (257, 25),
+                 (3, 70_001), (2, 1_700_000)):  # short and very wide: 1-D grids (more than 65535 series blocks), thread-per-series scan
         base = np.cumsum(rng.normal(0, 0.08, (T, S, 4)), axis=0) + rng.normal(0, 1, (1, S, 4))
         q = (base * rng.choice([-1.0, 1.0], (T, S, 1))).astype(np.float32)
         got = quat.unroll(q, 0)
