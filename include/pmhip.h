@@ -151,8 +151,11 @@ int pm_quat_from_scaled_angle_axis_f32(const float *v, int64_t N, float *out, pm
 int pm_quat_to_angle_axis_f32(const float *q, int64_t N, float *angle, float *axis, pm_stream_t stream);
 /* rotations/quat.py:230-244  to_scaled_angle_axis(q) -> [N,3] */
 int pm_quat_to_scaled_angle_axis_f32(const float *q, int64_t N, float *out, pm_stream_t stream);
-/* rotations/quat.py:43-82  from_euler(euler [N,3], order): order = device uint8 [N,3] codes
- * 0/1/2 for 'x'/'y'/'z', or, with order_per_element == 0, a single uint8[3] triple (device). */
+/* rotations/quat.py:43-82  from_euler(euler [N,3], order): order = device uint8 codes 0/1/2 for 'x'/'y'/'z':
+ *   order_per_element == 0   one uint8[3] triple for every element,
+ *   order_per_element == 1   uint8[N,3], an order per element (what the reference's signature literally asks for),
+ *   order_per_element == P>=2  uint8[P,3], element e uses row e % P -- a [F, J, 3] clip with one order per joint
+ *                            (P = J), which is what a BVH file gives and what tiling the order array F times means. */
 int pm_quat_from_euler_f32(const float *euler, const uint8_t *order, int order_per_element, int64_t N,
                            float *out, pm_stream_t stream);
 /* rotations/quat.py:159-227  to_euler(q, order) -> [N,3] in [0, 2pi) */

@@ -98,9 +98,19 @@ def quat_to_scaled_angle_axis(be, q):
 
 def _order_codes(order, lead):
     """The reference takes a NumPy array of 'x'|'y'|'z' strings shaped like euler (quat.py:51-53).
-    Encode as uint8 codes; a single triple (or a constant array) becomes the per-call form."""
+    Encode as uint8 codes and compress what repeats: a constant array becomes one triple (mode 0), an array whose
+    rows repeat with the period of the last leading axis -- an order per joint, tiled over the frames, which is what
+    `BVH.get_data` and every caller with a BVH-style clip builds -- becomes a [P, 3] table (mode P); anything else
+    stays an order per element (mode 1).  Returns (codes, mode) for pm_quat_{from,to}_euler_f32."""
     order = np.asarray(order)
-    if order.dtype.kind in "US":
+    if order.dtype.kind in "US" and order.dtype.itemsize == (4 if order.dtype.kind == "U" else 1):
+        # single-character strings: reinterpret the code points instead of comparing strings three times
+        v = np.ascontiguousarray(order).view(np.uint32 if order.dtype.kind == "U" else np.uint8)
+        if v.size and (v.min() < 120 or v.max() > 122):  # ord('x') .. ord('z')
+            raise ValueError("order entries must be 'x', 'y' or 'z'")
+        codes = v.astype(np.uint8)  # (subtracting on the uint32 view would promote to int64: 40x slower)
+        codes -= 120
+    elif order.dtype.kind in "US":
         codes = np.zeros(order.shape, dtype=np.uint8)
         for ch, v in _AXIS.items():
             codes[order == ch] = v
@@ -114,14 +124,31 @@ def _order_codes(order, lead):
         # same assertion as the reference (quat.py:60-62)
         raise AssertionError("euler and order must have the same shape except for the last dimension")
     flat = codes.reshape(-1, 3)
+    if len(lead) >= 2 and lead[-1] >= 2 and len(flat) > lead[-1]:
+        per = flat.reshape(-1, lead[-1] * 3)  # rows = frames: the cheap test first (wide rows compare fast)
+        if (per == per[0]).all():
+            table = np.ascontiguousarray(per[0].reshape(lead[-1], 3))
+            return (table[0].copy(), 0) if (table == table[0]).all() else (table, int(lead[-1]))
     if len(flat) and (flat == flat[0]).all():
         return np.ascontiguousarray(flat[0]), 0
     return np.ascontiguousarray(flat), 1
 
 
-def _euler_like(be, fname, x, trail, out_trail, order, out_dtype):
+def _order_table(table, lead):
+    """One order per joint, given as a [J, 3] table for euler [..., J, 3] (what a BVH header holds): the compressed
+    form of _order_codes without ever materialising the tiled array."""
+    codes, _ = _order_codes(np.asarray(table), np.asarray(table).shape[:-1])
+    if codes.ndim == 1:
+        return codes, 0
+    J = codes.shape[0]
+    if not lead or lead[-1] != J:
+        raise ValueError(f"order table has {J} rows, euler has {lead[-1] if lead else 0} joints")
+    return codes, (J if J >= 2 else 0)
+
+
+def _euler_like(be, fname, x, trail, out_trail, order, out_dtype, per_joint_table=False):
     lead = be.shape(x)[: len(be.shape(x)) - 1]
-    codes, per_elem = _order_codes(order, lead)
+    codes, per_elem = _order_table(order, lead) if per_joint_table else _order_codes(order, lead)
     be.begin(x)
     try:
         n = _prod(lead)
@@ -140,12 +167,12 @@ def _u8(be):
     return np.uint8 if be.name == "numpy" else be.torch.uint8
 
 
-def quat_from_euler(be, euler, order):
-    return _euler_like(be, "pm_quat_from_euler_f32", euler, (3,), (4,), order, be.result_dtype(euler))
+def quat_from_euler(be, euler, order, per_joint_table=False):
+    return _euler_like(be, "pm_quat_from_euler_f32", euler, (3,), (4,), order, be.result_dtype(euler), per_joint_table)
 
 
-def quat_to_euler(be, q, order):
-    return _euler_like(be, "pm_quat_to_euler_f32", q, (4,), (3,), order, be.always64)
+def quat_to_euler(be, q, order, per_joint_table=False):
+    return _euler_like(be, "pm_quat_to_euler_f32", q, (4,), (3,), order, be.always64, per_joint_table)
 
 
 def quat_slerp(be, q0, q1, t, shortest=True):

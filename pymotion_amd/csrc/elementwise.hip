@@ -22,7 +22,10 @@ struct EwArgs {
     const uint8_t *order;  // euler ops
     int64_t N;
     float eps;
-    int flag;  // slerp: shortest; euler: order_per_element
+    int flag;  // slerp: shortest; from_to: normalize_input; euler: 0 = one order, 1 = an order per element, P >= 2 = a table
+               // of P orders, element e using row e % P (one order per joint of a [F, J, 3] clip)
+    int64_t tile_e0;   // filled by the kernel: first element of the wave's tile ...
+    int order_r0;      // ... and its row in the order table (tile_e0 % P), so that a row index is a 32-bit affair
 };
 
 // Records of 4 (dwordx4), 3 (dwordx3) or 1 float: one record per lane with consecutive lanes on consecutive
@@ -97,6 +100,9 @@ __global__ __launch_bounds__(PM_WAVE) void ew_kernel(const EwArgs a) {
     float *t0 = s2 + EW_TILE * ew_lds_in(I2);
     float *t1 = t0 + EW_TILE * ew_lds_out(O0);
 
+    EwArgs b = a;
+    b.tile_e0 = e0;
+    b.order_r0 = (a.order != nullptr && a.flag >= 2) ? (int)(e0 % a.flag) : 0;  // wave-uniform, once per tile
     ew_stage_in<I0, VEC>(a.in0, s0, e0, n, lane);
     ew_stage_in<I1, VEC>(a.in1, s1, e0, n, lane);
     ew_stage_in<I2, VEC>(a.in2, s2, e0, n, lane);
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(PM_WAVE) void ew_kernel(const EwArgs a) {
     for (int m = 0; m < EW_PER_LANE; ++m) {
         const int idx = m * PM_WAVE + lane, ic = idx < n ? idx : n - 1;
         float y0[O0 ? O0 : 1], y1[O1 ? O1 : 1];
-        Op::apply(x0[m], x1[m], x2[m], y0, y1, a, e0 + ic);  // (ops that index global side tables stay in bounds)
+        Op::apply(x0[m], x1[m], x2[m], y0, y1, b, e0 + ic);  // (ops that index global side tables stay in bounds)
         if (idx < n) {
             ew_put<O0, VEC>(a.out0, t0, e0, idx, y0);
             ew_put<O1, VEC>(a.out1, t1, e0, idx, y1);
@@ -261,7 +267,10 @@ PM_OP(OpToScaledAA, 4, 0, 0, 3, 0) {
 } PM_OP_END
 
 __device__ __forceinline__ void load_order(const EwArgs &a, int64_t elem, int (&o)[3]) {
-    const uint8_t *p = a.order + (a.flag ? elem * 3 : 0);
+    int64_t row = 0;
+    if (a.flag == 1) row = elem;
+    else if (a.flag >= 2) row = (unsigned)(a.order_r0 + (int)(elem - a.tile_e0)) % (unsigned)a.flag;  // < P + EW_TILE: 32-bit
+    const uint8_t *p = a.order + row * 3;
     o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
 }
 // rotations/quat.py:43-82 : q = q0 (x) (q1 (x) q2), each an axis rotation about order[k]
@@ -326,6 +335,7 @@ static EwArgs mk(const float *i0, const float *i1, const float *i2, float *o0, f
                  int flag = 0, const uint8_t *order = nullptr) {
     EwArgs a;
     a.in0 = i0; a.in1 = i1; a.in2 = i2; a.out0 = o0; a.out1 = o1; a.order = order; a.N = N; a.eps = eps; a.flag = flag;
+    a.tile_e0 = 0; a.order_r0 = 0;
     return a;
 }
 
@@ -506,11 +516,13 @@ extern "C" int pm_quat_to_scaled_angle_axis_f32(const float *q, int64_t N, float
 extern "C" int pm_quat_from_euler_f32(const float *euler, const uint8_t *order, int order_per_element, int64_t N,
                                       float *out, pm_stream_t s) {
     PM_CHECK_ARGS(order != nullptr || N == 0, "quat_from_euler: null order");
+    PM_CHECK_ARGS(order_per_element >= 0, "quat_from_euler: order_per_element must be 0, 1 or a table length");
     return launch_ew<OpFromEuler>(mk(euler, nullptr, nullptr, out, nullptr, N, 0.0f, order_per_element, order), s, "quat_from_euler");
 }
 extern "C" int pm_quat_to_euler_f32(const float *q, const uint8_t *order, int order_per_element, int64_t N, float *out,
                                     pm_stream_t s) {
     PM_CHECK_ARGS(order != nullptr || N == 0, "quat_to_euler: null order");
+    PM_CHECK_ARGS(order_per_element >= 0, "quat_to_euler: order_per_element must be 0, 1 or a table length");
     return launch_ew<OpToEuler>(mk(q, nullptr, nullptr, out, nullptr, N, 0.0f, order_per_element, order), s, "quat_to_euler");
 }
 extern "C" int pm_quat_slerp_f32(const float *q0, const float *q1, const float *t, int64_t N, int shortest, float *out,

@@ -13,7 +13,12 @@ import warnings
 
 import numpy as np
 
+from .. import _backend, _ops
 from ..rotations import quat
+
+
+def _be():
+    return _backend.numpy_backend()
 
 _ROT = {"Xrotation": "x", "Yrotation": "y", "Zrotation": "z"}
 _POS = {"Xposition": 0, "Yposition": 1, "Zposition": 2}
@@ -132,14 +137,13 @@ class BVH:
         end_sites_parents) -- reference bvh.py:332-365; the rotations go through from_euler -> unroll
         (frame axis) -> normalize on the GPU."""
         d = self.data
-        order = np.tile(d["rot_order"], (d["rotations"].shape[0], 1, 1))
-        rots = quat.unroll(quat.from_euler(np.radians(d["rotations"]), order=order), axis=0)
+        # the reference tiles the per-joint order over the frames (bvh.py:352); the kernel takes the [J, 3] table itself
+        rots = quat.unroll(_ops.quat_from_euler(_be(), np.radians(d["rotations"]), d["rot_order"], per_joint_table=True), axis=0)
         rots = quat.normalize(rots)
         return rots, d["positions"], d["parents"], d["offsets"], d["end_sites"], d["end_sites_parents"]
 
     def set_data(self, rots, pos):
         """Store quaternions back as Euler angles in the file's channel order (reference bvh.py:367-389)."""
         assert self.data is not None and self.data["rot_order"] is not None, "load a BVH file first"
-        order = np.tile(self.data["rot_order"], (rots.shape[0], 1, 1))
-        self.data["rotations"] = np.degrees(quat.to_euler(rots, order=order))
+        self.data["rotations"] = np.degrees(_ops.quat_to_euler(_be(), rots, self.data["rot_order"], per_joint_table=True))
         self.data["positions"] = pos

@@ -46,3 +46,37 @@ def test_interp_coefficients_follow_the_reference_formula():
     assert idx.dtype == np.int32
     np.testing.assert_array_equal(idx, [0, 0, 0, 0, 1, 3, 3])
     np.testing.assert_allclose(w, [-0.5, 0.0, 0.25, 1.0, 0.5, 1.0, 4.0])
+
+
+def test_euler_order_arrays_are_compressed_to_what_repeats():
+    """quat.from_euler / to_euler take an order array shaped like euler (quat.py:51-62); the host encodes it as
+    uint8 and keeps a constant array as one triple, a per-joint pattern tiled over the frames as a [J, 3] table."""
+    import pytest
+
+    from pymotion_amd import _ops
+
+    rng = np.random.default_rng(1)
+    F, J = 50, 7
+    per_joint = np.array(list("xyz"))[rng.permuted(np.tile(np.arange(3), (J, 1)), axis=1)]
+    tiled = np.tile(per_joint, (F, 1, 1))
+    codes, mode = _ops._order_codes(tiled, (F, J))
+    assert mode == J and codes.shape == (J, 3) and codes.dtype == np.uint8
+    np.testing.assert_array_equal(np.array(list("xyz"))[codes], per_joint)
+    c2, m2 = _ops._order_codes(tiled.astype("S1"), (F, J))  # bytes strings take the same fast path
+    assert m2 == J and np.array_equal(c2, codes)
+    const = np.tile(np.array(["z", "x", "y"]), (F, J, 1))
+    c0, m0 = _ops._order_codes(const, (F, J))
+    assert m0 == 0 and c0.tolist() == [2, 0, 1]
+    odd = tiled.copy()
+    odd[17, 3] = odd[17, 3][::-1]  # one frame differs: an order per element
+    c1, m1 = _ops._order_codes(odd, (F, J))
+    assert m1 == 1 and c1.shape == (F * J, 3)
+    assert _ops._order_codes(per_joint, (J,))[1] == 1          # 2-D euler [J, 3]: no frame axis to repeat over
+    assert _ops._order_table(per_joint, (F, J)) [1] == J
+    assert _ops._order_table(np.tile(np.array(["x", "y", "z"]), (J, 1)), (F, J))[1] == 0
+    with pytest.raises(ValueError):
+        _ops._order_codes(np.array([["x", "y", "w"]]), (1,))
+    with pytest.raises(AssertionError):
+        _ops._order_codes(tiled, (F, J + 1))
+    with pytest.raises(ValueError):
+        _ops._order_table(per_joint, (F, J + 1))

@@ -165,6 +165,27 @@ def test_euler_vs_reference_golden():
     assert np.minimum(d, 2 * np.pi - d).max() < 5e-4
 
 
+@pytest.mark.parametrize("F,J", [(1000, 22), (257, 52), (5000, 7), (3, 130)])
+def test_euler_with_one_order_per_joint_tiled_over_the_frames(F, J):
+    """the layout of every BVH clip: the order array repeats with period J and travels as a [J, 3] table; results must
+    equal the order-per-element path and the oracle, whatever the tile boundaries do to e % J"""
+    rng = np.random.default_rng(F + J)
+    per_joint = np.array(list("xyz"))[rng.permuted(np.tile(np.arange(3), (J, 1)), axis=1)]
+    order = np.tile(per_joint, (F, 1, 1))
+    e = rng.uniform(-3, 3, (F, J, 3)).astype(np.float32)
+    q = quat.from_euler(e, order)
+    assert_close(q, co.quat_from_euler(e.astype(np.float64), order), ATOL, "from_euler, per-joint table")
+    odd = order.copy()
+    odd[0, 0] = odd[0, 0][::-1]  # breaks the period -> order-per-element path; every other element must agree bit for bit
+    q1 = quat.from_euler(e, odd)
+    np.testing.assert_array_equal(q1.reshape(-1, 4)[1:], q.reshape(-1, 4)[1:])
+    a = quat.to_euler(q.astype(np.float32), order)
+    b = quat.to_euler(q.astype(np.float32), odd)
+    np.testing.assert_array_equal(a.reshape(-1, 3)[1:], b.reshape(-1, 3)[1:])
+    back = co.quat_from_euler(a, order)
+    assert np.minimum(np.abs(back - q).max(-1), np.abs(back + q).max(-1)).max() < 2e-3
+
+
 def test_to_euler_on_quadrant_boundaries_and_identity():
     """the library's own atan2 must keep np.arctan2's conventions where they matter: axis-aligned rotations
     (operands exactly 0), the identity (atan2(0, 0) family) and every quadrant"""
