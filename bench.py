@@ -8,7 +8,9 @@
 A "step" is one pass of the fk hot path over one device-resident batch of synthetic frames
 (config 2 of BASELINE.json: 2^20 frames x 22 joints per GPU, fp32, quaternions not
 pre-normalised, metre-scale offsets).  Frames shard across ranks with no data-path collective
-(weak scaling: per-GPU batch fixed); the optional output all-gather is timed separately.
+(weak scaling: per-GPU batch fixed).  `python bench.py --gpus N` with N > 1 launches itself under
+torch.distributed.run.  Multi-GPU runs also report, after the timed region and never inside `value`, the reassembly
+all-gather (ms, xGMI GB/s per GPU vs the link roofline, both implementations) and compute + gather combined.
 Rank 0 prints ONE JSON line.  Extra objects in that line:
 
   roofline      the fk kernel against the HBM roofline: algorithmic bytes (64*J+12 per frame)
@@ -28,6 +30,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy reaches
+# xGMI: 7 point-to-point links per GPU, 153.6 GB/s each counting both directions = 76.8 GB/s per direction.  An
+# all-gather is receive-bound: every GPU takes W-1 shards, one per link, so its roofline is 76.8 GB/s x (W-1) links.
+XGMI_LINK_GBPS_PER_DIRECTION = 76.8
 
 
 def parse():
@@ -42,12 +47,33 @@ def parse():
     ap.add_argument("--joints", type=int, default=22, choices=[22, 52])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=1 << 20)
-    ap.add_argument("--gather", action="store_true",
-                    help="N>1: also time (separately, after the timed region) one RCCL all-gather of (pos, rotmats); the path "
-                         "itself has no exchange step, so this is off by default and never part of `value`")
+    ap.add_argument("--no-gather", action="store_true",
+                    help="N>1: skip the reassembly measurements.  By default every multi-GPU run reports, AFTER the timed region "
+                         "and never inside `value`: (ii) the all-gather of (pos, rotmats) -- ms and achieved xGMI GB/s per GPU for "
+                         "both RCCL's all_gather_into_tensor and the direct full-mesh send/recv -- and (iii) compute + gather combined")
+    ap.add_argument("--gather", action="store_true", help=argparse.SUPPRESS)  # round-1 spelling, now the default
+    ap.add_argument("--dry-run-shared-gpu", action="store_true",
+                    help="launch-path rehearsal on a box with fewer GPUs than ranks: every rank uses cuda:0 and the process group is "
+                         "gloo (RCCL refuses two ranks on one device).  Numbers from such a run mean nothing; the JSON says so")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short measurements of BASELINE configs 3 and 4 (N=1)")
+    ap.add_argument("--oracle-slice-frames", type=int, default=1 << 16,
+                    help="N>1: frames of its own shard every rank checks against the CPU oracle (SURVEY 8d config 5: 2^16)")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: become the launcher (one rank per GPU, same
+    flags), exactly the command the driver uses."""
+    import socket
+
+    with socket.socket() as sk_:
+        sk_.bind(("127.0.0.1", 0))
+        port = sk_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
 
 
 def _blas_threads():
@@ -149,6 +175,57 @@ def secondary_configs(torch, _lib, syn, dev, rot, root, off, parents, sptr):
     return out
 
 
+def gather_report(torch, dist, a, world, rank, F, J, pos, rm, barrier, compute_s, cdev, shared):
+    """(ii) reassembling (pos, rotmats) on every GPU -- the ONE collective a caller may ask for -- timed for
+    both implementations in pymotion_amd.parallel, with the achieved xGMI receive rate per GPU against the (W-1)-link
+    roofline, and (iii) compute + gather combined.  After the timed region, never part of `value`, never fatal."""
+    from pymotion_amd.parallel import GATHER_METHODS, all_gather_frames
+
+    shard_bytes = F * J * 48  # pos 12 J + rotmats 36 J bytes per frame
+    recv_bytes = shard_bytes * (world - 1)
+    peak = XGMI_LINK_GBPS_PER_DIRECTION * (world - 1)
+    rep = {"shard_GB": shard_bytes / 1e9, "received_GB_per_gpu": recv_bytes / 1e9,
+           "xgmi_peak_GBps_per_gpu": peak,
+           "xgmi_peak_note": "%d links x %.1f GB/s per direction (153.6 GB/s per link counts both directions)"
+                             % (world - 1, XGMI_LINK_GBPS_PER_DIRECTION),
+           "compute_only_ms": compute_s * 1e3, "methods": {}}
+    src = (pos.cpu(), rm.cpu()) if shared else (pos, rm)  # gloo has no device all-gather: the rehearsal stages through the host
+    for method in GATHER_METHODS:
+        try:
+            times = []
+            for it in range(3):  # first pass pays RCCL's per-peer connection set-up; report the best of the rest
+                torch.cuda.synchronize()
+                barrier()
+                g0 = time.perf_counter()
+                gp = all_gather_frames(src[0], F * world, method=method)
+                gr = all_gather_frames(src[1], F * world, method=method)
+                torch.cuda.synchronize()
+                barrier()
+                times.append(time.perf_counter() - g0)
+                if it == 0:  # the reassembled arrays must hold every rank's shard in rank order: check our own block
+                    ok = bool(torch.equal(gp[rank * F:(rank + 1) * F], src[0])) and bool(torch.equal(gr[rank * F:(rank + 1) * F], src[1]))
+                    okt = torch.tensor([0.0 if ok else 1.0], device=cdev, dtype=torch.float64)
+                    dist.all_reduce(okt, op=dist.ReduceOp.MAX)
+                    ok = float(okt[0]) == 0.0
+                del gp, gr
+            tt = torch.tensor([min(times[1:])], device=cdev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            sec = float(tt[0])
+            rep["methods"][method] = {"ms": sec * 1e3, "first_call_ms": times[0] * 1e3, "xgmi_recv_GBps_per_gpu": recv_bytes / sec / 1e9,
+                                      "frac_of_xgmi_peak": recv_bytes / sec / 1e9 / peak, "own_block_intact": ok}
+        except Exception as exc:  # noqa: BLE001
+            rep["methods"][method] = {"error": repr(exc)[:300]}
+    good = {k: v for k, v in rep["methods"].items() if "ms" in v}
+    if good:
+        best = min(good, key=lambda k: good[k]["ms"])
+        rep["selected"] = best
+        rep["ms"] = good[best]["ms"]
+        comb = compute_s + good[best]["ms"] * 1e-3
+        rep["combined_compute_plus_gather"] = {"ms": comb * 1e3, "frames_per_s": F * world / comb,
+                                               "note": "one fk pass + one reassembly on every GPU; `value` is compute-only"}
+    return rep
+
+
 def main():
     a = parse()
     import numpy as np
@@ -163,18 +240,27 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        if world == 1 and a.gpus > 1 and "RANK" not in os.environ:
+            self_launch(a)  # does not return
         a.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    shared = a.dry_run_shared_gpu
+    if not shared and torch.cuda.device_count() < world:
+        sys.exit(f"bench.py: {world} ranks but {torch.cuda.device_count()} visible GPU(s); --dry-run-shared-gpu rehearses the "
+                 "launch path on one device")
+    dev_index = 0 if shared else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("PM_BENCH_FORCE_DIST") == "1"
     if use_dist:  # one rank per GPU over RCCL (backend "nccl" on ROCm); also taken by `torchrun --nproc-per-node 1`
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if shared:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         dist.barrier()  # pay RCCL's lazy communicator set-up now, not inside the barrier that opens the timed region
+    cdev = torch.device("cpu") if shared else dev  # where the tiny control-plane tensors (timings, errors) live
 
     J = a.joints
     parents = syn.PARENTS_22 if J == 22 else syn.PARENTS_52
@@ -238,15 +324,18 @@ def main():
     wall = t1 - t0
     kern_ms = ms.value / a.steps  # average launch-to-launch time of the fk kernel on its stream
 
+    kernel_name = _lib.last_kernel_name()  # what pm_fk_f32 dispatched to, spelled like rocprofv3 prints it
     if use_dist:
-        tt = torch.tensor([wall, kern_ms], device=dev, dtype=torch.float64)
+        tt = torch.tensor([wall, kern_ms], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, kern_ms = float(tt[0]), float(tt[1])
 
     extra = {}
+    if shared:
+        extra["dry_run_shared_gpu"] = "launch-path rehearsal: every rank on cuda:0, gloo process group -- the numbers mean nothing"
     if use_dist:
         # every rank checks a slice of ITS shard against the CPU oracle (the checker, not the measured path)
-        n_chk = min(F, 1 << 12)
+        n_chk = min(F, a.oracle_slice_frames)
         sl = slice(F // 2, F // 2 + n_chk) if F >= 2 * n_chk else slice(0, n_chk)
         try:
             from oracle import c_oracle as co
@@ -256,28 +345,11 @@ def main():
             err = max(float(np.abs(pos[sl].cpu().numpy() - p_o).max()), float(np.abs(rm[sl].cpu().numpy() - r_o).max()))
         except Exception:  # noqa: BLE001  (checker unavailable on this box: report it, keep every rank in the collective)
             err = float("inf")
-        et = torch.tensor([err], device=dev, dtype=torch.float64)
+        et = torch.tensor([err], device=cdev, dtype=torch.float64)
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
         extra["max_abs_err_vs_oracle_slice"] = {"value": float(et[0]), "frames_per_rank": n_chk}
-    if use_dist and world > 1 and a.gather:
-        from pymotion_amd.parallel import all_gather_frames
-
-        try:  # an optional extra after the timed region: never let it take the bench line down with it
-            torch.cuda.synchronize()
-            barrier()
-            g0 = time.perf_counter()
-            gp = all_gather_frames(pos, F * world)
-            gr = all_gather_frames(rm, F * world)
-            torch.cuda.synchronize()
-            barrier()
-            g1 = time.perf_counter()
-            shard_bytes = F * J * 48
-            extra["gather"] = {"ms": (g1 - g0) * 1e3, "shard_GB": shard_bytes / 1e9,
-                               "busbw_GBps_per_gpu": shard_bytes * (world - 1) / (g1 - g0) / 1e9,
-                               "note": "one all_gather_into_tensor per output; compute-only value excludes it"}
-            del gp, gr
-        except Exception as exc:  # noqa: BLE001
-            extra["gather"] = {"error": repr(exc)[:200]}
+    if use_dist and world > 1 and not a.no_gather:
+        extra["gather"] = gather_report(torch, dist, a, world, rank, F, J, pos, rm, barrier, wall / a.steps, cdev, shared)
 
     if world == 1 and not a.no_secondary and J == 22:
         extra["secondary"] = secondary_configs(torch, _lib, syn, dev, rot, root, off, parents, sptr)
@@ -287,12 +359,13 @@ def main():
         achieved = bytes_per_frame * F / (kern_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE,
         # corrections per MI355X_MICROARCH.md, calibrated on a known-byte copy kernel); same workload only.
-        traffic = None
+        traffic, traffic_source = None, None
         try:
             latest = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_fk_hbm_traffic.json"))[-1]
             prof = json.load(open(os.path.join(ROOT, "profiles", latest)))
             if prof["workload"] == {"frames": F, "joints": J}:
                 traffic = prof["corrected_bytes_per_launch"]["total"]
+                traffic_source = "profiles/%s (rocprofv3 --pmc passes of this same command, not re-measured in this run)" % latest
         except (OSError, IndexError, KeyError, ValueError):
             pass
         line = {
@@ -312,9 +385,9 @@ def main():
             "config": {"workload": "fk: %d frames x %d joints per GPU, fp32 (BASELINE.json configs[1])" % (F, J),
                        "frames_per_gpu": F, "joints": J, "sharding": "frames, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes": bytes_per_frame * F,
-                         "kernel": "pm::fk_kernel<20,true,false,0,false>", "kernel_ms": kern_ms,
+                         "kernel": kernel_name, "kernel_ms": kern_ms,
                          "bytes_per_frame": bytes_per_frame},
         }
         line.update(extra)

@@ -44,6 +44,8 @@ typedef void *pm_stream_t; /* hipStream_t */
 /* ---- library / device plumbing ------------------------------------------------------------ */
 int pm_version(void);                      /* ABI version, currently 1 */
 const char *pm_last_error_string(void);    /* thread-local, valid until the next failing call */
+const char *pm_last_kernel_name(void);     /* thread-local: the kernel the last skeleton-op call dispatched to,
+                                              spelled as rocprofv3 prints it (bench.py's roofline.kernel) */
 int pm_device_count(void);                 /* number of visible HIP devices, <0 on error */
 int pm_set_device(int device);
 int pm_get_device(int *device);

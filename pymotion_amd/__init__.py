@@ -6,3 +6,10 @@ names and signatures; the work is done by hand-written gfx950 kernels in ``libpm
 (C ABI: ``include/pmhip.h``).  No CPU fallback.
 """
 __version__ = "0.1.0"
+
+
+def trim():
+    """Release the NumPy door's cached device blocks (per HIP device) and host staging buffers."""
+    from ._backend import trim as _trim
+
+    _trim()

@@ -34,11 +34,21 @@ def _prod(shape):
 # ---------------------------------------------------------------------------------------------
 # NumPy front door
 # ---------------------------------------------------------------------------------------------
-class _DevPool:
-    """Tiny size-class pool over pm_malloc so repeated NumPy-path calls do not pay hipMalloc."""
+def _current_device():
+    d = C.c_int(0)
+    _lib.call("pm_get_device", C.byref(d))
+    return d.value
 
-    def __init__(self, cap_bytes=8 << 30):
-        self.free = {}
+
+class _DevPool:
+    """Tiny size-class pool over pm_malloc so repeated NumPy-path calls do not pay hipMalloc.
+
+    Free lists are keyed by HIP device: pm_malloc allocates on the calling thread's current device, and a block
+    cached while device 0 was current must never be handed to a call that runs on device 1
+    (``torch.cuda.set_device(local_rank)`` in the same process, threads on different GPUs)."""
+
+    def __init__(self, cap_bytes=4 << 30):
+        self.free = {}      # (device, size class) -> [ptr]
         self.cached = 0
         self.cap = cap_bytes
         self.lock = threading.Lock()
@@ -48,10 +58,10 @@ class _DevPool:
         n = max(int(nbytes), 256)
         return 1 << (n - 1).bit_length()
 
-    def get(self, nbytes):
+    def get(self, nbytes, dev):
         c = self._cls(nbytes)
         with self.lock:
-            lst = self.free.get(c)
+            lst = self.free.get((dev, c))
             if lst:
                 self.cached -= c
                 return lst.pop(), c
@@ -63,10 +73,10 @@ class _DevPool:
             _lib.call("pm_malloc", C.byref(p), c)
         return p.value, c
 
-    def put(self, ptr, c):
+    def put(self, ptr, c, dev):
         with self.lock:
             if self.cached + c <= self.cap:
-                self.free.setdefault(c, []).append(ptr)
+                self.free.setdefault((dev, c), []).append(ptr)
                 self.cached += c
                 return
         _lib.call("pm_free", C.c_void_p(ptr))
@@ -77,20 +87,21 @@ class _DevPool:
             self.free.clear()
             self.cached = 0
         for p in blocks:
-            _lib.call("pm_free", C.c_void_p(p))
+            _lib.call("pm_free", C.c_void_p(p))  # hipFree takes a pointer of any device
 
 
 _pool = _DevPool()
 
 
 class _DevBuf:
-    def __init__(self, nbytes):
-        self.ptr, self.cls = _pool.get(nbytes)
+    def __init__(self, nbytes, dev):
+        self.dev = dev
+        self.ptr, self.cls = _pool.get(nbytes, dev)
         self.nbytes = nbytes
 
     def release(self):
         if self.ptr is not None:
-            _pool.put(self.ptr, self.cls)
+            _pool.put(self.ptr, self.cls, self.dev)
             self.ptr = None
 
     def __del__(self):
@@ -98,6 +109,12 @@ class _DevBuf:
             self.release()
         except Exception:
             pass
+
+
+def trim():
+    """Give the NumPy door's cached device blocks and host staging buffers back (public: ``pymotion_amd.trim()``)."""
+    _pool.trim()
+    _stage.trim()
 
 
 # ---- host side of the NumPy door: staging buffers that are reused (no page faults on the copy path) and
@@ -135,7 +152,7 @@ def _parallel_copyto(dst, src):
 class _HostStage:
     """Reusable fp32 host buffers (size classes, a few kept): already-touched memory for H2D / D2H staging."""
 
-    def __init__(self, cap_bytes=8 << 30):
+    def __init__(self, cap_bytes=4 << 30):
         self.free = {}
         self.cached = 0
         self.cap = cap_bytes
@@ -155,6 +172,11 @@ class _HostStage:
             if self.cached + buf.nbytes <= self.cap:
                 self.free.setdefault(buf.nbytes, []).append(buf)
                 self.cached += buf.nbytes
+
+    def trim(self):
+        with self.lock:
+            self.free.clear()
+            self.cached = 0
 
 
 _stage = _HostStage()
@@ -188,6 +210,7 @@ class NumpyBackend:
 
     def begin(self, *_):
         _lib.require_device()
+        self._dev = _current_device()  # device blocks are pooled per device
         self._live = []
         self._stages = []
 
@@ -205,7 +228,7 @@ class NumpyBackend:
             _parallel_copyto(src, a if a.flags.c_contiguous else np.ascontiguousarray(a))
         else:
             src = np.ascontiguousarray(a, dtype=dtype)
-        buf = _DevBuf(src.nbytes)
+        buf = _DevBuf(src.nbytes, self._dev)
         _lib.call("pm_memcpy_h2d", C.c_void_p(buf.ptr), src.ctypes.data_as(C.c_void_p), src.nbytes, None)
         self._live.append((buf, src))
         if keep is not None:
@@ -213,7 +236,7 @@ class NumpyBackend:
         return C.c_void_p(buf.ptr)
 
     def dev_out(self, shape):
-        buf = _DevBuf(_prod(shape) * 4)
+        buf = _DevBuf(_prod(shape) * 4, self._dev)
         self._live.append((buf, None))
         return C.c_void_p(buf.ptr), (buf, tuple(shape))
 
@@ -237,7 +260,7 @@ class NumpyBackend:
         return out
 
     def scratch(self, nbytes):
-        buf = _DevBuf(max(int(nbytes), 4))
+        buf = _DevBuf(max(int(nbytes), 4), self._dev)
         self._live.append((buf, None))
         return C.c_void_p(buf.ptr)
 
@@ -247,7 +270,7 @@ class NumpyBackend:
 
     def flags_alloc(self, n=3):
         """Zeroed device int32[n] for kernels that report batch-wide predicates."""
-        buf = _DevBuf(4 * n)
+        buf = _DevBuf(4 * n, self._dev)
         _lib.call("pm_memset", C.c_void_p(buf.ptr), 0, 4 * n, None)
         self._live.append((buf, None))
         return C.c_void_p(buf.ptr), (buf, n)
@@ -269,7 +292,7 @@ class NumpyBackend:
         self._stages = []
 
     @staticmethod
-    def host_ints(x):
+    def host_ints(x, slot="parents"):
         return np.ascontiguousarray(np.asarray(x), dtype=np.int32)
 
     @staticmethod
@@ -376,20 +399,35 @@ class TorchBackend:
         self._keep = []
         self._guard.__exit__(None, None, None)
 
+    # One-entry memos keyed on the tensor OBJECT (weak reference) + torch's in-place version counter.  An address is not
+    # an identity: the caching allocator hands a freed block to the next tensor of the same size, and a tensor fresh
+    # from `.cuda()` has version 0 -- keying on data_ptr made a new skeleton of the same J hit the previous one's entry.
     _ints_memo = {}
 
-    def host_ints(self, x):
+    @staticmethod
+    def _memo_get(table, slot, x):
+        hit = table.get(slot)
+        if hit is not None and hit[0]() is x and hit[1] == x._version:
+            return hit[2]
+        return None
+
+    @staticmethod
+    def _memo_put(table, slot, x, value):
+        import weakref
+
+        table[slot] = (weakref.ref(x), x._version, value)
+
+    def host_ints(self, x, slot="parents"):
         torch = self.torch
         if isinstance(x, torch.Tensor):
             if x.is_cuda:
-                # J integers living on the device: the copy is a synchronisation, so remember it per tensor version
-                # (a loop over clips with one `parents` tensor pays once)
-                key = (x.data_ptr(), x._version, tuple(x.shape), x.dtype, x.device)
-                hit = TorchBackend._ints_memo.get("key")
-                if hit is not None and hit[0] == key:
-                    return hit[1]
-                arr = np.ascontiguousarray(x.detach().cpu().numpy(), dtype=np.int32)
-                TorchBackend._ints_memo["key"] = (key, arr)
+                # J integers living on the device: the copy is a synchronisation, so remember it per tensor object and
+                # version (a loop over clips with one `parents` tensor pays once; the reference re-reads every call,
+                # skeleton_torch.py:56, which any NEW tensor still gets here)
+                arr = self._memo_get(TorchBackend._ints_memo, slot, x)
+                if arr is None:
+                    arr = np.ascontiguousarray(x.detach().cpu().numpy(), dtype=np.int32)
+                    self._memo_put(TorchBackend._ints_memo, slot, x, arr)
                 return arr
             x = x.detach().numpy()
         return np.ascontiguousarray(np.asarray(x), dtype=np.int32)

@@ -10,6 +10,14 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpmhip.so")
+# Other builds of the same sources (pymotion_amd/csrc/Makefile): "tuning" reads the PM_* tuning / ablation variables,
+# "debug" bounds-checks the kernels and synchronises after every launch.  The product is always "prod"; the others are
+# selected explicitly -- `with _lib.variant("tuning"):` in tests and probes, or PMHIP_VARIANT=tuning for a whole process.
+VARIANT_PATHS = {
+    "prod": LIB_PATH,
+    "tuning": os.path.join(_HERE, "libpmhip_tuning.so"),
+    "debug": os.path.join(_HERE, "libpmhip_debug.so"),
+}
 
 PM_OK, PM_EINVAL, PM_ETOPOLOGY, PM_EHIP, PM_EUNSUPPORTED = 0, -1, -2, -3, -4
 
@@ -114,25 +122,65 @@ class PmhipError(RuntimeError):
         self.code = code
 
 
+_handles = {}
+
+
+def _load(path):
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: the HIP extension is not built and pymotion_amd has no CPU "
+            "fallback. Run `python __graft_entry__.py` (or `make -C pymotion_amd/csrc`)."
+        )
+    _preload_hip_runtime()
+    h = C.CDLL(path)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(h, name)  # AttributeError = ABI mismatch, let it surface
+        fn.argtypes = argtypes
+        fn.restype = C.c_int64 if name.endswith("_bytes") else C.c_int
+    h.pm_last_error_string.argtypes = []
+    h.pm_last_error_string.restype = C.c_char_p
+    h.pm_last_kernel_name.argtypes = []
+    h.pm_last_kernel_name.restype = C.c_char_p
+    return h
+
+
 def lib():
     """Load (once) and return the ctypes handle; raises if the HIP extension is not built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(
-                f"{LIB_PATH} is missing: the HIP extension is not built and pymotion_amd has no CPU "
-                "fallback. Run `python __graft_entry__.py` (or `make -C pymotion_amd/csrc`)."
-            )
-        _preload_hip_runtime()
-        h = C.CDLL(LIB_PATH)
-        for name, argtypes in SIGNATURES.items():
-            fn = getattr(h, name)  # AttributeError = ABI mismatch, let it surface
-            fn.argtypes = argtypes
-            fn.restype = C.c_int64 if name.endswith("_bytes") else C.c_int
-        h.pm_last_error_string.argtypes = []
-        h.pm_last_error_string.restype = C.c_char_p
-        _lib = h
+        name = os.environ.get("PMHIP_VARIANT", "prod")
+        if name not in VARIANT_PATHS:
+            raise RuntimeError(f"PMHIP_VARIANT={name!r}: expected one of {sorted(VARIANT_PATHS)}")
+        _lib = _handles.setdefault(name, _load(VARIANT_PATHS[name]))
     return _lib
+
+
+class variant:
+    """``with variant("tuning"): ...`` -- route every call of this process through another build of the library
+    (tests of the tile-group kernels, probes).  Not thread-safe; never used by the product itself."""
+
+    def __init__(self, name):
+        if name not in VARIANT_PATHS:
+            raise ValueError(f"unknown library variant {name!r}")
+        self.name = name
+
+    def __enter__(self):
+        global _lib
+        self._prev = _lib
+        if self.name not in _handles:
+            _handles[self.name] = _load(VARIANT_PATHS[self.name])
+        _lib = _handles[self.name]
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._prev
+        return False
+
+
+def last_kernel_name():
+    """Name of the kernel the last skeleton-op call of this thread dispatched to (bench.py's roofline.kernel)."""
+    return lib().pm_last_kernel_name().decode("utf-8", "replace")
 
 
 def check(code):

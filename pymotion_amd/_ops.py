@@ -437,17 +437,17 @@ _ROOT_OFFSET_CHECKED = {}
 
 def _assert_root_offset_is_zero(be, offsets):
     """The reference's ``assert (offsets[0] == 0).all()`` (skeleton.py:227 / skeleton_torch.py:242).  On a HIP
-    tensor that comparison is a device->host synchronisation per call; the verdict is remembered per tensor
-    (storage pointer + torch's in-place version counter), so a loop over clips of one skeleton pays it once."""
+    tensor that comparison is a device->host synchronisation per call; the verdict is remembered per tensor OBJECT
+    (weak reference, never its address: freed blocks are reused) and in-place version, so a loop over clips of one
+    skeleton pays it once and every new tensor is checked."""
     if be.name != "torch" or not getattr(offsets, "is_cuda", False):
         off0 = np.asarray(offsets[0].detach().cpu() if be.name == "torch" else offsets[0])
         assert (off0 == 0).all()
         return
-    key = (offsets.data_ptr(), offsets._version, tuple(offsets.shape), offsets.dtype, offsets.device)
-    if _ROOT_OFFSET_CHECKED.get("key") == key:
+    if be._memo_get(_ROOT_OFFSET_CHECKED, "offsets", offsets):
         return
     assert bool((offsets[0] == 0).all())
-    _ROOT_OFFSET_CHECKED["key"] = key
+    be._memo_put(_ROOT_OFFSET_CHECKED, "offsets", offsets, True)
 
 
 def to_root_dual_quat(be, rotations, global_pos, parents, offsets):
@@ -565,7 +565,7 @@ def mirror(be, local_rotations, global_translation, parents, offsets, end_sites=
             raise ValueError("joints_mapping must be provided for mode 'symmetry'")
         if len(joints_mapping) != J:
             raise ValueError("joints_mapping must have the same length as the number of joints")
-        mp = be.host_ints(joints_mapping)
+        mp = be.host_ints(joints_mapping, slot="joints_mapping")
     ax = _MIRROR_AXIS[axis]
     # world rotations come out of fk (float64 through the NumPy door, rot.dtype through torch), then
     # from_matrix / from_global_rotations keep that dtype

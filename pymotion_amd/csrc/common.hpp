@@ -352,11 +352,24 @@ __device__ __forceinline__ void from_to_axis(const float (&v1)[3], const float (
 
 // ---- host-side helpers -------------------------------------------------------------------------------
 
+// Tuning aids (frames per wave, tiles per workgroup, ablations) exist ONLY in the -DPM_TUNING build
+// (libpmhip_tuning.so, `make tuning`): the production library never reads the environment and carries no
+// ablation branch, so a stray PM_* variable cannot change a result or turn a valid call into an error.
+#ifdef PM_TUNING
+int tune_env(const char *name, int dflt);  // atoi(getenv(name)) or dflt (host.hip)
+#define PM_ABLATED(a, bit) (((a).ablate & (bit)) != 0)
+#else
+constexpr int tune_env(const char *, int dflt) { return dflt; }
+#define PM_ABLATED(a, bit) false
+#endif
+
 struct Parents {  // passed to kernels BY VALUE (kernarg segment -> s_load_dword, uniform index)
     int32_t p[PM_MAX_JOINTS];
 };
 
 void set_error(const char *fmt, ...);
+void set_kernel_name(const char *fmt, ...);  // what the call dispatched to, as rocprofv3 prints it (pm_last_kernel_name)
+inline const char *tf(bool b) { return b ? "true" : "false"; }
 int check_hip(hipError_t e, const char *what);
 int pack_parents(const int32_t *parents, int32_t J, Parents &out);  // validates topology
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -41,7 +41,7 @@ struct ToRootArgs {
     float *dq;              // [F,J,8]
     int64_t F;
     int32_t J;
-    int32_t ablate;  // tuning aid (env PM_DQ_ABLATE): 1 = skip the walk, 2 = skip phase C
+    int32_t ablate;  // PM_TUNING build only (env PM_DQ_ABLATE): 1 = skip the walk, 2 = skip phase C; always 0 in production
     Parents parents;
 };
 
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
         S.vc = tb[(o >> 3) * 12 + 24]; S.w1 = tb[(o >> 3) * 12 + 25]; S.w2 = tb[(o >> 3) * 12 + 26];
         gq = q; gt = t; par = parn;
     };
-    for (int jb = (a.ablate & 1) ? J : 0; jb < J; jb += PM_WAVE) {
+    for (int jb = PM_ABLATED(a, 1) ? J : 0; jb < J; jb += PM_WAVE) {
         // effective parents of joints jb+1 .. jb+64 across the lanes: one v_readlane per step
         const int i0 = jb + 1 + lane;
         const int pv = sPar[i0 < J ? i0 : J];
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
     }
     wave_sync();
     // phase C, lane per (frame, joint): (q, t) -> [q, 0.5 (0,t) (x) q]  (dual_quat.py:28-36), off the chain
-    for_each_slot<2>((a.ablate & 2) ? 0 : n, lane, [&](const int e, const bool valid) {
+    for_each_slot<2>(PM_ABLATED(a, 2) ? 0 : n, lane, [&](const int e, const bool valid) {
         const int f = (int)(((float)e + 0.5f) * invJ);
         const int j = e - f * J;
         float *slot = sDq + f * FS + j * 8;
@@ -229,6 +229,7 @@ static int launch_to_root(const ToRootArgs &a, bool vec, hipStream_t s) {
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
     const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
     if (grid > 0x7fffffffLL) { set_error("to_root_dq: grid too large"); return PM_EUNSUPPORTED; }
+    set_kernel_name("void pm::to_root_dq_kernel<%d, %s>(pm::ToRootArgs)", FPW, tf(vec));
     if (vec) {
         auto k = to_root_dq_kernel<FPW, true>;
         if (int e = allow_lds(k, lds)) return e;
@@ -337,16 +338,14 @@ static int launch_gather(const GatherArgs &a, bool vec, hipStream_t s) {
     const size_t extra = (size_t)a.J * sizeof(int);  // parents table
     int fpw = ((160 + a.J - 1) / a.J + 3) & ~3;
     if (fpw < 4) fpw = 4;
-    {
-        const char *e = getenv("PM_GATHER_FPW");  // tuning aid
-        if (e && atoi(e) >= 4) fpw = atoi(e) & ~3;
-    }
+    if (const int v = tune_env("PM_GATHER_FPW", 0); v >= 4) fpw = v & ~3;  // PM_TUNING build only
     while (fpw > 4 && fpw * per_frame + extra > kMaxLds / 4) fpw -= 4;
     if (fpw * per_frame + extra > kMaxLds) { set_error("gather: J too large for LDS"); return PM_EUNSUPPORTED; }
     const size_t lds = fpw * per_frame + extra;
     const int64_t ntiles = (a.F + fpw - 1) / fpw;
     const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
     if (grid > 0x7fffffffLL) { set_error("gather: grid too large"); return PM_EUNSUPPORTED; }
+    set_kernel_name("void pm::gather_parent_kernel<%d, %s>(pm::GatherArgs, int)", MODE, tf(vec));
     if (vec) {
         auto k = gather_parent_kernel<MODE, true>;
         if (int e = allow_lds(k, lds)) return e;
@@ -369,16 +368,13 @@ extern "C" int pm_to_root_dq_f32(const float *rot, const float *root_pos, const 
     PM_CHECK_ARGS(rot && root_pos && parents && offsets && dq, "to_root_dq: null pointer");
     ToRootArgs a;
     a.rot = rot; a.root_pos = root_pos; a.offsets = offsets; a.dq = dq; a.F = F; a.J = J;
-    { const char *ab = getenv("PM_DQ_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
+    a.ablate = tune_env("PM_DQ_ABLATE", 0);
     if (int e = pack_parents(parents, J, a.parents)) return e;
     const bool vec = aligned16(rot) && aligned16(dq);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t per_frame = (size_t)to_root_frame_stride(J) * sizeof(float), fixed = (13 * (size_t)J + 37) * sizeof(float) + 256;
     int pick = (7 * (16 * per_frame + fixed) <= kMaxLds) ? 16 : 8;  // 4 lanes per frame; keep >= 7 waves per CU if possible
-    {
-        const char *e = getenv("PM_DQ_FPW");  // tuning aid
-        if (e && (atoi(e) == 16 || atoi(e) == 8 || atoi(e) == 4)) pick = atoi(e);
-    }
+    if (const int v = tune_env("PM_DQ_FPW", 0); v == 16 || v == 8 || v == 4) pick = v;  // PM_TUNING build only
     while (pick > 4 && pick * per_frame + fixed > kMaxLds) pick >>= 1;
     if (pick * per_frame + fixed <= kMaxLds) {
         if (pick == 16) return launch_to_root<16>(a, vec, s);

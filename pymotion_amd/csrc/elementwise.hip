@@ -582,8 +582,7 @@ extern "C" int pm_dq_unit_flags_f32(const float *dq, int64_t N, float atol, int3
 extern "C" int pm_stream_plain_f32(const float *src, float *dst, int64_t n4, int32_t ratio, int32_t blocks, pm_stream_t stream) {
     PM_CHECK_ARGS(src && dst && n4 >= 0 && ratio >= 1 && blocks >= 1 && aligned16(src) && aligned16(dst), "stream_plain: bad arguments");
     if (n4 == 0) return PM_OK;
-    const char *m = getenv("PM_PLAIN_MODE");  // tuning aid: 0..3 = nontemporal {none, loads, stores, both}
-    const int mode = m ? atoi(m) : 3;
+    const int mode = tune_env("PM_PLAIN_MODE", 3);  // PM_TUNING build only: 0..3 = nontemporal {none, loads, stores, both}
     auto *s4 = reinterpret_cast<const v4f *>(src);
     auto *d4 = reinterpret_cast<v4f *>(dst);
     hipStream_t st = static_cast<hipStream_t>(stream);

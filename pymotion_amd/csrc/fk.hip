@@ -43,7 +43,7 @@ struct FkArgs {
     int64_t F;
     int32_t J;
     float eps;              // ortho6d Gram-Schmidt floor
-    int32_t ablate;         // tuning aid (env PM_FK_ABLATE): 2 = no tree walk; 0 in production
+    int32_t ablate;         // PM_TUNING build only (env PM_FK_ABLATE): 2 = no tree walk; always 0 in production
     int32_t pad;            // floats of padding per frame in each per-frame LDS region (0 or 4), set by dispatch_fk
     Parents parents;
 };
@@ -414,9 +414,9 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
 
     if constexpr (QUAD) {
         const float seed = (c == 3) ? gp : ((c == r) ? 1.0f : 0.0f);
-        if (!(a.ablate & 2)) tree_walk_quad<PFO>(sRot, sPos, sOff, sConst, J, pad, f, r, c, seed, lane);
+        if (!PM_ABLATED(a, 2)) tree_walk_quad<PFO>(sRot, sPos, sOff, sConst, J, pad, f, r, c, seed, lane);
     } else {
-        tree_walk<PFO>(sRot, sPos, sOff, sConst, J, pad, f, r, gp, (a.ablate & 2) != 0);
+        tree_walk<PFO>(sRot, sPos, sOff, sConst, J, pad, f, r, gp, PM_ABLATED(a, 2));
     }
     wave_sync();
     image_store<VEC>(a.rotmats + f0 * J * 9, sRot, nf, J * 9, pad, lane);
@@ -564,9 +564,9 @@ __global__ __launch_bounds__(PM_WAVE) void fk_pipe_kernel(const FkArgs a, const 
         wave_sync();
         if constexpr (QUAD) {
             const float seed = (c == 3) ? gp_i : ((c == r) ? 1.0f : 0.0f);
-            if (!(a.ablate & 2)) tree_walk_quad<PFO>(sRot, sPos, sOff, sConst, J, pad, f, r, c, seed, lane);
+            if (!PM_ABLATED(a, 2)) tree_walk_quad<PFO>(sRot, sPos, sOff, sConst, J, pad, f, r, c, seed, lane);
         } else {
-            tree_walk<PFO>(sRot, sPos, sOff, sConst, J, pad, f, r, gp_i, (a.ablate & 2) != 0);
+            tree_walk<PFO>(sRot, sPos, sOff, sConst, J, pad, f, r, gp_i, PM_ABLATED(a, 2));
         }
         wave_sync();
     }
@@ -585,6 +585,7 @@ static int launch_fk_p(const FkArgs &a, hipStream_t s) {
         set_error("fk: %lld tiles exceed the grid limit", (long long)grid);
         return PM_EUNSUPPORTED;
     }
+    set_kernel_name("void pm::fk_kernel<%d, %s, %s, %d, %s, %s>(pm::FkArgs)", FPW, tf(VEC), tf(PFO), SRC, tf(QOUT), tf(PAD));
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
     return check_hip(hipGetLastError(), "fk launch");
 }
@@ -597,6 +598,7 @@ static int launch_fk_pipe_p(const FkArgs &a, const int nt, hipStream_t s) {
     const int64_t ntiles = (a.F + FPW - 1) / FPW, ngroups = (ntiles + nt - 1) / nt;
     const int64_t grid = ((ngroups + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
     if (grid > 0x7fffffffLL) { set_error("fk: grid too large"); return PM_EUNSUPPORTED; }
+    set_kernel_name("void pm::fk_pipe_kernel<%d, %d, %s, %d, %s, %s, %s>(pm::FkArgs, int)", FPW, EPL, tf(VEC), SRC, tf(QOUT), tf(PAD), tf(PFO));
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a, nt);
     return check_hip(hipGetLastError(), "fk launch");
 }
@@ -662,8 +664,8 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
     // The variants with a bigger image or a heavier phase A do better on the quad shape earlier (2^20 x 22: per-frame
     // offsets 422 us three-lane vs 358 us quad; ortho6d source 371 vs 350 us, at J = 24 226 vs 181 us, at J = 16 130 vs 139 us).
     if (pfo || (SRC == SRC_O6D && a.J >= 20)) pick = 4;
-    const char *ov = getenv("PM_FK_FPW");  // tuning aid: 20, 8 or 4
-    if (ov && atoi(ov) > 0) pick = atoi(ov);
+    pick = tune_env("PM_FK_FPW", pick);  // PM_TUNING build only: 20, 8 or 4
+    if (pick != 20 && pick != 8 && pick != 4) { set_error("PM_FK_FPW must be 20, 8 or 4"); return PM_EINVAL; }
     if ((size_t)pick * frame_bytes(pad3) + fixed > kMaxLds) pick = 4;
     a.pad = (pick == 4) ? pad12 : pad3;
     const size_t per_frame = frame_bytes(a.pad);
@@ -673,8 +675,7 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
         // 187 / 198 us with 1 / 2 / 4 / 8 tiles per workgroup; the same structure on the 20-frame tile of J = 22 is
         // slower (293 vs 270 us).
         int nt = ((a.F + 3) / 4 >= 16384) ? 2 : 1;
-        const char *e = getenv("PM_FK_NT");  // tuning aid: tiles per workgroup, 0 = fk_kernel
-        if (e) nt = atoi(e);
+        nt = tune_env("PM_FK_NT", nt);  // PM_TUNING build only: tiles per workgroup, 0 = fk_kernel
         if (nt > 0) return a.J <= 64 ? dispatch_fk_pipe<4, 4, SRC>(a, vec, pfo, nt, s) : dispatch_fk_pipe<4, 8, SRC>(a, vec, pfo, nt, s);
     }
     switch (pick) {
@@ -695,10 +696,7 @@ static int fk_common(int src_kind, const float *src, const float *root_pos, cons
     FkArgs a;
     a.src = src; a.root_pos = root_pos; a.offsets = offsets; a.pos = pos; a.rotmats = rotmats;
     a.quat_out = quat_out; a.F = F; a.J = J; a.eps = eps; a.pad = 0;  // set by dispatch_fk, per walk shape
-    {
-        const char *ab = getenv("PM_FK_ABLATE");
-        a.ablate = ab ? atoi(ab) : 0;
-    }
+    a.ablate = tune_env("PM_FK_ABLATE", 0);
     if (int e = pack_parents(parents, J, a.parents)) return e;
     const bool vec = aligned16(src) && aligned16(pos) && aligned16(rotmats) &&
                      (!offsets_per_frame || aligned16(offsets)) && (!quat_out || aligned16(quat_out));

@@ -2,6 +2,7 @@
 // memory / stream / event helpers for callers without their own HIP runtime binding.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "common.hpp"
 
@@ -9,12 +10,28 @@ namespace pm {
 
 static thread_local char g_err[512] = "";
 
+static thread_local char g_kernel[256] = "";
+
+void set_kernel_name(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+    va_end(ap);
+}
+
 void set_error(const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+#ifdef PM_TUNING
+int tune_env(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+#endif
 
 int check_hip(hipError_t e, const char *what) {
     if (e == hipSuccess) return PM_OK;
@@ -44,6 +61,7 @@ using namespace pm;
 
 extern "C" int pm_version(void) { return 1; }
 extern "C" const char *pm_last_error_string(void) { return g_err; }
+extern "C" const char *pm_last_kernel_name(void) { return g_kernel; }
 
 extern "C" int pm_device_count(void) {
     int n = 0;

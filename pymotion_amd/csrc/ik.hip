@@ -210,8 +210,7 @@ extern "C" int pm_from_root_positions_f32(const float *positions, const int32_t 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t per_frame = (size_t)ik_frame_stride(J) * sizeof(float), fixed = (size_t)(6 * J + 2) * sizeof(float) + 256;
     {
-        const char *e = getenv("PM_IK_FPW");  // tuning aid
-        const int v = e ? atoi(e) : 0;
+        const int v = tune_env("PM_IK_FPW", 0);  // PM_TUNING build only
         if (v == 64 && 64 * per_frame + fixed <= kMaxLds) return launch_ik<64>(a, vec, s);
         if (v == 32 && 32 * per_frame + fixed <= kMaxLds) return launch_ik<32>(a, vec, s);
         if (v == 16) return launch_ik<16>(a, vec, s);

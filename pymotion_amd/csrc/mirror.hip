@@ -190,10 +190,7 @@ extern "C" int pm_mirror_rotations_f32(const float *rot, const int32_t *parents,
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t per_frame = (size_t)mirror_frame_stride(J) * sizeof(float), fixed = (3 * (size_t)J + 9) * sizeof(float) + 256;
     int pick = (7 * (16 * per_frame + fixed) <= kMaxLds) ? 16 : 8;  // 4 lanes per frame; keep >= 7 waves per CU if possible
-    {
-        const char *e = getenv("PM_MIRROR_FPW");  // tuning aid
-        if (e && (atoi(e) == 16 || atoi(e) == 8 || atoi(e) == 4)) pick = atoi(e);
-    }
+    if (const int v = tune_env("PM_MIRROR_FPW", 0); v == 16 || v == 8 || v == 4) pick = v;  // PM_TUNING build only
     while (pick > 4 && pick * per_frame + fixed > kMaxLds) pick >>= 1;
     if (pick * per_frame + fixed <= kMaxLds) {
         if (pick == 16) return launch_mirror<16>(a, vec, s);

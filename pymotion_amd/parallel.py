@@ -4,8 +4,9 @@ backend ``"nccl"`` is RCCL over xGMI on ROCm, ``"gloo"`` on CPU for tests).
 Every op on the hot path is independent per frame (the joint chain is inside a frame), so the
 batch splits into contiguous frame blocks with NO data-path collective: rank r owns frames
 ``[r*F/W, (r+1)*F/W)`` (the first ``F % W`` ranks take one extra).  The only communication is the
-optional reassembly of ``(positions, rotmats)`` with ONE all-gather per output
-(``all_gather_into_tensor``; uneven shards are padded to the largest and trimmed).  At config-5
+optional reassembly of ``(positions, rotmats)`` with ONE all-gather per output, in two interchangeable forms:
+RCCL's ``all_gather_into_tensor`` (uneven shards padded to the largest and trimmed) and an explicit full-mesh
+``send/recv`` group (7 concurrent peer transfers per GPU, one per xGMI link; ``bench.py --gpus N`` times both).  At config-5
 sizes the gather moves 2.2 GB per GPU and costs 20-40x the kernel, so callers
 that consume the result data-parallel should pass ``gather=False`` and keep outputs sharded.
 """
@@ -25,19 +26,25 @@ def shard_sizes(F: int, world_size: int):
     return [shard_bounds(F, world_size, r)[1] - shard_bounds(F, world_size, r)[0] for r in range(world_size)]
 
 
-def all_gather_frames(local, F_total: int, group=None):
-    """All-gather shards along dim 0 (frames) into the full ``[F_total, ...]`` tensor on every rank.
+GATHER_METHODS = ("all_gather_into_tensor", "mesh_send_recv")
+_default_method = "all_gather_into_tensor"
 
-    One collective: shards are padded to the largest shard so ``all_gather_into_tensor`` applies,
-    then the padding rows are dropped.  With even shards no copy besides the collective happens.
-    """
+
+def set_default_gather_method(method: str) -> None:
+    """Pick what ``all_gather_frames`` uses when no ``method`` is given (``bench.py --gpus N`` measures both and
+    reports which one won on the node it ran on)."""
+    global _default_method
+    if method not in GATHER_METHODS:
+        raise ValueError(f"unknown gather method {method!r}; choose from {GATHER_METHODS}")
+    _default_method = method
+
+
+def _gather_collective(local, sizes, group):
+    """ONE ``all_gather_into_tensor``: shards padded to the largest so the collective applies, padding dropped after."""
     import torch
     import torch.distributed as dist
 
-    W = dist.get_world_size(group)
-    sizes = shard_sizes(F_total, W)
-    assert local.shape[0] == sizes[dist.get_rank(group)], "local shard does not match shard_bounds()"
-    mx = max(sizes)
+    W, mx = len(sizes), max(sizes)
     tail = tuple(local.shape[1:])
     if local.shape[0] != mx:
         pad = torch.zeros((mx - local.shape[0],) + tail, dtype=local.dtype, device=local.device)
@@ -49,7 +56,56 @@ def all_gather_frames(local, F_total: int, group=None):
     return torch.cat([out[r * mx: r * mx + sizes[r]] for r in range(W)], dim=0)
 
 
-def sharded_apply(fn: Callable, frame_args: Sequence, F_total: int, gather: bool = True, group=None):
+def _gather_mesh(local, sizes, group):
+    """Direct full mesh: every rank sends its shard to each of the W-1 peers and receives theirs straight into its
+    block of the result, all 2(W-1) transfers in ONE group (``batch_isend_irecv`` = ncclGroupStart ... ncclGroupEnd on
+    RCCL), so on a fully connected xGMI node each of a GPU's 7 links carries exactly one shard in each direction --
+    the pattern SURVEY 8(e) asks for; no padding for uneven shards, no staging copy besides our own block."""
+    import torch
+    import torch.distributed as dist
+
+    W, r = dist.get_world_size(group), dist.get_rank(group)
+    tail = tuple(local.shape[1:])
+    starts = [sum(sizes[:k]) for k in range(W)]
+    out = torch.empty((sum(sizes),) + tail, dtype=local.dtype, device=local.device)
+    local = local.contiguous()
+    ops = []
+    for step in range(1, W):  # peer order staggered by rank: at every step each link has one sender and one receiver
+        to, frm = (r + step) % W, (r - step) % W
+        g_to = dist.get_global_rank(group, to) if group is not None else to
+        g_frm = dist.get_global_rank(group, frm) if group is not None else frm
+        if sizes[r]:
+            ops.append(dist.P2POp(dist.isend, local, g_to, group))
+        if sizes[frm]:
+            ops.append(dist.P2POp(dist.irecv, out[starts[frm]: starts[frm] + sizes[frm]], g_frm, group))
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    out[starts[r]: starts[r] + sizes[r]].copy_(local)  # our own block, overlapping the transfers
+    for q in reqs:
+        q.wait()
+    return out
+
+
+def all_gather_frames(local, F_total: int, group=None, method=None):
+    """All-gather shards along dim 0 (frames) into the full ``[F_total, ...]`` tensor on every rank.
+
+    ``method``: ``"all_gather_into_tensor"`` (one RCCL collective; RCCL picks ring / direct itself) or
+    ``"mesh_send_recv"`` (explicit full-mesh point-to-point, one group); default = ``set_default_gather_method``.
+    Both return identical tensors.
+    """
+    import torch.distributed as dist
+
+    method = method or _default_method
+    if method not in GATHER_METHODS:
+        raise ValueError(f"unknown gather method {method!r}; choose from {GATHER_METHODS}")
+    W = dist.get_world_size(group)
+    sizes = shard_sizes(F_total, W)
+    assert local.shape[0] == sizes[dist.get_rank(group)], "local shard does not match shard_bounds()"
+    if W == 1:
+        return local.contiguous().clone() if method == "mesh_send_recv" else _gather_collective(local, sizes, group)
+    return _gather_mesh(local, sizes, group) if method == "mesh_send_recv" else _gather_collective(local, sizes, group)
+
+
+def sharded_apply(fn: Callable, frame_args: Sequence, F_total: int, gather: bool = True, group=None, method=None):
     """Run ``fn(*local_frame_args)`` on this rank's frame block of each ``[F_total, ...]`` argument.
 
     ``fn`` returns a tensor or a tuple of tensors with frames on dim 0.  With ``gather`` the
@@ -62,11 +118,11 @@ def sharded_apply(fn: Callable, frame_args: Sequence, F_total: int, gather: bool
     out = fn(*[a[s:e] for a in frame_args])
     outs = out if isinstance(out, tuple) else (out,)
     if gather:
-        outs = tuple(all_gather_frames(o, F_total, group) for o in outs)
+        outs = tuple(all_gather_frames(o, F_total, group, method) for o in outs)
     return outs if isinstance(out, tuple) else outs[0]
 
 
-def fk_sharded(rot, global_pos, offsets, parents, gather: bool = True, group=None, fk_fn=None):
+def fk_sharded(rot, global_pos, offsets, parents, gather: bool = True, group=None, fk_fn=None, method=None):
     """``fk`` over a frame-sharded batch.  ``rot [F, J, 4]`` and ``global_pos [F, 3]`` are the FULL
     arrays (or views of them); each rank computes only its block with the HIP kernel.
     ``fk_fn`` defaults to ``pymotion_amd.ops.skeleton_torch.fk`` (injectable for CPU/gloo tests).
@@ -76,5 +132,5 @@ def fk_sharded(rot, global_pos, offsets, parents, gather: bool = True, group=Non
         from .ops.skeleton_torch import fk as fk_fn
     per_frame = offsets.dim() > 2
     if per_frame:
-        return sharded_apply(lambda r_, g_, o_: fk_fn(r_, g_, o_, parents), [rot, global_pos, offsets], rot.shape[0], gather, group)
-    return sharded_apply(lambda r_, g_: fk_fn(r_, g_, offsets, parents), [rot, global_pos], rot.shape[0], gather, group)
+        return sharded_apply(lambda r_, g_, o_: fk_fn(r_, g_, o_, parents), [rot, global_pos, offsets], rot.shape[0], gather, group, method)
+    return sharded_apply(lambda r_, g_: fk_fn(r_, g_, offsets, parents), [rot, global_pos], rot.shape[0], gather, group, method)

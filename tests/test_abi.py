@@ -24,10 +24,34 @@ def test_header_and_library_agree():
     missing = [n for n in names if not hasattr(h, n)]
     assert not missing, f"declared in pmhip.h but not exported: {missing}"
     # and the Python binding table covers the whole header
-    unbound = set(names) - set(_lib.SIGNATURES) - {"pm_last_error_string"}
+    unbound = set(names) - set(_lib.SIGNATURES) - {"pm_last_error_string", "pm_last_kernel_name"}
     assert not unbound, f"declared but not bound in _lib.SIGNATURES: {unbound}"
     stale = set(_lib.SIGNATURES) - set(names)
     assert not stale, f"bound but not declared: {stale}"
+
+
+def test_production_library_never_reads_the_environment():
+    """Tuning / ablation aids live in libpmhip_tuning.so (-DPM_TUNING) only: the shipped library must not even
+    import getenv, so no PM_* variable can change a result (round-1 ADVICE)."""
+    import subprocess
+
+    def undefined(path):
+        out = subprocess.run(["nm", "-D", "--undefined-only", path], check=True, capture_output=True, text=True).stdout
+        return {line.split()[-1].split("@")[0] for line in out.splitlines() if line.strip()}
+
+    assert "getenv" not in undefined(_lib.VARIANT_PATHS["prod"])
+    if os.path.exists(_lib.VARIANT_PATHS["tuning"]):
+        assert "getenv" in undefined(_lib.VARIANT_PATHS["tuning"])
+
+
+def test_every_built_variant_exports_the_whole_header():
+    names = declared_symbols()
+    for name, path in _lib.VARIANT_PATHS.items():
+        if not os.path.exists(path):
+            assert name != "prod"
+            continue
+        h = C.CDLL(path)
+        assert not [n for n in names if not hasattr(h, n)], name
 
 
 def test_version_and_error_string():

@@ -80,3 +80,62 @@ def test_euler_order_arrays_are_compressed_to_what_repeats():
         _ops._order_codes(tiled, (F, J + 1))
     with pytest.raises(ValueError):
         _ops._order_table(per_joint, (F, J + 1))
+
+
+def test_torch_door_memo_is_keyed_on_the_tensor_object_not_its_address():
+    """The memo of device-resident `parents` must miss for a different tensor object even when address, version,
+    shape and dtype all coincide (caching-allocator reuse), hit for the same object, and miss after an in-place edit."""
+    from pymotion_amd._backend import TorchBackend
+
+    class FakeTensor:  # only what the memo looks at
+        def __init__(self, version=0):
+            self._version = version
+
+    table = {}
+    a, b = FakeTensor(), FakeTensor()
+    assert TorchBackend._memo_get(table, "parents", a) is None
+    TorchBackend._memo_put(table, "parents", a, "topology-a")
+    assert TorchBackend._memo_get(table, "parents", a) == "topology-a"
+    assert TorchBackend._memo_get(table, "parents", b) is None          # another object: never a hit
+    a._version = 1                                                       # in-place edit
+    assert TorchBackend._memo_get(table, "parents", a) is None
+    TorchBackend._memo_put(table, "parents", a, "topology-a1")
+    TorchBackend._memo_put(table, "joints_mapping", b, "mapping-b")      # independent slots do not evict each other
+    assert TorchBackend._memo_get(table, "parents", a) == "topology-a1"
+    assert TorchBackend._memo_get(table, "joints_mapping", b) == "mapping-b"
+    del a                                                                # the entry must not keep the tensor alive
+    import gc
+
+    gc.collect()
+    assert table["parents"][0]() is None
+    assert TorchBackend._memo_get(table, "parents", FakeTensor(1)) is None
+
+
+def test_device_pool_never_hands_a_block_to_another_device(monkeypatch):
+    """cached device blocks are keyed by the HIP device they were allocated on."""
+    import ctypes as C
+
+    from pymotion_amd import _backend, _lib
+
+    next_ptr = [0x1000]
+    freed = []
+
+    def fake_call(name, *args):
+        if name == "pm_malloc":
+            C.cast(args[0], C.POINTER(C.c_void_p))[0] = next_ptr[0]
+            next_ptr[0] += 0x1000
+        elif name == "pm_free":
+            freed.append(args[0].value)
+
+    monkeypatch.setattr(_lib, "call", fake_call)
+    pool = _backend._DevPool(cap_bytes=1 << 20)
+    p0, c0 = pool.get(1000, dev=0)
+    pool.put(p0, c0, dev=0)
+    p1, c1 = pool.get(1000, dev=1)          # same size class, other device: must be a fresh allocation
+    assert p1 != p0 and c1 == c0
+    p0b, _ = pool.get(1000, dev=0)          # same device: the cached block comes back
+    assert p0b == p0
+    pool.put(p0b, c0, dev=0)
+    pool.put(p1, c1, dev=1)
+    pool.trim()
+    assert sorted(freed) == sorted([p0, p1]) and pool.cached == 0

@@ -44,7 +44,7 @@ def _oracle_fk(rot, gpos, off, parents):
     return torch.from_numpy(p), torch.from_numpy(r)
 
 
-def _worker(rank, world, port, F, q):
+def _worker(rank, world, port, F, q, method="all_gather_into_tensor"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -53,7 +53,7 @@ def _worker(rank, world, port, F, q):
     try:
         rot, root, off, parents = syn.fk_workload(F, seed=42)
         rot, root, off, parents = map(torch.from_numpy, (rot, root, off, parents))
-        pos, rm = parallel.fk_sharded(rot, root, off, parents, gather=True, fk_fn=_oracle_fk)
+        pos, rm = parallel.fk_sharded(rot, root, off, parents, gather=True, fk_fn=_oracle_fk, method=method)
         lp, lr = parallel.fk_sharded(rot, root, off, parents, gather=False, fk_fn=_oracle_fk)
         s, e = parallel.shard_bounds(F, world, rank)
         full_p, full_r = _oracle_fk(rot, root, off, parents)
@@ -63,23 +63,44 @@ def _worker(rank, world, port, F, q):
         )
         # per-frame offsets take the 3-argument sharded path
         offs = off.unsqueeze(0).repeat(F, 1, 1) * torch.linspace(0.5, 1.5, F).view(F, 1, 1)
+        parallel.set_default_gather_method(method)  # ... and the process-wide default is honoured
         p2, _ = parallel.fk_sharded(rot, root, offs, parents, gather=True, fk_fn=_oracle_fk)
         ok = ok and torch.equal(p2, _oracle_fk(rot, root, offs, parents)[0])
+        # both reassemblies give the same tensor, shard by shard
+        a1 = parallel.all_gather_frames(lp, F, method="all_gather_into_tensor")
+        a2 = parallel.all_gather_frames(lp, F, method="mesh_send_recv")
+        ok = ok and torch.equal(a1, a2)
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("F", [64, 101])  # even and uneven shards
-def test_fk_sharded_gloo_world2(F):
+def _run(world, F, method):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, F, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, F, q, method)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(180)
         assert p.exitcode == 0
-    res = dict(q.get(timeout=5) for _ in range(2))
-    assert res == {0: True, 1: True}
+    res = dict(q.get(timeout=5) for _ in range(world))
+    assert res == {r: True for r in range(world)}
+
+
+@pytest.mark.parametrize("method", parallel.GATHER_METHODS)
+@pytest.mark.parametrize("F", [64, 101])  # even and uneven shards
+def test_fk_sharded_gloo_world2(F, method):
+    _run(2, F, method)
+
+
+def test_fk_sharded_gloo_world3_with_an_empty_shard():
+    """F < world: one rank owns no frames; the full-mesh gather must not post zero-size transfers"""
+    _run(3, 2, "mesh_send_recv")
+    _run(3, 2, "all_gather_into_tensor")
+
+
+def test_unknown_gather_method_is_rejected():
+    with pytest.raises(ValueError):
+        parallel.set_default_gather_method("ring")

@@ -399,11 +399,20 @@ def test_fk_and_dq_vs_oracle_sizes(F, J):
 @pytest.mark.parametrize("nt", ["0", "1", "2", "3", "7"])
 @pytest.mark.parametrize("F,J", [(4 * 7 + 1, 52), (4 * 6, 28), (3, 64), (4 * 13 + 2, 33), (4 * 5 + 3, 65), (9, 128), (6, 96)])
 def test_fk_pipelined_tiles_ragged_groups(monkeypatch, nt, F, J):
-    """28 <= J <= 128 runs fk_pipe_kernel (4 records per lane up to 64 joints, 8 beyond): `nt` tiles per workgroup (PM_FK_NT; 0 = the one-tile kernel).
-    Odd tile counts, a partial last tile and a partial last group must all come out identical."""
+    """28 <= J <= 128 runs fk_pipe_kernel (4 records per lane up to 64 joints, 8 beyond): `nt` tiles per workgroup (0 = the
+    one-tile kernel).  Odd tile counts, a partial last tile and a partial last group must all come out identical.
+    Production picks nt from the batch size; the tuning build of the library (-DPM_TUNING) takes it from PM_FK_NT."""
+    from pymotion_amd import _lib
     from pymotion_amd import synthetic as syn
 
     monkeypatch.setenv("PM_FK_NT", nt)
+    with _lib.variant("tuning"):
+        _fk_pipelined_body(F, J)
+
+
+def _fk_pipelined_body(F, J):
+    from pymotion_amd import synthetic as syn
+
     rng = np.random.default_rng(F * 100 + J)
     parents = syn.PARENTS_52 if J == 52 else syn.random_parents(J, rng)
     rot = rng.standard_normal((F, J, 4)).astype(np.float32)
@@ -478,6 +487,53 @@ def test_device_resident_parents_and_offsets_are_rechecked_when_they_change():
     tp[3] = 7  # not topological any more
     with pytest.raises(ValueError):
         skt.fk(tr, tg, to, tp)
+
+
+def test_a_new_parents_tensor_at_a_recycled_address_is_a_new_skeleton():
+    """Regression (round-1 verdict, ADVICE): torch's caching allocator hands the freed block of one `parents` tensor to
+    the next tensor of the same size, with version 0 again -- an (address, version) key then serves the PREVIOUS
+    skeleton's topology.  The memo is keyed on the tensor object; every new tensor is re-read like the reference does
+    (skeleton_torch.py:56)."""
+    torch, skt = _torch_mods()[:2]
+    from pymotion_amd import synthetic as syn
+
+    J, F = 22, 65
+    rng = np.random.default_rng(5)
+    rot, root, off, _ = syn.fk_workload(F, seed=6, normalized=True)
+    tr, tg, to = (torch.from_numpy(a).cuda() for a in (rot, root, off))
+    chain = np.maximum(np.arange(J) - 1, 0).astype(np.int64)
+    topologies = [syn.PARENTS_22.astype(np.int64), chain] + [syn.random_parents(J, rng).astype(np.int64) for _ in range(6)]
+    reused, prev_ptr = 0, None
+    for k, par in enumerate(topologies * 3):
+        tp = torch.from_numpy(par).cuda()          # fresh tensor, version 0
+        reused += int(tp.data_ptr() == prev_ptr)
+        pos, rm = skt.fk(tr, tg, to, tp)
+        p_o, r_o = co.fk(rot.astype(np.float64), root.astype(np.float64), off.astype(np.float64), par.astype(np.int32))
+        assert_close(pos.cpu().numpy(), p_o, ATOL, f"topology {k}")
+        assert_close(rm.cpu().numpy(), r_o, ATOL, f"topology {k}")
+        dq = skt.to_root_dual_quat(tr, tg, tp, to)
+        assert_close(dq.cpu().numpy(), co.to_root_dual_quat(rot.astype(np.float64), root.astype(np.float64),
+                                                           par.astype(np.int32), off.astype(np.float64)), ATOL, f"dq {k}")
+        prev_ptr = tp.data_ptr()
+        del tp                                      # the block goes back to the allocator ...
+    assert reused > 0, "the allocator never recycled the address: the regression was not exercised"
+    # same hazard for the root-offset assertion (skeleton_torch.py:242): a NEW offsets tensor with offsets[0] != 0 that
+    # lands on the address of one already checked must still trip it
+    tp = torch.from_numpy(topologies[0]).cuda()
+    for _ in range(4):
+        good = torch.from_numpy(off).cuda()
+        skt.to_root_dual_quat(tr, tg, tp, good)
+        ptr = good.data_ptr()
+        del good
+        bad_np = off.copy()
+        bad_np[0, 2] = 0.25
+        bad = torch.from_numpy(bad_np).cuda()
+        if bad.data_ptr() == ptr:
+            reused += 100
+        with pytest.raises(AssertionError):
+            skt.to_root_dual_quat(tr, tg, tp, bad)
+        del bad
+    assert reused >= 100, "offsets address was never recycled"
 
 
 def test_numpy_door_large_inputs_take_the_threaded_staging_path():
