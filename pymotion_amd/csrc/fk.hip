@@ -56,15 +56,73 @@ struct FkArgs {
 // of 4 then); the image is then no longer the HBM layout verbatim and phase A / copy-out address it per frame
 // (image_slot / image_store).  Every other J keeps the linear image.  The choice is made in dispatch_fk.
 
-// LDS floats per frame-joint: rot 9 + pos 3 (+ per-frame offsets 3) (+ quat_out 4)
+// LDS floats per frame-joint: rot 9 + pos 3 (+ per-frame offsets 3) (+ quat_out 4) (+ position residuals 3, PREC_T64)
 template <int SRC, bool PFO, bool QOUT>
 constexpr int fk_lds_floats() { return 12 + (PFO ? 3 : 0) + (QOUT ? 4 : 0); }
 
-// quaternion -> local rotation of fk: normalise (skeleton.py:45, quat.py:423) then quat.py:276-317
+// quaternion -> local rotation of fk: normalise (skeleton.py:45, quat.py:423) then quat.py:276-317.
+//
+// PREC (bit mask) selects how much arithmetic the conversion gets.  The reference does all of this in float64
+// (skeleton.py:44); what an all-fp32 evaluation loses is dominated by ONE term: q^ = q * rcp(|q| + eps) misses unit
+// length by ~1.5 ulp, and the matrix is a quadratic form of q^, so (L - I) is off by twice that relative error
+// (up to 1.3e-6 absolute).  Down the chain that error is multiplied by the bone offsets: harmless at metre scale,
+// 2e-4 at centimetre scale (offsets ~30, |pos| ~400).
+//   PREC_FAST    the plain fp32 evaluation (round 1)
+//   PREC_RESID   fp32, but the matrix is scaled by 2 / |q^|^2 with |q^|^2 - 1 taken from an FMA chain (the residual
+//                of the normalisation, accurate to a few 1e-8): + 9 instructions, L error 1.3e-6 -> 5e-7
+//   PREC_F64     normalisation and quadratic form in float64 (products of fp32 inputs are exact there), one rounding
+//                per matrix entry: L error 3e-8
+//   PREC_T64     (walks) the translation chain is accumulated in float64 and rounded once per joint
+enum { PREC_FAST = 0, PREC_RESID = 1, PREC_F64 = 2, PREC_T64 = 4, PREC_NOLO = 8 /* experiment: T64 without residual storage */ };
+
+template <int PREC>
 __device__ __forceinline__ void local_from_quat(const float (&qi)[4], float (&L)[9]) {
-    float q[4];
-    qnormalize(qi, 1e-8f, q);
-    q2m(q, L);
+    if constexpr ((PREC & PREC_F64) != 0) {
+        const double w = qi[0], x = qi[1], y = qi[2], z = qi[3];
+        const double xx = x * x, yy = y * y, zz = z * z;
+        const double n2 = __builtin_fma(w, w, xx + (yy + zz));
+        const float n2f = (float)n2;
+        // 1 / |q|: hardware rsq (1 ulp) + one Newton step in float64 -> relative error ~1e-14
+        double yd = (double)__builtin_amdgcn_rsqf(n2f);
+        const double e = __builtin_fma(-n2 * yd, yd, 1.0);
+        yd = __builtin_fma(yd * e, 0.5, yd);
+        // 1 / (|q| + eps) = yd / (1 + eps yd) = yd (1 - eps yd) up to (eps yd)^2 < 1e-12 for |q| > 1e-2
+        const double inv = __builtin_fma(-1e-8 * yd, yd, yd);
+        const double s = 2.0 * inv * inv;
+        const double wz = w * z, wy = w * y, wx = w * x;
+        L[0] = (float)__builtin_fma(-s, yy + zz, 1.0); L[1] = (float)(s * __builtin_fma(x, y, -wz)); L[2] = (float)(s * __builtin_fma(x, z, wy));
+        L[3] = (float)(s * __builtin_fma(x, y, wz));   L[4] = (float)__builtin_fma(-s, xx + zz, 1.0); L[5] = (float)(s * __builtin_fma(y, z, -wx));
+        L[6] = (float)(s * __builtin_fma(x, z, -wy));  L[7] = (float)(s * __builtin_fma(y, z, wx));   L[8] = (float)__builtin_fma(-s, xx + yy, 1.0);
+        // tiny or zero quaternions (|q| < 1e-2: eps is no longer a perturbation; zero -> identity, skeleton.py:45): fp32 path
+        const bool tiny = !(n2f >= 1e-4f);
+        if (__builtin_amdgcn_ballot_w64(tiny) != 0) {  // wave-uniform, practically never taken
+            float q[4], Lf[9];
+            qnormalize(qi, 1e-8f, q);
+            q2m(q, Lf);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) L[k] = tiny ? Lf[k] : L[k];
+        }
+    } else if constexpr ((PREC & PREC_RESID) != 0) {
+        float q[4];
+        const float n = fsqrt(qi[0] * qi[0] + qi[1] * qi[1] + qi[2] * qi[2] + qi[3] * qi[3]);
+        const float inv = frcp(n + 1e-8f);
+        q[0] = qi[0] * inv; q[1] = qi[1] * inv; q[2] = qi[2] * inv; q[3] = qi[3] * inv;
+        const float w = q[0], x = q[1], y = q[2], z = q[3];
+        // |q^|^2 - 1 as the fp32 arithmetic left it; the reference's q^ has |q^| = |q| / (|q| + eps) = 1 - eps inv, so the
+        // scale that reproduces ITS matrix is 2 (1 - eps inv)^2 / |q^|^2 = 2 (1 - r - 2 eps inv) to first order.
+        const float r = __builtin_fmaf(w, w, __builtin_fmaf(x, x, __builtin_fmaf(y, y, __builtin_fmaf(z, z, -1.0f))));
+        float s = __builtin_fmaf(-2.0f, __builtin_fmaf(2e-8f, inv, r), 2.0f);
+        s = (n >= 1e-2f) ? s : 2.0f;  // tiny / zero quaternions: the reference's formula as it is (L = I + 2 M(q^))
+        const float zz = z * z, yy = y * y;
+        const float wz = w * z, wy = w * y, wx = w * x;
+        L[0] = __builtin_fmaf(-s, __builtin_fmaf(y, y, zz), 1.0f); L[1] = s * __builtin_fmaf(x, y, -wz); L[2] = s * __builtin_fmaf(x, z, wy);
+        L[3] = s * __builtin_fmaf(x, y, wz); L[4] = __builtin_fmaf(-s, __builtin_fmaf(x, x, zz), 1.0f); L[5] = s * __builtin_fmaf(y, z, -wx);
+        L[6] = s * __builtin_fmaf(x, z, -wy); L[7] = s * __builtin_fmaf(y, z, wx); L[8] = __builtin_fmaf(-s, __builtin_fmaf(x, x, yy), 1.0f);
+    } else {
+        float q[4];
+        qnormalize(qi, 1e-8f, q);
+        q2m(q, L);
+    }
 }
 
 
@@ -72,13 +130,18 @@ __device__ __forceinline__ void local_from_quat(const float (&qi)[4], float (&L)
 // sRot slot (f, j) holds the local rotation L_j on entry and row-by-row the world rotation on exit;
 // sPos receives the positions.  sConst[j] = {parent (int bits), t0, t1, t2}, entry J = clamp copy.
 // Lane (f, r) owns row r of frame f; `gp` = root_pos[f][r].
-template <bool PFO>
-__device__ __forceinline__ void tree_walk(float *sRot, float *sPos, const float *sOff, const float *sConst,
+// T64: the translation chain p_j = p_parent + R_parent t_j is carried in float64 (the dot product stays fp32: its
+// rounding is an ulp of |t|, not of |p|) and rounded ONCE per joint for the output; the part of p_j that the fp32
+// output cannot hold goes to sLo so that a child which re-reads its parent from the image resumes the exact chain.
+template <bool PFO, bool T64, bool LO = true>
+__device__ __forceinline__ void tree_walk(float *sRot, float *sPos, float *sLo, const float *sOff, const float *sConst,
                                           const int J, const int pad, const int f, const int r, const float gp, const bool skip) {
     float *fL = sRot + f * (J * 9 + pad);  // this frame's slots (L before, G after)
     float *fRot = fL + r * 3;              // this lane's row inside a slot
     float *fPos = sPos + f * (J * 3 + pad) + r;
+    float *fLo = sLo + f * (J * 3 + pad) + r;
     const float *fOff = sOff + f * (J * 3 + pad);
+    double gt64 = (double)gp;
 
     // Row r of joint j-1's transform, seeded so that joint 0 falls out of the same formula:
     // e_r . L = row r of L (exact: 1*x + 0*y + 0*z) and translation = root_pos[r] (offsets[0] ignored).
@@ -89,15 +152,23 @@ __device__ __forceinline__ void tree_walk(float *sRot, float *sPos, const float 
         const int par = __builtin_amdgcn_readfirstlane(__float_as_int(c.x));
         float t0 = c.y, t1 = c.z, t2 = c.w;
         float p0 = g0, p1 = g1, p2 = g2, pt = gt;
+        double pt64 = gt64;
         if (par != j - 1) {  // wave-uniform: not the previous joint -> its row is in the image
             p0 = fRot[par * 9]; p1 = fRot[par * 9 + 1]; p2 = fRot[par * 9 + 2];
             pt = fPos[par * 3];
+            if (T64) pt64 = LO ? (double)pt + (double)fLo[par * 3] : (double)pt;
         }
         if (PFO && j > 0) { t0 = fOff[3 * j]; t1 = fOff[3 * j + 1]; t2 = fOff[3 * j + 2]; }
         g0 = p0 * L[0] + p1 * L[3] + p2 * L[6];
         g1 = p0 * L[1] + p1 * L[4] + p2 * L[7];
         g2 = p0 * L[2] + p1 * L[5] + p2 * L[8];
-        gt = p0 * t0 + p1 * t1 + p2 * t2 + pt;
+        if (T64) {
+            gt64 = pt64 + (double)(p0 * t0 + p1 * t1 + p2 * t2);
+            gt = (float)gt64;
+            if (LO) fLo[j * 3] = (float)(gt64 - (double)gt);
+        } else {
+            gt = p0 * t0 + p1 * t1 + p2 * t2 + pt;
+        }
         // all three lanes of the frame have read slot j (in-order DS) -> overwrite in place
         fRot[j * 9] = g0; fRot[j * 9 + 1] = g1; fRot[j * 9 + 2] = g2;
         fPos[j * 3] = gt;
@@ -151,10 +222,10 @@ __device__ __forceinline__ float quad_dot3(const float e, const float a0, const 
     return acc;
 }
 
-template <bool PFO>
-__device__ __forceinline__ void tree_walk_quad(float *sRot, float *sPos, const float *sOff, const float *sConst,
+template <bool PFO, bool T64, bool LO = true>
+__device__ __forceinline__ void tree_walk_quad(float *sRot, float *sPos, float *sLo, const float *sOff, const float *sConst,
                                                const int J, const int pad, const int f, const int r, const int c, const float seed,
-                                               const int lane) {
+                                               const int lane, float *lo_scratch) {
     float *fL = sRot + f * (J * 9 + pad);
     // what this lane multiplies the parent row with at joint j: column c of L_j = row c of the transposed
     // slot, or, for the position lane, the offset t_j (constant table, or the per-frame offsets tile)
@@ -168,6 +239,13 @@ __device__ __forceinline__ void tree_walk_quad(float *sRot, float *sPos, const f
     float g = seed;  // element (r, c) of joint j-1: joint 0 multiplies the seed row e_r | root_pos[r] (exact)
     float *own = own0;
     int par = -1;
+    // T64 (see tree_walk): the position lane carries its element in float64; on the rotation lanes the same
+    // instructions reduce to g = dot exactly (m3 = 0) and the residual they park is 0, in one scratch word.
+    double g64 = (double)seed;
+    const double m3d = (double)m3;
+    float *lo0 = (c == 3) ? (sLo + f * (J * 3 + pad) + r) : lo_scratch;
+    const int lstep = (c == 3) ? 3 : 0;
+    float *lo_own = lo0;
     // One step, straight-line (no branch, so every LDS wait is a counted one):
     //   * `a` = this joint's coefficients, requested two steps ago; once used the same registers are
     //     refilled with joint j+2's (slots j+1, j+2 still hold L^T; the image and the table have two
@@ -175,10 +253,19 @@ __device__ __forceinline__ void tree_walk_quad(float *sRot, float *sPos, const f
     //   * `pe` = the parent's element read from the image one step ago -- used when the parent is not
     //     joint j-1 (then it was finished, and written, before step j-1); otherwise the register chain;
     //   * first thing, the same read is issued for joint j+1 (`pen`).
-    auto step = [&](const int j, const int parn, float (&a)[3], const float pe, float &pen, const bool last_may_be_dummy) {
+    auto step = [&](const int j, const int parn, float (&a)[3], const float pe, float &pen, const float pl, float &pln,
+                    const bool last_may_be_dummy) {
         pen = own0[__umul24(parn, ostep)];
+        if (T64 && LO) pln = lo0[__umul24(parn, lstep)];
         const float e = (par == j - 1) ? g : pe;  // wave-uniform
-        g = __builtin_fmaf(m3, e, quad_dot3(e, a[0], a[1], a[2]));  // + Gp[r][3] on the position lane
+        if (T64) {
+            const double e64 = (par == j - 1) ? g64 : (LO ? (double)pe + (double)pl : (double)pe);
+            g64 = __builtin_fma(m3d, e64, (double)quad_dot3(e, a[0], a[1], a[2]));
+            g = (float)g64;
+            if (LO) { if (!last_may_be_dummy || j < J) *lo_own = (float)(g64 - (double)g); lo_own += lstep; }
+        } else {
+            g = __builtin_fmaf(m3, e, quad_dot3(e, a[0], a[1], a[2]));  // + Gp[r][3] on the position lane
+        }
         if (!last_may_be_dummy || j < J) *own = g;
         own += ostep;
         a[0] = coef[2 * cstep]; a[1] = coef[2 * cstep + 1]; a[2] = coef[2 * cstep + 2];
@@ -187,7 +274,7 @@ __device__ __forceinline__ void tree_walk_quad(float *sRot, float *sPos, const f
     };
     float A[3] = {coef[0], coef[1], coef[2]}, B[3] = {coef[cstep], coef[cstep + 1], coef[cstep + 2]};
     if (c == 3) { A[0] = 0.0f; A[1] = 0.0f; A[2] = 0.0f; }  // root: translation = the seed itself (offsets[0] ignored)
-    float peA = 0.0f, peB = 0.0f;
+    float peA = 0.0f, peB = 0.0f, plA = 0.0f, plB = 0.0f;
     for (int jb = 0; jb < J; jb += PM_WAVE) {
         // parents of joints jb+1 .. jb+64 across the lanes (the table repeats its last entry past J)
         const int i0 = jb + 1 + lane;
@@ -195,8 +282,8 @@ __device__ __forceinline__ void tree_walk_quad(float *sRot, float *sPos, const f
         const int jend = (J - jb) < PM_WAVE ? (J - jb) : PM_WAVE;
         asm volatile("" ::"v"(pv));  // settle the window load here, not as an lgkmcnt(0) inside the loop
         for (int jj = 0; jj < jend; jj += 2) {  // pairs; for odd J the very last step is a dummy that stores nothing
-            step(jb + jj, __builtin_amdgcn_readlane(pv, jj), A, peA, peB, false);
-            step(jb + jj + 1, __builtin_amdgcn_readlane(pv, jj + 1), B, peB, peA, true);
+            step(jb + jj, __builtin_amdgcn_readlane(pv, jj), A, peA, peB, plA, plB, false);
+            step(jb + jj + 1, __builtin_amdgcn_readlane(pv, jj + 1), B, peB, peA, plB, plA, true);
         }
     }
 }
@@ -268,8 +355,9 @@ __device__ __forceinline__ void image_load(const float *__restrict__ g, float *l
     }
 }
 
-template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT, bool PAD>
+template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT, bool PAD, int PREC>
 __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int64_t f0, const int nf, const int lane) {
+    constexpr bool T64 = (PREC & PREC_T64) != 0;
     const int J = a.J;
     const int FJ = FPW * J;
     const int n = nf * J;  // (frame, joint) elements in this tile
@@ -282,6 +370,7 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
     float *sOff = sPos + FJ * 3 + FPW * pad;           // [FPW*(J*3+pad)]  (PFO)
     float *sQo = sOff + (PFO ? FJ * 3 + FPW * pad : 0);  // [FPW*J*4]  (QOUT; lane-per-record access only: linear)
     float *sConst = sQo + (QOUT ? FJ * 4 : 0);         // [(J+4)*4]  per joint {parent (int bits), t0, t1, t2}
+    float *sLo = sConst + 4 * (J + 4);                 // [FPW*(J*3+pad) + 4]  (PREC_T64: what fp32 positions cannot hold)
 
     // Every global load of the tile is issued up front, back to back, so the wave pays ONE memory
     // latency: root position (used first by phase B), skeleton constants, then the rotations.
@@ -322,7 +411,7 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
             if (e0 >= n) return;  // wave-uniform
             float L[4][9];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) local_from_quat(qi[u], L[u]);
+            for (int u = 0; u < 4; ++u) local_from_quat<PREC>(qi[u], L[u]);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int e = e0 + u * PM_WAVE + lane;
@@ -378,7 +467,7 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
                     float m[9];
                     o6d2m(xx, a.eps, m);
                     m2q(m, Q[u]);
-                    local_from_quat(Q[u], L[u]);
+                    local_from_quat<PREC>(Q[u], L[u]);
                 } else {
                     // Without the quaternion output the trip matrix -> quaternion -> normalise -> matrix is the
                     // identity on an orthonormal matrix up to fp32 rounding (~2e-7, two orders inside the parity
@@ -414,9 +503,9 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
 
     if constexpr (QUAD) {
         const float seed = (c == 3) ? gp : ((c == r) ? 1.0f : 0.0f);
-        if (!PM_ABLATED(a, 2)) tree_walk_quad<PFO>(sRot, sPos, sOff, sConst, J, pad, f, r, c, seed, lane);
+        if (!PM_ABLATED(a, 2)) tree_walk_quad<PFO, T64, !(PREC & PREC_NOLO)>(sRot, sPos, sLo, sOff, sConst, J, pad, f, r, c, seed, lane, sLo + FPW * (J * 3 + pad));
     } else {
-        tree_walk<PFO>(sRot, sPos, sOff, sConst, J, pad, f, r, gp, PM_ABLATED(a, 2));
+        tree_walk<PFO, T64, !(PREC & PREC_NOLO)>(sRot, sPos, sLo, sOff, sConst, J, pad, f, r, gp, PM_ABLATED(a, 2));
     }
     wave_sync();
     image_store<VEC>(a.rotmats + f0 * J * 9, sRot, nf, J * 9, pad, lane);
@@ -425,7 +514,7 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
 }
 
 // One tile (FPW frames) per single-wave workgroup; XCD-aware tile order (common.hpp).
-template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT, bool PAD>
+template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT, bool PAD, int PREC>
 __global__ __launch_bounds__(PM_WAVE) void fk_kernel(const FkArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
@@ -433,7 +522,7 @@ __global__ __launch_bounds__(PM_WAVE) void fk_kernel(const FkArgs a) {
     if (tile < 0) return;
     const int64_t f0 = tile * FPW;
     const int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
-    fk_tile<FPW, VEC, PFO, SRC, QOUT, PAD>(a, smem, f0, nf, threadIdx.x);
+    fk_tile<FPW, VEC, PFO, SRC, QOUT, PAD, PREC>(a, smem, f0, nf, threadIdx.x);
 }
 
 // ---- pipelined form for mid-size skeletons (tree_walk_quad shape: FPW = 4, J <= 64, shared offsets) ---
@@ -446,9 +535,10 @@ __global__ __launch_bounds__(PM_WAVE) void fk_kernel(const FkArgs a) {
 // so loads overlap the walk and the stores overlap the next tile's math and walk.  The vmcnt wait in
 // front of math(i+1) only ever covers loads that are a whole walk old (the stores of tile i are issued
 // after it).  The skeleton table is staged once per workgroup.
-template <int FPW, int EPL, bool VEC, int SRC, bool QOUT, bool PAD, bool PFO>
+template <int FPW, int EPL, bool VEC, int SRC, bool QOUT, bool PAD, bool PFO, int PREC>
 __global__ __launch_bounds__(PM_WAVE) void fk_pipe_kernel(const FkArgs a, const int nt) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr bool T64 = (PREC & PREC_T64) != 0;
     constexpr bool QUAD = FPW <= 5;  // records per lane: FPW * J <= 64 * EPL
     const int lane = threadIdx.x;
     const int J = a.J;
@@ -466,6 +556,7 @@ __global__ __launch_bounds__(PM_WAVE) void fk_pipe_kernel(const FkArgs a, const 
     float *sOff = sPos + FJ * 3 + FPW * pad;     // [FPW*(J*3+pad)]  (PFO: per-frame offsets)
     float *sQo = sOff + (PFO ? FJ * 3 + FPW * pad : 0);  // [FJ*4]  (QOUT)
     float *sConst = sQo + (QOUT ? FJ * 4 : 0);   // [(J+4)*4]
+    float *sLo = sConst + 4 * (J + 4);           // [FPW*(J*3+pad) + 4]  (PREC_T64)
     for (int j = lane; j <= J; j += PM_WAVE) reinterpret_cast<v4f *>(sConst)[j] = load_joint_const<PFO>(a.parents, a.offsets, J, j);
 
     const int wl = lane % ((QUAD ? 12 : 3) * FPW);
@@ -528,14 +619,14 @@ __global__ __launch_bounds__(PM_WAVE) void fk_pipe_kernel(const FkArgs a, const 
         for (int u = 0; u < EPL; ++u) {
             if constexpr (SRC == SRC_QUAT) {
                 const float qi[4] = {in4[u].x, in4[u].y, in4[u].z, in4[u].w};
-                local_from_quat(qi, L[u]);
+                local_from_quat<PREC>(qi, L[u]);
             } else {
                 const float xx[6] = {in2[u][0].x, in2[u][0].y, in2[u][1].x, in2[u][1].y, in2[u][2].x, in2[u][2].y};
                 if constexpr (QOUT) {
                     float m[9];
                     o6d2m(xx, a.eps, m);
                     m2q(m, Q[u]);
-                    local_from_quat(Q[u], L[u]);
+                    local_from_quat<PREC>(Q[u], L[u]);
                 } else {
                     o6d2m(xx, a.eps, L[u]);  // the Gram-Schmidt result IS the local rotation (see fk_tile)
                 }
@@ -564,9 +655,9 @@ __global__ __launch_bounds__(PM_WAVE) void fk_pipe_kernel(const FkArgs a, const 
         wave_sync();
         if constexpr (QUAD) {
             const float seed = (c == 3) ? gp_i : ((c == r) ? 1.0f : 0.0f);
-            if (!PM_ABLATED(a, 2)) tree_walk_quad<PFO>(sRot, sPos, sOff, sConst, J, pad, f, r, c, seed, lane);
+            if (!PM_ABLATED(a, 2)) tree_walk_quad<PFO, T64, !(PREC & PREC_NOLO)>(sRot, sPos, sLo, sOff, sConst, J, pad, f, r, c, seed, lane, sLo + FPW * (J * 3 + pad));
         } else {
-            tree_walk<PFO>(sRot, sPos, sOff, sConst, J, pad, f, r, gp_i, PM_ABLATED(a, 2));
+            tree_walk<PFO, T64, !(PREC & PREC_NOLO)>(sRot, sPos, sLo, sOff, sConst, J, pad, f, r, gp_i, PM_ABLATED(a, 2));
         }
         wave_sync();
     }
@@ -574,10 +665,23 @@ __global__ __launch_bounds__(PM_WAVE) void fk_pipe_kernel(const FkArgs a, const 
 }
 
 
-template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT, bool PAD>
-static int launch_fk_p(const FkArgs &a, hipStream_t s) {
-    const size_t lds = ((size_t)FPW * (a.J * fk_lds_floats<SRC, PFO, QOUT>() + a.pad * (PFO ? 3 : 2)) + 4 * (a.J + 4)) * sizeof(float);
-    auto k = fk_kernel<FPW, VEC, PFO, SRC, QOUT, PAD>;
+// Arithmetic of the production library (see local_from_quat); the PM_TUNING build can override it per call (PM_FK_PREC)
+// on the main variants to measure what each step costs.
+#ifndef PM_FK_PREC_DEFAULT
+#define PM_FK_PREC_DEFAULT PREC_RESID
+#endif
+
+// LDS of the position residuals (PREC_T64): one float per position element + the rotation lanes' scratch word
+static size_t fk_lo_floats(const int prec, const int fpw, const int J, const int pad) {
+    if (tune_env("PM_FK_LOALLOC", 0)) return (size_t)fpw * (J * 3 + pad) + 4;  // experiment: the LDS cost alone
+    return ((prec & PREC_T64) && !(prec & PREC_NOLO)) ? (size_t)fpw * (J * 3 + pad) + 4 : 0;
+}
+
+template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT, bool PAD, int PREC>
+static int launch_fk_pp(const FkArgs &a, hipStream_t s) {
+    const size_t lds = ((size_t)FPW * (a.J * fk_lds_floats<SRC, PFO, QOUT>() + a.pad * (PFO ? 3 : 2)) + 4 * (a.J + 4) +
+                        fk_lo_floats(PREC, FPW, a.J, a.pad)) * sizeof(float);
+    auto k = fk_kernel<FPW, VEC, PFO, SRC, QOUT, PAD, PREC>;
     if (int e = allow_lds(k, lds)) return e;
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
     const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
@@ -585,22 +689,61 @@ static int launch_fk_p(const FkArgs &a, hipStream_t s) {
         set_error("fk: %lld tiles exceed the grid limit", (long long)grid);
         return PM_EUNSUPPORTED;
     }
-    set_kernel_name("void pm::fk_kernel<%d, %s, %s, %d, %s, %s>(pm::FkArgs)", FPW, tf(VEC), tf(PFO), SRC, tf(QOUT), tf(PAD));
+    set_kernel_name("void pm::fk_kernel<%d, %s, %s, %d, %s, %s, %d>(pm::FkArgs)", FPW, tf(VEC), tf(PFO), SRC, tf(QOUT), tf(PAD), PREC);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
+    return check_hip(hipGetLastError(), "fk launch");
+}
+
+template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT, bool PAD>
+static int launch_fk_p(const FkArgs &a, hipStream_t s) {
+#ifdef PM_TUNING
+    if constexpr (VEC && !PFO && !QOUT) {
+        switch (tune_env("PM_FK_PREC", PM_FK_PREC_DEFAULT)) {
+            case 0: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 0>(a, s);
+            case 1: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 1>(a, s);
+            case 2: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 2>(a, s);
+            case 4: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 4>(a, s);
+            case 5: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 5>(a, s);
+            case 6: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 6>(a, s);
+            case 13: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 13>(a, s);
+            default: set_error("PM_FK_PREC must be 0, 1, 2, 4, 5 or 6"); return PM_EINVAL;
+        }
+    }
+#endif
+    return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, PM_FK_PREC_DEFAULT>(a, s);
+}
+
+template <int FPW, int EPL, bool VEC, int SRC, bool QOUT, bool PAD, bool PFO, int PREC>
+static int launch_fk_pipe_pp(const FkArgs &a, const int nt, hipStream_t s) {
+    const size_t lds = ((size_t)FPW * (a.J * (12 + (PFO ? 3 : 0) + (QOUT ? 4 : 0)) + (PFO ? 3 : 2) * a.pad) + 4 * (a.J + 4) +
+                        fk_lo_floats(PREC, FPW, a.J, a.pad)) * sizeof(float);
+    auto k = fk_pipe_kernel<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, PREC>;
+    if (int e = allow_lds(k, lds)) return e;
+    const int64_t ntiles = (a.F + FPW - 1) / FPW, ngroups = (ntiles + nt - 1) / nt;
+    const int64_t grid = ((ngroups + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
+    if (grid > 0x7fffffffLL) { set_error("fk: grid too large"); return PM_EUNSUPPORTED; }
+    set_kernel_name("void pm::fk_pipe_kernel<%d, %d, %s, %d, %s, %s, %s, %d>(pm::FkArgs, int)", FPW, EPL, tf(VEC), SRC, tf(QOUT), tf(PAD), tf(PFO), PREC);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a, nt);
     return check_hip(hipGetLastError(), "fk launch");
 }
 
 template <int FPW, int EPL, bool VEC, int SRC, bool QOUT, bool PAD, bool PFO>
 static int launch_fk_pipe_p(const FkArgs &a, const int nt, hipStream_t s) {
-    const size_t lds = ((size_t)FPW * (a.J * (12 + (PFO ? 3 : 0) + (QOUT ? 4 : 0)) + (PFO ? 3 : 2) * a.pad) + 4 * (a.J + 4)) * sizeof(float);
-    auto k = fk_pipe_kernel<FPW, EPL, VEC, SRC, QOUT, PAD, PFO>;
-    if (int e = allow_lds(k, lds)) return e;
-    const int64_t ntiles = (a.F + FPW - 1) / FPW, ngroups = (ntiles + nt - 1) / nt;
-    const int64_t grid = ((ngroups + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
-    if (grid > 0x7fffffffLL) { set_error("fk: grid too large"); return PM_EUNSUPPORTED; }
-    set_kernel_name("void pm::fk_pipe_kernel<%d, %d, %s, %d, %s, %s, %s>(pm::FkArgs, int)", FPW, EPL, tf(VEC), SRC, tf(QOUT), tf(PAD), tf(PFO));
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a, nt);
-    return check_hip(hipGetLastError(), "fk launch");
+#ifdef PM_TUNING
+    if constexpr (VEC && !PFO && !QOUT && EPL == 4) {
+        switch (tune_env("PM_FK_PREC", PM_FK_PREC_DEFAULT)) {
+            case 0: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 0>(a, nt, s);
+            case 1: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 1>(a, nt, s);
+            case 2: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 2>(a, nt, s);
+            case 4: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 4>(a, nt, s);
+            case 5: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 5>(a, nt, s);
+            case 6: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 6>(a, nt, s);
+            case 13: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 13>(a, nt, s);
+            default: set_error("PM_FK_PREC must be 0, 1, 2, 4, 5 or 6"); return PM_EINVAL;
+        }
+    }
+#endif
+    return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, PM_FK_PREC_DEFAULT>(a, nt, s);
 }
 
 template <int FPW, int EPL, bool VEC, int SRC, bool QOUT>
