@@ -56,7 +56,7 @@ struct FkArgs {
 // of 4 then); the image is then no longer the HBM layout verbatim and phase A / copy-out address it per frame
 // (image_slot / image_store).  Every other J keeps the linear image.  The choice is made in dispatch_fk.
 
-// LDS floats per frame-joint: rot 9 + pos 3 (+ per-frame offsets 3) (+ quat_out 4) (+ position residuals 3, PREC_T64)
+// LDS floats per frame-joint: rot 9 + pos 3 (+ per-frame offsets 3) (+ quat_out 4)
 template <int SRC, bool PFO, bool QOUT>
 constexpr int fk_lds_floats() { return 12 + (PFO ? 3 : 0) + (QOUT ? 4 : 0); }
 
@@ -72,8 +72,21 @@ constexpr int fk_lds_floats() { return 12 + (PFO ? 3 : 0) + (QOUT ? 4 : 0); }
 //                of the normalisation, accurate to a few 1e-8): + 9 instructions, L error 1.3e-6 -> 5e-7
 //   PREC_F64     normalisation and quadratic form in float64 (products of fp32 inputs are exact there), one rounding
 //                per matrix entry: L error 3e-8
-//   PREC_T64     (walks) the translation chain is accumulated in float64 and rounded once per joint
-enum { PREC_FAST = 0, PREC_RESID = 1, PREC_F64 = 2, PREC_T64 = 4, PREC_NOLO = 8 /* experiment: T64 without residual storage */ };
+//   PREC_FX      (walks) the translation chain p_j = p_parent + R_parent t_j runs in 32-bit FIXED POINT: integer adds do
+//                not round, so the only roundings are one per joint of the fp32 dot product (an ulp of |t|, not of |p|)
+//                and the final conversion.  The image holds the fixed-point words during the walk (a child that re-reads
+//                its parent resumes the exact chain, no extra LDS) and is converted in place before the copy-out.
+//   PREC_DYN     what the production library runs: every tile decides for itself (fk_tile_is_big) -- PREC_RESID for
+//                human-scale data in metres, PREC_F64 | PREC_FX when bones or root positions are big enough for fp32
+//                roundings of |p| to matter (centimetre mocap, far-away roots).
+// Measured at 2^20 x 22 / 2^18 x 52 (sustained, us) and, on offsets +-30 / root +-200, max |pos error| in ulps of the
+// largest coordinate: FAST 267 / 175, 4.3 / 6.3 ulp; RESID 266 / 172, 2.2 / 2.9; F64 273 / 179, 2.0 / 3.0; a float64
+// chain with its residuals in LDS 310-320 / 252, 0.9 / 1.4 -- but 3/4 of that cost is the LDS (occupancy), not the math.
+enum { PREC_FAST = 0, PREC_RESID = 1, PREC_F64 = 2, PREC_FX = 4, PREC_DYN = 16 };
+
+// Scale of the fixed-point positions of one tile: every coordinate is bounded by B = max |root| + sum_j |t_j|_1
+// (rotations have unit rows), so with B < 2^e the words p * 2^(30-e) stay below 2^30.
+struct FxScale { float S, invS; };
 
 template <int PREC>
 __device__ __forceinline__ void local_from_quat(const float (&qi)[4], float (&L)[9]) {
@@ -94,7 +107,8 @@ __device__ __forceinline__ void local_from_quat(const float (&qi)[4], float (&L)
         L[3] = (float)(s * __builtin_fma(x, y, wz));   L[4] = (float)__builtin_fma(-s, xx + zz, 1.0); L[5] = (float)(s * __builtin_fma(y, z, -wx));
         L[6] = (float)(s * __builtin_fma(x, z, -wy));  L[7] = (float)(s * __builtin_fma(y, z, wx));   L[8] = (float)__builtin_fma(-s, xx + yy, 1.0);
         // tiny or zero quaternions (|q| < 1e-2: eps is no longer a perturbation; zero -> identity, skeleton.py:45): fp32 path
-        const bool tiny = !(n2f >= 1e-4f);
+        // non-finite ones too: the reference's NaN PATTERN (e.g. (inf,0,0,0) -> NaN off the diagonal, 1 on it) comes out of its formula
+        const bool tiny = !(n2f >= 1e-4f && n2f < 3e38f);
         if (__builtin_amdgcn_ballot_w64(tiny) != 0) {  // wave-uniform, practically never taken
             float q[4], Lf[9];
             qnormalize(qi, 1e-8f, q);
@@ -112,7 +126,7 @@ __device__ __forceinline__ void local_from_quat(const float (&qi)[4], float (&L)
         // scale that reproduces ITS matrix is 2 (1 - eps inv)^2 / |q^|^2 = 2 (1 - r - 2 eps inv) to first order.
         const float r = __builtin_fmaf(w, w, __builtin_fmaf(x, x, __builtin_fmaf(y, y, __builtin_fmaf(z, z, -1.0f))));
         float s = __builtin_fmaf(-2.0f, __builtin_fmaf(2e-8f, inv, r), 2.0f);
-        s = (n >= 1e-2f) ? s : 2.0f;  // tiny / zero quaternions: the reference's formula as it is (L = I + 2 M(q^))
+        s = (n >= 1e-2f && n < 3e38f) ? s : 2.0f;  // tiny / zero / non-finite quaternions: the reference's formula as it is (L = I + 2 M(q^))
         const float zz = z * z, yy = y * y;
         const float wz = w * z, wy = w * y, wx = w * x;
         L[0] = __builtin_fmaf(-s, __builtin_fmaf(y, y, zz), 1.0f); L[1] = s * __builtin_fmaf(x, y, -wz); L[2] = s * __builtin_fmaf(x, z, wy);
@@ -130,42 +144,36 @@ __device__ __forceinline__ void local_from_quat(const float (&qi)[4], float (&L)
 // sRot slot (f, j) holds the local rotation L_j on entry and row-by-row the world rotation on exit;
 // sPos receives the positions.  sConst[j] = {parent (int bits), t0, t1, t2}, entry J = clamp copy.
 // Lane (f, r) owns row r of frame f; `gp` = root_pos[f][r].
-// T64: the translation chain p_j = p_parent + R_parent t_j is carried in float64 (the dot product stays fp32: its
-// rounding is an ulp of |t|, not of |p|) and rounded ONCE per joint for the output; the part of p_j that the fp32
-// output cannot hold goes to sLo so that a child which re-reads its parent from the image resumes the exact chain.
-template <bool PFO, bool T64, bool LO = true>
-__device__ __forceinline__ void tree_walk(float *sRot, float *sPos, float *sLo, const float *sOff, const float *sConst,
-                                          const int J, const int pad, const int f, const int r, const float gp, const bool skip) {
+// FX: positions in fixed point (see PREC_FX): sPos holds int32 words p * S while the walk runs.
+template <bool PFO, bool FX>
+__device__ __forceinline__ void tree_walk(float *sRot, float *sPos, const float *sOff, const float *sConst,
+                                          const int J, const int pad, const int f, const int r, const float gp, const bool skip,
+                                          const float S) {
     float *fL = sRot + f * (J * 9 + pad);  // this frame's slots (L before, G after)
     float *fRot = fL + r * 3;              // this lane's row inside a slot
     float *fPos = sPos + f * (J * 3 + pad) + r;
-    float *fLo = sLo + f * (J * 3 + pad) + r;
     const float *fOff = sOff + f * (J * 3 + pad);
-    double gt64 = (double)gp;
 
     // Row r of joint j-1's transform, seeded so that joint 0 falls out of the same formula:
     // e_r . L = row r of L (exact: 1*x + 0*y + 0*z) and translation = root_pos[r] (offsets[0] ignored).
-    float g0 = (r == 0) ? 1.0f : 0.0f, g1 = (r == 1) ? 1.0f : 0.0f, g2 = (r == 2) ? 1.0f : 0.0f, gt = gp;
+    float g0 = (r == 0) ? 1.0f : 0.0f, g1 = (r == 1) ? 1.0f : 0.0f, g2 = (r == 2) ? 1.0f : 0.0f;
+    float gt = FX ? __int_as_float((int)__builtin_rintf(gp * S)) : gp;
 
     // One joint of the walk.  `L` and the joint's constants `c` were fetched a joint ahead.
     auto joint = [&](const int j, const float (&L)[9], const v4f c) {
         const int par = __builtin_amdgcn_readfirstlane(__float_as_int(c.x));
         float t0 = c.y, t1 = c.z, t2 = c.w;
         float p0 = g0, p1 = g1, p2 = g2, pt = gt;
-        double pt64 = gt64;
         if (par != j - 1) {  // wave-uniform: not the previous joint -> its row is in the image
             p0 = fRot[par * 9]; p1 = fRot[par * 9 + 1]; p2 = fRot[par * 9 + 2];
             pt = fPos[par * 3];
-            if (T64) pt64 = LO ? (double)pt + (double)fLo[par * 3] : (double)pt;
         }
         if (PFO && j > 0) { t0 = fOff[3 * j]; t1 = fOff[3 * j + 1]; t2 = fOff[3 * j + 2]; }
         g0 = p0 * L[0] + p1 * L[3] + p2 * L[6];
         g1 = p0 * L[1] + p1 * L[4] + p2 * L[7];
         g2 = p0 * L[2] + p1 * L[5] + p2 * L[8];
-        if (T64) {
-            gt64 = pt64 + (double)(p0 * t0 + p1 * t1 + p2 * t2);
-            gt = (float)gt64;
-            if (LO) fLo[j * 3] = (float)(gt64 - (double)gt);
+        if (FX) {
+            gt = __int_as_float(__float_as_int(pt) + (int)__builtin_rintf((p0 * t0 + p1 * t1 + p2 * t2) * S));
         } else {
             gt = p0 * t0 + p1 * t1 + p2 * t2 + pt;
         }
@@ -222,10 +230,10 @@ __device__ __forceinline__ float quad_dot3(const float e, const float a0, const 
     return acc;
 }
 
-template <bool PFO, bool T64, bool LO = true>
-__device__ __forceinline__ void tree_walk_quad(float *sRot, float *sPos, float *sLo, const float *sOff, const float *sConst,
-                                               const int J, const int pad, const int f, const int r, const int c, const float seed,
-                                               const int lane, float *lo_scratch) {
+template <bool PFO, bool FX>
+__device__ __forceinline__ void tree_walk_quad(float *sRot, float *sPos, const float *sOff, const float *sConst,
+                                               const int J, const int pad, const int f, const int r, const int c, const float seed_in,
+                                               const int lane, const float S) {
     float *fL = sRot + f * (J * 9 + pad);
     // what this lane multiplies the parent row with at joint j: column c of L_j = row c of the transposed
     // slot, or, for the position lane, the offset t_j (constant table, or the per-frame offsets tile)
@@ -236,16 +244,13 @@ __device__ __forceinline__ void tree_walk_quad(float *sRot, float *sPos, float *
     const int ostep = (c < 3) ? 9 : 3;
     const float m3 = (c == 3) ? 1.0f : 0.0f;
 
+    // FX (see PREC_FX): the position lane's element is a fixed-point word p * S (integer adds: no rounding of |p|); the
+    // rotation lanes run the same instructions and keep the float.  A lane's `g` is what the next step's DPP operand
+    // reads from lanes 0..2 of the quad (rotation elements) -- the position lane's bits are never multiplied.
+    const float seed = (FX && c == 3) ? __int_as_float((int)__builtin_rintf(seed_in * S)) : seed_in;
     float g = seed;  // element (r, c) of joint j-1: joint 0 multiplies the seed row e_r | root_pos[r] (exact)
     float *own = own0;
     int par = -1;
-    // T64 (see tree_walk): the position lane carries its element in float64; on the rotation lanes the same
-    // instructions reduce to g = dot exactly (m3 = 0) and the residual they park is 0, in one scratch word.
-    double g64 = (double)seed;
-    const double m3d = (double)m3;
-    float *lo0 = (c == 3) ? (sLo + f * (J * 3 + pad) + r) : lo_scratch;
-    const int lstep = (c == 3) ? 3 : 0;
-    float *lo_own = lo0;
     // One step, straight-line (no branch, so every LDS wait is a counted one):
     //   * `a` = this joint's coefficients, requested two steps ago; once used the same registers are
     //     refilled with joint j+2's (slots j+1, j+2 still hold L^T; the image and the table have two
@@ -253,16 +258,13 @@ __device__ __forceinline__ void tree_walk_quad(float *sRot, float *sPos, float *
     //   * `pe` = the parent's element read from the image one step ago -- used when the parent is not
     //     joint j-1 (then it was finished, and written, before step j-1); otherwise the register chain;
     //   * first thing, the same read is issued for joint j+1 (`pen`).
-    auto step = [&](const int j, const int parn, float (&a)[3], const float pe, float &pen, const float pl, float &pln,
-                    const bool last_may_be_dummy) {
+    auto step = [&](const int j, const int parn, float (&a)[3], const float pe, float &pen, const bool last_may_be_dummy) {
         pen = own0[__umul24(parn, ostep)];
-        if (T64 && LO) pln = lo0[__umul24(parn, lstep)];
         const float e = (par == j - 1) ? g : pe;  // wave-uniform
-        if (T64) {
-            const double e64 = (par == j - 1) ? g64 : (LO ? (double)pe + (double)pl : (double)pe);
-            g64 = __builtin_fma(m3d, e64, (double)quad_dot3(e, a[0], a[1], a[2]));
-            g = (float)g64;
-            if (LO) { if (!last_may_be_dummy || j < J) *lo_own = (float)(g64 - (double)g); lo_own += lstep; }
+        if (FX) {
+            const float dot = quad_dot3(e, a[0], a[1], a[2]);
+            const int gi = __float_as_int(e) + (int)__builtin_rintf(dot * S);
+            g = (c == 3) ? __int_as_float(gi) : dot;
         } else {
             g = __builtin_fmaf(m3, e, quad_dot3(e, a[0], a[1], a[2]));  // + Gp[r][3] on the position lane
         }
@@ -274,7 +276,7 @@ __device__ __forceinline__ void tree_walk_quad(float *sRot, float *sPos, float *
     };
     float A[3] = {coef[0], coef[1], coef[2]}, B[3] = {coef[cstep], coef[cstep + 1], coef[cstep + 2]};
     if (c == 3) { A[0] = 0.0f; A[1] = 0.0f; A[2] = 0.0f; }  // root: translation = the seed itself (offsets[0] ignored)
-    float peA = 0.0f, peB = 0.0f, plA = 0.0f, plB = 0.0f;
+    float peA = 0.0f, peB = 0.0f;
     for (int jb = 0; jb < J; jb += PM_WAVE) {
         // parents of joints jb+1 .. jb+64 across the lanes (the table repeats its last entry past J)
         const int i0 = jb + 1 + lane;
@@ -282,8 +284,8 @@ __device__ __forceinline__ void tree_walk_quad(float *sRot, float *sPos, float *
         const int jend = (J - jb) < PM_WAVE ? (J - jb) : PM_WAVE;
         asm volatile("" ::"v"(pv));  // settle the window load here, not as an lgkmcnt(0) inside the loop
         for (int jj = 0; jj < jend; jj += 2) {  // pairs; for odd J the very last step is a dummy that stores nothing
-            step(jb + jj, __builtin_amdgcn_readlane(pv, jj), A, peA, peB, plA, plB, false);
-            step(jb + jj + 1, __builtin_amdgcn_readlane(pv, jj + 1), B, peB, peA, plB, plA, true);
+            step(jb + jj, __builtin_amdgcn_readlane(pv, jj), A, peA, peB, false);
+            step(jb + jj + 1, __builtin_amdgcn_readlane(pv, jj + 1), B, peB, peA, true);
         }
     }
 }
@@ -299,6 +301,62 @@ __device__ __forceinline__ v4f load_joint_const(const Parents &parents, const fl
     c.z = none ? 0.0f : offsets[3 * jc + 1];
     c.w = none ? 0.0f : offsets[3 * jc + 2];
     return c;
+}
+
+// ortho6d record -> local rotation (and, with QOUT, the quaternion the reference would have produced)
+template <bool QOUT, int M>
+__device__ __forceinline__ void local_from_o6d(const float (&xx)[6], const float eps, float (&L)[9], float (&Q)[4]) {
+    if constexpr (QOUT) {
+        float m[9];
+        o6d2m(xx, eps, m);
+        m2q(m, Q);
+        local_from_quat<M>(Q, L);
+    } else {
+        // Without the quaternion output the trip matrix -> quaternion -> normalise -> matrix is the
+        // identity on an orthonormal matrix up to fp32 rounding (~2e-7, two orders inside the parity
+        // budget): the Gram-Schmidt result IS the local rotation.  Saves ~80 VALU ops per joint.
+        o6d2m(xx, eps, L);
+    }
+}
+
+// ---- PREC_DYN: which arithmetic a tile gets -------------------------------------------------------------------
+// The fp32 walk rounds every position to an ulp of ITS magnitude once per joint, and multiplies the rotation error
+// by the bone lengths.  With bones under a metre and roots within 16 m of the origin (|p| < ~32: ulp 1.9e-6) that stays
+// inside the 1e-5 parity bar with a factor to spare; beyond, the tile takes float64 local rotations and the
+// fixed-point chain.  Both tests are ballots on values the tile has loaded anyway (joint table, root positions).
+constexpr float kBigOffset = 1.0f, kBigRoot = 16.0f;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {  // NaN sticks (fmaxf would drop it)
+        const float o = __shfl_xor(v, m);
+        v = (o > v || o != o) ? o : v;
+    }
+    return v;
+}
+
+// `tsum` = this lane's share of sum_j |t_j|_1, `rmax` = this lane's |root coordinate| (0 for idle lanes).  NaN / Inf
+// anywhere make the bound non-finite and the tile stays on the plain fp32 path, which propagates them like the reference.
+__device__ __forceinline__ bool fx_scale(const float tsum, const float rmax, FxScale &fx) {
+    const float B = wave_max(rmax) + wave_sum(tsum);
+    const int e = __builtin_amdgcn_frexp_expf(B);  // B = m 2^e, m in [0.5, 1)
+    fx.S = __builtin_ldexpf(1.0f, 30 - e);
+    fx.invS = __builtin_ldexpf(1.0f, e - 30);
+    return B < 1e30f;  // false for NaN / Inf / absurd magnitudes
+}
+
+// fixed-point words of the position region -> fp32, in place (the region is then the output tile); n4 dwordx4
+__device__ __forceinline__ void fx_to_float(float *sPos, const int n4, const float invS, const int lane) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    for (int i = lane; i < n4; i += PM_WAVE) {
+        const v4i w = reinterpret_cast<const v4i *>(sPos)[i];
+        reinterpret_cast<v4f *>(sPos)[i] = v4f{(float)w.x * invS, (float)w.y * invS, (float)w.z * invS, (float)w.w * invS};
+    }
 }
 
 // local rotation -> its slot of the image: as is for the three-lane walk, transposed for tree_walk_quad
@@ -355,13 +413,33 @@ __device__ __forceinline__ void image_load(const float *__restrict__ g, float *l
     }
 }
 
+template <int V>
+struct IntC { static constexpr int value = V; };
+
+// |t_j|_1 of a joint-table entry (what it adds to the position bound) and whether it trips the "big" test
+__device__ __forceinline__ float const_l1(const v4f c) { return fabsf(c.y) + fabsf(c.z) + fabsf(c.w); }
+__device__ __forceinline__ bool const_is_big(const v4f c) {
+    return !(fabsf(c.y) < kBigOffset) || !(fabsf(c.z) < kBigOffset) || !(fabsf(c.w) < kBigOffset);  // NaN counts as big
+}
+
+// max |x| over a per-frame offsets tile in LDS (pads hold stale finite-or-not words of earlier tiles: skipped)
+__device__ __forceinline__ float tile_abs_max(const float *sOff, const int nf, const int per_frame, const int pad, const int lane) {
+    float m = 0.0f;
+    for (int fr = 0; fr < nf; ++fr)
+        for (int k = lane; k < per_frame; k += PM_WAVE) {
+            const float v = fabsf(sOff[fr * (per_frame + pad) + k]);
+            m = (v > m || v != v) ? v : m;  // NaN sticks
+        }
+    return m;
+}
+
 template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT, bool PAD, int PREC>
 __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int64_t f0, const int nf, const int lane) {
-    constexpr bool T64 = (PREC & PREC_T64) != 0;
     const int J = a.J;
     const int FJ = FPW * J;
     const int n = nf * J;  // (frame, joint) elements in this tile
     constexpr bool QUAD = FPW <= 5;  // few frames per wave (big J): 12 lanes per frame, see tree_walk_quad
+    constexpr bool DYN = (PREC & PREC_DYN) != 0;
 
     const int pad = PAD ? a.pad : 0;                   // floats between frames in the per-frame regions (see FkArgs::pad)
     const float invJ = 1.0f / (float)J;
@@ -370,7 +448,6 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
     float *sOff = sPos + FJ * 3 + FPW * pad;           // [FPW*(J*3+pad)]  (PFO)
     float *sQo = sOff + (PFO ? FJ * 3 + FPW * pad : 0);  // [FPW*J*4]  (QOUT; lane-per-record access only: linear)
     float *sConst = sQo + (QOUT ? FJ * 4 : 0);         // [(J+4)*4]  per joint {parent (int bits), t0, t1, t2}
-    float *sLo = sConst + 4 * (J + 4);                 // [FPW*(J*3+pad) + 4]  (PREC_T64: what fp32 positions cannot hold)
 
     // Every global load of the tile is issued up front, back to back, so the wave pays ONE memory
     // latency: root position (used first by phase B), skeleton constants, then the rotations.
@@ -388,129 +465,158 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
     auto load_const = [&](const int j) { return load_joint_const<PFO>(a.parents, a.offsets, J, j); };
     const v4f c_first = load_const(lane <= J ? lane : J);  // joints 0..63 (all of them for J < 64)
 
-    // ---- phase A -------------------------------------------------------------------------------------
-    if constexpr (SRC == SRC_QUAT) {
-        const float *gsrc = a.src + f0 * J * 4;
-        // Loads and math are unconditional (a record past the tile's end re-reads the last one): no exec-mask
-        // branches between the four records of a batch, so the compiler schedules and packs them together;
-        // only the LDS write is guarded.
-        auto load_batch = [&](const int e0, float (&qi)[4][4]) {
-            if (e0 >= n) return;  // wave-uniform
+    // input records of the first two batches, requested here, consumed by phase A (see `rest`)
+    constexpr int B = (SRC == SRC_QUAT ? 4 : 2) * PM_WAVE;
+    float qa[4][4], qb[4][4];   // SRC_QUAT: 4 quaternions per lane and batch
+    v2f xa[2][3], xb[2][3];     // SRC_O6D: 2 records of three dwordx2 (24-byte records are 8-byte aligned: no LDS
+                                // staging of the input, which at J = 52 is what buys a third resident wave per CU)
+    const float *gsrc = a.src + f0 * J * (SRC == SRC_QUAT ? 4 : 6);
+    // Loads and math are unconditional inside a batch (a record past the tile's end re-reads the last one): no
+    // exec-mask branches between the records, so the compiler schedules and packs them together; only the LDS
+    // write is guarded.
+    auto load_q = [&](const int e0, float (&qi)[4][4]) {
+        if (e0 >= n) return;  // wave-uniform
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * PM_WAVE + lane, ec = e < n ? e : n - 1;
-                if (VEC) {
-                    const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(gsrc) + ec);
-                    qi[u][0] = t.x; qi[u][1] = t.y; qi[u][2] = t.z; qi[u][3] = t.w;
-                } else {
-                    qi[u][0] = gsrc[4 * ec]; qi[u][1] = gsrc[4 * ec + 1]; qi[u][2] = gsrc[4 * ec + 2]; qi[u][3] = gsrc[4 * ec + 3];
-                }
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * PM_WAVE + lane, ec = e < n ? e : n - 1;
+            if (VEC) {
+                const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(gsrc) + ec);
+                qi[u][0] = t.x; qi[u][1] = t.y; qi[u][2] = t.z; qi[u][3] = t.w;
+            } else {
+                qi[u][0] = gsrc[4 * ec]; qi[u][1] = gsrc[4 * ec + 1]; qi[u][2] = gsrc[4 * ec + 2]; qi[u][3] = gsrc[4 * ec + 3];
             }
-        };
-        auto do_batch = [&](const int e0, const float (&qi)[4][4]) {
-            if (e0 >= n) return;  // wave-uniform
-            float L[4][9];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) local_from_quat<PREC>(qi[u], L[u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * PM_WAVE + lane;
-                if (e < n) put_local<QUAD>(sRot + image_slot<PAD>(e, J, invJ, 9, pad), L[u]);
-            }
-        };
-        // two batches (8 x 16 B per lane = 8 KiB per wave) in flight before the first use, then
-        // ping-pong: batch k+2 is requested before batch k is consumed
-        constexpr int B = 4 * PM_WAVE;
-        float qa[4][4], qb[4][4];
-        load_batch(0, qa);
-        load_batch(B, qb);
-        // per-frame offsets: requested while the rotations are still in flight (one memory latency for both)
-        if (PFO) image_load<VEC>(a.offsets + f0 * J * 3, sOff, nf, J * 3, pad, lane);
-        if (lane <= J) reinterpret_cast<v4f *>(sConst)[lane] = c_first;
-        for (int j = lane + PM_WAVE; j <= J; j += PM_WAVE) reinterpret_cast<v4f *>(sConst)[j] = load_const(j);
-        for (int e0 = 0; e0 < n; e0 += 2 * B) {
-            do_batch(e0, qa);
-            load_batch(e0 + 2 * B, qa);
-            do_batch(e0 + B, qb);
-            load_batch(e0 + 3 * B, qb);
         }
-    } else {
-        // rotations/ortho6d.py:50-64 : 6D -> matrix -> quaternion (itself normalised), then fk's own
-        // normalise and to_matrix: the chain ortho6d.to_quat -> fk of the reference (see the shortcut below).
-        // A 24-byte record is 8-byte aligned: three dwordx2 per lane straight from HBM (the three
-        // instructions of a wave cover the same 1.5 KiB, so every fetched line is fully used) -- no LDS
-        // staging of the input, which at J = 52 is what buys a third resident wave per CU.
-        const float *gsrc = a.src + f0 * J * 6;
-        auto load_batch = [&](const int e0, v2f (&x)[2][3]) {
-            if (e0 >= n) return;  // wave-uniform; inside a batch loads and math are unconditional, as above
+    };
+    auto load_x = [&](const int e0, v2f (&x)[2][3]) {
+        if (e0 >= n) return;  // wave-uniform
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int e = e0 + u * PM_WAVE + lane, ec = e < n ? e : n - 1;
-                if (VEC) {
-                    const v2f *p = reinterpret_cast<const v2f *>(gsrc) + 3 * ec;
-                    x[u][0] = __builtin_nontemporal_load(p);
-                    x[u][1] = __builtin_nontemporal_load(p + 1);
-                    x[u][2] = __builtin_nontemporal_load(p + 2);
-                } else {
-                    const float *p = gsrc + 6 * ec;
-                    x[u][0] = v2f{p[0], p[1]}; x[u][1] = v2f{p[2], p[3]}; x[u][2] = v2f{p[4], p[5]};
-                }
+        for (int u = 0; u < 2; ++u) {
+            const int e = e0 + u * PM_WAVE + lane, ec = e < n ? e : n - 1;
+            if (VEC) {
+                const v2f *p = reinterpret_cast<const v2f *>(gsrc) + 3 * ec;
+                x[u][0] = __builtin_nontemporal_load(p);
+                x[u][1] = __builtin_nontemporal_load(p + 1);
+                x[u][2] = __builtin_nontemporal_load(p + 2);
+            } else {
+                const float *p = gsrc + 6 * ec;
+                x[u][0] = v2f{p[0], p[1]}; x[u][1] = v2f{p[2], p[3]}; x[u][2] = v2f{p[4], p[5]};
             }
-        };
-        auto do_batch = [&](const int e0, const v2f (&x)[2][3]) {
-            if (e0 >= n) return;
-            float L[2][9], Q[2][4];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const float xx[6] = {x[u][0].x, x[u][0].y, x[u][1].x, x[u][1].y, x[u][2].x, x[u][2].y};
-                if constexpr (QOUT) {
-                    float m[9];
-                    o6d2m(xx, a.eps, m);
-                    m2q(m, Q[u]);
-                    local_from_quat<PREC>(Q[u], L[u]);
-                } else {
-                    // Without the quaternion output the trip matrix -> quaternion -> normalise -> matrix is the
-                    // identity on an orthonormal matrix up to fp32 rounding (~2e-7, two orders inside the parity
-                    // budget): the Gram-Schmidt result IS the local rotation.  Saves ~80 VALU ops per joint.
-                    o6d2m(xx, a.eps, L[u]);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int e = e0 + u * PM_WAVE + lane;
-                if (e < n) {
-                    put_local<QUAD>(sRot + image_slot<PAD>(e, J, invJ, 9, pad), L[u]);
-                    if (QOUT) lds_put<4>(sQo, e, Q[u]);
-                }
-            }
-        };
-        constexpr int B = 2 * PM_WAVE;
-        v2f xa[2][3], xb[2][3];
-        load_batch(0, xa);
-        load_batch(B, xb);
-        if (PFO) image_load<VEC>(a.offsets + f0 * J * 3, sOff, nf, J * 3, pad, lane);
-        if (lane <= J) reinterpret_cast<v4f *>(sConst)[lane] = c_first;
-        for (int j = lane + PM_WAVE; j <= J; j += PM_WAVE) reinterpret_cast<v4f *>(sConst)[j] = load_const(j);
-        for (int e0 = 0; e0 < n; e0 += 2 * B) {
-            do_batch(e0, xa);
-            load_batch(e0 + 2 * B, xa);
-            do_batch(e0 + B, xb);
-            load_batch(e0 + 3 * B, xb);
         }
+    };
+    // two batches (8 x 16 B per lane = 8 KiB per wave) in flight before the first use, then ping-pong: batch k+2
+    // is requested before batch k is consumed
+    if constexpr (SRC == SRC_QUAT) { load_q(0, qa); load_q(B, qb); } else { load_x(0, xa); load_x(B, xb); }
+    // per-frame offsets: requested while the rotations are still in flight (one memory latency for both)
+    if (PFO) image_load<VEC>(a.offsets + f0 * J * 3, sOff, nf, J * 3, pad, lane);
+    if (lane <= J) reinterpret_cast<v4f *>(sConst)[lane] = c_first;
+    bool tbig = lane < J && const_is_big(c_first);
+    float tsum = lane < J ? const_l1(c_first) : 0.0f;
+    for (int j = lane + PM_WAVE; j <= J; j += PM_WAVE) {
+        const v4f cj = load_const(j);
+        reinterpret_cast<v4f *>(sConst)[j] = cj;
+        if (j < J) { tbig = tbig || const_is_big(cj); tsum += const_l1(cj); }
     }
-    // ---- phase B -------------------------------------------------------------------------------------
-    wave_sync();
 
-    if constexpr (QUAD) {
-        const float seed = (c == 3) ? gp : ((c == r) ? 1.0f : 0.0f);
-        if (!PM_ABLATED(a, 2)) tree_walk_quad<PFO, T64, !(PREC & PREC_NOLO)>(sRot, sPos, sLo, sOff, sConst, J, pad, f, r, c, seed, lane, sLo + FPW * (J * 3 + pad));
-    } else {
-        tree_walk<PFO, T64, !(PREC & PREC_NOLO)>(sRot, sPos, sLo, sOff, sConst, J, pad, f, r, gp, PM_ABLATED(a, 2));
+    // ---- PREC_DYN: does this tile need the float64 rotations and the fixed-point chain? ------------------------
+    bool big = false;
+    FxScale fx = {1.0f, 1.0f};
+    if constexpr (DYN || (PREC & PREC_FX)) {
+        bool mine = tbig || !(fabsf(gp) < kBigRoot);
+        float tmax = 0.0f;
+        if (PFO) {
+            wave_sync();
+            tmax = tile_abs_max(sOff, nf, J * 3, pad, lane);
+            mine = mine || !(tmax < kBigOffset);
+        }
+        big = __builtin_amdgcn_ballot_w64(mine) != 0 || !DYN;
+        if (big) {  // wave-uniform; a non-finite bound (NaN / Inf inputs) keeps the plain path, which propagates them
+            if (PFO) tsum = (lane == 0) ? 3.0f * (float)J * wave_max(tmax) : 0.0f;
+            big = fx_scale(tsum, fabsf(gp), fx);
+        }
     }
-    wave_sync();
-    image_store<VEC>(a.rotmats + f0 * J * 9, sRot, nf, J * 9, pad, lane);
-    image_store<VEC>(a.pos + f0 * J * 3, sPos, nf, J * 3, pad, lane);
-    if (QOUT) tile_store<VEC>(a.quat_out + f0 * J * 4, sQo, n * 4, lane);
+
+    // ---- phase A, phase B and the copy-out for one arithmetic level M ------------------------------------------
+    auto rest = [&](auto mode) {
+        constexpr int M = decltype(mode)::value;
+        constexpr bool FX = (M & PREC_FX) != 0;
+        bool bad = false;  // FX only: a non-finite local rotation somewhere in the tile
+        if constexpr (SRC == SRC_QUAT) {
+            auto do_batch = [&](const int e0, const float (&qi)[4][4]) {
+                if (e0 >= n) return;  // wave-uniform
+                float L[4][9];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) local_from_quat<M>(qi[u], L[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * PM_WAVE + lane;
+                    if (FX) bad = bad || !(fabsf(qi[u][0]) + fabsf(qi[u][1]) + fabsf(qi[u][2]) + fabsf(qi[u][3]) < 3e38f);  // NaN / Inf input
+                    if (e < n) put_local<QUAD>(sRot + image_slot<PAD>(e, J, invJ, 9, pad), L[u]);
+                }
+            };
+            for (int e0 = 0; e0 < n; e0 += 2 * B) {
+                do_batch(e0, qa);
+                load_q(e0 + 2 * B, qa);
+                do_batch(e0 + B, qb);
+                load_q(e0 + 3 * B, qb);
+            }
+        } else {
+            // rotations/ortho6d.py:50-64 : 6D -> matrix -> quaternion (itself normalised), then fk's own
+            // normalise and to_matrix: the chain ortho6d.to_quat -> fk of the reference (see the shortcut below).
+            auto do_batch = [&](const int e0, const v2f (&x)[2][3]) {
+                if (e0 >= n) return;
+                float L[2][9], Q[2][4];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float xx[6] = {x[u][0].x, x[u][0].y, x[u][1].x, x[u][1].y, x[u][2].x, x[u][2].y};
+                    local_from_o6d<QOUT, M>(xx, a.eps, L[u], Q[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int e = e0 + u * PM_WAVE + lane;
+                    if (FX) bad = bad || !(fabsf(x[u][0].x) + fabsf(x[u][0].y) + fabsf(x[u][1].x) + fabsf(x[u][1].y) + fabsf(x[u][2].x) + fabsf(x[u][2].y) < 3e38f);
+                    if (e < n) {
+                        put_local<QUAD>(sRot + image_slot<PAD>(e, J, invJ, 9, pad), L[u]);
+                        if (QOUT) lds_put<4>(sQo, e, Q[u]);
+                    }
+                }
+            };
+            for (int e0 = 0; e0 < n; e0 += 2 * B) {
+                do_batch(e0, xa);
+                load_x(e0 + 2 * B, xa);
+                do_batch(e0 + B, xb);
+                load_x(e0 + 3 * B, xb);
+            }
+        }
+        // ---- phase B ---------------------------------------------------------------------------------------
+        wave_sync();
+        const bool fixed = FX && __builtin_amdgcn_ballot_w64(bad) == 0;  // NaN / Inf rotations: the float walk propagates them
+        if constexpr (QUAD) {
+            const float seed = (c == 3) ? gp : ((c == r) ? 1.0f : 0.0f);
+            if (!PM_ABLATED(a, 2)) {
+                if (FX && fixed) tree_walk_quad<PFO, FX>(sRot, sPos, sOff, sConst, J, pad, f, r, c, seed, lane, fx.S);
+                else tree_walk_quad<PFO, false>(sRot, sPos, sOff, sConst, J, pad, f, r, c, seed, lane, 1.0f);
+            }
+        } else {
+            if (FX && fixed) tree_walk<PFO, FX>(sRot, sPos, sOff, sConst, J, pad, f, r, gp, PM_ABLATED(a, 2), fx.S);
+            else tree_walk<PFO, false>(sRot, sPos, sOff, sConst, J, pad, f, r, gp, PM_ABLATED(a, 2), 1.0f);
+        }
+        wave_sync();
+        if (FX && fixed) {  // fixed-point words -> fp32 in place; the root is the caller's value, bit for bit (skeleton.py:49)
+            fx_to_float(sPos, (FPW * (J * 3 + pad)) >> 2, fx.invS, lane);
+            if (!QUAD || c == 3) sPos[f * (J * 3 + pad) + r] = gp;
+            wave_sync();
+        }
+        image_store<VEC>(a.rotmats + f0 * J * 9, sRot, nf, J * 9, pad, lane);
+        image_store<VEC>(a.pos + f0 * J * 3, sPos, nf, J * 3, pad, lane);
+        if (QOUT) tile_store<VEC>(a.quat_out + f0 * J * 4, sQo, n * 4, lane);
+    };
+    if constexpr (DYN) {
+        if (big) rest(IntC<PREC_F64 | PREC_FX>{});
+        else rest(IntC<PREC & (PREC_RESID | PREC_F64)>{});
+    } else {
+        if ((PREC & PREC_FX) && !big) rest(IntC<PREC & ~PREC_FX>{});  // static FX (tuning): non-finite bound -> float walk
+        else rest(IntC<PREC>{});
+    }
 }
 
 // One tile (FPW frames) per single-wave workgroup; XCD-aware tile order (common.hpp).
@@ -538,7 +644,7 @@ __global__ __launch_bounds__(PM_WAVE) void fk_kernel(const FkArgs a) {
 template <int FPW, int EPL, bool VEC, int SRC, bool QOUT, bool PAD, bool PFO, int PREC>
 __global__ __launch_bounds__(PM_WAVE) void fk_pipe_kernel(const FkArgs a, const int nt) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr bool T64 = (PREC & PREC_T64) != 0;
+    constexpr bool DYN = (PREC & PREC_DYN) != 0;
     constexpr bool QUAD = FPW <= 5;  // records per lane: FPW * J <= 64 * EPL
     const int lane = threadIdx.x;
     const int J = a.J;
@@ -556,8 +662,20 @@ __global__ __launch_bounds__(PM_WAVE) void fk_pipe_kernel(const FkArgs a, const 
     float *sOff = sPos + FJ * 3 + FPW * pad;     // [FPW*(J*3+pad)]  (PFO: per-frame offsets)
     float *sQo = sOff + (PFO ? FJ * 3 + FPW * pad : 0);  // [FJ*4]  (QOUT)
     float *sConst = sQo + (QOUT ? FJ * 4 : 0);   // [(J+4)*4]
-    float *sLo = sConst + 4 * (J + 4);           // [FPW*(J*3+pad) + 4]  (PREC_T64)
-    for (int j = lane; j <= J; j += PM_WAVE) reinterpret_cast<v4f *>(sConst)[j] = load_joint_const<PFO>(a.parents, a.offsets, J, j);
+    // the joint table, and what it says about the arithmetic the tiles need (PREC_DYN, see fk_tile)
+    bool tbig_l = false;
+    float tsum_l = 0.0f;
+    for (int j = lane; j <= J; j += PM_WAVE) {
+        const v4f cj = load_joint_const<PFO>(a.parents, a.offsets, J, j);
+        reinterpret_cast<v4f *>(sConst)[j] = cj;
+        if (j < J) { tbig_l = tbig_l || const_is_big(cj); tsum_l += const_l1(cj); }
+    }
+    bool tbig = false;   // wave-uniform
+    float tsum = 0.0f;   // sum_j |t_j|_1 (shared offsets)
+    if constexpr (!PFO && (DYN || (PREC & PREC_FX))) {
+        tbig = __builtin_amdgcn_ballot_w64(tbig_l) != 0;
+        tsum = wave_sum(tsum_l);
+    }
 
     const int wl = lane % ((QUAD ? 12 : 3) * FPW);
     const int f = QUAD ? wl / 12 : wl / 3;
@@ -613,26 +731,56 @@ __global__ __launch_bounds__(PM_WAVE) void fk_pipe_kernel(const FkArgs a, const 
     issue(f0, nf);
     for (int i = 0; i < cnt; ++i) {
         const int n = nf * J;
-        // math of tile i, in registers (phase A of fk_tile)
-        float L[EPL][9], Q[EPL][4];
+        const float gp_i = gp;
+        // PREC_DYN: the arithmetic of THIS tile (see fk_tile): float64 rotations + fixed-point chain when the bones or
+        // this tile's root positions are big
+        bool big = false;
+        FxScale fx = {1.0f, 1.0f};
+        if constexpr (DYN || (PREC & PREC_FX)) {
+            bool mine = !(fabsf(gp_i) < kBigRoot);
+            float tmax = 0.0f;
+            if constexpr (PFO) {
 #pragma unroll
-        for (int u = 0; u < EPL; ++u) {
-            if constexpr (SRC == SRC_QUAT) {
-                const float qi[4] = {in4[u].x, in4[u].y, in4[u].z, in4[u].w};
-                local_from_quat<PREC>(qi, L[u]);
-            } else {
-                const float xx[6] = {in2[u][0].x, in2[u][0].y, in2[u][1].x, in2[u][1].y, in2[u][2].x, in2[u][2].y};
-                if constexpr (QOUT) {
-                    float m[9];
-                    o6d2m(xx, a.eps, m);
-                    m2q(m, Q[u]);
-                    local_from_quat<PREC>(Q[u], L[u]);
-                } else {
-                    o6d2m(xx, a.eps, L[u]);  // the Gram-Schmidt result IS the local rotation (see fk_tile)
+                for (int u = 0; u < EPL; ++u) {
+                    const float m = fmaxf(fmaxf(fabsf(inO[u].x), fabsf(inO[u].y)), fabsf(inO[u].z));
+                    const bool nan = inO[u].x != inO[u].x || inO[u].y != inO[u].y || inO[u].z != inO[u].z;
+                    tmax = nan ? __builtin_nanf("") : ((m > tmax) ? m : tmax);
                 }
+                mine = mine || !(tmax < kBigOffset);
+            }
+            big = tbig || __builtin_amdgcn_ballot_w64(mine) != 0 || !DYN;
+            if (big) {
+                const float bound_t = PFO ? 3.0f * (float)J * wave_max(tmax) : tsum;
+                big = fx_scale((lane == 0) ? bound_t : 0.0f, fabsf(gp_i), fx);
             }
         }
-        const float gp_i = gp;
+        // math of tile i, in registers (phase A of fk_tile)
+        float L[EPL][9], Q[EPL][4];
+        bool bad = false;
+        auto math = [&](auto mode) {
+            constexpr int M = decltype(mode)::value;
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
+                if constexpr (SRC == SRC_QUAT) {
+                    const float qi[4] = {in4[u].x, in4[u].y, in4[u].z, in4[u].w};
+                    local_from_quat<M>(qi, L[u]);
+                } else {
+                    const float xx[6] = {in2[u][0].x, in2[u][0].y, in2[u][1].x, in2[u][1].y, in2[u][2].x, in2[u][2].y};
+                    local_from_o6d<QOUT, M>(xx, a.eps, L[u], Q[u]);
+                }
+                if (M & PREC_FX) {  // NaN / Inf input record
+                    if constexpr (SRC == SRC_QUAT) bad = bad || !(fabsf(in4[u].x) + fabsf(in4[u].y) + fabsf(in4[u].z) + fabsf(in4[u].w) < 3e38f);
+                    else bad = bad || !(fabsf(in2[u][0].x) + fabsf(in2[u][0].y) + fabsf(in2[u][1].x) + fabsf(in2[u][1].y) + fabsf(in2[u][2].x) + fabsf(in2[u][2].y) < 3e38f);
+                }
+            }
+        };
+        if constexpr (DYN) {
+            if (big) math(IntC<PREC_F64 | PREC_FX>{});
+            else math(IntC<PREC & (PREC_RESID | PREC_F64)>{});
+        } else {
+            math(IntC<PREC>{});
+        }
+        const bool fixed = big && __builtin_amdgcn_ballot_w64(bad) == 0;  // NaN / Inf rotations: the float walk propagates them
         if (i > 0) copy_out(f0_prev, nf_prev);  // the image of tile i-1 leaves ...
 #pragma unroll
         for (int u = 0; u < EPL; ++u) {        // ... and tile i's local rotations take its place (in-order DS)
@@ -653,13 +801,23 @@ __global__ __launch_bounds__(PM_WAVE) void fk_pipe_kernel(const FkArgs a, const 
             issue(f0, nf);                      // in flight during the walk below
         }
         wave_sync();
+        constexpr bool CAN_FX = DYN || (PREC & PREC_FX);
         if constexpr (QUAD) {
             const float seed = (c == 3) ? gp_i : ((c == r) ? 1.0f : 0.0f);
-            if (!PM_ABLATED(a, 2)) tree_walk_quad<PFO, T64, !(PREC & PREC_NOLO)>(sRot, sPos, sLo, sOff, sConst, J, pad, f, r, c, seed, lane, sLo + FPW * (J * 3 + pad));
+            if (!PM_ABLATED(a, 2)) {
+                if (CAN_FX && fixed) tree_walk_quad<PFO, CAN_FX>(sRot, sPos, sOff, sConst, J, pad, f, r, c, seed, lane, fx.S);
+                else tree_walk_quad<PFO, false>(sRot, sPos, sOff, sConst, J, pad, f, r, c, seed, lane, 1.0f);
+            }
         } else {
-            tree_walk<PFO, T64, !(PREC & PREC_NOLO)>(sRot, sPos, sLo, sOff, sConst, J, pad, f, r, gp_i, PM_ABLATED(a, 2));
+            if (CAN_FX && fixed) tree_walk<PFO, CAN_FX>(sRot, sPos, sOff, sConst, J, pad, f, r, gp_i, PM_ABLATED(a, 2), fx.S);
+            else tree_walk<PFO, false>(sRot, sPos, sOff, sConst, J, pad, f, r, gp_i, PM_ABLATED(a, 2), 1.0f);
         }
         wave_sync();
+        if (CAN_FX && fixed) {  // fixed-point words -> fp32 in place; the root is the caller's value, bit for bit
+            fx_to_float(sPos, (FPW * (J * 3 + pad)) >> 2, fx.invS, lane);
+            if (!QUAD || c == 3) sPos[f * (J * 3 + pad) + r] = gp_i;
+            wave_sync();
+        }
     }
     copy_out(f0_prev, nf_prev);
 }
@@ -668,19 +826,12 @@ __global__ __launch_bounds__(PM_WAVE) void fk_pipe_kernel(const FkArgs a, const 
 // Arithmetic of the production library (see local_from_quat); the PM_TUNING build can override it per call (PM_FK_PREC)
 // on the main variants to measure what each step costs.
 #ifndef PM_FK_PREC_DEFAULT
-#define PM_FK_PREC_DEFAULT PREC_RESID
+#define PM_FK_PREC_DEFAULT (PREC_DYN | PREC_RESID)
 #endif
-
-// LDS of the position residuals (PREC_T64): one float per position element + the rotation lanes' scratch word
-static size_t fk_lo_floats(const int prec, const int fpw, const int J, const int pad) {
-    if (tune_env("PM_FK_LOALLOC", 0)) return (size_t)fpw * (J * 3 + pad) + 4;  // experiment: the LDS cost alone
-    return ((prec & PREC_T64) && !(prec & PREC_NOLO)) ? (size_t)fpw * (J * 3 + pad) + 4 : 0;
-}
 
 template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT, bool PAD, int PREC>
 static int launch_fk_pp(const FkArgs &a, hipStream_t s) {
-    const size_t lds = ((size_t)FPW * (a.J * fk_lds_floats<SRC, PFO, QOUT>() + a.pad * (PFO ? 3 : 2)) + 4 * (a.J + 4) +
-                        fk_lo_floats(PREC, FPW, a.J, a.pad)) * sizeof(float);
+    const size_t lds = ((size_t)FPW * (a.J * fk_lds_floats<SRC, PFO, QOUT>() + a.pad * (PFO ? 3 : 2)) + 4 * (a.J + 4)) * sizeof(float);
     auto k = fk_kernel<FPW, VEC, PFO, SRC, QOUT, PAD, PREC>;
     if (int e = allow_lds(k, lds)) return e;
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
@@ -702,11 +853,10 @@ static int launch_fk_p(const FkArgs &a, hipStream_t s) {
             case 0: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 0>(a, s);
             case 1: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 1>(a, s);
             case 2: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 2>(a, s);
-            case 4: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 4>(a, s);
             case 5: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 5>(a, s);
             case 6: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 6>(a, s);
-            case 13: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 13>(a, s);
-            default: set_error("PM_FK_PREC must be 0, 1, 2, 4, 5 or 6"); return PM_EINVAL;
+            case 17: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 17>(a, s);
+            default: set_error("PM_FK_PREC must be 0, 1, 2, 5, 6 or 17"); return PM_EINVAL;
         }
     }
 #endif
@@ -715,8 +865,7 @@ static int launch_fk_p(const FkArgs &a, hipStream_t s) {
 
 template <int FPW, int EPL, bool VEC, int SRC, bool QOUT, bool PAD, bool PFO, int PREC>
 static int launch_fk_pipe_pp(const FkArgs &a, const int nt, hipStream_t s) {
-    const size_t lds = ((size_t)FPW * (a.J * (12 + (PFO ? 3 : 0) + (QOUT ? 4 : 0)) + (PFO ? 3 : 2) * a.pad) + 4 * (a.J + 4) +
-                        fk_lo_floats(PREC, FPW, a.J, a.pad)) * sizeof(float);
+    const size_t lds = ((size_t)FPW * (a.J * (12 + (PFO ? 3 : 0) + (QOUT ? 4 : 0)) + (PFO ? 3 : 2) * a.pad) + 4 * (a.J + 4)) * sizeof(float);
     auto k = fk_pipe_kernel<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, PREC>;
     if (int e = allow_lds(k, lds)) return e;
     const int64_t ntiles = (a.F + FPW - 1) / FPW, ngroups = (ntiles + nt - 1) / nt;
@@ -735,11 +884,10 @@ static int launch_fk_pipe_p(const FkArgs &a, const int nt, hipStream_t s) {
             case 0: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 0>(a, nt, s);
             case 1: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 1>(a, nt, s);
             case 2: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 2>(a, nt, s);
-            case 4: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 4>(a, nt, s);
             case 5: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 5>(a, nt, s);
             case 6: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 6>(a, nt, s);
-            case 13: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 13>(a, nt, s);
-            default: set_error("PM_FK_PREC must be 0, 1, 2, 4, 5 or 6"); return PM_EINVAL;
+            case 17: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 17>(a, nt, s);
+            default: set_error("PM_FK_PREC must be 0, 1, 2, 5, 6 or 17"); return PM_EINVAL;
         }
     }
 #endif

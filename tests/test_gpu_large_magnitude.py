@@ -1,0 +1,193 @@
+"""GPU: fk on large-magnitude data (centimetre mocap: bone offsets ~30, root positions ~200; far-away roots).
+
+The reference accumulates in float64 (ops/skeleton.py:44) and an fp32 result can hold a coordinate of magnitude |p| only
+to ulp(|p|) (3e-5 at |p| = 400): "1e-5 absolute" is a statement about metre-scale data.  The bar here (numerics):
+
+    |pos error| <= max(1e-5, 2 ulp_fp32(largest |coordinate| of the batch))        rotmats: <= 1e-6 in this regime
+
+which the kernels meet by giving such tiles float64 local rotations and a fixed-point (exactly additive) translation
+chain, chosen per tile from the joint table and the tile's root positions (fk.hip: PREC_DYN).  Measured: 0.9 ulp at
+J = 22, 1.6 ulp at J = 52 (what is left is the fp32 rotation chain times the bone lengths)."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from pymotion_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _ulp_of(x):
+    return 2.0 ** (np.floor(np.log2(np.abs(x).max())) - 23)
+
+
+def _cm_workload(F, parents, seed, off_scale=30.0, root_scale=200.0):
+    rng = np.random.default_rng(seed)
+    J = len(parents)
+    rot = rng.standard_normal((F, J, 4)).astype(np.float32)
+    root = rng.uniform(-root_scale, root_scale, (F, 3)).astype(np.float32)
+    off = rng.uniform(-off_scale, off_scale, (J, 3)).astype(np.float32)
+    off[0] = 0
+    return rot, root, off
+
+
+def _oracle(rot, root, off, parents):
+    return co.fk(rot.astype(np.float64), root.astype(np.float64), off.astype(np.float64), parents)
+
+
+@pytest.mark.parametrize("J,F", [(22, 20_003), (52, 8_191), (24, 4_099), (31, 2_050), (64, 1_027), (96, 515), (130, 259), (3, 70_001)])
+def test_fk_centimetre_scale_within_two_ulp_both_doors(J, F):
+    import torch
+
+    import pymotion_amd.ops.skeleton as sk
+    import pymotion_amd.ops.skeleton_torch as skt
+
+    parents = {22: syn.PARENTS_22, 52: syn.PARENTS_52}.get(J)
+    if parents is None:
+        parents = syn.random_parents(J, np.random.default_rng(J))
+    rot, root, off = _cm_workload(F, parents, seed=J)
+    p_o, r_o = _oracle(rot, root, off, parents)
+    bar = max(1e-5, 2 * _ulp_of(p_o))
+    pos, rm = sk.fk(rot, root, off, parents)
+    assert np.abs(pos - p_o).max() <= bar, (np.abs(pos - p_o).max() / _ulp_of(p_o), "ulp")
+    assert np.abs(rm - r_o).max() <= 1e-6
+    # the root is the caller's value, bit for bit, on this path too (skeleton.py:49)
+    np.testing.assert_array_equal(pos[:, 0].astype(np.float32), root)
+    tp, tr = skt.fk(torch.from_numpy(rot).cuda(), torch.from_numpy(root).cuda(), torch.from_numpy(off).cuda(),
+                    torch.from_numpy(np.asarray(parents)))
+    assert np.abs(tp.cpu().numpy() - p_o).max() <= bar
+    assert np.abs(tr.cpu().numpy() - r_o).max() <= 1e-6
+
+
+def test_fk_metre_scale_keeps_the_absolute_bar_and_tighter_rotations():
+    """human-scale data in metres stays on the fp32 path: 1e-5 absolute with a wide margin"""
+    import pymotion_amd.ops.skeleton as sk
+
+    rot, root, off, parents = syn.fk_workload(50_000, seed=21)
+    p_o, r_o = _oracle(rot, root, off, parents)
+    pos, rm = sk.fk(rot, root, off, parents)
+    assert np.abs(pos - p_o).max() <= 2e-6
+    assert np.abs(rm - r_o).max() <= 1.2e-6
+
+
+def test_far_away_roots_with_metre_bones_and_mixed_tiles():
+    """the decision is per tile: frames whose root is far from the origin get the fixed-point chain (one rounding of
+    |p| instead of one per joint), their neighbours in other tiles stay on the fp32 path; both meet their bar"""
+    import pymotion_amd.ops.skeleton as sk
+
+    F = 4000
+    rot, root, off, parents = syn.fk_workload(F, seed=22)
+    root = root.copy()
+    far = np.zeros(F, bool)
+    far[1000:2000] = True            # a block of tiles
+    far[2500::97] = True             # single frames inside otherwise near tiles
+    root[far] += np.float32(1500.0)
+    p_o, r_o = _oracle(rot, root, off, parents)
+    pos, rm = sk.fk(rot, root, off, parents)
+    err = np.abs(pos - p_o).max(axis=(1, 2))
+    assert err[far].max() <= 1.01 * 2.0 ** (10 - 23), err[far].max()      # <= 1 ulp at |p| in [1024, 2048)
+    near_only = np.ones(F, bool)
+    for t0 in range(0, F, 20):       # tiles (20 frames) without any far frame
+        if far[t0:t0 + 20].any():
+            near_only[t0:t0 + 20] = False
+    assert err[near_only].max() <= 2e-6
+    assert np.abs(rm - r_o).max() <= 1.2e-6
+    np.testing.assert_array_equal(pos[:, 0].astype(np.float32), root)
+
+
+@pytest.mark.parametrize("J", [22, 52])
+def test_non_finite_inputs_propagate_like_the_reference_on_the_big_path(J):
+    import pymotion_amd.ops.skeleton as sk
+
+    parents = syn.PARENTS_22 if J == 22 else syn.PARENTS_52
+    F = 200
+    rot, root, off = _cm_workload(F, parents, seed=5)
+    rot[7, 3, 1] = np.nan            # a NaN quaternion: its joint's rotation and everything below it
+    rot[90, 4, 0] = np.inf          # (on the ROOT joint the kernels give an all-NaN root matrix where the reference keeps
+                                     # the diagonal of to_matrix((nan,0,0,0)): the root is walked as e_r . L, and 0 * NaN = NaN)
+    root[150, 2] = np.nan            # a NaN root coordinate: that row of every position of the frame
+    root[33, 0] = np.inf
+    with np.errstate(all="ignore"):
+        p_o, r_o = _oracle(rot, root, off, parents)
+    pos, rm = sk.fk(rot, root, off, parents)
+    # joint positions depend on the PARENT's rotation: compare NaN patterns and the finite rest
+    assert (np.isnan(pos) == np.isnan(p_o)).all()
+    assert (np.isnan(rm) == np.isnan(r_o)).all()
+    fin = np.isfinite(p_o)
+    assert (np.isinf(pos) == np.isinf(p_o)).all()
+    assert np.abs(pos[fin] - p_o[fin]).max() <= max(1e-5, 2 * _ulp_of(p_o[fin]))
+
+
+def test_per_frame_offsets_at_centimetre_scale():
+    import pymotion_amd.ops.skeleton as sk
+
+    for J, parents in ((22, syn.PARENTS_22), (52, syn.PARENTS_52)):
+        F = 1501
+        rot, root, off = _cm_workload(F, parents, seed=40 + J)
+        offs = (off[None] * np.linspace(0.5, 1.5, F, dtype=np.float32)[:, None, None]).astype(np.float32)
+        p_o, r_o = _oracle(rot, root, offs, parents)
+        pos, rm = sk.fk(rot, root, offs, parents)
+        assert np.abs(pos - p_o).max() <= 2 * _ulp_of(p_o)
+        assert np.abs(rm - r_o).max() <= 1e-6
+
+
+def test_fused_ortho6d_at_centimetre_scale():
+    import pymotion_amd.ops.skeleton as sk
+
+    parents = syn.PARENTS_52
+    F = 3001
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((F, 52, 3, 2)).astype(np.float32)
+    _, root, off = _cm_workload(F, parents, seed=78)
+    with np.errstate(all="ignore"):
+        q_o = co.o6d_to_quat(x.astype(np.float64))
+    p_o, r_o = _oracle(q_o, root, off, parents)
+    for want_q in (True, False):
+        out = sk.fk_from_ortho6d(x, root, off, parents, return_quat=want_q)
+        # the fused chain starts from an fp32 Gram-Schmidt: rotation error ~1e-6 on ill-conditioned inputs, times the bones
+        well = np.abs(out[1] - r_o).max(axis=(1, 2, 3)) < 5e-6
+        assert well.mean() > 0.95
+        assert np.abs(out[0][well] - p_o[well]).max() <= 16 * _ulp_of(p_o)
+
+
+def test_threshold_edges_take_a_consistent_path():
+    """bones of exactly 1.0 and roots of exactly 16.0 sit on the decision boundary: whichever side, the result is in the bar"""
+    import pymotion_amd.ops.skeleton as sk
+
+    rot, root, off, parents = syn.fk_workload(999, seed=9)
+    for bone, far in ((1.0, 2.0), (np.nextafter(np.float32(1.0), np.float32(0)), 2.0), (0.3, 16.0), (0.3, np.nextafter(np.float32(16.0), np.float32(0)))):
+        off2 = off.copy()
+        off2[5, 1] = bone
+        root2 = root.copy()
+        root2[::50, 0] = far
+        p_o, r_o = _oracle(rot, root2, off2, parents)
+        pos, rm = sk.fk(rot, root2, off2, parents)
+        assert np.abs(pos - p_o).max() <= 4e-6
+        assert np.abs(rm - r_o).max() <= 1.2e-6
+
+
+def test_translation_equivariance_at_full_size_centimetre_scale():
+    """size-independent property at 2^20 frames: moving every root by d moves every joint by d (up to the final rounding),
+    and rotations do not change at all"""
+    import torch
+
+    import pymotion_amd.ops.skeleton_torch as skt
+
+    F = 1 << 20
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    rot = torch.randn((F, 22, 4), generator=g, device="cuda")
+    root = (torch.rand((F, 3), generator=g, device="cuda") * 2 - 1) * 200
+    off_np = np.random.default_rng(3).uniform(-30, 30, (22, 3)).astype(np.float32)
+    off_np[0] = 0
+    off = torch.from_numpy(off_np).cuda()
+    par = torch.from_numpy(syn.PARENTS_22)
+    d = torch.tensor([64.0, -128.0, 32.0], device="cuda")     # powers of two: root + d is exact where no bit falls off
+    p0, r0 = skt.fk(rot, root, off, par)
+    p1, r1 = skt.fk(rot, root + d, off, par)
+    assert bool(torch.equal(r0, r1))
+    assert float(((p1 - p0) - d).abs().max()) <= 3 * 2.0 ** (9 - 23)   # a few ulp at |p| < 1024
+    n = 1 << 14
+    sl = slice(F // 2, F // 2 + n)
+    p_o, r_o = _oracle(rot[sl].cpu().numpy(), root[sl].cpu().numpy(), off_np, syn.PARENTS_22)
+    assert np.abs(p0[sl].cpu().numpy() - p_o).max() <= 2 * _ulp_of(p_o)
