@@ -435,6 +435,64 @@ def gen_skeleton_extra():
     s.save("skeleton_extra.npz")
 
 
+def degenerate_o6d(rng, F, J):
+    """6D inputs with the records Gram-Schmidt cannot handle gracefully, at fixed (frame, joint) places."""
+    x = rng.standard_normal((F, J, 3, 2)).astype(np.float32)
+    a = rng.standard_normal(3).astype(np.float32)
+    noise = rng.standard_normal(3).astype(np.float32)
+    special = {
+        "zero_matrix": np.zeros((3, 2), np.float32),
+        "zero_first_col": np.stack([np.zeros(3, np.float32), a], axis=1),
+        "zero_second_col": np.stack([a, np.zeros(3, np.float32)], axis=1),
+        "parallel": np.stack([a, 2 * a], axis=1),
+        "anti_parallel": np.stack([a, -0.5 * a], axis=1),
+        "near_parallel": np.stack([a, 1.5 * a + 1e-4 * noise], axis=1).astype(np.float32),
+        "tiny": (1e-20 * rng.standard_normal((3, 2))).astype(np.float32),
+        "huge": (1e15 * rng.standard_normal((3, 2))).astype(np.float32),
+    }
+    where = {}
+    for k, (name, rec) in enumerate(special.items()):
+        f, j = k % F, (1 + 3 * k) % J if name != "zero_matrix" else 0   # one of them on the root joint
+        x[f, j] = rec
+        where[name] = (f, j)
+    return x, where
+
+
+def gen_degenerate():
+    """tests/golden/degenerate.npz: the chain ortho6d.to_quat -> fk on zero / parallel / tiny / huge columns (round-1
+    verdict: the fused kernel must equal that chain on EVERY input, with and without the quaternion output)."""
+    s = Store()
+    rng = np.random.default_rng(2718)
+    for J, parents, F in ((22, syn.PARENTS_22, 9), (52, syn.PARENTS_52, 8)):
+        x, where = degenerate_o6d(rng, F, J)
+        gpos = rng.uniform(-2, 2, (F, 3)).astype(np.float32)
+        off = syn.make_offsets(J, rng, 0.3 if J == 22 else 0.15)
+
+        def comp_np(x_, g_, o_, p_):
+            with np.errstate(all="ignore"):
+                q_ = o6.to_quat(x_)
+                return sk.fk(q_, g_, o_, p_) + (q_,)
+
+        def comp_t(x_, g_, o_, p_):
+            q_ = o6t.to_quat(x_)
+            return skt.fk(q_, g_, o_, T(p_)) + (q_,)
+
+        case = f"fk_from_o6d_degenerate_J{J}"
+        ins = {"x": x, "gpos": gpos, "off": off, "parents": parents}
+        run3(s, case, ins, comp_np, comp_t, ["pos", "rotmats", "quat"], int_keys=("parents",))
+        # the torch twin's semantics (F.normalize eps = 1e-12: zero column -> zeros, ortho6d_torch.py:84-89) at full
+        # precision: what a float32 implementation is judged against on records whose answer lives below fp32's digits
+        r = comp_t(T(up(x)), T(up(gpos)), T(up(off)), parents)
+        s.add(case, "out_t64", **dict(zip(["pos", "rotmats", "quat"], r)))
+        s.add(case, "in", where=np.array([[f, j] for f, j in where.values()], dtype=np.int32))
+        # the element-wise conversions on the same records
+        run3(s, f"o6d_to_quat_degenerate_J{J}", {"x": x}, lambda x_: o6.to_quat(x_), o6t.to_quat, ["out"])
+        run3(s, f"o6d_to_matrix_degenerate_J{J}", {"x": x}, lambda x_: o6.to_matrix(x_), o6t.to_matrix, ["out"])
+        s.add(f"o6d_to_quat_degenerate_J{J}", "out_t64", out=o6t.to_quat(T(up(x))))
+        s.add(f"o6d_to_matrix_degenerate_J{J}", "out_t64", out=o6t.to_matrix(T(up(x))))
+    s.save("degenerate.npz")
+
+
 def gen_time():
     """tests/golden/time.npz: ops/time.py interpolate_positions -- the literal of the reference's own test
     (ops/tests/test_time.py:12-66) and seeded clips with non-uniform times, exact hits and extrapolation on
@@ -509,10 +567,10 @@ def check_oracle():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true", help="also cross-check oracle/ against the imported reference")
-    ap.add_argument("--only", default="", help="comma-separated subset of: elementwise,trig,skeleton,bvh,mirror,ik,time,skeleton_extra")
+    ap.add_argument("--only", default="", help="comma-separated subset of: elementwise,trig,skeleton,bvh,mirror,ik,time,skeleton_extra,degenerate")
     args = ap.parse_args()
     gens = {"elementwise": gen_elementwise, "trig": gen_trig, "skeleton": gen_skeleton, "bvh": gen_bvh, "mirror": gen_mirror,
-            "ik": gen_ik, "time": gen_time, "skeleton_extra": gen_skeleton_extra}
+            "ik": gen_ik, "time": gen_time, "skeleton_extra": gen_skeleton_extra, "degenerate": gen_degenerate}
     for name, gen in gens.items():
         if not args.only or name in args.only.split(","):
             gen()

@@ -264,17 +264,70 @@ __device__ __forceinline__ void m2q(const float (&m)[9], float (&o)[4]) {
 
 // rotations/ortho6d.py:67-90 : Gram-Schmidt on the two COLUMNS of x[3][2]; denominators
 // max(norm, eps): eps = 0 -> NumPy path (NaN on a zero column), 1e-12 -> torch twin.
-__device__ __forceinline__ void o6d2m(const float (&x)[6], float eps, float (&m)[9]) {
+// `ill` (optional): the record is one where fp32 Gram-Schmidt is not the reference's answer to fp32 accuracy -- a zero or
+// non-finite column (the eps floor / NaN decide the result), or columns closer than ~0.6 degrees to (anti-)parallel
+// (what is left of b after the projection is rounding noise: relative error 6e-8 / sin).  Callers that chain further
+// re-do such records in float64 (o6d_chain_f64).
+__device__ __forceinline__ void o6d2m(const float (&x)[6], float eps, float (&m)[9], bool *ill = nullptr) {
     const float a0 = x[0], a1 = x[2], a2 = x[4], b0 = x[1], b1 = x[3], b2 = x[5];
-    const float ia = frcp(fmaxf(fsqrt(a0 * a0 + a1 * a1 + a2 * a2), eps));
+    const float na = fsqrt(a0 * a0 + a1 * a1 + a2 * a2);
+    const float ia = frcp(fmaxf(na, eps));
     const float c10 = a0 * ia, c11 = a1 * ia, c12 = a2 * ia;
     const float d = c10 * b0 + c11 * b1 + c12 * b2;
     float c20 = b0 - d * c10, c21 = b1 - d * c11, c22 = b2 - d * c12;
-    const float ib = frcp(fmaxf(fsqrt(c20 * c20 + c21 * c21 + c22 * c22), eps));
+    const float n2c = c20 * c20 + c21 * c21 + c22 * c22;
+    const float ib = frcp(fmaxf(fsqrt(n2c), eps));
     c20 *= ib; c21 *= ib; c22 *= ib;
     m[0] = c10; m[1] = c20; m[2] = c11 * c22 - c12 * c21;
     m[3] = c11; m[4] = c21; m[5] = c12 * c20 - c10 * c22;
     m[6] = c12; m[7] = c22; m[8] = c10 * c21 - c11 * c20;
+    // sin^2 / cos^2 of the angle between the columns <= 1e-4, a (near-)zero first column, or anything non-finite
+    if (ill) *ill = !(na > 1e-18f && na < 1e18f) || !(n2c > 1.0001e-4f * d * d) || !(n2c < 1e36f);
+}
+
+// float64 twins for the rare records o6d2m flags.  o6d_chain_f64 = the whole chain ortho6d.to_quat -> fk's local
+// rotation: rotations/ortho6d.py:67-90 (Gram-Schmidt, denominators max(norm, eps)), quat.py:85-156 (from_matrix incl.
+// its normalize), then fk's own normalize (skeleton.py:45) and quat.py:276-317; Q = the quaternion to_quat returns.
+__device__ __forceinline__ void o6d2m_f64(const float (&x)[6], const float eps_f, double (&r)[9]) {
+    const double eps = (double)eps_f;
+    const double a0 = x[0], a1 = x[2], a2 = x[4], b0 = x[1], b1 = x[3], b2 = x[5];
+    const double ia = 1.0 / fmax(__builtin_sqrt(a0 * a0 + a1 * a1 + a2 * a2), eps);
+    const double c10 = a0 * ia, c11 = a1 * ia, c12 = a2 * ia;
+    const double d = c10 * b0 + c11 * b1 + c12 * b2;
+    double c20 = b0 - d * c10, c21 = b1 - d * c11, c22 = b2 - d * c12;
+    const double ib = 1.0 / fmax(__builtin_sqrt(c20 * c20 + c21 * c21 + c22 * c22), eps);
+    c20 *= ib; c21 *= ib; c22 *= ib;
+    r[0] = c10; r[1] = c20; r[2] = c11 * c22 - c12 * c21;
+    r[3] = c11; r[4] = c21; r[5] = c12 * c20 - c10 * c22;
+    r[6] = c12; r[7] = c22; r[8] = c10 * c21 - c11 * c20;
+}
+
+// quat.py:85-156 in float64, incl. its normalize(eps = 1e-8)
+__device__ __forceinline__ void m2q_f64(const double (&m)[9], double (&q)[4]) {
+    const double r00 = m[0], r01 = m[1], r02 = m[2], r10 = m[3], r11 = m[4], r12 = m[5], r20 = m[6], r21 = m[7], r22 = m[8];
+    const bool neg = r22 < 0.0, a = r00 > r11, b = r00 < -r11;
+    double c[4];
+    c[0] = neg ? (a ? r21 - r12 : r02 - r20) : (b ? r10 - r01 : 1.0 + r00 + r11 + r22);
+    c[1] = neg ? (a ? 1.0 + r00 - r11 - r22 : r10 + r01) : (b ? r02 + r20 : r21 - r12);
+    c[2] = neg ? (a ? r10 + r01 : 1.0 - r00 + r11 - r22) : (b ? r21 + r12 : r02 - r20);
+    c[3] = neg ? (a ? r02 + r20 : r21 + r12) : (b ? 1.0 - r00 - r11 + r22 : r10 - r01);
+    const double iq = 1.0 / (__builtin_sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3]) + 1e-8);
+    q[0] = c[0] * iq; q[1] = c[1] * iq; q[2] = c[2] * iq; q[3] = c[3] * iq;
+}
+
+__device__ __forceinline__ void o6d_chain_f64(const float (&x)[6], const float eps_f, float (&L)[9], float (&Q)[4]) {
+    double m[9], q[4];
+    o6d2m_f64(x, eps_f, m);
+    m2q_f64(m, q);
+    const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    Q[0] = (float)q0; Q[1] = (float)q1; Q[2] = (float)q2; Q[3] = (float)q3;
+    const double in = 1.0 / (__builtin_sqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3) + 1e-8);
+    const double w = q0 * in, xq = q1 * in, y = q2 * in, z = q3 * in;
+    const double x2 = xq + xq, y2 = y + y, z2 = z + z;
+    const double xx = xq * x2, yy = y * y2, wx = w * x2, xy = xq * y2, yz = y * z2, wy = w * y2, xz = xq * z2, zz = z * z2, wz = w * z2;
+    L[0] = (float)(1.0 - (yy + zz)); L[1] = (float)(xy - wz);         L[2] = (float)(xz + wy);
+    L[3] = (float)(xy + wz);         L[4] = (float)(1.0 - (xx + zz)); L[5] = (float)(yz - wx);
+    L[6] = (float)(xz - wy);         L[7] = (float)(yz + wx);         L[8] = (float)(1.0 - (xx + yy));
 }
 
 // rotations/dual_quat.py:12-36 : dq = [qr, 0.5 * (0,t) (x) qr]

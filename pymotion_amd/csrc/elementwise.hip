@@ -184,9 +184,32 @@ PM_OP(OpDqFromT, 3, 0, 0, 8, 0) {
     y0[5] = x0[0] * 0.5f; y0[6] = x0[1] * 0.5f; y0[7] = x0[2] * 0.5f;
 } PM_OP_END
 // rotations/ortho6d.py:67-90
-PM_OP(OpO6dToMatrix, 6, 0, 0, 9, 0) { o6d2m(x0, a.eps, y0); } PM_OP_END
+// zero / non-finite / (anti-)parallel columns are re-done in float64 (o6d2m's `ill`): what the reference returns for them is
+// decided by digits fp32 does not have
+PM_OP(OpO6dToMatrix, 6, 0, 0, 9, 0) {
+    bool ill;
+    o6d2m(x0, a.eps, y0, &ill);
+    if (__builtin_amdgcn_ballot_w64(ill) != 0) {
+        double md[9];
+        o6d2m_f64(x0, a.eps, md);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) y0[k] = ill ? (float)md[k] : y0[k];
+    }
+} PM_OP_END
 // rotations/ortho6d.py:50-64
-PM_OP(OpO6dToQuat, 6, 0, 0, 4, 0) { float m[9]; o6d2m(x0, a.eps, m); m2q(m, y0); } PM_OP_END
+PM_OP(OpO6dToQuat, 6, 0, 0, 4, 0) {
+    float m[9];
+    bool ill;
+    o6d2m(x0, a.eps, m, &ill);
+    m2q(m, y0);
+    if (__builtin_amdgcn_ballot_w64(ill) != 0) {
+        double md[9], qd[4];
+        o6d2m_f64(x0, a.eps, md);
+        m2q_f64(md, qd);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y0[k] = ill ? (float)qd[k] : y0[k];
+    }
+} PM_OP_END
 // rotations/ortho6d.py:14-28
 PM_OP(OpO6dFromQuat, 4, 0, 0, 6, 0) {
     float m[9]; q2m(x0, m);

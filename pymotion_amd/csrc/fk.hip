@@ -303,19 +303,35 @@ __device__ __forceinline__ v4f load_joint_const(const Parents &parents, const fl
     return c;
 }
 
-// ortho6d record -> local rotation (and, with QOUT, the quaternion the reference would have produced)
+// ortho6d record -> local rotation (and, with QOUT, the quaternion the reference would have produced):
+// rotations/ortho6d.py:50-64 (6D -> matrix -> quaternion, itself normalised), then fk's own normalise and to_matrix.
 template <bool QOUT, int M>
 __device__ __forceinline__ void local_from_o6d(const float (&xx)[6], const float eps, float (&L)[9], float (&Q)[4]) {
+    bool ill;
     if constexpr (QOUT) {
         float m[9];
-        o6d2m(xx, eps, m);
+        o6d2m(xx, eps, m, &ill);
         m2q(m, Q);
         local_from_quat<M>(Q, L);
     } else {
-        // Without the quaternion output the trip matrix -> quaternion -> normalise -> matrix is the
-        // identity on an orthonormal matrix up to fp32 rounding (~2e-7, two orders inside the parity
-        // budget): the Gram-Schmidt result IS the local rotation.  Saves ~80 VALU ops per joint.
-        o6d2m(xx, eps, L);
+        // Without the quaternion output the trip matrix -> quaternion -> normalise -> matrix is the identity on an
+        // orthonormal matrix up to fp32 rounding (~2e-7, two orders inside the parity budget): the Gram-Schmidt
+        // result IS the local rotation.  Saves ~80 VALU ops per joint.  It is NOT the identity on what Gram-Schmidt
+        // returns for degenerate columns (zeros, NaN, rounding noise) -- those records take the full chain below.
+        o6d2m(xx, eps, L, &ill);
+    }
+    // Zero / non-finite / (anti-)parallel columns: the reference's answer is decided by its eps floors and NaN rules and,
+    // for near-parallel columns, by digits fp32 does not have -- re-do the record's whole chain in float64 (wave-uniform
+    // branch, ~1e-4 of random records), so that both variants equal ortho6d.to_quat -> fk on EVERY input.
+    if (__builtin_amdgcn_ballot_w64(ill) != 0) {
+        float Ld[9], Qd[4];
+        o6d_chain_f64(xx, eps, Ld, Qd);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) L[k] = ill ? Ld[k] : L[k];
+        if constexpr (QOUT) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) Q[k] = ill ? Qd[k] : Q[k];
+        }
     }
 }
 

@@ -163,3 +163,40 @@ def test_reference_literals_fk():
     np.testing.assert_allclose(
         out["pos"], [[[0, 0, 0], [0, -1, 0], [2, -1, 0]], [[1, 1, 1], [1.707107, 1, 1.707107], [3.12132, 1, 3.12132]]], atol=1e-6
     )
+
+
+# ---- degenerate 6D records (tests/golden/degenerate.npz): the oracle's chain ortho6d.to_quat -> fk against the reference --
+_DEG_NAMES = ["zero_matrix", "zero_first_col", "zero_second_col", "parallel", "anti_parallel", "near_parallel", "tiny", "huge"]
+
+
+@pytest.mark.parametrize("J", [22, 52])
+@pytest.mark.parametrize("eps,kind", [(0.0, "out64"), (1e-12, "out_t64")])
+def test_oracle_fused_chain_on_degenerate_ortho6d_records(J, eps, kind):
+    """eps = 0: the NumPy reference (zero column -> NaN); eps = 1e-12: the torch twin's F.normalize floor, at float64.
+    Exactly (anti-)parallel columns are rounding noise in the reference itself and are skipped (see test_gpu_degenerate.py)."""
+    g = golden("degenerate.npz")
+    case = f"fk_from_o6d_degenerate_J{J}"
+    i, want = up64(g.get(case, "in")), g.get(case, "out64" if kind == "out64" else "out_t64")
+    parents = g.get(case, "in")["parents"]
+    with np.errstate(all="ignore"):
+        pos, rm, q = co.fk_from_ortho6d(i["x"], i["gpos"], i["off"], parents, eps=eps, return_quat=True)
+    rot_ok = np.ones(i["x"].shape[:2], bool)
+    pos_ok = rot_ok.copy()
+    q_ok = rot_ok.copy()
+    for name, (f, j) in zip(_DEG_NAMES, g.get(case, "in")["where"]):
+        if name in ("parallel", "anti_parallel"):
+            d = {int(j)}
+            for k in range(int(j) + 1, J):
+                if parents[k] in d:
+                    d.add(k)
+            rot_ok[f, sorted(d)] = False
+            pos_ok[f, sorted(d - {int(j)})] = False
+            q_ok[f, j] = False
+    for got, ref, ok, what in ((pos, want["pos"], pos_ok, "pos"), (rm, want["rotmats"], rot_ok, "rotmats"), (q, want["quat"], q_ok, "quat")):
+        ref = np.asarray(ref, np.float64)
+        sel = ok.reshape(ok.shape + (1,) * (got.ndim - 2)) & np.ones(got.shape, bool)
+        assert (np.isnan(got[sel]) == np.isnan(ref[sel])).all(), what
+        fin = sel & ~np.isnan(ref)
+        # (the torch twin's to_matrix allocates default-dtype = fp32 results even for float64 inputs, quat_torch.py:318)
+        tol = 1e-9 if kind == "out64" else 1e-6
+        assert np.abs(got[fin] - ref[fin]).max() <= tol, (what, np.abs(got[fin] - ref[fin]).max())
