@@ -490,6 +490,30 @@ def gen_degenerate():
         run3(s, f"o6d_to_matrix_degenerate_J{J}", {"x": x}, lambda x_: o6.to_matrix(x_), o6t.to_matrix, ["out"])
         s.add(f"o6d_to_quat_degenerate_J{J}", "out_t64", out=o6t.to_quat(T(up(x))))
         s.add(f"o6d_to_matrix_degenerate_J{J}", "out_t64", out=o6t.to_matrix(T(up(x))))
+    # unroll with RESETS (round-1 ADVICE): a neighbour dot product that is exactly 0 or NaN is "not < 0" whatever sign the
+    # previous frame ended up with (quat.py:453-458), so the accumulated sign starts over -- zero-padded rows, exact
+    # 90/180-degree steps ([1,0,0,0] -> [0,1,0,0]), NaN rows; placed inside, at the edges of and across the kernels'
+    # 256-frame chunks and 64-frame sub-tiles.
+    import pymotion.rotations.dual_quat as dq_ref
+    import pymotion.rotations.dual_quat_torch as dqt_ref
+    T_, S_ = 700, 7
+    q = rng.standard_normal((T_, S_, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    for t in range(1, T_):  # a smooth path ...
+        q[t] = 0.9 * q[t - 1] + 0.1 * q[t]
+        q[t] /= np.linalg.norm(q[t], axis=-1, keepdims=True)
+    q[rng.random((T_, S_)) < 0.3] *= -1          # ... with random sign flips
+    ex, ey = np.array([1, 0, 0, 0], np.float32), np.array([0, 1, 0, 0], np.float32)
+    q[5, 0] = 0; q[63, 0] = 0; q[64, 0] = 0; q[255, 0] = 0      # zero rows: sub-tile edge, chunk edge
+    q[256, 1] = 0; q[257, 1] = 0; q[511, 1] = 0; q[512, 1] = 0; q[699, 1] = 0
+    q[100, 2] = -ex; q[101, 2] = ey; q[102, 2] = -ex            # exactly orthogonal steps after a flipped frame
+    q[255, 3] = -ex; q[256, 3] = ey                              # ... across a chunk boundary
+    q[300, 4] = np.nan; q[301, 4, 2] = np.nan                    # NaN rows
+    q[1, 5] = 0                                                  # reset right after the first frame
+    # series 6 stays regular
+    run3(s, "unroll_resets", {"q": q}, lambda q_: qt.unroll(q_.copy(), 0), lambda q_: qtt.unroll(q_.clone(), 0), ["out"])
+    d8 = np.concatenate([q, rng.standard_normal((T_, S_, 4)).astype(np.float32)], axis=-1)
+    run3(s, "dq_unroll_resets", {"dq": d8}, lambda d_: dq_ref.unroll(d_.copy(), 0), lambda d_: dqt_ref.unroll(d_.clone(), 0), ["out"])
     s.save("degenerate.npz")
 
 

@@ -1,10 +1,13 @@
 // unroll.hip -- quat.unroll (pymotion/rotations/quat.py:426-462) for gfx950: the first frame-COUPLED op.
 //
-// Reference: walk the unroll axis; flip quaternion i when dot(q_i, q_{i-1}) < 0, q_{i-1} being the
-// already-corrected one.  Flipping both operands leaves the dot's sign unchanged, so the correction is a
-// prefix product of signs of the ORIGINAL neighbours:  s_i = prod_{k<=i} sgn(dot(q_k, q_{k-1}))  with
-// sgn = -1 iff dot < 0 (the reference's `d0 < d1`), s_0 = +1.  That is a prefix XOR along time per
-// series -- a scan, not a loop:
+// Reference: walk the unroll axis; flip quaternion i when d0 = dot(q_i, q'_{i-1}) < d1 = -d0, q'_{i-1} being the
+// already-corrected one.  With s_i the sign frame i ends up with (s_0 = +1) and dot_i the dot product of the ORIGINAL
+// neighbours, d0 = s_{i-1} dot_i, so
+//     dot_i > 0: s_i = s_{i-1}      dot_i < 0: s_i = -s_{i-1}      dot_i == 0 or NaN: s_i = +1   (`d0 < d1` is false)
+// i.e. every frame applies one of three maps to the running sign -- keep, negate, RESET to + -- and maps of that kind
+// compose associatively (affine maps over GF(2): (a, b): s -> a s xor b; keep = (1,0), negate = (1,1), reset = (0,0)).
+// Without resets that is a prefix XOR of the flip bits; a reset (a zero-padded row, an exactly orthogonal step, a NaN)
+// forgets everything before it.  A scan, not a loop:
 //   pass 1  each wave streams a chunk of 256 consecutive frames (one record per lane, the predecessor row an
 //           L1 / L2 hit) and XORs the flip bits into per-series parities (LDS atomics) -> workspace;
 //   pass 2  exclusive prefix XOR over chunks (lane = series; a few thousand independent loads);
@@ -26,7 +29,8 @@ constexpr int UR_SB_MAX = 24;     // series per block at most: 65 rows x 25 x 16
 struct UnrollArgs {
     const float *q;
     float *out;
-    int32_t *ws;      // [nchunks][S] chunk parities (pass 1 out), then exclusive prefixes (pass 2, in place)
+    int32_t *ws;      // [nchunks][S] chunk summaries (pass 1 out: bit 0 = parity of the flips after the chunk's last
+                      // reset, bit 1 = the chunk holds a reset), then exclusive prefixes (pass 2, in place: bit 0)
     int64_t T;
     int32_t S;
     int32_t nchunks;
@@ -83,15 +87,25 @@ __global__ __launch_bounds__(PM_WAVE) void unroll_apply_kernel(const UnrollArgs 
         unsigned long long newcarry = carry;
         for (int j = 0; j < sb; ++j) {
             const v4f cur = rows[((lane + 1) * rs + j) * V];
-            bool flip = false;
+            bool flip = false, reset = false;
             if (act && !(ts == 0 && lane == 0)) {
                 const v4f prv = rows[(lane * rs + j) * V];
-                flip = (cur.x * prv.x + cur.y * prv.y + cur.z * prv.z + cur.w * prv.w) < 0.0f;
+                const float d = cur.x * prv.x + cur.y * prv.y + cur.z * prv.z + cur.w * prv.w;
+                flip = d < 0.0f;
+                reset = !(d < 0.0f) && !(d > 0.0f);  // 0, -0 or NaN: the reference's `d0 < d1` is false whatever came before
             }
-            const unsigned long long m = __ballot(flip);
+            const unsigned long long m = __ballot(flip), mr = __ballot(reset);
             {
                 const unsigned long long upto = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);
-                const int par = (__popcll(m & upto) + (int)((carry >> j) & 1ull)) & 1;
+                int par = (__popcll(m & upto) + (int)((carry >> j) & 1ull)) & 1;
+                if (mr != 0) {  // wave-uniform, rare: lanes at or after a reset only see the flips after the LAST reset before them
+                    const unsigned long long rb = mr & upto;
+                    if (rb != 0) {
+                        const int r = 63 - __builtin_clzll(rb);
+                        const unsigned long long after = upto & ~((r == 63) ? ~0ull : ((2ull << r) - 1ull));
+                        par = __popcll(m & after) & 1;
+                    }
+                }
                 if (act) {
                     // corrected record back into its row, in place: every lane has read this series' `cur` and
                     // `prv` above (in-order DS), and the flip bits only ever use ORIGINAL neighbours
@@ -103,7 +117,13 @@ __global__ __launch_bounds__(PM_WAVE) void unroll_apply_kernel(const UnrollArgs 
                     }
                 }
             }
-            if (__popcll(m) & 1) newcarry ^= (1ull << j);
+            if (mr != 0) {
+                const int r = 63 - __builtin_clzll(mr);
+                const unsigned long long after = (r == 63) ? 0ull : ~((2ull << r) - 1ull);
+                newcarry = (newcarry & ~(1ull << j)) | ((unsigned long long)(__popcll(m & after) & 1) << j);
+            } else if (__popcll(m) & 1) {
+                newcarry ^= (1ull << j);
+            }
         }
         {
             // rows 1..nfr leave the way they came: contiguous dwordx4, 4 stores in flight per lane
@@ -137,48 +157,80 @@ __global__ __launch_bounds__(PM_WAVE) void unroll_parity_kernel(const UnrollArgs
     const int sb = (a.S - s0) < a.p1_sb ? (a.S - s0) : a.p1_sb;
     const int64_t t0 = (int64_t)chunk * UR_CHUNK;
     const int64_t t1 = (t0 + UR_CHUNK) < a.T ? (t0 + UR_CHUNK) : a.T;
-    for (int i = lane; i < sb; i += PM_WAVE) par[i] = 0;
+    int *lastr = par + sb;  // local frame of the chunk's last reset per series, -1 = none
+    for (int i = lane; i < sb; i += PM_WAVE) { par[i] = 0; lastr[i] = -1; }
     wave_sync();
     const int n = (int)(t1 - t0) * sb;  // records of this chunk x series block (< 2^22: UR_CHUNK * UR_P1_SB = 2^21)
     const float inv_sb = 1.0f / (float)sb;
     const v4f *q = reinterpret_cast<const v4f *>(a.q);
-    for (int i0 = 0; i0 < n; i0 += 4 * PM_WAVE) {
-        v4f cur[4], prv[4];
-        int ser[4];
-        bool ok[4];
+    // `second`: the (rare) re-count after a reset was seen: only flips AFTER the series' last reset make the summary
+    auto sweep = [&](const bool second) {
+        for (int i0 = 0; i0 < n; i0 += 4 * PM_WAVE) {
+            v4f cur[4], prv[4];
+            int ser[4], row[4];
+            bool ok[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * PM_WAVE + lane, ic = i < n ? i : n - 1;
-            const int r = (int)(((float)ic + 0.5f) * inv_sb), c = ic - r * sb;
-            const int64_t t = t0 + r;
-            ser[u] = c;
-            ok[u] = (i < n) && (t > 0);
-            const int64_t e = (t * a.S + s0 + c) * V;
-            cur[u] = __builtin_nontemporal_load(q + e);
-            prv[u] = q[t > 0 ? e - (int64_t)a.S * V : e];
-        }
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * PM_WAVE + lane, ic = i < n ? i : n - 1;
+                const int r = (int)(((float)ic + 0.5f) * inv_sb), c = ic - r * sb;
+                const int64_t t = t0 + r;
+                ser[u] = c;
+                row[u] = r;
+                ok[u] = (i < n) && (t > 0);
+                const int64_t e = (t * a.S + s0 + c) * V;
+                cur[u] = __builtin_nontemporal_load(q + e);
+                prv[u] = q[t > 0 ? e - (int64_t)a.S * V : e];
+            }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const bool flip = ok[u] && (cur[u].x * prv[u].x + cur[u].y * prv[u].y + cur[u].z * prv[u].z + cur[u].w * prv[u].w) < 0.0f;
-            if (flip) __hip_atomic_fetch_xor(par + ser[u], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int u = 0; u < 4; ++u) {
+                const float d = cur[u].x * prv[u].x + cur[u].y * prv[u].y + cur[u].z * prv[u].z + cur[u].w * prv[u].w;
+                const bool flip = ok[u] && d < 0.0f;
+                const bool reset = ok[u] && !(d < 0.0f) && !(d > 0.0f);
+                if (!second) {
+                    if (flip) __hip_atomic_fetch_xor(par + ser[u], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (reset) __hip_atomic_fetch_max(lastr + ser[u], row[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else if (flip && row[u] > lastr[ser[u]]) {
+                    __hip_atomic_fetch_xor(par + ser[u], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
         }
-    }
+    };
+    sweep(false);
     wave_sync();
-    for (int i = lane; i < sb; i += PM_WAVE) a.ws[(int64_t)chunk * a.S + s0 + i] = par[i] & 1;
+    bool any = false;
+    for (int i = lane; i < sb; i += PM_WAVE) any = any || lastr[i] >= 0;
+    if (__ballot(any) != 0) {  // wave-uniform; zero-padded rows, exactly orthogonal steps, NaN: not on the usual path
+        for (int i = lane; i < sb; i += PM_WAVE) par[i] = 0;
+        wave_sync();
+        sweep(true);
+        wave_sync();
+    }
+    for (int i = lane; i < sb; i += PM_WAVE) a.ws[(int64_t)chunk * a.S + s0 + i] = (par[i] & 1) | (lastr[i] >= 0 ? 2 : 0);
 }
 
-// exclusive prefix XOR over chunks, in place: one wave per series, lane = chunk (64 at a time), the
-// prefix inside a group of 64 chunks is a ballot + popcount
+// exclusive prefix over chunks of the composed sign maps, in place: one wave per series, lane = chunk (64 at a time);
+// inside a group of 64 chunks the prefix is a ballot + popcount, cut at the last chunk with a reset
 __global__ __launch_bounds__(PM_WAVE) void unroll_scan_kernel(int32_t *ws, int nchunks, int S) {
     const int s = blockIdx.x, lane = threadIdx.x;
     int carry = 0;
     for (int base = 0; base < nchunks; base += PM_WAVE) {
         const int c = base + lane;
-        const int v = (c < nchunks) ? (ws[(int64_t)c * S + s] & 1) : 0;
-        const unsigned long long m = __ballot(v);
+        const int v = (c < nchunks) ? ws[(int64_t)c * S + s] : 0;
+        const unsigned long long m = __ballot(v & 1), mr = __ballot(v & 2);
         const unsigned long long below = (1ull << lane) - 1ull;
-        if (c < nchunks) ws[(int64_t)c * S + s] = (__popcll(m & below) + carry) & 1;
-        carry ^= __popcll(m) & 1;
+        int pre = (__popcll(m & below) + carry) & 1;
+        const unsigned long long rb = mr & below;
+        if (rb != 0) {  // a chunk with a reset before this one: its summary bit, then the parities after it
+            const int r = 63 - __builtin_clzll(rb);
+            pre = __popcll(m & below & ~((1ull << r) - 1ull)) & 1;
+        }
+        if (c < nchunks) ws[(int64_t)c * S + s] = pre;
+        if (mr != 0) {
+            const int r = 63 - __builtin_clzll(mr);
+            carry = __popcll(m & ~((1ull << r) - 1ull)) & 1;
+        } else {
+            carry ^= __popcll(m) & 1;
+        }
     }
 }
 
@@ -189,9 +241,9 @@ __global__ __launch_bounds__(256) void unroll_scan_wide_kernel(int32_t *ws, int 
     if (s >= S) return;
     int carry = 0;
     for (int c = 0; c < nchunks; ++c) {
-        const int v = ws[(int64_t)c * S + s] & 1;
+        const int v = ws[(int64_t)c * S + s];
         ws[(int64_t)c * S + s] = carry;
-        carry ^= v;
+        carry = (v & 2) ? (v & 1) : (carry ^ (v & 1));
     }
 }
 
@@ -226,7 +278,7 @@ static int unroll_launch(const float *q, int64_t T, int32_t S, float *out, void 
     if (int e = allow_lds(unroll_apply_kernel<W>, lds)) return e;
     const dim3 grid((unsigned)(nchunks * sblocks));
     {   // pass 1: chunk parities
-        const size_t p1_lds = (size_t)(S < p1_sb ? S : p1_sb) * sizeof(int);
+        const size_t p1_lds = 2 * (size_t)(S < p1_sb ? S : p1_sb) * sizeof(int);
         hipLaunchKernelGGL((unroll_parity_kernel<W>), dim3((unsigned)(nchunks * p1_blocks)), dim3(PM_WAVE), p1_lds, s, a);
     }
     if (nchunks <= 256) hipLaunchKernelGGL(unroll_scan_wide_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, s, a.ws, (int)nchunks, (int)S);

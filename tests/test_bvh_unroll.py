@@ -130,3 +130,49 @@ def test_config1_bvh_1000_frames_gpu_vs_numpy_cpu_reference(tmp_path):
     p_cpu, r_cpu = nr.fk(rots, pos[:, 0, :], offsets, parents)  # the reference algorithm, float64
     assert_close(p_gpu, np.ascontiguousarray(p_cpu), 1e-5, "config 1 positions")
     assert_close(r_gpu, np.ascontiguousarray(r_cpu), 1e-5, "config 1 rotation matrices")
+
+
+# ---- resets: a neighbour dot product of exactly 0 / NaN restarts the accumulated sign (tests/golden/degenerate.npz) ----
+
+def test_oracle_unroll_with_resets_matches_reference():
+    g = golden("degenerate.npz")
+    i, want = g.get("unroll_resets", "in"), g.get("unroll_resets", "out64")["out"]
+    got = co.quat_unroll(i["q"].astype(np.float64), 0)
+    assert (np.isnan(got) == np.isnan(want)).all()
+    np.testing.assert_array_equal(np.nan_to_num(got), np.nan_to_num(want))
+
+
+@pytest.mark.gpu
+def test_gpu_unroll_with_resets_matches_reference():
+    """zero-padded rows, exactly orthogonal steps and NaN rows, inside / at the edge of / across the 256-frame chunks and
+    64-frame sub-tiles of the scan: the kernel must forget the sign accumulated before them, like the reference's loop"""
+    import torch
+
+    import pymotion_amd.rotations.dual_quat as dq
+    import pymotion_amd.rotations.quat as quat
+    import pymotion_amd.rotations.quat_torch as quat_t
+
+    g = golden("degenerate.npz")
+    i, want = g.get("unroll_resets", "in"), g.get("unroll_resets", "out64")["out"]
+    for got in (quat.unroll(i["q"], 0), quat_t.unroll(torch.from_numpy(i["q"]).cuda(), 0).cpu().numpy()):
+        assert (np.isnan(got) == np.isnan(want)).all()
+        np.testing.assert_array_equal(np.nan_to_num(got).astype(np.float32), np.nan_to_num(want).astype(np.float32))
+    # the same series as columns of a wide clip (thread-per-series chunk scan) and with the unroll axis last-but-one
+    wide = np.tile(i["q"], (1, 40, 1))
+    got = quat.unroll(wide, 0)
+    np.testing.assert_array_equal(np.nan_to_num(got).astype(np.float32), np.nan_to_num(np.tile(want, (1, 40, 1))).astype(np.float32))
+    got = quat.unroll(np.ascontiguousarray(np.moveaxis(i["q"], 0, 1)), 1)
+    np.testing.assert_array_equal(np.nan_to_num(got).astype(np.float32), np.nan_to_num(np.moveaxis(want, 0, 1)).astype(np.float32))
+    # a long clip: the ballot scan over chunks (> 256 chunks), resets sprinkled over it
+    T = 256 * 300 + 17
+    rng = np.random.default_rng(8)
+    q = rng.standard_normal((T, 3, 4)).astype(np.float32)
+    q[rng.random((T, 3)) < 0.001] = 0
+    q[255::256, 1] = 0
+    got = quat.unroll(q, 0)
+    ref = co.quat_unroll(q.astype(np.float64), 0)
+    np.testing.assert_array_equal(got.astype(np.float32), ref.astype(np.float32))
+    i8, want8 = g.get("dq_unroll_resets", "in"), g.get("dq_unroll_resets", "out64")["out"]
+    got8 = dq.unroll(i8["dq"], 0)
+    assert (np.isnan(got8) == np.isnan(want8)).all()
+    np.testing.assert_array_equal(np.nan_to_num(got8).astype(np.float32), np.nan_to_num(want8).astype(np.float32))
