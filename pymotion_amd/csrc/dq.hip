@@ -4,6 +4,7 @@
 //   from_global_rotations pymotion/ops/skeleton.py:64-93    (same gather shape)
 // Same wave-private tiling as fk.hip: HBM <-> LDS with contiguous dwordx4, AoS access from LDS.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.hpp"
 
@@ -243,6 +244,261 @@ static int launch_to_root(const ToRootArgs &a, bool vec, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// to_root_dual_quat for bigger skeletons: C independent chains per frame.
+// The walk above is J serial steps per tile, and from ~28 joints on the LDS image only leaves room for 8 frames per
+// wave: half the lanes walk, and the serial part is a third of the kernel (2^18 x 52: 182 us with the walk, 120 without).
+// A skeleton is a TREE, though: subtrees (the limbs, the fingers) are independent once their common ancestor is done.
+// Here 4 C lanes own a frame -- C quads, each walking its own sequence of joints in lockstep -- and a wave covers
+// 16 / C frames.  The host list-schedules the joints onto the C chains (longest remaining path first; a joint may
+// follow its parent immediately only on the parent's own chain, where the parent's value is still in registers,
+// otherwise two steps later, when the parent's slot has been written AND the look-ahead read was issued after it),
+// so the walk is K = max(ceil(J / C), depth, ...) steps instead of J: 27 for the 52-joint SMPL-H tree with two
+// chains, 15 with four.  The schedule travels in the kernarg segment (one byte per step and chain) and is expanded
+// once per tile into an LDS "program": byte offsets of the joint's slot, its parent's slot and its table row.
+// Everything else (image = output tile + identity slot, phase A / C, copy-out, the 12-instruction DPP step) is the
+// kernel above.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kSchedMax = 768;  // bytes of schedule in the kernarg segment (steps x chains)
+constexpr int kSchedMaxJoints = 250;
+
+struct SchedArgs {
+    const float *rot;
+    const float *root_pos;
+    const float *offsets;
+    float *dq;
+    int64_t F;
+    int32_t J;
+    int32_t K;                       // steps
+    int16_t parent[kSchedMaxJoints + 2];
+    uint8_t sched[kSchedMax];        // [K][C]: joint index, 255 = idle
+};
+
+__host__ __device__ constexpr int sched_frame_stride(const int J) { return 8 * J + 20; }  // J slots + identity + idle slot + pad; (FS / 4) odd
+
+template <int C, bool VEC>
+__global__ __launch_bounds__(PM_WAVE) void to_root_dq_sched_kernel(const SchedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    constexpr int FPW = 16 / C;
+    const int lane = threadIdx.x;
+    const int J = a.J, K = a.K;
+    const int64_t ntiles = (a.F + FPW - 1) / FPW;
+    const int64_t tile = xcd_tile(ntiles);
+    if (tile < 0) return;
+    const int64_t f0 = tile * FPW;
+    const int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
+    const int n = nf * J;
+    const int FS = sched_frame_stride(J);
+    float *sDq = smem;                                             // [FPW * FS]
+    float *sTab = sDq + FPW * FS;                                  // [(J + 2) * 12]  rows J, J+1 (identity, idle) are zero
+    v4i *sProg = reinterpret_cast<v4i *>(sTab + 12 * (J + 2));     // [(K + 2) * C]  {own, parent, table row (bytes), on-chain}
+    const float invJ = 1.0f / (float)J;
+
+    const int fq = lane / (4 * C), k = (lane >> 2) % C, c = lane & 3;
+    const float rp = (c > 0 && fq < nf) ? a.root_pos[(f0 + fq) * 3 + c - 1] : 0.0f;  // (0, root_pos) component c
+    // (Staging the raw constants through LDS first, so that the tile pays one memory latency instead of one per table
+    // batch, was measured and is SLOWER -- 150 -> 178 us at J = 52: with ~9 resident waves the latencies are hidden anyway and
+    // the kernel is bound by instruction issue, which the extra LDS round trip adds to.)
+    for (int i = lane; i < 4 * (J + 2); i += PM_WAVE) {  // the joint table, as in to_root_dq_kernel; row 0 is zero (skeleton.py:227)
+        const int j = i >> 2, cc = i & 3;
+        float vc = 0.0f, w1 = 0.0f, w2 = 0.0f;
+        if (cc > 0 && j > 0 && j < J) {
+            const float o[3] = {a.offsets[3 * j], a.offsets[3 * j + 1], a.offsets[3 * j + 2]};
+            const int cur = cc - 1, nx = cur == 2 ? 0 : cur + 1, nn = nx == 2 ? 0 : nx + 1;
+            vc = o[cur]; w1 = 2.0f * o[nn]; w2 = 2.0f * o[nx];
+        }
+        sTab[3 * i] = vc; sTab[3 * i + 1] = w1; sTab[3 * i + 2] = w2;
+    }
+    for (int i = lane; i < (K + 2) * C; i += PM_WAVE) {  // the program; two idle steps of slack for the look-ahead
+        const int st = i / C, kk = i - st * C;
+        int j = (st < K) ? a.sched[i] : 255;
+        v4i e;
+        if (j == 255) {
+            e = v4i{(J + 1) * 32, J * 32, (J + 1) * 48, 0};  // idle: the scratch slot, composed with the identity
+        } else {
+            const int p = a.parent[j];
+            const int pe = (j == 0 || p == 0) ? J : p;  // the root and its children compose with the identity (skeleton.py:232-237)
+            const int prev = (st > 0) ? a.sched[(st - 1) * C + kk] : 255;
+            e = v4i{j * 32, pe * 32, j * 48, (pe != J && prev == pe) ? 1 : 0};
+        }
+        sProg[i] = e;
+    }
+    const float *gsrc = a.rot + f0 * J * 4;
+    auto load_batch = [&](const int e0, v4f (&q)[4]) {
+        if (e0 >= n) return;  // wave-uniform
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * PM_WAVE + lane, ec = e < n ? e : n - 1;
+            if (VEC) q[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(gsrc) + ec);
+            else q[u] = v4f{gsrc[4 * ec], gsrc[4 * ec + 1], gsrc[4 * ec + 2], gsrc[4 * ec + 3]};
+        }
+    };
+    auto park_batch = [&](const int e0, const v4f (&q)[4]) {
+        if (e0 >= n) return;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * PM_WAVE + lane;
+            const int f = (int)(((float)e + 0.5f) * invJ);  // e / J, exact for e < 2^22
+            const int j = e - f * J;
+            if (e < n) *reinterpret_cast<v4f *>(sDq + f * FS + j * 8) = q[u];
+        }
+    };
+    {
+        constexpr int BATCH = 4 * PM_WAVE;
+        v4f qa[4], qb[4];
+        load_batch(0, qa);
+        load_batch(BATCH, qb);
+        for (int e0 = 0; e0 < n; e0 += 2 * BATCH) {
+            park_batch(e0, qa);
+            load_batch(e0 + 2 * BATCH, qa);
+            park_batch(e0 + BATCH, qb);
+            load_batch(e0 + 3 * BATCH, qb);
+        }
+    }
+    float *fD = sDq + fq * FS;
+    if (k == 0) {  // identity slot (1,0,0,0 | 0,0,0,0); the idle slot just has to hold finite words
+        fD[J * 8 + c] = (c == 0) ? 1.0f : 0.0f;
+        fD[J * 8 + 4 + c] = 0.0f;
+        fD[(J + 1) * 8 + c] = 0.0f;
+        fD[(J + 1) * 8 + 4 + c] = 0.0f;
+    }
+    wave_sync();
+
+    // ---- the walk: K steps, every quad on its own joint ---------------------------------------------------
+    const float s1 = (c == 0 || c == 2) ? -1.0f : 1.0f;   // S[c][1]:  - + - +
+    const float s2 = (c == 0 || c == 3) ? -1.0f : 1.0f;   // S[c][2]:  - + + -
+    const float s3 = (c == 0 || c == 1) ? -1.0f : 1.0f;   // S[c][3]:  - - + +
+    const float live = (c == 0) ? 0.0f : 1.0f;
+    const int toff = (c == 0) ? 7 : 3 + c;                // where component c of (0,t) sits in a slot: t0 t1 t2 0
+    const char *bq = reinterpret_cast<const char *>(fD + c), *bt = reinterpret_cast<const char *>(fD + toff);
+    const char *btab = reinterpret_cast<const char *>(sTab + 3 * c);
+    const v4i *prog = sProg + k;
+    struct In { float b, vc, w1, w2, peq, pet; v4i e; };
+    auto fetch = [&](const v4i e, In &x, const bool root_lane) {
+        x.e = e;
+        x.b = *reinterpret_cast<const float *>(bq + e.x);
+        const float *row = reinterpret_cast<const float *>(btab + e.z);
+        x.vc = row[0]; x.w1 = row[1]; x.w2 = row[2];
+        if (root_lane) x.vc = rp;  // the root's "offset" is the frame's root position (skeleton.py:232)
+        x.peq = *reinterpret_cast<const float *>(bq + e.y);
+        x.pet = *reinterpret_cast<const float *>(bt + e.y);
+    };
+    float gq = 0.0f, gt = 0.0f;  // what this quad produced in the previous step
+    auto step = [&](const In &x) {
+        const float sb1 = quad_perm_mul<1, 0, 3, 2>(x.b, s1), sb2 = quad_perm_mul<2, 3, 0, 1>(x.b, s2),
+                    sb3 = quad_perm_mul<3, 2, 1, 0>(x.b, s3);
+        const bool chain = x.e.w != 0;
+        const float pq = chain ? gq : x.peq, pt = chain ? gt : x.pet;
+        const float s = x.vc + pt;
+        float q, t;
+        dq_step_math(pq, s, x.b, sb1, sb2, sb3, x.w1, x.w2, live, q, t);
+        *reinterpret_cast<float *>(const_cast<char *>(bq) + x.e.x) = q;
+        *reinterpret_cast<float *>(const_cast<char *>(bt) + x.e.x) = t;
+        gq = q; gt = t;
+    };
+    // The root (joint 0) is always the first entry of chain 0 (the scheduler puts it there).
+    In A, B;
+    fetch(prog[0], A, k == 0);
+    v4i en = prog[C];
+    for (int st = 0; st < K; st += 2) {
+        // operands of step st+1 are requested before step st computes: a parent finished at step st-1 or earlier is in its
+        // slot by now (in-order DS), one finished at step st is this quad's own register chain (the scheduler guarantees it)
+        fetch(en, B, false);
+        en = prog[(st + 2) * C];
+        step(A);
+        if (st + 1 >= K) break;
+        fetch(en, A, false);
+        en = prog[(st + 3) * C];
+        step(B);
+    }
+    wave_sync();
+    // phase C, lane per (frame, joint): (q, t) -> [q, 0.5 (0,t) (x) q]  (dual_quat.py:28-36), off the chain
+    for_each_slot<2>(n, lane, [&](const int e, const bool valid) {
+        const int f = (int)(((float)e + 0.5f) * invJ);
+        const int j = e - f * J;
+        float *slot = sDq + f * FS + j * 8;
+        float qt[8], d[8];
+        lds_get<8>(slot, 0, qt);
+        const float q[4] = {qt[0], qt[1], qt[2], qt[3]}, t[3] = {qt[4], qt[5], qt[6]};
+        rt2dq(q, t, d);
+        if (valid) *reinterpret_cast<v4f *>(slot + 4) = v4f{d[4], d[5], d[6], d[7]};
+    });
+    wave_sync();
+    float *gout = a.dq + f0 * J * 8;
+    const int n4 = n * 2, J2 = 2 * J;
+    const float invJ2 = 1.0f / (float)J2;
+    for (int i = lane; i < n4; i += PM_WAVE) {
+        const int f = (int)(((float)i + 0.5f) * invJ2);
+        const int r = i - f * J2;
+        const v4f v = *reinterpret_cast<const v4f *>(sDq + f * FS + r * 4);
+        if (VEC) __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(gout) + i);
+        else { gout[4 * i] = v.x; gout[4 * i + 1] = v.y; gout[4 * i + 2] = v.z; gout[4 * i + 3] = v.w; }
+    }
+}
+
+// image + joint table + program
+static size_t sched_lds_bytes(const int J, const int K, const int C) {
+    return ((size_t)(16 / C) * sched_frame_stride(J) + 12 * (J + 2)) * sizeof(float) + (size_t)(K + 2) * C * 16;
+}
+
+// List scheduling of the joints onto C chains (see above).  Returns the number of steps K, or 0 if the schedule does
+// not fit the kernarg table.  sched[st * C + k] = joint or 255.
+static int schedule_chains(const Parents &par, const int J, const int C, uint8_t *sched) {
+    int height[PM_MAX_JOINTS], done_step[PM_MAX_JOINTS], done_chain[PM_MAX_JOINTS];
+    for (int j = 0; j < J; ++j) { height[j] = 1; done_step[j] = -1; done_chain[j] = -1; }
+    for (int j = J - 1; j >= 1; --j) {  // joints hanging off the root do not wait for it (they stay local)
+        const int p = par.p[j];
+        if (p != 0 && height[p] < height[j] + 1) height[p] = height[j] + 1;
+    }
+    int left = J, K = 0;
+    for (int st = 0; left > 0; ++st) {
+        if ((st + 1) * C > kSchedMax) return 0;
+        for (int k = 0; k < C; ++k) {
+            int best = -1, best_on_chain = 0;
+            if (st == 0 && k == 0) {
+                best = 0;  // the root opens chain 0: the kernel hands it the frame's root position there
+            } else {
+                for (int j = 1; j < J; ++j) {
+                    if (done_step[j] >= 0) continue;
+                    const int p = par.p[j];
+                    int on_chain = 0;
+                    if (p != 0) {
+                        if (done_step[p] < 0 || done_step[p] == st) continue;             // parent not done (or done in this very step)
+                        if (done_step[p] == st - 1) { if (done_chain[p] != k) continue; on_chain = 1; }  // only on the parent's chain
+                    }
+                    // a continuation of this chain first (nobody else can take it now), then the longest remaining path
+                    if (best < 0 || on_chain > best_on_chain || (on_chain == best_on_chain && height[j] > height[best])) { best = j; best_on_chain = on_chain; }
+                }
+            }
+            sched[st * C + k] = (uint8_t)(best < 0 ? 255 : best);
+            if (best >= 0) { done_step[best] = st; done_chain[best] = k; --left; }
+        }
+        K = st + 1;
+    }
+    return K;
+}
+
+template <int C>
+static int launch_to_root_sched(const SchedArgs &a, bool vec, hipStream_t s) {
+    constexpr int FPW = 16 / C;
+    const size_t lds = sched_lds_bytes(a.J, a.K, C);
+    const int64_t ntiles = (a.F + FPW - 1) / FPW;
+    const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
+    if (grid > 0x7fffffffLL) { set_error("to_root_dq: grid too large"); return PM_EUNSUPPORTED; }
+    set_kernel_name("void pm::to_root_dq_sched_kernel<%d, %s>(pm::SchedArgs)", C, tf(vec));
+    if (vec) {
+        auto kf = to_root_dq_sched_kernel<C, true>;
+        if (int e = allow_lds(kf, lds)) return e;
+        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
+    } else {
+        auto kf = to_root_dq_sched_kernel<C, false>;
+        if (int e = allow_lds(kf, lds)) return e;
+        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
+    }
+    return check_hip(hipGetLastError(), "to_root_dq launch");
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Gather-parent kernels: one lane per (frame, joint); every lane reads its own and its parent's
 // INPUT record from the LDS tile -- no dependency chain.
 //   MODE 0  from_root_dual_quat: in dq[8] -> out trans[3], rot[4]
@@ -374,6 +630,31 @@ extern "C" int pm_to_root_dq_f32(const float *rot, const float *root_pos, const 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t per_frame = (size_t)to_root_frame_stride(J) * sizeof(float), fixed = (13 * (size_t)J + 37) * sizeof(float) + 256;
     int pick = (7 * (16 * per_frame + fixed) <= kMaxLds) ? 16 : 8;  // 4 lanes per frame; keep >= 7 waves per CU if possible
+    // Bigger skeletons: several chains per frame if the tree is wide enough for the shorter walk to pay
+    // (cost of the walk per frame ~ steps x chains / 16; a pure chain stays on the one-chain kernel).
+    int chains = tune_env("PM_DQ_CHAINS", -1);  // PM_TUNING build only: 0 = the one-chain kernel, 2 / 4
+    if ((chains < 0 ? (pick != 16) : (chains == 2 || chains == 4)) && J <= kSchedMaxJoints) {
+        SchedArgs sa;
+        int K2 = 0, K4 = 0;
+        uint8_t s2[kSchedMax], s4[kSchedMax];
+        if (chains != 4) K2 = schedule_chains(a.parents, J, 2, s2);
+        if (chains != 2) K4 = schedule_chains(a.parents, J, 4, s4);
+        int use = 0;
+        if (chains == 2) use = K2 ? 2 : 0;
+        else if (chains == 4) use = K4 ? 4 : 0;
+        else {  // walk cost per frame in sixteenths of a step: J x 2 today (8 frames per wave)
+            const int c1 = 2 * J, c2 = K2 ? 2 * K2 : 1 << 30, c4 = K4 ? 4 * K4 : 1 << 30;
+            if (c4 <= c2 && 4 * c4 <= 3 * c1) use = 4;          // ties go to the smaller tile (more resident waves)
+            else if (4 * c2 <= 3 * c1) use = 2;
+        }
+        if (use) {
+            sa.rot = rot; sa.root_pos = root_pos; sa.offsets = offsets; sa.dq = dq; sa.F = F; sa.J = J;
+            sa.K = use == 2 ? K2 : K4;
+            memcpy(sa.sched, use == 2 ? s2 : s4, (size_t)sa.K * use);
+            for (int j = 0; j < J; ++j) sa.parent[j] = (int16_t)a.parents.p[j];
+            if (sched_lds_bytes(J, sa.K, use) <= kMaxLds) return use == 2 ? launch_to_root_sched<2>(sa, vec, s) : launch_to_root_sched<4>(sa, vec, s);
+        }
+    }
     if (const int v = tune_env("PM_DQ_FPW", 0); v == 16 || v == 8 || v == 4) pick = v;  // PM_TUNING build only
     while (pick > 4 && pick * per_frame + fixed > kMaxLds) pick >>= 1;
     if (pick * per_frame + fixed <= kMaxLds) {

@@ -741,3 +741,55 @@ def test_numpy_float64_output_opt_out():
     finally:
         config.numpy_float64_outputs = True
     assert_close(p32, sk.fk(rot, root, off, par)[0], 0, "same values, only the dtype differs")
+
+
+def _tree(kind, J, rng):
+    """topologies that stress the chain scheduler of to_root_dual_quat: pure chain, star, binary heap (breadth-first
+    order), two long chains hanging off a deep trunk, random"""
+    p = np.zeros(J, dtype=np.int32)
+    if kind == "chain":
+        p[1:] = np.arange(J - 1)
+    elif kind == "star":
+        p[:] = 0
+    elif kind == "star_off_1":
+        p[1:] = 1
+        p[1] = 0
+    elif kind == "heap":
+        p[1:] = (np.arange(1, J) - 1) // 2
+    elif kind == "two_arms":
+        t = J // 3
+        p[1:t] = np.arange(t - 1)
+        p[t] = t - 1
+        p[t + 1:2 * t] = np.arange(t, 2 * t - 1)
+        p[2 * t] = t - 1
+        p[2 * t + 1:] = np.arange(2 * t, J - 1)
+    else:
+        for i in range(1, J):
+            p[i] = rng.integers(0, i)
+    return p
+
+
+@pytest.mark.parametrize("kind", ["chain", "star", "star_off_1", "heap", "two_arms", "random", "random2"])
+@pytest.mark.parametrize("J", [28, 31, 52, 64, 65, 100, 129, 250, 251])
+def test_to_root_dq_chain_scheduler_on_many_topologies(kind, J):
+    """28 <= J <= 250 walks several chains per frame (dq.hip: schedule_chains) when the tree is wide enough; every shape of
+    tree -- including the ones that must fall back to one chain -- has to give the oracle's dual quaternions, and the
+    decode has to bring the inputs back"""
+    rng = np.random.default_rng(hash((kind, J)) % (1 << 31))
+    parents = _tree(kind, J, rng)
+    F = 37
+    rot = rng.standard_normal((F, J, 4))
+    rot = (rot / np.linalg.norm(rot, axis=-1, keepdims=True)).astype(np.float32)
+    gpos = rng.uniform(-2, 2, (F, 3)).astype(np.float32)
+    off = rng.uniform(-0.3, 0.3, (J, 3)).astype(np.float32)
+    off[0] = 0
+    d = sk.to_root_dual_quat(rot, gpos, parents, off)
+    d_o = co.to_root_dual_quat(rot.astype(np.float64), gpos.astype(np.float64), parents, off.astype(np.float64))
+    depth = 1
+    dd = np.zeros(J, int)
+    for i in range(1, J):
+        dd[i] = dd[parents[i]] + 1
+    depth = dd.max()
+    assert_close(d, d_o, max(ATOL, 3e-7 * depth * depth), f"{kind} J={J} depth={depth}")  # (a 250-joint chain accumulates 250 fp32 products)
+    t, q = sk.from_root_dual_quat(d, parents)
+    assert_close(q, rot, max(ATOL, 3e-7 * depth * depth), "round trip rot")
