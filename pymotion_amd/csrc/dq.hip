@@ -276,18 +276,15 @@ struct SchedArgs {
 __host__ __device__ constexpr int sched_frame_stride(const int J) { return 8 * J + 20; }  // J slots + identity + idle slot + pad; (FS / 4) odd
 
 template <int C, bool VEC>
-__global__ __launch_bounds__(PM_WAVE) void to_root_dq_sched_kernel(const SchedArgs a) {
+__global__ __launch_bounds__(PM_WAVE) void to_root_dq_sched_kernel(const SchedArgs a, const int nt) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef int v4i __attribute__((ext_vector_type(4)));
     constexpr int FPW = 16 / C;
     const int lane = threadIdx.x;
     const int J = a.J, K = a.K;
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
-    const int64_t tile = xcd_tile(ntiles);
-    if (tile < 0) return;
-    const int64_t f0 = tile * FPW;
-    const int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
-    const int n = nf * J;
+    const int64_t group = xcd_tile((ntiles + nt - 1) / nt);  // a workgroup owns `nt` consecutive tiles: table and program are built once
+    if (group < 0) return;
     const int FS = sched_frame_stride(J);
     float *sDq = smem;                                             // [FPW * FS]
     float *sTab = sDq + FPW * FS;                                  // [(J + 2) * 12]  rows J, J+1 (identity, idle) are zero
@@ -295,7 +292,6 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_sched_kernel(const SchedAr
     const float invJ = 1.0f / (float)J;
 
     const int fq = lane / (4 * C), k = (lane >> 2) % C, c = lane & 3;
-    const float rp = (c > 0 && fq < nf) ? a.root_pos[(f0 + fq) * 3 + c - 1] : 0.0f;  // (0, root_pos) component c
     // (Staging the raw constants through LDS first, so that the tile pays one memory latency instead of one per table
     // batch, was measured and is SLOWER -- 150 -> 178 us at J = 52: with ~9 resident waves the latencies are hidden anyway and
     // the kernel is bound by instruction issue, which the extra LDS round trip adds to.)
@@ -323,6 +319,11 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_sched_kernel(const SchedAr
         }
         sProg[i] = e;
     }
+  for (int64_t tile = group * nt; tile < ntiles && tile < (group + 1) * nt; ++tile) {
+    const int64_t f0 = tile * FPW;
+    const int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
+    const int n = nf * J;
+    const float rp = (c > 0 && fq < nf) ? a.root_pos[(f0 + fq) * 3 + c - 1] : 0.0f;  // (0, root_pos) component c
     const float *gsrc = a.rot + f0 * J * 4;
     auto load_batch = [&](const int e0, v4f (&q)[4]) {
         if (e0 >= n) return;  // wave-uniform
@@ -434,6 +435,8 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_sched_kernel(const SchedAr
         if (VEC) __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(gout) + i);
         else { gout[4 * i] = v.x; gout[4 * i + 1] = v.y; gout[4 * i + 2] = v.z; gout[4 * i + 3] = v.w; }
     }
+    wave_sync();  // the image is reused by the next tile
+  }
 }
 
 // image + joint table + program
@@ -483,17 +486,23 @@ static int launch_to_root_sched(const SchedArgs &a, bool vec, hipStream_t s) {
     constexpr int FPW = 16 / C;
     const size_t lds = sched_lds_bytes(a.J, a.K, C);
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
-    const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
+    // tiles per workgroup: the joint table and the program cost ~7 % of a tile's instructions; big batches share them
+    // (measured at 2^18 frames, 1 / 2 / 4 / 8 tiles: J = 52 149 / 139 / 143 / 150 us, J = 128 507 / 441 / 409 / 401 us)
+    int nt = ntiles >= 16384 ? (C == 4 ? 4 : 2) : 1;
+    nt = tune_env("PM_DQ_NT", nt);  // PM_TUNING build only
+    if (nt < 1) nt = 1;
+    const int64_t ngroups = (ntiles + nt - 1) / nt;
+    const int64_t grid = ((ngroups + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
     if (grid > 0x7fffffffLL) { set_error("to_root_dq: grid too large"); return PM_EUNSUPPORTED; }
-    set_kernel_name("void pm::to_root_dq_sched_kernel<%d, %s>(pm::SchedArgs)", C, tf(vec));
+    set_kernel_name("void pm::to_root_dq_sched_kernel<%d, %s>(pm::SchedArgs, int)", C, tf(vec));
     if (vec) {
         auto kf = to_root_dq_sched_kernel<C, true>;
         if (int e = allow_lds(kf, lds)) return e;
-        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
+        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a, nt);
     } else {
         auto kf = to_root_dq_sched_kernel<C, false>;
         if (int e = allow_lds(kf, lds)) return e;
-        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
+        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a, nt);
     }
     return check_hip(hipGetLastError(), "to_root_dq launch");
 }
@@ -644,8 +653,10 @@ extern "C" int pm_to_root_dq_f32(const float *rot, const float *root_pos, const 
         else if (chains == 4) use = K4 ? 4 : 0;
         else {  // walk cost per frame in sixteenths of a step: J x 2 today (8 frames per wave)
             const int c1 = 2 * J, c2 = K2 ? 2 * K2 : 1 << 30, c4 = K4 ? 4 * K4 : 1 << 30;
-            if (c4 <= c2 && 4 * c4 <= 3 * c1) use = 4;          // ties go to the smaller tile (more resident waves)
-            else if (4 * c2 <= 3 * c1) use = 2;
+            // near-ties go to four chains: the tile is half the size, twice as many waves are resident (measured, 2^18 frames:
+            // J = 96 two / four chains 384 / 342 us, J = 65 235 / 228 us; the 52-joint SMPL-H tree, 26 vs 17 steps: 150 / 179 us)
+            if (K4 && 20 * c4 <= 23 * c2 && 4 * c4 <= 3 * c1) use = 4;
+            else if (K2 && 4 * c2 <= 3 * c1) use = 2;
         }
         if (use) {
             sa.rot = rot; sa.root_pos = root_pos; sa.offsets = offsets; sa.dq = dq; sa.F = F; sa.J = J;
