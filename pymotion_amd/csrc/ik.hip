@@ -8,11 +8,11 @@
 //   * after rotations[j] is set, world rotation of j            = G_pre (x) rot_j,  rest dir of a further child gc = offsets[gc].
 // So one walk over the joints in index order (parents first) with the world quaternions of finished joints in
 // LDS does the same thing in O(J):  one lane per frame,
-//     rot_j = from_to(offsets[c0], inv(G_pre) (P_c0 - P_j))                                   (:136-141)
-//     for each further child gc:  G_j = G_pre (x) rot_j
-//         rot_j = rot_j (x) from_to_axis(offsets[gc], inv(G_j)(P_gc - P_j), inv(G_j) normalize(P_c0 - P_j))   (:147-168)
-//     G_j = G_pre (x) rot_j/(|rot_j| + 1e-8)  (fk normalises its inputs, skeleton.py:45; from_to's axis is only
-//     unit up to its own eps);  joints without children keep the identity (:126-130).
+//     G_j = G_pre (x) from_to(offsets[c0], inv(G_pre) (P_c0 - P_j))                                   (:136-141)
+//     for each further child gc:
+//         G_j = G_j (x) from_to_axis(offsets[gc], inv(G_j)(P_gc - P_j), inv(G_j) normalize(P_c0 - P_j))   (:147-168)
+//     (the reference's fk re-normalises its local rotations, skeleton.py:45; here from_to returns exactly unit
+//     quaternions);  joints without children keep the identity (:126-130).
 // HBM traffic: 12 J B/frame in, 16 J out, both as coalesced one-record-per-lane streams.
 #include <stdlib.h>
 
@@ -32,6 +32,7 @@ struct IkArgs {
     float *out;            // [F,J,4] local rotations
     int64_t F;
     int32_t J;
+    int32_t ablate;  // PM_TUNING build only (env PM_IK_ABLATE): 1 = no walk, 2 = no final pass, 4 = no position staging
     Topo16 topo;
 };
 
@@ -45,43 +46,41 @@ struct IkArgs {
 // Joints without children keep the exact identity (:126-130).
 __host__ __device__ constexpr int ik_frame_stride(const int J) { return 4 * ((J + 1) | 1); }  // (stride / 4) odd: the lanes (= frames) of a ds_read_b128 spread over all banks
 
-template <int FPW, bool VEC>
-__global__ __launch_bounds__(PM_WAVE) void from_root_positions_kernel(const IkArgs a) {
+// NL > 0: the pipelined form.  Loading the positions, walking and storing the rotations are three phases of comparable
+// length (2^20 x 22: 47 + 91 + 70 us when run alone) and a wave does them one after the other; with 23 KiB of image only six
+// waves share a CU, too few for the phases of different waves to overlap, so the kernel ran at their SUM.  Here a
+// workgroup owns `nt` consecutive tiles and all of a tile's position records (<= NL per lane) are requested into
+// registers BEFORE the previous tile is walked: loads fly during the walk, and the rotations of the previous tile drain
+// (fire-and-forget stores) while the next tile is parked and walked.  NL = 0: one tile per workgroup, batched loads
+// (skeletons whose tile does not fit the register file).
+template <int FPW, bool VEC, int NL>
+__global__ __launch_bounds__(PM_WAVE) void from_root_positions_kernel(const IkArgs a, const int nt) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
     const int J = a.J;
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
-    const int64_t tile = xcd_tile(ntiles);
-    if (tile < 0) return;
-    const int64_t f0 = tile * FPW;
-    const int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
-    const int n = nf * J;
+    const int64_t group = xcd_tile((ntiles + nt - 1) / nt);
+    if (group < 0) return;
     const int FS = ik_frame_stride(J);
     float *sS = smem;                         // [FPW * FS]  slot (f, j): position, then world quaternion
     float *sOff = sS + FPW * FS;              // [J * 3]
     int *sTopo = reinterpret_cast<int *>(sOff + 3 * J);  // [J] parent | [J+1] cstart | [J] clist
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    v4i *sItem = reinterpret_cast<v4i *>(sTopo + 3 * J + 4);  // [J + 2] the walk's program: {joint, parent, first child, first further child | count << 16}
     const float invJ = 1.0f / (float)J;
-
-    // positions: one 12-byte record per lane, consecutive lanes on consecutive records (coalesced dwordx3),
-    // four loads per lane in flight, re-packed into the 16-byte slots
-    {
+    constexpr int NR = NL > 0 ? NL : 1;
+    v3f_a4 pre[NR];  // NL > 0: the next tile's position records, one 12-byte record per lane and load (coalesced dwordx3)
+    auto issue = [&](const int64_t tile) {
+        const int64_t f0 = tile * FPW;
+        const int n = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW) * J;
         const float *g = a.pos + f0 * J * 3;
-        for (int e0 = 0; e0 < n; e0 += 4 * PM_WAVE) {
-            v3f_a4 p[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * PM_WAVE + lane, ec = e < n ? e : n - 1;
-                p[u] = __builtin_nontemporal_load(reinterpret_cast<const v3f_a4 *>(g + 3 * ec));
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * PM_WAVE + lane;
-                const int f = (int)(((float)e + 0.5f) * invJ);  // e / J, exact for e < 2^22
-                const int j = e - f * J;
-                if (e < n) { float *sl = sS + f * FS + 4 * j; sl[0] = p[u].x; sl[1] = p[u].y; sl[2] = p[u].z; }
-            }
+        for (int u = 0; u < NR; ++u) {
+            const int e = u * PM_WAVE + lane;
+            if (u * PM_WAVE < n) pre[u] = __builtin_nontemporal_load(reinterpret_cast<const v3f_a4 *>(g + 3 * (e < n ? e : n - 1)));
         }
-    }
+    };
+    if constexpr (NL > 0) issue(group * nt);
     for (int j = lane; j < J; j += PM_WAVE) {  // rest directions, normalised once (from_to would do it per frame: quat.py:541)
         const float o[3] = {a.offsets[3 * j], a.offsets[3 * j + 1], a.offsets[3 * j + 2]};
         float u[3];
@@ -92,64 +91,162 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_kernel(const IkAr
         if (j < J) { sTopo[j] = a.topo.parent[j]; sTopo[2 * J + 1 + j] = a.topo.clist[j]; }
         sTopo[J + j] = a.topo.cstart[j];
     }
+    // The walk visits the joints that have children, in index order.  Its topology reads are wave-uniform but DEPENDENT
+    // (child range -> first child -> that child's slot): three LDS round trips in a row per joint, with 1.5 waves per SIMD
+    // to hide them.  They are flattened once into one record per visited joint, which the walk reads two steps ahead.
+    int nitems_all = 0;  // wave-uniform
+    for (int j0 = 0; j0 < J; j0 += PM_WAVE) {  // compaction: ballot + prefix popcount
+        const int j = j0 + lane;
+        const int cs = (j < J) ? a.topo.cstart[j] : 0, ce = (j < J) ? a.topo.cstart[j + 1] : 0;
+        const bool has = ce > cs;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
+        if (has) sItem[nitems_all + __popcll(m & ((1ull << lane) - 1ull))] =
+            v4i{j, (j == 0) ? -1 : (int)a.topo.parent[j], (int)a.topo.clist[cs], (cs + 1) | ((ce - cs - 1) << 16)};
+        nitems_all += __popcll(m);
+    }
+    if (lane < 2) sItem[nitems_all + lane] = v4i{0, -1, 0, 0};  // slack for the look-ahead
+  for (int64_t tile = group * nt; tile < ntiles && tile < (group + 1) * nt; ++tile) {
+    const int64_t f0 = tile * FPW;
+    const int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
+    const int n = nf * J;
+    // positions -> the 16-byte slots of the image
+    auto park = [&](const int e, const v3f_a4 pv) {
+        const int f = (int)(((float)e + 0.5f) * invJ);  // e / J, exact for e < 2^22
+        const int j = e - f * J;
+        if (e < n) { float *sl = sS + f * FS + 4 * j; sl[0] = pv.x; sl[1] = pv.y; sl[2] = pv.z; }
+    };
+    if constexpr (NL > 0) {
+        if (!PM_ABLATED(a, 4)) {
+#pragma unroll
+            for (int u = 0; u < NR; ++u)
+                if (u * PM_WAVE < n) park(u * PM_WAVE + lane, pre[u]);
+        }
+        if (tile + 1 < ntiles && tile + 1 < (group + 1) * nt) issue(tile + 1);  // in flight during this tile's walk
+    } else {
+        // two batches of 8 loads per lane (12 KiB per wave) in flight before the first one is parked, batch k+2 requested
+        // before batch k is consumed (four loads at a time -- one memory latency per 256 records -- cost 10 %)
+        const float *g = a.pos + f0 * J * 3;
+        constexpr int NB = 8, BT = NB * PM_WAVE;
+        auto load_b = [&](const int e0, v3f_a4 (&pv)[NB]) {
+            if (e0 >= n) return;  // wave-uniform
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int e = e0 + u * PM_WAVE + lane, ec = e < n ? e : n - 1;
+                pv[u] = __builtin_nontemporal_load(reinterpret_cast<const v3f_a4 *>(g + 3 * ec));
+            }
+        };
+        auto park_b = [&](const int e0, const v3f_a4 (&pv)[NB]) {
+            if (e0 >= n) return;
+#pragma unroll
+            for (int u = 0; u < NB; ++u) park(e0 + u * PM_WAVE + lane, pv[u]);
+        };
+        v3f_a4 pa[NB], pb[NB];
+        load_b(0, pa);
+        load_b(BT, pb);
+        for (int e0 = PM_ABLATED(a, 4) ? n : 0; e0 < n; e0 += 2 * BT) {
+            park_b(e0, pa);
+            load_b(e0 + 2 * BT, pa);
+            park_b(e0 + BT, pb);
+            load_b(e0 + 3 * BT, pb);
+        }
+    }
     wave_sync();
 
     // ---- the walk: one lane per frame ------------------------------------------------------------------------
+    // Only WORLD quaternions are produced here (the final pass recovers the local ones), and the two alignment
+    // primitives are folded to one reciprocal square root each:
+    //   from_to(a, b), a unit, b = p / L of length-L p:  the reference's (sqrt((1+c)/2), sqrt((1-c)/2) normalize(a x b))
+    //   (quat.py:545-549) is the half-angle form of (1 + c, a x b) / |(1 + c, a x b)|, i.e. (L + a.p, a x p) normalised --
+    //   no separate normalisation of p, of the cross product, of the result (the reference's fk then divides by |q| + 1e-8,
+    //   skeleton.py:45: invisible in fp32 on a unit quaternion).  Its special cases are kept as selects on the same
+    //   thresholds: c ~ 1 (np.isclose: |c - 1| <= 1.001e-5) snaps to the identity (:551-552), c ~ -1 takes the
+    //   rare branch (:554-571), and a zero-length p gives the identity (what (sqrt(.5), 0) normalises to).
+    //   Roll about a further child (from_to_axis, :579-650): the axis the reference derives, inv(G_j) normalize(P_c0 - P_j), IS
+    //   the rest direction of the first child, which the alignment just mapped there -- except where that alignment snapped
+    //   to the identity, and those lanes derive it the long way.
+    // (Two joints in flight per lane -- independent subtrees scheduled by the host onto two instruction streams -- was built
+    // and measured: 286 us against 262 us for the same code with one stream.  The walk is not what the kernel waits for.)
     const int f = lane % FPW;  // lanes >= FPW shadow lanes 0.. ; frames past a partial tile use their own slots
     float *fS = sS + f * FS;
     float g[4] = {1.0f, 0.0f, 0.0f, 0.0f};  // world quaternion of the previous joint
-    for (int j = 0; j < J; ++j) {
-        const int par = sTopo[j];
-        float gpre[4] = {g[0], g[1], g[2], g[3]};
-        if (j == 0) { gpre[0] = 1.0f; gpre[1] = 0.0f; gpre[2] = 0.0f; gpre[3] = 0.0f; }
-        else if (par != j - 1) lds_get<4>(fS, par, gpre);  // wave-uniform: a finished joint's slot holds its G
-        const int cs = sTopo[J + j], ce = sTopo[J + j + 1];  // wave-uniform
-        float rot[4] = {1.0f, 0.0f, 0.0f, 0.0f};
-        if (ce > cs) {
-            const int c0 = sTopo[2 * J + 1 + cs];
-            float pj[4], pc[4];
-            lds_get<4>(fS, j, pj);
-            lds_get<4>(fS, c0, pc);  // children come later: their slots still hold positions
-            const float d[3] = {pc[0] - pj[0], pc[1] - pj[1], pc[2] - pj[2]};
-            const float inv[4] = {gpre[0], -gpre[1], -gpre[2], -gpre[3]};
-            float pred[3];
-            qmulvec(inv, d, pred);
-            const float rest[3] = {sOff[3 * c0], sOff[3 * c0 + 1], sOff[3 * c0 + 2]};  // already unit
-            float predn[3];
-            vnormalize(pred, 1e-8f, predn);
-            from_to_unit(rest, predn, rot);
-            for (int k = cs + 1; k < ce; ++k) {  // roll correction from every further child
-                const int gc = sTopo[2 * J + 1 + k];
-                float gj[4], rn[4], pg[4];
-                qnormalize(rot, 1e-8f, rn);  // the reference's fk normalises local rotations (skeleton.py:45)
-                qmul(gpre, rn, gj);
-                const float ginv[4] = {gj[0], -gj[1], -gj[2], -gj[3]};
-                lds_get<4>(fS, gc, pg);
-                const float dg[3] = {pg[0] - pj[0], pg[1] - pj[1], pg[2] - pj[2]};
-                float predg[3], dn[3], axis[3], roll[4], r2[4];
-                qmulvec(ginv, dg, predg);
+    struct Ops { float gl[4], pj[4], pc[4], a[3]; };
+    auto fetch = [&](const v4i it, Ops &o) {  // operands of one step: positions are static until their joint is aligned, a
+        const int jj = __builtin_amdgcn_readfirstlane(it.x), pp = __builtin_amdgcn_readfirstlane(it.y);  // finished parent's slot holds its G
+        const int cc = __builtin_amdgcn_readfirstlane(it.z);
+        lds_get<4>(fS, pp < 0 ? 0 : pp, o.gl);
+        lds_get<4>(fS, jj, o.pj);
+        lds_get<4>(fS, cc, o.pc);  // children come later: their slots still hold positions
+        o.a[0] = sOff[3 * cc]; o.a[1] = sOff[3 * cc + 1]; o.a[2] = sOff[3 * cc + 2];  // rest direction, unit
+    };
+    const int nitems = PM_ABLATED(a, 1) ? 0 : nitems_all;
+    v4i cur = sItem[0], nxt = sItem[1];
+    Ops oc, on;
+    fetch(cur, oc);
+    int prevj = -2;
+    for (int st = 0; st < nitems; ++st) {
+        const v4i nn = sItem[st + 2];
+        fetch(nxt, on);  // issued before this step computes; if next's parent is THIS joint its gl is stale, and unused (register chain)
+        const int j = __builtin_amdgcn_readfirstlane(cur.x), par = __builtin_amdgcn_readfirstlane(cur.y);
+        const int xs = __builtin_amdgcn_readfirstlane(cur.w) & 0xffff, nx = __builtin_amdgcn_readfirstlane(cur.w) >> 16;
+        float gpre[4];
+        const bool chain = par == prevj, root = par < 0;  // wave-uniform
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gpre[k] = root ? (k == 0 ? 1.0f : 0.0f) : (chain ? g[k] : oc.gl[k]);
+        const float (&pj)[4] = oc.pj, (&pc)[4] = oc.pc;
+        const float a[3] = {oc.a[0], oc.a[1], oc.a[2]};
+        const float d[3] = {pc[0] - pj[0], pc[1] - pj[1], pc[2] - pj[2]};
+        const float inv[4] = {gpre[0], -gpre[1], -gpre[2], -gpre[3]};
+        float p[3];
+        qmulvec(inv, d, p);  // the child's direction in the parent's frame, length L
+        const float L = fsqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+        const float dp = a[0] * p[0] + a[1] * p[1] + a[2] * p[2];  // L cos
+        float r[4] = {L + dp, a[1] * p[2] - a[2] * p[1], a[2] * p[0] - a[0] * p[2], a[0] * p[1] - a[1] * p[0]};
+        const float rn = __builtin_amdgcn_rsqf(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+        r[0] *= rn; r[1] *= rn; r[2] *= rn; r[3] *= rn;
+        const float tol = 1.001e-5f * L;  // np.isclose(dot, +-1): atol 1e-8 + rtol 1e-5, on dot = dp / L
+        const bool snap = fabsf(dp - L) <= tol || !(L > 0.0f);
+        if (snap) { r[0] = 1.0f; r[1] = 0.0f; r[2] = 0.0f; r[3] = 0.0f; }
+        const bool anti = fabsf(dp + L) <= tol && L > 0.0f;
+        if (__builtin_amdgcn_ballot_w64(anti) != 0 && anti) {  // anti-parallel (:554-571), rare: skipped by the whole wave otherwise
+            const bool xlike = isclose_to(fabsf(a[0]), 1.0f);
+            const float og[3] = {xlike ? 0.0f : 1.0f, xlike ? 1.0f : 0.0f, 0.0f};
+            const float c2[3] = {a[1] * og[2] - a[2] * og[1], a[2] * og[0] - a[0] * og[2], a[0] * og[1] - a[1] * og[0]};
+            float ax2[3];
+            vnormalize(c2, 1e-8f, ax2);
+            r[0] = 0.0f; r[1] = ax2[0]; r[2] = ax2[1]; r[3] = ax2[2];
+        }
+        qmul(gpre, r, g);  // G_j once the first child is aligned
+        for (int k = xs; k < xs + nx; ++k) {  // roll correction from every further child: G_j <- G_j (x) roll
+            const int gc = sTopo[2 * J + 1 + k];
+            float pg[4];
+            lds_get<4>(fS, gc, pg);
+            const float ginv[4] = {g[0], -g[1], -g[2], -g[3]};
+            const float dg[3] = {pg[0] - pj[0], pg[1] - pj[1], pg[2] - pj[2]};
+            float pgd[3], bn[3];
+            qmulvec(ginv, dg, pgd);
+            vnormalize(pgd, 1e-8f, bn);
+            float axis[3] = {a[0], a[1], a[2]};
+            if (__builtin_amdgcn_ballot_w64(snap) != 0) {  // where the alignment snapped, G_j does not take the rest direction onto d
+                float dn[3], ax[3];
                 vnormalize(d, 1e-8f, dn);
-                qmulvec(ginv, dn, axis);
-                const float restg[3] = {sOff[3 * gc], sOff[3 * gc + 1], sOff[3 * gc + 2]};  // already unit
-                float predgn[3];
-                vnormalize(predg, 1e-8f, predgn);
-                from_to_axis_unit(restg, predgn, axis, roll);
-                qmul(rot, roll, r2);
-                rot[0] = r2[0]; rot[1] = r2[1]; rot[2] = r2[2]; rot[3] = r2[3];
+                qmulvec(ginv, dn, ax);
+                axis[0] = snap ? ax[0] : axis[0]; axis[1] = snap ? ax[1] : axis[1]; axis[2] = snap ? ax[2] : axis[2];
             }
+            const float bg[3] = {sOff[3 * gc], sOff[3 * gc + 1], sOff[3 * gc + 2]};  // rest direction of this child, unit
+            float roll[4], g2[4];
+            from_to_axis_unit(bg, bn, axis, roll);
+            qmul(g, roll, g2);
+            g[0] = g2[0]; g[1] = g2[1]; g[2] = g2[2]; g[3] = g2[3];
         }
-        if (ce > cs) {  // (a childless joint keeps the identity, nobody reads its G: nothing to do)
-            float rn[4];
-            qnormalize(rot, 1e-8f, rn);
-            qmul(gpre, rn, g);
-            lds_put<4>(fS, j, g);  // P_j is dead from here on
-        }
+        lds_put<4>(fS, j, g);  // P_j is dead from here on
+        prevj = j;
+        cur = nxt; nxt = nn; oc = on;
     }
     wave_sync();
 
     // ---- local rotations back out of the world quaternions, lane per (frame, joint), straight to HBM -----------
     float *gout = a.out + f0 * J * 4;
-    for_each_slot<2>(n, lane, [&](const int e, const bool valid) {
+    for_each_slot<2>(PM_ABLATED(a, 2) ? 0 : n, lane, [&](const int e, const bool valid) {
         const int fr = (int)(((float)e + 0.5f) * invJ);
         const int j = e - fr * J;
         const float *fq = sS + fr * FS;
@@ -166,23 +263,35 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_kernel(const IkAr
             else { gout[4 * e] = o[0]; gout[4 * e + 1] = o[1]; gout[4 * e + 2] = o[2]; gout[4 * e + 3] = o[3]; }
         }
     });
+    wave_sync();  // the image is reused by the next tile
+  }
 }
 
 template <int FPW>
 static int launch_ik(const IkArgs &a, bool vec, hipStream_t s) {
-    const size_t lds = ((size_t)FPW * ik_frame_stride(a.J) + 3 * a.J + 3 * a.J + 2) * sizeof(float);
+    const size_t lds = ((size_t)FPW * ik_frame_stride(a.J) + 3 * a.J + 3 * a.J + 4) * sizeof(float) + (size_t)(a.J + 2) * 16;
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
-    const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
+    // records per lane of one tile -> the pipelined instantiation that holds them in registers (3 VGPRs each)
+    const int nl = (FPW * a.J + PM_WAVE - 1) / PM_WAVE;
+    int cap = nl <= 24 ? 24 : (nl <= 56 ? 56 : 0);
+    if (tune_env("PM_IK_PIPE", 1) == 0) cap = 0;  // PM_TUNING build only
+    // (measured, tiles per workgroup 1 / 2 / 4: 2^20 x 22 196 / 191 / 216 us, 2^18 x 128 899 / 863 / 845 us; unpipelined 206 / 992)
+    int nt = cap == 0 ? 1 : (ntiles >= 4096 ? (cap == 24 ? 2 : 4) : 1);
+    nt = tune_env("PM_IK_NT", nt);
+    if (nt < 1 || cap == 0) nt = 1;
+    const int64_t ngroups = (ntiles + nt - 1) / nt;
+    const int64_t grid = ((ngroups + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
     if (grid > 0x7fffffffLL) { set_error("from_root_positions: grid too large"); return PM_EUNSUPPORTED; }
-    if (vec) {
-        auto k = from_root_positions_kernel<FPW, true>;
-        if (int e = allow_lds(k, lds)) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
-    } else {
-        auto k = from_root_positions_kernel<FPW, false>;
-        if (int e = allow_lds(k, lds)) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
+    set_kernel_name("void pm::from_root_positions_kernel<%d, %s, %d>(pm::IkArgs, int)", FPW, tf(vec), cap);
+#define PM_IK_LAUNCH(V, N)                                                          \
+    {                                                                               \
+        auto k = from_root_positions_kernel<FPW, V, N>;                             \
+        if (int e = allow_lds(k, lds)) return e;                                    \
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a, nt);  \
     }
+    if (vec) { if (cap == 24) PM_IK_LAUNCH(true, 24) else if (cap == 56) PM_IK_LAUNCH(true, 56) else PM_IK_LAUNCH(true, 0) }
+    else { if (cap == 24) PM_IK_LAUNCH(false, 24) else if (cap == 56) PM_IK_LAUNCH(false, 56) else PM_IK_LAUNCH(false, 0) }
+#undef PM_IK_LAUNCH
     return check_hip(hipGetLastError(), "from_root_positions launch");
 }
 
@@ -196,6 +305,7 @@ extern "C" int pm_from_root_positions_f32(const float *positions, const int32_t 
     PM_CHECK_ARGS(positions && parents && offsets && rotations, "from_root_positions: null pointer");
     IkArgs a;
     a.pos = positions; a.offsets = offsets; a.out = rotations; a.F = F; a.J = J;
+    a.ablate = tune_env("PM_IK_ABLATE", 0);
     Parents p;
     if (int e = pack_parents(parents, J, p)) return e;
     // children in index order, exactly the lists the reference builds (skeleton.py:121-125)
@@ -208,7 +318,7 @@ extern "C" int pm_from_root_positions_f32(const float *positions, const int32_t 
     for (int32_t j = 1; j < J; ++j) a.topo.clist[fill[p.p[j]]++] = (int16_t)j;
     const bool vec = aligned16(positions) && aligned16(rotations);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t per_frame = (size_t)ik_frame_stride(J) * sizeof(float), fixed = (size_t)(6 * J + 2) * sizeof(float) + 256;
+    const size_t per_frame = (size_t)ik_frame_stride(J) * sizeof(float), fixed = (size_t)(6 * J + 4) * sizeof(float) + (size_t)(J + 2) * 16 + 256;
     {
         const int v = tune_env("PM_IK_FPW", 0);  // PM_TUNING build only
         if (v == 64 && 64 * per_frame + fixed <= kMaxLds) return launch_ik<64>(a, vec, s);
