@@ -278,7 +278,10 @@ PM_OP(OpFromScaledAA, 3, 0, 0, 4, 0) {
 __device__ __forceinline__ void q2aa(const float (&q)[4], float &angle, float (&axis)[3]) {
     const float w = q[0];
     angle = 2.0f * acosf(fminf(fmaxf(w, -1.0f), 1.0f));
-    const float s = __fsqrt_rn(fminf(fmaxf(1.0f - w * w, 0.0f), 1.0f));
+    // 1 - w^2 cancels near |w| = 1 (small rotations, where the axis matters most): in fp32 its 6e-8 absolute error is a
+    // 3e-4 relative error of s at a 1-degree rotation.  The product and the difference are exact in float64 (three
+    // full-rate instructions); only the result is rounded.
+    const float s = __fsqrt_rn(fminf(fmaxf((float)__builtin_fma(-(double)w, (double)w, 1.0), 0.0f), 1.0f));
     const bool ok = s > 1e-8f;
     axis[0] = ok ? q[1] / s : 0.0f; axis[1] = ok ? q[2] / s : 0.0f; axis[2] = ok ? q[3] / s : 0.0f;
 }
@@ -316,7 +319,10 @@ PM_OP(OpToEuler, 4, 0, 0, 3, 0) {
     const float qi = (i == 0) ? x0[1] : (i == 1 ? x0[2] : x0[3]);
     const float qj = (j == 0) ? x0[1] : (j == 1 ? x0[2] : x0[3]);
     const float qk = (k == 0) ? x0[1] : (k == 1 ? x0[2] : x0[3]);
-    const float aa = x0[0] - qj, bb = qi + qk * sg, cc = qj + x0[0], dd = qk * sg - qi;
+    // sums / differences of two fp32 components cancel (w ~ q_j: near gimbal lock both operands of an atan2 are small and
+    // its argument takes their RELATIVE error): formed in float64, where they are exact, and rounded once
+    const double wd = x0[0], qid = qi, qjd = qj, qks = (double)(qk * sg);  // sg = +-1: exact
+    const float aa = (float)(wd - qjd), bb = (float)(qid + qks), cc = (float)(qjd + wd), dd = (float)(qks - qid);
     const float two_pi = 6.283185307179586f;
     float e[3];
     // (np.hypot on quaternion-sized operands: no overflow to guard against, plain sqrt of the sum of squares)
