@@ -208,29 +208,61 @@ __global__ __launch_bounds__(PM_WAVE) void unroll_parity_kernel(const UnrollArgs
     for (int i = lane; i < sb; i += PM_WAVE) a.ws[(int64_t)chunk * a.S + s0 + i] = (par[i] & 1) | (lastr[i] >= 0 ? 2 : 0);
 }
 
-// exclusive prefix over chunks of the composed sign maps, in place: one wave per series, lane = chunk (64 at a time);
-// inside a group of 64 chunks the prefix is a ballot + popcount, cut at the last chunk with a reset
-__global__ __launch_bounds__(PM_WAVE) void unroll_scan_kernel(int32_t *ws, int nchunks, int S) {
-    const int s = blockIdx.x, lane = threadIdx.x;
-    int carry = 0;
-    for (int base = 0; base < nchunks; base += PM_WAVE) {
-        const int c = base + lane;
-        const int v = (c < nchunks) ? ws[(int64_t)c * S + s] : 0;
-        const unsigned long long m = __ballot(v & 1), mr = __ballot(v & 2);
-        const unsigned long long below = (1ull << lane) - 1ull;
-        int pre = (__popcll(m & below) + carry) & 1;
-        const unsigned long long rb = mr & below;
-        if (rb != 0) {  // a chunk with a reset before this one: its summary bit, then the parities after it
-            const int r = 63 - __builtin_clzll(rb);
-            pre = __popcll(m & below & ~((1ull << r) - 1ull)) & 1;
+// exclusive prefix over chunks of the composed sign maps, in place: one 16-wave workgroup per series, 4096 chunks per
+// trip -- every wave requests its 4 x 64 summaries up front (the one-wave form paid a memory latency per 64 chunks:
+// 28 us of the 280 at 2^20 frames), prefixes inside a group of 64 are a ballot + popcount cut at the last reset, and the
+// waves' totals meet in LDS.
+__global__ __launch_bounds__(1024) void unroll_scan_kernel(int32_t *ws, int nchunks, int S) {
+    __shared__ int wtot[16];
+    const int s = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int carry = 0;  // sign parity entering this trip (uniform over the workgroup)
+    for (int base = 0; base < nchunks; base += 4096) {
+        int v[4], pre[4];
+        bool cut[4];  // a reset lies between the start of this wave's range and the element: its prefix is absolute
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = base + wave * 256 + g * 64 + lane;
+            v[g] = (c < nchunks) ? ws[(int64_t)c * S + s] : 0;
         }
-        if (c < nchunks) ws[(int64_t)c * S + s] = pre;
-        if (mr != 0) {
-            const int r = 63 - __builtin_clzll(mr);
-            carry = __popcll(m & ~((1ull << r) - 1ull)) & 1;
-        } else {
-            carry ^= __popcll(m) & 1;
+        int run = 0;        // composition of the groups of this wave so far, entered with parity 0
+        bool seen = false;  // ... contained a reset
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const unsigned long long m = __ballot(v[g] & 1), mr = __ballot(v[g] & 2);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const unsigned long long rb = mr & below;
+            if (rb != 0) {
+                const int r = 63 - __builtin_clzll(rb);
+                pre[g] = __popcll(m & below & ~((1ull << r) - 1ull)) & 1;
+                cut[g] = true;
+            } else {
+                pre[g] = (__popcll(m & below) + run) & 1;
+                cut[g] = seen;
+            }
+            if (mr != 0) {
+                const int r = 63 - __builtin_clzll(mr);
+                run = __popcll(m & ~((1ull << r) - 1ull)) & 1;
+                seen = true;
+            } else {
+                run ^= __popcll(m) & 1;
+            }
         }
+        if (lane == 0) wtot[wave] = (seen ? 2 : 0) | run;
+        __syncthreads();
+        int cin = carry, all = carry;
+        for (int w = 0; w < 16; ++w) {
+            const int t = wtot[w];
+            const int nxt = (t & 2) ? (t & 1) : (all ^ (t & 1));
+            if (w < wave) cin = nxt;
+            all = nxt;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = base + wave * 256 + g * 64 + lane;
+            if (c < nchunks) ws[(int64_t)c * S + s] = cut[g] ? pre[g] : (pre[g] ^ cin);
+        }
+        carry = all;
+        __syncthreads();
     }
 }
 
@@ -282,7 +314,7 @@ static int unroll_launch(const float *q, int64_t T, int32_t S, float *out, void 
         hipLaunchKernelGGL((unroll_parity_kernel<W>), dim3((unsigned)(nchunks * p1_blocks)), dim3(PM_WAVE), p1_lds, s, a);
     }
     if (nchunks <= 256) hipLaunchKernelGGL(unroll_scan_wide_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, s, a.ws, (int)nchunks, (int)S);
-    else hipLaunchKernelGGL(unroll_scan_kernel, dim3((unsigned)S), dim3(PM_WAVE), 0, s, a.ws, (int)nchunks, (int)S);
+    else hipLaunchKernelGGL(unroll_scan_kernel, dim3((unsigned)S), dim3(1024), 0, s, a.ws, (int)nchunks, (int)S);
     hipLaunchKernelGGL((unroll_apply_kernel<W>), grid, dim3(PM_WAVE), lds, s, a);
     return check_hip(hipGetLastError(), "quat_unroll");
 }
