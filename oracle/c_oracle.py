@@ -11,7 +11,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "liboracle.so")
+# PM_ORACLE_ASAN=1: the AddressSanitizer / UBSan build (`make -C oracle asan`; the process must have libasan preloaded)
+_ASAN = os.environ.get("PM_ORACLE_ASAN") == "1"
+_SO = os.path.join(_HERE, "_build", "liboracle_asan.so" if _ASAN else "liboracle.so")
 _lib = None
 
 
@@ -21,7 +23,7 @@ def build(force=False):
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_SO)
         for f in ("pm_oracle.c", "pm_oracle_impl.h")
     ):
-        subprocess.run(["make", "-C", _HERE, "-B", "_build/liboracle.so"], check=True,
+        subprocess.run(["make", "-C", _HERE, "-B", "_build/" + os.path.basename(_SO)], check=True,
                        stdout=subprocess.DEVNULL)
     return _SO
 

@@ -11,12 +11,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpmhip.so")
 # Other builds of the same sources (pymotion_amd/csrc/Makefile): "tuning" reads the PM_* tuning / ablation variables,
-# "debug" bounds-checks the kernels and synchronises after every launch.  The product is always "prod"; the others are
+# "debug" bounds-checks the kernels and synchronises after every launch, "asan" has its host code under ASan + UBSan.  The product is always "prod"; the others are
 # selected explicitly -- `with _lib.variant("tuning"):` in tests and probes, or PMHIP_VARIANT=tuning for a whole process.
 VARIANT_PATHS = {
     "prod": LIB_PATH,
     "tuning": os.path.join(_HERE, "libpmhip_tuning.so"),
     "debug": os.path.join(_HERE, "libpmhip_debug.so"),
+    "asan": os.path.join(_HERE, "libpmhip_asan.so"),  # host code under ASan + UBSan (tests/test_sanitizers.py)
 }
 
 PM_OK, PM_EINVAL, PM_ETOPOLOGY, PM_EHIP, PM_EUNSUPPORTED = 0, -1, -2, -3, -4

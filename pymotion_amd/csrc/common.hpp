@@ -23,6 +23,28 @@ typedef float v4f __attribute__((ext_vector_type(4)));  // native vectors: nonte
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v3f_a4 __attribute__((ext_vector_type(3), aligned(4)));  // 12-byte record at 4-byte alignment (global dwordx3)
 
+// ---- PM_DEBUG build (libpmhip_debug.so, `make debug`) -------------------------------------------------------
+// Every LDS access that goes through the helpers of this file (tile copies, lds_get / lds_put, the image copies of
+// fk.hip) is checked against the workgroup's dynamic LDS allocation; a violation is recorded (first offender wins:
+// source line | 1 << 31) instead of performed, and every launch is followed by a device synchronisation, the HIP error
+// check and a read of that record, so the failing call returns PM_EHIP with the line.  The production build compiles
+// all of it away.  (The tree walks' raw pointer reads -- e.g. the "slack past the last joint" look-ahead -- stay inside
+// the allocation by construction of the launchers' LDS sizes; tests/test_gpu_debug_build.py runs them under this build
+// with guard words around every global buffer.)
+#ifdef PM_DEBUG
+static __device__ unsigned int g_pm_lds_bytes = 0;   // set by the launcher (post_launch serialises the stream anyway)
+static __device__ unsigned int g_pm_violation = 0;
+__device__ __forceinline__ bool pm_lds_ok(const void *p, const unsigned bytes, const int line) {
+    const unsigned off = (unsigned)(uintptr_t)p;  // generic pointer into the LDS aperture: the low 32 bits are the LDS offset
+    if (off + bytes <= g_pm_lds_bytes) return true;
+    atomicCAS(&g_pm_violation, 0u, 0x80000000u | (unsigned)line);
+    return false;
+}
+#define PM_LDS_OK(p, bytes) pm::pm_lds_ok((p), (bytes), __LINE__)
+#else
+#define PM_LDS_OK(p, bytes) true
+#endif
+
 // Compiler-level ordering of LDS traffic inside one wave (hardware already executes a wave's
 // DS instructions in order).  Emits no instruction beyond the waitcnt the compiler needs.
 __device__ __forceinline__ void wave_sync() {
@@ -99,11 +121,13 @@ __device__ __forceinline__ void tile_load(const float *__restrict__ g, float *ld
     } else {
         for (int k = lane; k < n; k += PM_WAVE) lds[k] = g[k];
     }
+    (void)PM_LDS_OK(lds, (unsigned)n * 4u);  // the whole destination range of the tile
 }
 
 // LDS -> global, n floats, contiguous, streaming (write-once) stores.
 template <bool VEC>
 __device__ __forceinline__ void tile_store(float *__restrict__ g, const float *lds, int n, int lane) {
+    if (!PM_LDS_OK(lds, (unsigned)n * 4u)) return;
     if (VEC) {
         v4f *g4 = reinterpret_cast<v4f *>(g);
         const v4f *l4 = reinterpret_cast<const v4f *>(lds);
@@ -171,6 +195,11 @@ __device__ __forceinline__ void for_each_slot(const int n, const int lane, Fn &&
 template <int W>
 __device__ __forceinline__ void lds_get(const float *base, int idx, float (&v)[W]) {
     const float *p = base + idx * W;
+    if (!PM_LDS_OK(p, W * 4u)) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) v[k] = 0.0f;
+        return;
+    }
     if constexpr (W % 4 == 0) {
 #pragma unroll
         for (int k = 0; k < W / 4; ++k) {
@@ -192,6 +221,7 @@ __device__ __forceinline__ void lds_get(const float *base, int idx, float (&v)[W
 template <int W>
 __device__ __forceinline__ void lds_put(float *base, int idx, const float (&v)[W]) {
     float *p = base + idx * W;
+    if (!PM_LDS_OK(p, W * 4u)) return;
     if constexpr (W % 4 == 0) {
 #pragma unroll
         for (int k = 0; k < W / 4; ++k)
@@ -420,6 +450,33 @@ struct Parents {  // passed to kernels BY VALUE (kernarg segment -> s_load_dword
     int32_t p[PM_MAX_JOINTS];
 };
 
+// After every kernel launch.  Production: the HIP launch error.  PM_DEBUG: also waits for the kernel, surfaces
+// asynchronous faults and reads this translation unit's LDS violation record.
+#ifdef PM_DEBUG
+int debug_after_launch(const char *what, unsigned int *violation_symbol_value);
+#define PM_SET_LDS(bytes)                                                                                         \
+    do {                                                                                                          \
+        const unsigned int pm_lds_b_ = (unsigned int)(bytes);                                                     \
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(pm::g_pm_lds_bytes), &pm_lds_b_, sizeof(pm_lds_b_));                   \
+    } while (0)
+#define PM_AFTER_LAUNCH(what)                                                                                     \
+    [&]() -> int {                                                                                                \
+        if (int e_ = pm::check_hip(hipGetLastError(), what)) return e_;                                           \
+        if (int e_ = pm::check_hip(hipDeviceSynchronize(), what)) return e_;                                      \
+        unsigned int v_ = 0, z_ = 0;                                                                              \
+        (void)hipMemcpyFromSymbol(&v_, HIP_SYMBOL(pm::g_pm_violation), sizeof(v_));                               \
+        if (v_) {                                                                                                 \
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(pm::g_pm_violation), &z_, sizeof(z_));                             \
+            pm::set_error("%s: LDS access outside the workgroup's allocation (common.hpp / kernel line %u)", what, v_ & 0x7fffffffu); \
+            return PM_EHIP;                                                                                       \
+        }                                                                                                         \
+        return PM_OK;                                                                                             \
+    }()
+#else
+#define PM_SET_LDS(bytes) ((void)0)
+#define PM_AFTER_LAUNCH(what) pm::check_hip(hipGetLastError(), what)
+#endif
+
 void set_error(const char *fmt, ...);
 void set_kernel_name(const char *fmt, ...);  // what the call dispatched to, as rocprofv3 prints it (pm_last_kernel_name)
 inline const char *tf(bool b) { return b ? "true" : "false"; }
@@ -430,6 +487,7 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Dynamic LDS above 64 KiB needs an explicit opt-in per kernel function.
 template <class K>
 int allow_lds(K kernel, size_t bytes) {
+    PM_SET_LDS(bytes);  // PM_DEBUG: what the helpers check LDS accesses against
     if (bytes <= 64 * 1024) return PM_OK;
     return check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes),

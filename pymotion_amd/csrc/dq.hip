@@ -240,7 +240,7 @@ static int launch_to_root(const ToRootArgs &a, bool vec, hipStream_t s) {
         if (int e = allow_lds(k, lds)) return e;
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
     }
-    return check_hip(hipGetLastError(), "to_root_dq launch");
+    return PM_AFTER_LAUNCH("to_root_dq launch");
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -504,7 +504,7 @@ static int launch_to_root_sched(const SchedArgs &a, bool vec, hipStream_t s) {
         if (int e = allow_lds(kf, lds)) return e;
         hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a, nt);
     }
-    return check_hip(hipGetLastError(), "to_root_dq launch");
+    return PM_AFTER_LAUNCH("to_root_dq launch");
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -620,7 +620,7 @@ static int launch_gather(const GatherArgs &a, bool vec, hipStream_t s) {
         if (int e = allow_lds(k, lds)) return e;
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a, fpw);
     }
-    return check_hip(hipGetLastError(), "gather launch");
+    return PM_AFTER_LAUNCH("gather launch");
 }
 
 }  // namespace pm

@@ -11,6 +11,14 @@
 
 #include "common.hpp"
 
+#ifdef PM_DEBUG
+static int g_debug_shrink = 0;  // tests/test_gpu_debug_build.py: what the LDS checker is told the element-wise tiles own (0 = the truth)
+#define PM_DEBUG_SHRINK g_debug_shrink
+extern "C" void pm_debug_shrink_lds(int bytes) { g_debug_shrink = bytes; }
+#else
+#define PM_DEBUG_SHRINK 0
+#endif
+
 namespace pm {
 
 constexpr int EW_TILE = 128;  // elements per wave
@@ -147,9 +155,10 @@ static int launch_ew(const EwArgs &a, pm_stream_t stream, const char *name) {
     if (grid > 0x7fffffffLL) { set_error("%s: grid too large", name); return PM_EUNSUPPORTED; }
     const bool vec = aligned16(a.in0) && aligned16(a.in1) && aligned16(a.in2) && aligned16(a.out0) && aligned16(a.out1);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    PM_SET_LDS(PM_DEBUG_SHRINK > 0 ? (size_t)PM_DEBUG_SHRINK : lds);
     if (vec) hipLaunchKernelGGL((ew_kernel<Op, true>), dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
     else hipLaunchKernelGGL((ew_kernel<Op, false>), dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
-    return check_hip(hipGetLastError(), name);
+    return PM_AFTER_LAUNCH(name);
 }
 
 #define PM_OP(NAME, i0, i1, i2, o0, o1)                                                          \
@@ -568,9 +577,10 @@ extern "C" int pm_stream_ceiling_f32(const float *src, float *dst, int64_t F, in
     if (lds > 64 * 1024) { set_error("stream_ceiling: tile too large"); return PM_EUNSUPPORTED; }
     const int64_t ntiles = (F + fpw - 1) / fpw;
     const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
+    PM_SET_LDS(lds);
     hipLaunchKernelGGL(ceiling_kernel, dim3((unsigned)grid), dim3(PM_WAVE), lds, static_cast<hipStream_t>(stream), src, dst, F,
                        (int)rd, (int)wr, fpw);
-    return check_hip(hipGetLastError(), "stream_ceiling");
+    return PM_AFTER_LAUNCH("stream_ceiling");
 }
 
 extern "C" int pm_dq_normalize_f32(const float *dq, int64_t N, int orthogonalize, float atol, float *out, int32_t *flags,
@@ -585,13 +595,15 @@ extern "C" int pm_dq_normalize_f32(const float *dq, int64_t N, int orthogonalize
     const bool vec = aligned16(dq) && aligned16(out);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (orthogonalize) {
+        PM_SET_LDS(lds);
         if (vec) hipLaunchKernelGGL((dq_norm_kernel<1, true>), dim3((unsigned)grid), dim3(PM_WAVE), lds, s, dq, out, N, atol, flags);
         else hipLaunchKernelGGL((dq_norm_kernel<1, false>), dim3((unsigned)grid), dim3(PM_WAVE), lds, s, dq, out, N, atol, flags);
     } else {
+        PM_SET_LDS(lds);
         if (vec) hipLaunchKernelGGL((dq_norm_kernel<0, true>), dim3((unsigned)grid), dim3(PM_WAVE), lds, s, dq, out, N, atol, flags);
         else hipLaunchKernelGGL((dq_norm_kernel<0, false>), dim3((unsigned)grid), dim3(PM_WAVE), lds, s, dq, out, N, atol, flags);
     }
-    return check_hip(hipGetLastError(), "dq_normalize");
+    return PM_AFTER_LAUNCH("dq_normalize");
 }
 
 extern "C" int pm_dq_unit_flags_f32(const float *dq, int64_t N, float atol, int32_t *flags, pm_stream_t stream) {
@@ -603,9 +615,10 @@ extern "C" int pm_dq_unit_flags_f32(const float *dq, int64_t N, float atol, int3
     if (grid > 0x7fffffffLL) { set_error("dq_unit_flags: grid too large"); return PM_EUNSUPPORTED; }
     const size_t lds = (size_t)EW_TILE * 16 * sizeof(float);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    PM_SET_LDS(lds);
     if (aligned16(dq)) hipLaunchKernelGGL((dq_norm_kernel<2, true>), dim3((unsigned)grid), dim3(PM_WAVE), lds, s, dq, nullptr, N, atol, flags);
     else hipLaunchKernelGGL((dq_norm_kernel<2, false>), dim3((unsigned)grid), dim3(PM_WAVE), lds, s, dq, nullptr, N, atol, flags);
-    return check_hip(hipGetLastError(), "dq_unit_flags");
+    return PM_AFTER_LAUNCH("dq_unit_flags");
 }
 
 extern "C" int pm_stream_plain_f32(const float *src, float *dst, int64_t n4, int32_t ratio, int32_t blocks, pm_stream_t stream) {
@@ -621,7 +634,7 @@ extern "C" int pm_stream_plain_f32(const float *src, float *dst, int64_t n4, int
         case 2: hipLaunchKernelGGL(plain_stream_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, s4, d4, n4, (int)ratio); break;
         default: hipLaunchKernelGGL(plain_stream_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, st, s4, d4, n4, (int)ratio); break;
     }
-    return check_hip(hipGetLastError(), "stream_plain");
+    return PM_AFTER_LAUNCH("stream_plain");
 }
 
 extern "C" int pm_quat_from_to_f32(const float *v1, const float *v2, int64_t N, int normalize_input, float *out, pm_stream_t s) {

@@ -858,7 +858,7 @@ static int launch_fk_pp(const FkArgs &a, hipStream_t s) {
     }
     set_kernel_name("void pm::fk_kernel<%d, %s, %s, %d, %s, %s, %d>(pm::FkArgs)", FPW, tf(VEC), tf(PFO), SRC, tf(QOUT), tf(PAD), PREC);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
-    return check_hip(hipGetLastError(), "fk launch");
+    return PM_AFTER_LAUNCH("fk launch");
 }
 
 template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT, bool PAD>
@@ -889,7 +889,7 @@ static int launch_fk_pipe_pp(const FkArgs &a, const int nt, hipStream_t s) {
     if (grid > 0x7fffffffLL) { set_error("fk: grid too large"); return PM_EUNSUPPORTED; }
     set_kernel_name("void pm::fk_pipe_kernel<%d, %d, %s, %d, %s, %s, %s, %d>(pm::FkArgs, int)", FPW, EPL, tf(VEC), SRC, tf(QOUT), tf(PAD), tf(PFO), PREC);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a, nt);
-    return check_hip(hipGetLastError(), "fk launch");
+    return PM_AFTER_LAUNCH("fk launch");
 }
 
 template <int FPW, int EPL, bool VEC, int SRC, bool QOUT, bool PAD, bool PFO>

@@ -292,7 +292,7 @@ static int launch_ik(const IkArgs &a, bool vec, hipStream_t s) {
     if (vec) { if (cap == 24) PM_IK_LAUNCH(true, 24) else if (cap == 56) PM_IK_LAUNCH(true, 56) else PM_IK_LAUNCH(true, 0) }
     else { if (cap == 24) PM_IK_LAUNCH(false, 24) else if (cap == 56) PM_IK_LAUNCH(false, 56) else PM_IK_LAUNCH(false, 0) }
 #undef PM_IK_LAUNCH
-    return check_hip(hipGetLastError(), "from_root_positions launch");
+    return PM_AFTER_LAUNCH("from_root_positions launch");
 }
 
 }  // namespace pm

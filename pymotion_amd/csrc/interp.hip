@@ -99,5 +99,5 @@ extern "C" int pm_interpolate_linear_f32(const float *positions, const int32_t *
     if (vw == 4) hipLaunchKernelGGL(interp_linear_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, a);
     else if (vw == 2) hipLaunchKernelGGL(interp_linear_kernel<2>, dim3((unsigned)grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(interp_linear_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, a);
-    return check_hip(hipGetLastError(), "interpolate_linear launch");
+    return PM_AFTER_LAUNCH("interpolate_linear launch");
 }

@@ -164,7 +164,7 @@ static int launch_mirror(const MirrorArgs &a, bool vec, hipStream_t s) {
         if (int e = allow_lds(k, lds)) return e;
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
     }
-    return check_hip(hipGetLastError(), "mirror launch");
+    return PM_AFTER_LAUNCH("mirror launch");
 }
 
 }  // namespace pm

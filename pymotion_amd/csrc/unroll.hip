@@ -316,7 +316,7 @@ static int unroll_launch(const float *q, int64_t T, int32_t S, float *out, void 
     if (nchunks <= 256) hipLaunchKernelGGL(unroll_scan_wide_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, s, a.ws, (int)nchunks, (int)S);
     else hipLaunchKernelGGL(unroll_scan_kernel, dim3((unsigned)S), dim3(1024), 0, s, a.ws, (int)nchunks, (int)S);
     hipLaunchKernelGGL((unroll_apply_kernel<W>), grid, dim3(PM_WAVE), lds, s, a);
-    return check_hip(hipGetLastError(), "quat_unroll");
+    return PM_AFTER_LAUNCH("quat_unroll");
 }
 
 extern "C" int pm_quat_unroll_f32(const float *q, int64_t T, int32_t S, float *out, void *workspace, pm_stream_t stream) {

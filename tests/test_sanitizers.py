@@ -1,0 +1,95 @@
+"""CPU-only: the host-side code under AddressSanitizer + UndefinedBehaviorSanitizer ("-fsanitize=address,
+undefined host build of the CPU restatement + ctypes layer").
+
+  * oracle/_build/liboracle_asan.so (gcc): the whole oracle test-suite against the reference goldens, in a subprocess with
+    gcc's libasan preloaded;
+  * pymotion_amd/libpmhip_asan.so (hipcc, -Xarch_host -fsanitize=...): everything the library does on the host before a
+    kernel launch -- argument validation, topology packing, the chain / program schedulers of to_root_dual_quat and
+    from_root_positions -- driven through the C ABI on a box WITHOUT a GPU (the launch itself then fails with PM_EHIP,
+    which is the expected end of every call here), in a subprocess with clang's ASan runtime preloaded.
+A sanitizer report aborts the subprocess (halt_on_error) and fails the test."""
+import glob
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+ASAN_OPTS = "detect_leaks=0:halt_on_error=1:abort_on_error=1"
+UBSAN_OPTS = "halt_on_error=1:print_stacktrace=1"
+
+
+def _run(code_or_args, preload, extra_env):
+    env = dict(os.environ)
+    env.update({"LD_PRELOAD": preload, "ASAN_OPTIONS": ASAN_OPTS, "UBSAN_OPTIONS": UBSAN_OPTS, "PYTHONPATH": ROOT})
+    env.update(extra_env)
+    r = subprocess.run([sys.executable] + code_or_args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error:" not in r.stderr, r.stderr[-3000:]
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    return r.stdout
+
+
+def test_oracle_suite_under_asan_ubsan():
+    so = os.path.join(ROOT, "oracle", "_build", "liboracle_asan.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "asan"], check=True, stdout=subprocess.DEVNULL)
+    libasan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True, check=True).stdout.strip()
+    out = _run(["-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", "tests/test_oracle.py", "tests/test_bvh_unroll.py", "tests/test_ik.py",
+                "tests/test_time.py", "-m", "not gpu"], libasan, {"PM_ORACLE_ASAN": "1"})
+    assert " passed" in out and "failed" not in out, out[-800:]
+
+
+_HOST_DRIVER = r"""
+import ctypes as C, numpy as np, sys
+from pymotion_amd import _lib
+from pymotion_amd import synthetic as syn
+assert _lib.VARIANT_PATHS["asan"].endswith("libpmhip_asan.so")
+h = _lib.lib()
+buf = (C.c_float * 4096)()
+p = C.cast(buf, C.c_void_p)
+rng = np.random.default_rng(0)
+calls = 0
+def trees(J):
+    yield np.maximum(np.arange(J) - 1, 0).astype(np.int32)          # chain
+    yield np.zeros(J, np.int32)                                      # star
+    yield ((np.arange(J) - 1) // 2).clip(0).astype(np.int32)         # heap
+    for _ in range(3):
+        yield syn.random_parents(J, rng)
+for J in (1, 2, 3, 22, 27, 28, 52, 64, 65, 128, 250, 251, 254, 255, 512):
+    for par in trees(J):
+        pp = par.ctypes.data_as(C.c_void_p)
+        for F in (1, 7, 4099):
+            # no GPU here: every call runs its host side (validation, packing, scheduling, dispatch) and ends in PM_EHIP
+            rcs = [h.pm_fk_f32(p, p, p, 0, pp, F, J, p, p, None),
+                   h.pm_fk_f32(p, p, p, 1, pp, F, J, p, p, None),
+                   h.pm_fk_from_ortho6d_f32(p, p, p, 0, pp, F, J, C.c_float(0.0), p, p, p, None),
+                   h.pm_to_root_dq_f32(p, p, pp, p, F, J, p, None),
+                   h.pm_from_root_dq_f32(p, pp, F, J, p, p, None),
+                   h.pm_from_global_rotations_f32(p, pp, F, J, p, None),
+                   h.pm_from_root_positions_f32(p, pp, p, F, J, p, None),
+                   h.pm_mirror_rotations_f32(p, pp, None, 0, F, J, p, None)]
+            calls += len(rcs)
+            assert all(rc in (_lib.PM_EHIP, _lib.PM_EUNSUPPORTED) for rc in rcs), (J, F, rcs)
+bad = np.array([0, 2, 1], np.int32)
+assert h.pm_fk_f32(p, p, p, 0, bad.ctypes.data_as(C.c_void_p), 4, 3, p, p, None) == _lib.PM_ETOPOLOGY
+assert h.pm_fk_f32(None, p, p, 0, bad.ctypes.data_as(C.c_void_p), 4, 3, p, p, None) == _lib.PM_EINVAL
+assert h.pm_quat_mul_f32(p, p, 10, p, None) in (_lib.PM_EHIP,)
+assert h.pm_quat_unroll_workspace_bytes(1000, 22) > 0
+print("host paths exercised:", calls)
+"""
+
+
+def test_library_host_side_under_asan_ubsan():
+    from pymotion_amd import _lib
+
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible: the launches would go through (the sanitizer run is for the host side)")
+    so = _lib.VARIANT_PATHS["asan"]
+    if not os.path.exists(so):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "pymotion_amd", "csrc"), "-j8", "asan"], check=True, stdout=subprocess.DEVNULL)
+    rts = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
+    assert rts, "clang's ASan runtime not found"
+    out = _run(["-c", _HOST_DRIVER], rts[0], {"PMHIP_VARIANT": "asan"})
+    assert "host paths exercised" in out
