@@ -61,6 +61,13 @@ int pm_event_create(void **ev);
 int pm_event_destroy(void *ev);
 int pm_event_record(void *ev, pm_stream_t stream);
 int pm_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on `stop` */
+int pm_event_synchronize(void *ev);
+/* Streams and page-locked host memory for callers that overlap H2D / kernel / D2H themselves (the NumPy front-end's
+ * chunked pipeline: pymotion_amd/_backend.py). */
+int pm_stream_create(pm_stream_t *stream);
+int pm_stream_destroy(pm_stream_t stream);
+int pm_host_alloc(void **hptr, size_t bytes); /* hipHostMalloc: page-locked, DMA-able at full PCIe rate */
+int pm_host_free(void *hptr);
 
 /* ---- skeleton ops ---------------------------------------------------------------------------- */
 

@@ -115,6 +115,7 @@ def trim():
     """Give the NumPy door's cached device blocks and host staging buffers back (public: ``pymotion_amd.trim()``)."""
     _pool.trim()
     _stage.trim()
+    _pinned.trim()
 
 
 # ---- host side of the NumPy door: staging buffers that are reused (no page faults on the copy path) and
@@ -122,7 +123,7 @@ def trim():
 # GPU box: a fresh 830 MB array costs 68 ms of first-touch page faults single-threaded, `astype(float64)` 95 ms;
 # eight threads do cast + first touch in 15 ms.  Small arrays take the plain path.
 _PAR_MIN_BYTES = 4 << 20
-_PAR_THREADS = max(1, min(8, (os.cpu_count() or 1)))
+_PAR_THREADS = max(1, min(int(os.environ.get("PM_HOST_THREADS", "8")), (os.cpu_count() or 1)))
 _executor = None
 _exec_lock = threading.Lock()
 
@@ -182,6 +183,218 @@ class _HostStage:
 _stage = _HostStage()
 
 
+# ---- chunked, double-buffered pipeline of the NumPy door ------------------------------------------------------
+# A big frame batch that arrives in host memory costs PCIe time both ways (2^20 x 22 fk: 0.38 GB in, 1.1 GB out), a cast
+# of the inputs to fp32 and of the outputs to the dtype the reference returns.  Done one after the other that was 47.7 ms
+# per 2^20 frames against 0.26 ms of kernel.  Here the batch is cut into frame chunks; chunk k's inputs are staged into
+# PAGE-LOCKED memory (threads), copied, computed and copied back on stream k % 2 while the host casts chunk k-1's
+# results into the final arrays and the other stream's transfer runs the opposite way on the bus: the call costs about
+# what the larger direction of the bus does.
+_PIPE_MIN_BYTES = 48 << 20      # below this the plain path wins (fixed costs of a second stream, events, pinned staging)
+_PIPE_CHUNK_BYTES = 160 << 20   # payload (in + out, fp32) per chunk (measured 48 / 96 / 192 MB: 55 / 48 / 46 ms at 2^20 x 22)
+
+
+class _PinnedPool:
+    """page-locked staging buffers (hipHostMalloc is expensive: cached by size class, a few kept)"""
+
+    def __init__(self, cap_bytes=2 << 30):
+        self.free = {}
+        self.cached = 0
+        self.cap = cap_bytes
+        self.lock = threading.Lock()
+
+    def get(self, nbytes):
+        c = 1 << (max(int(nbytes), 1 << 16) - 1).bit_length()
+        with self.lock:
+            lst = self.free.get(c)
+            if lst:
+                self.cached -= c
+                return lst.pop()
+        p = C.c_void_p()
+        _lib.call("pm_host_alloc", C.byref(p), c)
+        arr = np.ctypeslib.as_array(C.cast(p.value, C.POINTER(C.c_float)), shape=(c // 4,))
+        return (p.value, c, arr)
+
+    def put(self, item):
+        with self.lock:
+            if self.cached + item[1] <= self.cap:
+                self.free.setdefault(item[1], []).append(item)
+                self.cached += item[1]
+                return
+        _lib.call("pm_host_free", C.c_void_p(item[0]))
+
+    def trim(self):
+        with self.lock:
+            items = [i for lst in self.free.values() for i in lst]
+            self.free.clear()
+            self.cached = 0
+        for i in items:
+            _lib.call("pm_host_free", C.c_void_p(i[0]))
+
+
+_pinned = _PinnedPool()
+_pipe_streams = {}  # device -> (stream0, stream1, event0, event1): created once per device
+
+
+def _pipe_ctx(dev):
+    ctx = _pipe_streams.get(dev)
+    if ctx is None:
+        hs = [C.c_void_p(), C.c_void_p()]
+        ev = [C.c_void_p(), C.c_void_p(), C.c_void_p()]  # one per staging slot
+        for h in hs:
+            _lib.call("pm_stream_create", C.byref(h))
+        for e in ev:
+            _lib.call("pm_event_create", C.byref(e))
+        ctx = _pipe_streams[dev] = (hs, ev)
+    return ctx
+
+
+_libc = None
+
+
+def _big_empty(shape, dtype):
+    """np.empty + a transparent-huge-page hint: a fresh multi-GB result is ~500 k first-touch page faults with 4 KiB pages
+    (the largest host cost of the door); with 2 MiB pages it is a thousand.  No effect where THP is disabled."""
+    global _libc
+    out = np.empty(shape, dtype=dtype)
+    if out.nbytes >= (32 << 20) and os.environ.get("PM_NO_THP") != "1":
+        try:
+            if _libc is None:
+                _libc = C.CDLL(None, use_errno=True)
+            a0 = (out.ctypes.data + (1 << 21) - 1) & ~((1 << 21) - 1)
+            n = (out.ctypes.data + out.nbytes - a0) & ~((1 << 21) - 1)
+            if n > 0:
+                _libc.madvise(C.c_void_p(a0), C.c_size_t(n), 14)  # MADV_HUGEPAGE
+        except Exception:  # noqa: BLE001  (a hint, never an error)
+            pass
+    return out
+
+
+def pipelined_frames(F, ins, outs, launch):
+    """Run ``launch`` over frame chunks with H2D / kernel / D2H / host casts overlapped (NumPy door).
+
+    ins   list of (array, per_frame): per-frame arrays have F on axis 0 (any float dtype / layout), the others are
+          uploaded once as they are (already contiguous fp32 / int arrays)
+    outs  list of (trailing shape, result dtype)
+    launch(in_ptrs, out_ptrs, n_frames, stream)  -> enqueues the kernel for one chunk
+    Returns the list of result arrays [F, *trailing].
+    """
+    _lib.require_device()
+    dev = _current_device()
+    (streams, events) = _pipe_ctx(dev)
+    per_in = [int(np.prod(a.shape[1:])) * 4 if pf else 0 for a, pf in ins]
+    per_out = [_prod(t) * 4 for t, _ in outs]
+    per_frame = max(1, sum(per_in) + sum(per_out))
+    chunk = max(1, min(F, _PIPE_CHUNK_BYTES // per_frame))
+    nchunks = -(-F // chunk)
+    results = [_big_empty((F,) + tuple(t), dt) for t, dt in outs]
+    live, consts, slots = [], [], []
+    try:
+        # constants: one plain upload, visible to both streams (default-stream sync before the pipeline starts)
+        const_ptrs = {}
+        for i, (a, pf) in enumerate(ins):
+            if not pf:
+                buf = _DevBuf(max(a.nbytes, 4), dev)
+                live.append(buf)
+                _lib.call("pm_memcpy_h2d", C.c_void_p(buf.ptr), a.ctypes.data_as(C.c_void_p), a.nbytes, None)
+                consts.append(a)
+                const_ptrs[i] = C.c_void_p(buf.ptr)
+        _lib.call("pm_stream_synchronize", None)
+        for _ in range(min(3, nchunks)):
+            slot = {"din": [], "dout": [], "hin": [], "hout": []}
+            for i, (a, pf) in enumerate(ins):
+                if pf:
+                    slot["din"].append(_DevBuf(chunk * per_in[i], dev))
+                    slot["hin"].append(_pinned.get(chunk * per_in[i]))
+            for nb in per_out:
+                slot["dout"].append(_DevBuf(chunk * nb, dev))
+                slot["hout"].append(_pinned.get(chunk * nb))
+            slots.append(slot)
+
+        def submit(k):
+            sl, st = slots[k % len(slots)], streams[k % 2]
+            f0, f1 = k * chunk, min(F, (k + 1) * chunk)
+            n = f1 - f0
+            in_ptrs, j = [], 0
+            for i, (a, pf) in enumerate(ins):
+                if not pf:
+                    in_ptrs.append(const_ptrs[i])
+                    continue
+                cnt = n * (per_in[i] // 4)
+                stage = sl["hin"][j][2][:cnt].reshape((n,) + a.shape[1:])
+                _parallel_copyto(stage, a[f0:f1])          # cast / gather / plain copy into page-locked memory, threaded
+                _lib.call("pm_memcpy_h2d", C.c_void_p(sl["din"][j].ptr), C.c_void_p(sl["hin"][j][0]), cnt * 4, st)
+                in_ptrs.append(C.c_void_p(sl["din"][j].ptr))
+                j += 1
+            out_ptrs = [C.c_void_p(b.ptr) for b in sl["dout"]]
+            launch(in_ptrs, out_ptrs, n, st)
+            for b, h, nb in zip(sl["dout"], sl["hout"], per_out):
+                _lib.call("pm_memcpy_d2h", C.c_void_p(h[0]), C.c_void_p(b.ptr), n * nb, st)
+            _lib.call("pm_event_record", events[k % len(events)], st)
+
+        def finish(k):
+            sl = slots[k % len(slots)]
+            f0, f1 = k * chunk, min(F, (k + 1) * chunk)
+            n = f1 - f0
+            _lib.call("pm_event_synchronize", events[k % len(events)])
+            for res, h, (t, _) in zip(results, sl["hout"], outs):
+                cnt = n * _prod(t)
+                _parallel_copyto(res[f0:f1], h[2][:cnt].reshape((n,) + tuple(t)))
+
+        # The main thread stages and submits; a helper thread waits for each chunk's event and casts its results into the
+        # final arrays (both sides fan their copies out over the cast pool, NumPy releases the GIL inside them): staging
+        # chunk k+1 and un-staging chunk k-1 overlap each other as well as the transfers.  A slot is reused only after
+        # its previous occupant has been finished.
+        import queue
+
+        done = [threading.Event() for _ in range(nchunks)]
+        todo = queue.Queue()
+        err = []
+
+        def finisher():
+            while True:
+                k = todo.get()
+                if k is None:
+                    return
+                try:
+                    if not err:
+                        finish(k)
+                except Exception as exc:  # noqa: BLE001
+                    err.append(exc)
+                finally:
+                    done[k].set()
+
+        th = threading.Thread(target=finisher, name="pm-door-finish", daemon=True)
+        th.start()
+        try:
+            for k in range(nchunks):
+                if k >= len(slots):
+                    done[k - len(slots)].wait()  # the slot's previous chunk has left its staging buffers
+                if err:
+                    break
+                submit(k)
+                todo.put(k)
+        finally:
+            todo.put(None)
+            th.join()
+        if err:
+            raise err[0]
+    finally:
+        for st in streams:
+            try:
+                _lib.call("pm_stream_synchronize", st)
+            except Exception:  # noqa: BLE001  (already failing: release what we hold)
+                pass
+        for sl in slots:
+            for b in sl["din"] + sl["dout"]:
+                b.release()
+            for h in sl["hin"] + sl["hout"]:
+                _pinned.put(h)
+        for b in live:
+            b.release()
+    return results
+
+
 class NumpyBackend:
     name = "numpy"
 
@@ -207,6 +420,11 @@ class NumpyBackend:
 
     def stream(self):
         return None
+
+    @staticmethod
+    def wants_pipeline(F, bytes_per_frame):
+        """big host-resident frame batches go through pipelined_frames (chunked, double-buffered)"""
+        return F >= 2 and F * bytes_per_frame >= _PIPE_MIN_BYTES
 
     def begin(self, *_):
         _lib.require_device()
@@ -350,6 +568,10 @@ class TorchBackend:
         self._guard = torch.cuda.device(self.dev)
         self._guard.__enter__()
         self._keep = []
+
+    @staticmethod
+    def wants_pipeline(F, bytes_per_frame):
+        return False  # device tensors: nothing to overlap
 
     def stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)

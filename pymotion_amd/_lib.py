@@ -41,6 +41,11 @@ SIGNATURES = {
     "pm_event_destroy": [C.c_void_p],
     "pm_event_record": [C.c_void_p, _strm],
     "pm_event_elapsed_ms": [C.c_void_p, C.c_void_p, C.POINTER(_flt)],
+    "pm_event_synchronize": [C.c_void_p],
+    "pm_stream_create": [C.POINTER(C.c_void_p)],
+    "pm_stream_destroy": [_strm],
+    "pm_host_alloc": [C.POINTER(C.c_void_p), C.c_size_t],
+    "pm_host_free": [C.c_void_p],
     # skeleton ops
     "pm_fk_f32": [_f, _f, _f, _int, C.c_void_p, _i64, _i32, _f, _f, _strm],
     "pm_fk_from_ortho6d_f32": [_f, _f, _f, _int, C.c_void_p, _i64, _i32, _flt, _f, _f, _f, _strm],

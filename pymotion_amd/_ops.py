@@ -25,12 +25,35 @@ def _bshape(*shapes):
     return tuple(np.broadcast_shapes(*shapes))
 
 
+def _pipe_np(a, lead, trail):
+    """host array -> [N, *trail] view (broadcast over `lead` if needed) for the chunked pipeline"""
+    a = np.asarray(a)
+    if a.shape != tuple(lead) + tuple(trail):
+        a = np.broadcast_to(a, tuple(lead) + tuple(trail))
+    return a.reshape((-1,) + tuple(trail)) if a.flags.c_contiguous else np.ascontiguousarray(a).reshape((-1,) + tuple(trail))
+
+
 def ew(be, fname, ins, in_trail, out_trail, out_dtypes, pre=(), mid=()):
     """Generic element-wise launch.
 
     ins[k] has trailing shape in_trail[k]; leading shapes broadcast against each other.
     C call: fname(in_ptrs..., *pre, N, *mid, out_ptrs..., stream).
     """
+    if be.name == "numpy":
+        shapes = [np.shape(x) for x in ins]
+        if all(tuple(sh[len(sh) - len(t):]) == tuple(t) for sh, t in zip(shapes, in_trail)):
+            lead = _bshape(*[sh[: len(sh) - len(t)] for sh, t in zip(shapes, in_trail)])
+            n = _prod(lead)
+            per = 4 * (sum(_prod(t) for t in in_trail) + sum(_prod(t) for t in out_trail))
+            if be.wants_pipeline(n, per):
+                from ._backend import pipelined_frames
+
+                res = pipelined_frames(
+                    n, [(_pipe_np(x, lead, t), True) for x, t in zip(ins, in_trail)],
+                    [(tuple(t), np.dtype(dt)) for t, dt in zip(out_trail, out_dtypes)],
+                    lambda ip, op, cnt, st: _lib.call(fname, *ip, *pre, cnt, *mid, *op, st))
+                res = [r.reshape(tuple(lead) + tuple(t)) for r, t in zip(res, out_trail)]
+                return res[0] if len(res) == 1 else tuple(res)
     be.begin(*ins)
     try:
         leads = [be.shape(x)[: len(be.shape(x)) - len(t)] for x, t in zip(ins, in_trail)]
@@ -387,6 +410,15 @@ def fk(be, rot, global_pos, offsets, parents):
     oshape = be.shape(offsets)
     per_frame = len(oshape) > 2
     out_dt = be.always64 if be.name == "numpy" else rot.dtype  # skeleton.py:44 / skeleton_torch.py:45-49
+    if be.wants_pipeline(_prod(lead), 4 * (J * (16 + (3 if per_frame else 0)) + 3) ):
+        from ._backend import pipelined_frames
+
+        off_np = _pipe_np(offsets, lead, (J, 3)) if per_frame else np.ascontiguousarray(np.asarray(offsets), dtype=np.float32).reshape(J, 3)
+        pos, rm = pipelined_frames(
+            _prod(lead), [(_pipe_np(rot, lead, (J, 4)), True), (_pipe_np(global_pos, lead, (3,)), True), (off_np, per_frame)],
+            [((J, 3), np.dtype(out_dt)), ((J, 3, 3), np.dtype(out_dt))],
+            lambda ip, op, n, st: _lib.call("pm_fk_f32", ip[0], ip[1], ip[2], int(per_frame), p.ctypes.data_as(C.c_void_p), n, J, op[0], op[1], st))
+        return pos.reshape(lead + (J, 3)), rm.reshape(lead + (J, 3, 3))
     be.begin(rot, global_pos, offsets)
     try:
         F = _prod(lead)
@@ -412,6 +444,18 @@ def fk_from_ortho6d(be, o6d, global_pos, offsets, parents, return_quat=False):
     per_frame = len(be.shape(offsets)) > 2
     out_dt = be.always64 if be.name == "numpy" else o6d.dtype
     q_dt = be.result_dtype(o6d)
+    if be.wants_pipeline(_prod(lead), 4 * (J * 24 + 3)):
+        from ._backend import pipelined_frames
+
+        off_np = _pipe_np(offsets, lead, (J, 3)) if per_frame else np.ascontiguousarray(np.asarray(offsets), dtype=np.float32).reshape(J, 3)
+        outs = [((J, 3), np.dtype(out_dt)), ((J, 3, 3), np.dtype(out_dt))] + ([((J, 4), np.dtype(q_dt))] if return_quat else [])
+        eps = C.c_float(o6d_eps(be))
+        res = pipelined_frames(
+            _prod(lead), [(_pipe_np(o6d, lead, (J, 3, 2)), True), (_pipe_np(global_pos, lead, (3,)), True), (off_np, per_frame)], outs,
+            lambda ip, op, n, st: _lib.call("pm_fk_from_ortho6d_f32", ip[0], ip[1], ip[2], int(per_frame), p.ctypes.data_as(C.c_void_p), n, J,
+                                            eps, op[0], op[1], op[2] if return_quat else None, st))
+        out = (res[0].reshape(lead + (J, 3)), res[1].reshape(lead + (J, 3, 3)))
+        return out + (res[2].reshape(lead + (J, 4)),) if return_quat else out
     be.begin(o6d, global_pos, offsets)
     try:
         F = _prod(lead)
@@ -460,6 +504,15 @@ def to_root_dual_quat(be, rotations, global_pos, parents, offsets):
         raise ValueError(f"offsets must be [{J}, 3], got {be.shape(offsets)}")
     _assert_root_offset_is_zero(be, offsets)  # skeleton.py:227
     out_dt = be.always64 if be.name == "numpy" else rotations.dtype
+    if be.wants_pipeline(_prod(lead), 4 * (J * 12 + 3)):
+        from ._backend import pipelined_frames
+
+        off_np = np.ascontiguousarray(np.asarray(offsets), dtype=np.float32)
+        (dq,) = pipelined_frames(
+            _prod(lead), [(_pipe_np(rotations, lead, (J, 4)), True), (_pipe_np(global_pos, lead, (3,)), True), (off_np, False)],
+            [((J, 8), np.dtype(out_dt))],
+            lambda ip, op, n, st: _lib.call("pm_to_root_dq_f32", ip[0], ip[1], p.ctypes.data_as(C.c_void_p), ip[2], n, J, op[0], st))
+        return dq.reshape(lead + (J, 8))
     be.begin(rotations, global_pos, offsets)
     try:
         F = _prod(lead)
@@ -482,6 +535,13 @@ def from_root_dual_quat(be, dq, parents):
     lead, J = shp[:-2], shp[-2]
     p = _parents_host(be, parents, J)
     dt = be.result_dtype(dq)
+    if be.wants_pipeline(_prod(lead), 4 * J * 15):
+        from ._backend import pipelined_frames
+
+        t, q = pipelined_frames(
+            _prod(lead), [(_pipe_np(dq, lead, (J, 8)), True)], [((J, 3), np.dtype(dt)), ((J, 4), np.dtype(dt))],
+            lambda ip, op, n, st: _lib.call("pm_from_root_dq_f32", ip[0], p.ctypes.data_as(C.c_void_p), n, J, op[0], op[1], st))
+        return t.reshape(lead + (J, 3)), q.reshape(lead + (J, 4))  # (translations, rotations): skeleton.py:204
     be.begin(dq)
     try:
         F = _prod(lead)

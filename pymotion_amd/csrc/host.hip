@@ -108,6 +108,27 @@ extern "C" int pm_event_destroy(void *ev) { return ev ? check_hip(hipEventDestro
 extern "C" int pm_event_record(void *ev, pm_stream_t s) {
     return check_hip(hipEventRecord((hipEvent_t)ev, static_cast<hipStream_t>(s)), "hipEventRecord");
 }
+extern "C" int pm_event_synchronize(void *ev) {
+    PM_CHECK_ARGS(ev, "pm_event_synchronize: null");
+    return check_hip(hipEventSynchronize((hipEvent_t)ev), "hipEventSynchronize");
+}
+extern "C" int pm_stream_create(pm_stream_t *stream) {
+    PM_CHECK_ARGS(stream, "pm_stream_create: null");
+    hipStream_t s;
+    int r = check_hip(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+    *stream = r ? nullptr : (pm_stream_t)s;
+    return r;
+}
+extern "C" int pm_stream_destroy(pm_stream_t stream) {
+    return stream ? check_hip(hipStreamDestroy(static_cast<hipStream_t>(stream)), "hipStreamDestroy") : PM_OK;
+}
+extern "C" int pm_host_alloc(void **hptr, size_t bytes) {
+    PM_CHECK_ARGS(hptr, "pm_host_alloc: null");
+    *hptr = nullptr;
+    if (bytes == 0) return PM_OK;
+    return check_hip(hipHostMalloc(hptr, bytes, hipHostMallocDefault), "hipHostMalloc");
+}
+extern "C" int pm_host_free(void *hptr) { return hptr ? check_hip(hipHostFree(hptr), "hipHostFree") : PM_OK; }
 extern "C" int pm_event_elapsed_ms(void *start, void *stop, float *ms) {
     PM_CHECK_ARGS(start && stop && ms, "pm_event_elapsed_ms: null");
     if (int r = check_hip(hipEventSynchronize((hipEvent_t)stop), "hipEventSynchronize")) return r;
