@@ -21,7 +21,7 @@ for J in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "8,1
     par[3 * J // 4] = J // 4
     rot = torch.randn((F, J, 4), device="cuda")
     root = torch.randn((F, 3), device="cuda")
-    off = torch.randn((J, 3), device="cuda")
+    off = torch.randn((J, 3), device="cuda") * 0.15  # human-scale bones in metres: the fp32 walk (bones >= 1 m take the fixed-point one, see fk.hip PREC_DYN)
     pos = torch.empty((F, J, 3), device="cuda")
     rm = torch.empty((F, J, 3, 3), device="cuda")
     pp_ = par.ctypes.data_as(C.c_void_p)
