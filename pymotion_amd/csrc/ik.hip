@@ -33,7 +33,9 @@ struct IkArgs {
     int64_t F;
     int32_t J;
     int32_t ablate;  // PM_TUNING build only (env PM_IK_ABLATE): 1 = no walk, 2 = no final pass, 4 = no position staging
+    int32_t K;       // two chains per frame: steps of the schedule (0: one chain, every joint with children in index order)
     Topo16 topo;
+    uint8_t sched[512];  // [K][2] joint aligned at step st by chain c, 255 = idle
 };
 
 // LDS image: ONE 16-byte slot per (frame, joint).  It holds the joint's position until the joint has been
@@ -53,7 +55,12 @@ __host__ __device__ constexpr int ik_frame_stride(const int J) { return 4 * ((J 
 // registers BEFORE the previous tile is walked: loads fly during the walk, and the rotations of the previous tile drain
 // (fire-and-forget stores) while the next tile is parked and walked.  NL = 0: one tile per workgroup, batched loads
 // (skeletons whose tile does not fit the register file).
-template <int FPW, bool VEC, int NL>
+// C = chains per frame.  The walk of a frame is a dependent chain that only occupancy hides (above), and the image bounds
+// occupancy at 64 frames per wave.  With C = 2 a wave holds 32 frames and lanes 32..63 walk a SECOND chain of the same
+// frames: the host schedules the joints that have children onto two chains (ik_schedule: a joint is ready two steps after
+// its parent, or right after it on the parent's own chain, where the parent's quaternion is still in registers), the
+// image and with it the LDS per wave halve, twice as many waves are resident, and a frame's walk is K ~ items / 2 steps.
+template <int FPW, bool VEC, int NL, int C>
 __global__ __launch_bounds__(PM_WAVE) void from_root_positions_kernel(const IkArgs a, const int nt) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
@@ -63,10 +70,10 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_kernel(const IkAr
     if (group < 0) return;
     const int FS = ik_frame_stride(J);
     float *sS = smem;                         // [FPW * FS]  slot (f, j): position, then world quaternion
-    float *sOff = sS + FPW * FS;              // [J * 3]
-    int *sTopo = reinterpret_cast<int *>(sOff + 3 * J);  // [J] parent | [J+1] cstart | [J] clist
+    float *sOff = sS + FPW * FS;              // [(J + 1) * 3]  (entry J: the idle item's zero "rest direction")
+    int *sTopo = reinterpret_cast<int *>(sOff + 3 * J + 3);  // [J] parent | [J+1] cstart | [J] clist
     typedef int v4i __attribute__((ext_vector_type(4)));
-    v4i *sItem = reinterpret_cast<v4i *>(sTopo + 3 * J + 4);  // [J + 2] the walk's program: {joint, parent, first child, first further child | count << 16}
+    v4i *sItem = reinterpret_cast<v4i *>(sTopo + 3 * J + 4);  // [(J + 2) * C] the walk's program: {joint, parent, first child, first further child | count << 16}
     const float invJ = 1.0f / (float)J;
     constexpr int NR = NL > 0 ? NL : 1;
     v3f_a4 pre[NR];  // NL > 0: the next tile's position records, one 12-byte record per lane and load (coalesced dwordx3)
@@ -91,20 +98,35 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_kernel(const IkAr
         if (j < J) { sTopo[j] = a.topo.parent[j]; sTopo[2 * J + 1 + j] = a.topo.clist[j]; }
         sTopo[J + j] = a.topo.cstart[j];
     }
+    if (lane < 3) sOff[3 * J + lane] = 0.0f;
     // The walk visits the joints that have children, in index order.  Its topology reads are wave-uniform but DEPENDENT
     // (child range -> first child -> that child's slot): three LDS round trips in a row per joint, with 1.5 waves per SIMD
     // to hide them.  They are flattened once into one record per visited joint, which the walk reads two steps ahead.
-    int nitems_all = 0;  // wave-uniform
-    for (int j0 = 0; j0 < J; j0 += PM_WAVE) {  // compaction: ballot + prefix popcount
-        const int j = j0 + lane;
-        const int cs = (j < J) ? a.topo.cstart[j] : 0, ce = (j < J) ? a.topo.cstart[j + 1] : 0;
-        const bool has = ce > cs;
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
-        if (has) sItem[nitems_all + __popcll(m & ((1ull << lane) - 1ull))] =
-            v4i{j, (j == 0) ? -1 : (int)a.topo.parent[j], (int)a.topo.clist[cs], (cs + 1) | ((ce - cs - 1) << 16)};
-        nitems_all += __popcll(m);
+    int nitems_all = 0;  // wave-uniform: steps of the walk
+    const v4i idle = v4i{J, -1, J, 0};  // a scratch slot aligned with itself: the identity, stored where nobody looks
+    if constexpr (C == 1) {
+        for (int j0 = 0; j0 < J; j0 += PM_WAVE) {  // compaction: ballot + prefix popcount
+            const int j = j0 + lane;
+            const int cs = (j < J) ? a.topo.cstart[j] : 0, ce = (j < J) ? a.topo.cstart[j + 1] : 0;
+            const bool has = ce > cs;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
+            if (has) sItem[nitems_all + __popcll(m & ((1ull << lane) - 1ull))] =
+                v4i{j, (j == 0) ? -1 : (int)a.topo.parent[j], (int)a.topo.clist[cs], (cs + 1) | ((ce - cs - 1) << 16)};
+            nitems_all += __popcll(m);
+        }
+        if (lane < 2) sItem[nitems_all + lane] = idle;  // slack for the look-ahead
+    } else {
+        nitems_all = a.K;
+        for (int i = lane; i < (a.K + 2) * C; i += PM_WAVE) {
+            const int j = (i < a.K * C) ? (int)a.sched[i] : 255;
+            v4i e = idle;
+            if (j != 255) {
+                const int cs = a.topo.cstart[j], ce = a.topo.cstart[j + 1];
+                e = v4i{j, (j == 0) ? -1 : (int)a.topo.parent[j], (int)a.topo.clist[cs], (cs + 1) | ((ce - cs - 1) << 16)};
+            }
+            sItem[i] = e;
+        }
     }
-    if (lane < 2) sItem[nitems_all + lane] = v4i{0, -1, 0, 0};  // slack for the look-ahead
   for (int64_t tile = group * nt; tile < ntiles && tile < (group + 1) * nt; ++tile) {
     const int64_t f0 = tile * FPW;
     const int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
@@ -166,30 +188,30 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_kernel(const IkAr
     //   to the identity, and those lanes derive it the long way.
     // (Two joints in flight per lane -- independent subtrees scheduled by the host onto two instruction streams -- was built
     // and measured: 286 us against 262 us for the same code with one stream.  The walk is not what the kernel waits for.)
-    const int f = lane % FPW;  // lanes >= FPW shadow lanes 0.. ; frames past a partial tile use their own slots
+    const int f = lane % FPW;  // C = 1: lanes >= FPW shadow lanes 0.. ; frames past a partial tile use their own slots
+    const int ch = (C == 1) ? 0 : (lane / FPW) % C;  // which chain of the frame this lane walks
     float *fS = sS + f * FS;
-    float g[4] = {1.0f, 0.0f, 0.0f, 0.0f};  // world quaternion of the previous joint
+    float g[4] = {1.0f, 0.0f, 0.0f, 0.0f};  // world quaternion of the joint this lane aligned last
     struct Ops { float gl[4], pj[4], pc[4], a[3]; };
     auto fetch = [&](const v4i it, Ops &o) {  // operands of one step: positions are static until their joint is aligned, a
-        const int jj = __builtin_amdgcn_readfirstlane(it.x), pp = __builtin_amdgcn_readfirstlane(it.y);  // finished parent's slot holds its G
-        const int cc = __builtin_amdgcn_readfirstlane(it.z);
-        lds_get<4>(fS, pp < 0 ? 0 : pp, o.gl);
-        lds_get<4>(fS, jj, o.pj);
-        lds_get<4>(fS, cc, o.pc);  // children come later: their slots still hold positions
-        o.a[0] = sOff[3 * cc]; o.a[1] = sOff[3 * cc + 1]; o.a[2] = sOff[3 * cc + 2];  // rest direction, unit
+        const int pp = it.y < 0 ? 0 : it.y;   // finished parent's slot holds its G
+        lds_get<4>(fS, pp, o.gl);
+        lds_get<4>(fS, it.x, o.pj);
+        lds_get<4>(fS, it.z, o.pc);  // children come later: their slots still hold positions
+        o.a[0] = sOff[3 * it.z]; o.a[1] = sOff[3 * it.z + 1]; o.a[2] = sOff[3 * it.z + 2];  // rest direction, unit
     };
     const int nitems = PM_ABLATED(a, 1) ? 0 : nitems_all;
-    v4i cur = sItem[0], nxt = sItem[1];
+    v4i cur = sItem[ch], nxt = sItem[C + ch];
     Ops oc, on;
     fetch(cur, oc);
     int prevj = -2;
     for (int st = 0; st < nitems; ++st) {
-        const v4i nn = sItem[st + 2];
-        fetch(nxt, on);  // issued before this step computes; if next's parent is THIS joint its gl is stale, and unused (register chain)
-        const int j = __builtin_amdgcn_readfirstlane(cur.x), par = __builtin_amdgcn_readfirstlane(cur.y);
-        const int xs = __builtin_amdgcn_readfirstlane(cur.w) & 0xffff, nx = __builtin_amdgcn_readfirstlane(cur.w) >> 16;
+        const v4i nn = sItem[(st + 2) * C + ch];
+        fetch(nxt, on);  // issued before this step computes; if next's parent is THIS lane's joint its gl is stale, and unused (register chain)
+        const int j = cur.x, par = cur.y;
+        const int xs = cur.w & 0xffff, nx = cur.w >> 16;
         float gpre[4];
-        const bool chain = par == prevj, root = par < 0;  // wave-uniform
+        const bool chain = par == prevj, root = par < 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) gpre[k] = root ? (k == 0 ? 1.0f : 0.0f) : (chain ? g[k] : oc.gl[k]);
         const float (&pj)[4] = oc.pj, (&pc)[4] = oc.pc;
@@ -216,8 +238,10 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_kernel(const IkAr
             r[0] = 0.0f; r[1] = ax2[0]; r[2] = ax2[1]; r[3] = ax2[2];
         }
         qmul(gpre, r, g);  // G_j once the first child is aligned
-        for (int k = xs; k < xs + nx; ++k) {  // roll correction from every further child: G_j <- G_j (x) roll
-            const int gc = sTopo[2 * J + 1 + k];
+        // roll correction from every further child: G_j <- G_j (x) roll; per lane with two chains (the other chain's lanes wait)
+        for (int rr = 0; __builtin_amdgcn_ballot_w64(rr < nx) != 0; ++rr) {
+            const bool act = rr < nx;
+            const int gc = sTopo[2 * J + 1 + (act ? xs + rr : xs)];
             float pg[4];
             lds_get<4>(fS, gc, pg);
             const float ginv[4] = {g[0], -g[1], -g[2], -g[3]};
@@ -226,7 +250,7 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_kernel(const IkAr
             qmulvec(ginv, dg, pgd);
             vnormalize(pgd, 1e-8f, bn);
             float axis[3] = {a[0], a[1], a[2]};
-            if (__builtin_amdgcn_ballot_w64(snap) != 0) {  // where the alignment snapped, G_j does not take the rest direction onto d
+            if (__builtin_amdgcn_ballot_w64(snap && act) != 0) {  // where the alignment snapped, G_j does not take the rest direction onto d
                 float dn[3], ax[3];
                 vnormalize(d, 1e-8f, dn);
                 qmulvec(ginv, dn, ax);
@@ -236,7 +260,7 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_kernel(const IkAr
             float roll[4], g2[4];
             from_to_axis_unit(bg, bn, axis, roll);
             qmul(g, roll, g2);
-            g[0] = g2[0]; g[1] = g2[1]; g[2] = g2[2]; g[3] = g2[3];
+            g[0] = act ? g2[0] : g[0]; g[1] = act ? g2[1] : g[1]; g[2] = act ? g2[2] : g[2]; g[3] = act ? g2[3] : g[3];
         }
         lds_put<4>(fS, j, g);  // P_j is dead from here on
         prevj = j;
@@ -267,9 +291,47 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_kernel(const IkAr
   }
 }
 
-template <int FPW>
+// Joints with children onto two chains, one item per chain and step.  A joint is ready two steps after its parent, or
+// right after it on the parent's own chain (its quaternion is still in that lane's registers; the look-ahead fetch of the
+// next step is issued before the current one stores).  Longest remaining path first, a further child counting like an
+// alignment.  Returns the number of steps; 0 if it does not fit or the tree is too narrow to pay.
+static int ik_schedule(const Topo16 &t, const int J, uint8_t *sched) {
+    int height[PM_MAX_JOINTS], done_step[PM_MAX_JOINTS], done_chain[PM_MAX_JOINTS], items = 0;
+    for (int j = 0; j < J; ++j) { height[j] = 0; done_step[j] = -1; done_chain[j] = -1; }
+    for (int j = J - 1; j >= 0; --j) {
+        const int nc = t.cstart[j + 1] - t.cstart[j];
+        if (nc > 0) {
+            ++items;
+            height[j] += nc;
+            if (j > 0 && height[t.parent[j]] < height[j]) height[t.parent[j]] = height[j];
+        }
+    }
+    int left = items, K = 0;
+    for (int st = 0; left > 0; ++st) {
+        if (2 * (st + 1) > 512) return 0;
+        for (int k = 0; k < 2; ++k) {
+            int best = -1, best_on = 0;
+            for (int j = 0; j < J; ++j) {
+                if (done_step[j] >= 0 || t.cstart[j + 1] <= t.cstart[j]) continue;
+                int on = 0;
+                if (j > 0) {
+                    const int p = t.parent[j];
+                    if (done_step[p] < 0 || done_step[p] == st) continue;
+                    if (done_step[p] == st - 1) { if (done_chain[p] != k) continue; on = 1; }
+                }
+                if (best < 0 || on > best_on || (on == best_on && height[j] > height[best])) { best = j; best_on = on; }
+            }
+            sched[2 * st + k] = (uint8_t)(best < 0 ? 255 : best);
+            if (best >= 0) { done_step[best] = st; done_chain[best] = k; --left; }
+        }
+        K = st + 1;
+    }
+    return (4 * K <= 3 * items) ? K : 0;
+}
+
+template <int FPW, int C>
 static int launch_ik(const IkArgs &a, bool vec, hipStream_t s) {
-    const size_t lds = ((size_t)FPW * ik_frame_stride(a.J) + 3 * a.J + 3 * a.J + 4) * sizeof(float) + (size_t)(a.J + 2) * 16;
+    const size_t lds = ((size_t)FPW * ik_frame_stride(a.J) + 3 * a.J + 3 + 3 * a.J + 4) * sizeof(float) + (size_t)(a.J + 2) * C * 16;
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
     // records per lane of one tile -> the pipelined instantiation that holds them in registers (3 VGPRs each)
     const int nl = (FPW * a.J + PM_WAVE - 1) / PM_WAVE;
@@ -282,10 +344,10 @@ static int launch_ik(const IkArgs &a, bool vec, hipStream_t s) {
     const int64_t ngroups = (ntiles + nt - 1) / nt;
     const int64_t grid = ((ngroups + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
     if (grid > 0x7fffffffLL) { set_error("from_root_positions: grid too large"); return PM_EUNSUPPORTED; }
-    set_kernel_name("void pm::from_root_positions_kernel<%d, %s, %d>(pm::IkArgs, int)", FPW, tf(vec), cap);
+    set_kernel_name("void pm::from_root_positions_kernel<%d, %s, %d, %d>(pm::IkArgs, int)", FPW, tf(vec), cap, C);
 #define PM_IK_LAUNCH(V, N)                                                          \
     {                                                                               \
-        auto k = from_root_positions_kernel<FPW, V, N>;                             \
+        auto k = from_root_positions_kernel<FPW, V, N, C>;                          \
         if (int e = allow_lds(k, lds)) return e;                                    \
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a, nt);  \
     }
@@ -318,18 +380,22 @@ extern "C" int pm_from_root_positions_f32(const float *positions, const int32_t 
     for (int32_t j = 1; j < J; ++j) a.topo.clist[fill[p.p[j]]++] = (int16_t)j;
     const bool vec = aligned16(positions) && aligned16(rotations);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t per_frame = (size_t)ik_frame_stride(J) * sizeof(float), fixed = (size_t)(6 * J + 4) * sizeof(float) + (size_t)(J + 2) * 16 + 256;
+    const size_t per_frame = (size_t)ik_frame_stride(J) * sizeof(float), fixed = (size_t)(6 * J + 8) * sizeof(float) + (size_t)(J + 2) * 32 + 256;
     {
         const int v = tune_env("PM_IK_FPW", 0);  // PM_TUNING build only
-        if (v == 64 && 64 * per_frame + fixed <= kMaxLds) return launch_ik<64>(a, vec, s);
-        if (v == 32 && 32 * per_frame + fixed <= kMaxLds) return launch_ik<32>(a, vec, s);
-        if (v == 16) return launch_ik<16>(a, vec, s);
-        if (v == 8) return launch_ik<8>(a, vec, s);
+        a.K = 0;
+        if (v == 64 && 64 * per_frame + fixed <= kMaxLds) return launch_ik<64, 1>(a, vec, s);
+        if (v == 32 && 32 * per_frame + fixed <= kMaxLds) return launch_ik<32, 1>(a, vec, s);
+        if (v == 16) return launch_ik<16, 1>(a, vec, s);
     }
-    if (4 * (64 * per_frame + fixed) <= kMaxLds) return launch_ik<64>(a, vec, s);  // every lane busy, >= 4 waves per CU
-    if (4 * (32 * per_frame + fixed) <= kMaxLds) return launch_ik<32>(a, vec, s);
-    if (2 * (16 * per_frame + fixed) <= kMaxLds) return launch_ik<16>(a, vec, s);
-    if (4 * per_frame + fixed <= kMaxLds) return launch_ik<4>(a, vec, s);
+    // two chains per frame when the tree is wide enough for the schedule to pay (PM_IK_CHAINS=1 in the tuning build: never)
+    a.K = (J <= 254 && tune_env("PM_IK_CHAINS", 2) == 2) ? ik_schedule(a.topo, J, a.sched) : 0;
+    if (a.K > 0 && 2 * (32 * per_frame + fixed) <= kMaxLds) return launch_ik<32, 2>(a, vec, s);
+    a.K = 0;
+    if (4 * (64 * per_frame + fixed) <= kMaxLds) return launch_ik<64, 1>(a, vec, s);  // every lane busy, >= 4 waves per CU
+    if (4 * (32 * per_frame + fixed) <= kMaxLds) return launch_ik<32, 1>(a, vec, s);
+    if (2 * (16 * per_frame + fixed) <= kMaxLds) return launch_ik<16, 1>(a, vec, s);
+    if (4 * per_frame + fixed <= kMaxLds) return launch_ik<4, 1>(a, vec, s);
     set_error("from_root_positions: J=%d does not fit the LDS tile", J);
     return PM_EUNSUPPORTED;
 }

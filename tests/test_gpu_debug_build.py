@@ -116,6 +116,14 @@ def test_skeleton_kernels_under_the_debug_build(J, F, osc, rsc):
 
     a, b = _both(run)
     for k, (x, y) in enumerate(zip(a, b)):
+        if k == len(a) - 1:
+            # from_root_positions amplifies last-ulp differences ~100x (rotations from normalised differences of positions; a
+            # direction within 0.26 degrees of its rest pose snaps to the identity like the reference's np.isclose): the two
+            # builds must agree like either agrees with the float64 oracle (tests/test_ik.py: 2e-4, rare snap flips aside)
+            d = torch.minimum((x - y).abs().amax(dim=-1), (x + y).abs().amax(dim=-1))  # q and -q are one rotation
+            # (a flipped snap / anti-parallel decision changes a joint's answer completely: at most one element in a thousand)
+            assert float(d.median()) <= 1e-6 and float((d > 5e-4).float().mean()) <= 1e-3, (k, float(d.median()), float((d > 5e-4).float().mean()))
+            continue
         assert _same(torch, x, y), f"result {k} differs between the builds"
 
 
