@@ -15,11 +15,13 @@ cp $(find $OUT/trace -name '*kernel_stats.csv' | head -1) $OUT/r${RN}_bench_kern
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f --output-format csv -- python $R/tools/perf_probe.py --only fk,ceiling,dq,o6d --sustained 20 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o w --output-format csv -- python $R/tools/perf_probe.py --only fk,ceiling,dq,o6d --sustained 20 > $OUT/pmc_write.log 2>&1
 python $R/tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $((10#$RN)) > $OUT/r${RN}_fk_hbm_traffic.json
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT -d $OUT/pmc_sq -o q --output-format csv -- python $R/tools/perf_probe.py --only fk,dq,mirror,o6d,ik,unroll --sustained 10 > $OUT/pmc_sq.log 2>&1
+python $R/tools/sq_cycles.py $OUT/pmc_sq $((10#$RN)) > $OUT/r${RN}_sq_wave_cycles.json
 python $R/tools/perf_probe.py --sustained 100 > $OUT/r${RN}_kernel_probe.txt 2>&1
 PM_SWEEP_ALL=1 python $R/tools/jsweep_probe.py 4,8,16,22,23,24,28,32,40,48,52,56,64,65,72,96,128 > $OUT/r${RN}_joint_sweep.txt 2>&1
 python $R/tools/dq_probe.py 22,28,40,48,52,56,64,65,96,128 > $OUT/r${RN}_to_root_dq_sweep.txt 2>&1
 python $R/tools/ik_probe.py 4,22,28,52,96,128 > $OUT/r${RN}_from_root_positions_sweep.txt 2>&1
 python $R/tools/prec_probe.py > $OUT/r${RN}_fk_precision_levels.txt 2>&1
 python $R/tools/numpy_door_probe.py > $OUT/r${RN}_numpy_door.txt 2>&1
-rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
 ls -la $OUT
