@@ -985,6 +985,9 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
         nt = tune_env("PM_FK_NT", nt);  // PM_TUNING build only: tiles per workgroup, 0 = fk_kernel
         if (nt > 0) return a.J <= 64 ? dispatch_fk_pipe<4, 4, SRC>(a, vec, pfo, nt, s) : dispatch_fk_pipe<4, 8, SRC>(a, vec, pfo, nt, s);
     }
+    // (The pipelined multi-tile structure on the 20-frame three-lane tile, measured again in round 2 with the current kernels:
+    // 257 us against 270 us on one box, 295-310 us against 271 us on the next -- fewer, longer workgroups cannot absorb
+    // per-XCD bandwidth differences the way one-tile workgroups under hardware dispatch do.  Not used.)
     switch (pick) {
         case 20: return dispatch_fk2<20, SRC>(a, vec, pfo, s);
         case 8: return dispatch_fk2<8, SRC>(a, vec, pfo, s);
