@@ -52,6 +52,9 @@ def parse():
                          "and never inside `value`: (ii) the all-gather of (pos, rotmats) -- ms and achieved xGMI GB/s per GPU for "
                          "both RCCL's all_gather_into_tensor and the direct full-mesh send/recv -- and (iii) compute + gather combined")
     ap.add_argument("--gather", action="store_true", help=argparse.SUPPRESS)  # round-1 spelling, now the default
+    ap.add_argument("--gather-timeout-s", type=int, default=180,
+                    help="N>1: the reassembly measurements run last, under a watchdog; past this they are abandoned and the bench line "
+                         "is printed without them")
     ap.add_argument("--dry-run-shared-gpu", action="store_true",
                     help="launch-path rehearsal on a box with fewer GPUs than ranks: every rank uses cuda:0 and the process group is "
                          "gloo (RCCL refuses two ranks on one device).  Numbers from such a run mean nothing; the JSON says so")
@@ -348,9 +351,6 @@ def main():
         et = torch.tensor([err], device=cdev, dtype=torch.float64)
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
         extra["max_abs_err_vs_oracle_slice"] = {"value": float(et[0]), "frames_per_rank": n_chk}
-    if use_dist and world > 1 and not a.no_gather:
-        extra["gather"] = gather_report(torch, dist, a, world, rank, F, J, pos, rm, barrier, wall / a.steps, cdev, shared)
-
     if world == 1 and not a.no_secondary and J == 22:
         extra["secondary"] = secondary_configs(torch, _lib, syn, dev, rot, root, off, parents, sptr)
 
@@ -391,6 +391,28 @@ def main():
                          "bytes_per_frame": bytes_per_frame},
         }
         line.update(extra)
+    else:
+        line = None
+    if use_dist and world > 1 and not a.no_gather:
+        # The reassembly measurements come LAST and under a watchdog: they are the only part of this script that talks over
+        # xGMI peer to peer, nothing measured above depends on them, and a collective that hangs on some node must cost the
+        # run its `gather` object, not its bench line.
+        import threading
+
+        def bail():
+            if rank == 0:
+                line["gather"] = {"error": "reassembly measurements did not finish within %d s: abandoned" % a.gather_timeout_s}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(a.gather_timeout_s, bail)
+        dog.daemon = True
+        dog.start()
+        g = gather_report(torch, dist, a, world, rank, F, J, pos, rm, barrier, wall / a.steps, cdev, shared)
+        dog.cancel()
+        if rank == 0:
+            line["gather"] = g
+    if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             rot_h, root_h = rot.cpu().numpy(), root.cpu().numpy()
             info, p_cpu, r_cpu = cpu_baseline(rot_h, root_h, off_np, parents, a.cpu_sample_frames)

@@ -142,3 +142,13 @@ def test_bench_under_torchrun_one_rank_rccl():
     assert line["max_abs_err_vs_oracle_slice"]["frames_per_rank"] == 1 << 16
     assert line["max_abs_err_vs_oracle_slice"]["value"] <= ATOL
     assert line["roofline"]["kernel"].startswith("void pm::fk_kernel<20, true, false, 0, false, false, 17>")
+
+
+def test_bench_line_survives_a_reassembly_that_never_finishes():
+    """the gather measurements run last and under a watchdog: with a zero budget they are abandoned at once, every rank
+    exits cleanly and the bench line still carries the compute-only result and the oracle check"""
+    line = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--prewarm-ms", "0", "--frames-per-gpu", "65536",
+                   "--oracle-slice-frames", "4096", "--dry-run-shared-gpu", "--gather-timeout-s", "0"])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert line["max_abs_err_vs_oracle_slice"]["value"] <= ATOL
+    assert "error" in line["gather"] and "abandoned" in line["gather"]["error"]
