@@ -270,6 +270,22 @@ __device__ __forceinline__ float atan2_rr(const float y, const float x) {
     return a;
 }
 
+// atan2(sqrt(p), sqrt(q)) for p, q >= 0 (the middle Euler angle, quat.py:214: np.arctan2 of two hypotenuses): the square
+// roots are monotonic, so the reduced argument is sqrt(min / max) -- one hardware sqrt and one rcp instead of two correctly
+// rounded square roots and a general atan2 (quadrants, signs): same polynomial, first quadrant only.  atan2(0, 0) = 0.
+__device__ __forceinline__ float atan2_sqrt_rr(const float p, const float q) {
+    const float hi = fmaxf(p, q), lo = fminf(p, q);
+    const float t = fsqrt(lo * frcp(hi));                  // in [0, 1]
+    const bool mid = t > 0.4142135623730950f;
+    const float u = mid ? (t - 1.0f) * frcp(t + 1.0f) : t;
+    const float z = u * u;
+    float a = (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * u + u;
+    a += mid ? 0.7853981633974483f : 0.0f;
+    a = (p > q) ? 1.5707963267948966f - a : a;
+    a = (hi > 0.0f) ? a : ((hi == 0.0f) ? 0.0f : hi);      // 0/0 -> 0 like np.arctan2(0, 0); NaN stays NaN
+    return (hi < 3.0e38f) ? a : atan2f(sqrtf(p), sqrtf(q)); // inf operands: libm's conventions
+}
+
 // rotations/quat.py:24-40
 __device__ __forceinline__ void aa2q(float angle, float ax, float ay, float az, float (&o)[4]) {
     const float h = angle / 2.0f;
@@ -335,7 +351,7 @@ PM_OP(OpToEuler, 4, 0, 0, 3, 0) {
     const float two_pi = 6.283185307179586f;
     float e[3];
     // (np.hypot on quaternion-sized operands: no overflow to guard against, plain sqrt of the sum of squares)
-    e[1] = 2.0f * atan2_rr(__fsqrt_rn(cc * cc + dd * dd), __fsqrt_rn(aa * aa + bb * bb)) - 1.5707963267948966f;
+    e[1] = 2.0f * atan2_sqrt_rr(cc * cc + dd * dd, aa * aa + bb * bb) - 1.5707963267948966f;
     const float hs = atan2_rr(bb, aa), hd = atan2_rr(dd, cc);
     e[2] = hs - hd;
     e[0] = (hs + hd) * sg;
