@@ -793,3 +793,51 @@ def test_to_root_dq_chain_scheduler_on_many_topologies(kind, J):
     assert_close(d, d_o, max(ATOL, 3e-7 * depth * depth), f"{kind} J={J} depth={depth}")  # (a 250-joint chain accumulates 250 fp32 products)
     t, q = sk.from_root_dual_quat(d, parents)
     assert_close(q, rot, max(ATOL, 3e-7 * depth * depth), "round trip rot")
+
+
+@pytest.mark.parametrize("J,osc", [(22, 0.3), (22, 30.0), (52, 0.15), (52, 30.0), (100, 0.2)])
+def test_every_skeleton_kernel_on_views_that_are_only_4_byte_aligned(J, osc):
+    """base pointers that are not 16-byte aligned take the scalar-access instantiation of each kernel (VEC = false) --
+    the several-chains dual-quaternion walk, the two-chain IK, both arithmetic levels of fk and the fused ortho6d source
+    included -- with the aligned call's results (bit for bit where the arithmetic is a plain chain)"""
+    torch, skt = _torch_mods()[:2]
+    from pymotion_amd import synthetic as syn
+
+    rng = np.random.default_rng(J + int(osc))
+    parents = {22: syn.PARENTS_22, 52: syn.PARENTS_52}.get(J)
+    if parents is None:
+        parents = syn.random_parents(J, rng)
+    F = 203
+    rot = rng.standard_normal((F, J, 4)).astype(np.float32)
+    rot /= np.linalg.norm(rot, axis=-1, keepdims=True)
+    root = rng.uniform(-2, 2, (F, 3)).astype(np.float32) * (100 if osc > 1 else 1)
+    off = rng.uniform(-osc, osc, (J, 3)).astype(np.float32)
+    off[0] = 0
+    x6 = rng.standard_normal((F, J, 3, 2)).astype(np.float32)
+    par_t = torch.from_numpy(np.asarray(parents))
+
+    def shifted(a):  # the same values at an address that is 4 bytes past a 16-byte boundary
+        big = torch.empty(a.size + 1, dtype=torch.float32, device="cuda")
+        v = big[1:].view(a.shape)
+        v.copy_(torch.from_numpy(a))
+        assert v.data_ptr() % 16 == 4
+        return v
+
+    al = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    for mk in (al, shifted):
+        r, g, o, x = mk(rot), mk(root), mk(off), mk(x6)
+        res = list(skt.fk(r, g, o, par_t)) + list(skt.fk_from_ortho6d(x, g, o, par_t, return_quat=True)) + list(skt.fk_from_ortho6d(x, g, o, par_t))
+        dq = skt.to_root_dual_quat(r, g, par_t, o)
+        res += [dq] + list(skt.from_root_dual_quat(mk(dq.cpu().numpy()), par_t))
+        res += [skt.from_global_rotations(r, par_t), skt.from_root_positions(mk(res[0].cpu().numpy()), par_t, o)]
+        res += [skt.mirror(r, g, par_t, o)[0]]
+        if mk is al:
+            want = [t.cpu().numpy() for t in res]
+        else:
+            for k, (t, w) in enumerate(zip(res, want)):
+                if k >= 11:  # from_root_positions amplifies the last-ulp differences between two instantiations (where the
+                    # compiler contracts a multiply-add) ~100x; mirror's from_matrix sign sits on branch boundaries
+                    d = np.minimum(np.abs(t.cpu().numpy() - w).max(-1), np.abs(t.cpu().numpy() + w).max(-1))
+                    assert np.median(d) <= 1e-6 and (d > 5e-4).mean() <= 2e-3, (k, np.median(d), d.max())
+                    continue
+                np.testing.assert_array_equal(t.cpu().numpy(), w, err_msg=f"result {k}")
