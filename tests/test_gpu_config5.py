@@ -152,3 +152,37 @@ def test_bench_line_survives_a_reassembly_that_never_finishes():
     assert line["n_gpus"] == 2 and line["value"] > 0
     assert line["max_abs_err_vs_oracle_slice"]["value"] <= ATOL
     assert "error" in line["gather"] and "abandoned" in line["gather"]["error"]
+
+
+def test_fk_on_all_16m_frames_of_config5_in_one_call():
+    """BASELINE.json configs[4] names 16 777 216 frames x 22 joints.  Sharded over 8 GPUs that is 2^21 per rank (tested
+    above); one MI355X has the memory for the WHOLE batch (rot 5.9 GB, pos 4.4 GB, rotmats 13.3 GB), so the workload itself --
+    and the 64-bit element offsets it needs: 3.3e9 floats of rotation matrices -- runs here in one call, with oracle slices
+    from the start, the 2^31-element boundary region and the end, and the per-rank blocks compared with separate calls."""
+    import torch
+
+    import pymotion_amd.ops.skeleton_torch as skt
+
+    F = 1 << 24
+    g = torch.Generator(device="cuda")
+    g.manual_seed(2024)
+    rot = torch.randn((F, 22, 4), generator=g, device="cuda")
+    root = torch.rand((F, 3), generator=g, device="cuda") * 4 - 2
+    off_np = syn.make_offsets(22, np.random.default_rng(1), 0.3)
+    off = torch.from_numpy(off_np).cuda()
+    par = torch.from_numpy(syn.PARENTS_22)
+    pos, rm = skt.fk(rot, root, off, par)
+    torch.cuda.synchronize()
+    n = 1 << 13
+    f_cross = (1 << 31) // (22 * 9)  # the frame whose rotation matrices straddle element 2^31
+    for s0 in (0, f_cross - n // 2, F // 2 + 7, F - n):
+        sl = slice(s0, s0 + n)
+        p_o, r_o = co.fk(rot[sl].cpu().numpy().astype(np.float64), root[sl].cpu().numpy().astype(np.float64),
+                         off_np.astype(np.float64), syn.PARENTS_22)
+        assert float(np.abs(pos[sl].cpu().numpy() - p_o).max()) <= ATOL
+        assert float(np.abs(rm[sl].cpu().numpy() - r_o).max()) <= ATOL
+    assert bool(torch.equal(pos[:, 0], root))
+    # rank 6's block of the 8-way sharding, computed on its own, is the same bits
+    s, e = 6 * SHARD, 7 * SHARD
+    p6, r6 = skt.fk(rot[s:e], root[s:e], off, par)
+    assert bool(torch.equal(p6, pos[s:e])) and bool(torch.equal(r6, rm[s:e]))
