@@ -382,7 +382,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "prewarm_ms": a.prewarm_ms,
-            "config": {"workload": "fk: %d frames x %d joints per GPU, fp32 (BASELINE.json configs[1])" % (F, J),
+            "config": {"workload": "fk: %d frames x %d joints per GPU, fp32 (%s)" % (
+                F, J, "BASELINE.json configs[1]" if (F, J) == (1 << 20, 22) else
+                ("all 16 777 216 frames of BASELINE.json configs[4] on one GPU" if (F, J, world) == (1 << 24, 22, 1) else "non-default size")),
                        "frames_per_gpu": F, "joints": J, "sharding": "frames, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
