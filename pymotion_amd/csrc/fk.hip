@@ -868,11 +868,9 @@ static int launch_fk_p(const FkArgs &a, hipStream_t s) {
         switch (tune_env("PM_FK_PREC", PM_FK_PREC_DEFAULT)) {
             case 0: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 0>(a, s);
             case 1: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 1>(a, s);
-            case 2: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 2>(a, s);
-            case 5: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 5>(a, s);
             case 6: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 6>(a, s);
             case 17: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 17>(a, s);
-            default: set_error("PM_FK_PREC must be 0, 1, 2, 5, 6 or 17"); return PM_EINVAL;
+            default: set_error("PM_FK_PREC must be 0, 1, 6 or 17"); return PM_EINVAL;
         }
     }
 #endif
@@ -899,11 +897,9 @@ static int launch_fk_pipe_p(const FkArgs &a, const int nt, hipStream_t s) {
         switch (tune_env("PM_FK_PREC", PM_FK_PREC_DEFAULT)) {
             case 0: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 0>(a, nt, s);
             case 1: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 1>(a, nt, s);
-            case 2: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 2>(a, nt, s);
-            case 5: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 5>(a, nt, s);
             case 6: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 6>(a, nt, s);
             case 17: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 17>(a, nt, s);
-            default: set_error("PM_FK_PREC must be 0, 1, 2, 5, 6 or 17"); return PM_EINVAL;
+            default: set_error("PM_FK_PREC must be 0, 1, 6 or 17"); return PM_EINVAL;
         }
     }
 #endif

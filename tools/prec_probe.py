@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What each arithmetic level of fk costs and buys (tuning build of the library, PM_FK_PREC):
-   0 fp32 as in round 1 | 1 residual-scaled phase A | 2 float64 phase A | +4 fixed-point translation chain |
+   0 fp32 as in round 1 | 1 residual-scaled phase A | 6 float64 phase A + fixed-point translation chain |
    17 = what production runs: per tile, 1 for human-scale metre data, 6 when bones / roots are big.
 For every level: sustained time at 2^20 x 22 and 2^18 x 52, and the max error against the float64 C oracle on a
 2^14-frame sample at metre scale (offsets 0.3, root 2) and centimetre scale (offsets 30, root 200), in absolute terms
@@ -40,7 +40,7 @@ def sustained(fn, n=100, warm=150):
 
 def main():
     dev = torch.device("cuda:0")
-    levels = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,1,2,5,6,17".split(","))]
+    levels = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,1,6,17".split(","))]
     with _lib.variant("tuning"):
         for J, parents, F in ((22, syn.PARENTS_22, 1 << 20), (52, syn.PARENTS_52, 1 << 18)):
             g = torch.Generator(device=dev)
