@@ -655,7 +655,9 @@ extern "C" int pm_to_root_dq_f32(const float *rot, const float *root_pos, const 
             const int c1 = 2 * J, c2 = K2 ? 2 * K2 : 1 << 30, c4 = K4 ? 4 * K4 : 1 << 30;
             // near-ties go to four chains: the tile is half the size, twice as many waves are resident (measured, 2^18 frames:
             // J = 96 two / four chains 384 / 342 us, J = 65 235 / 228 us; the 52-joint SMPL-H tree, 26 vs 17 steps: 150 / 179 us)
-            if (K4 && 20 * c4 <= 23 * c2 && 4 * c4 <= 3 * c1) use = 4;
+            // ... and so do skeletons whose two-chain tile (8 frames) is too big for more than four waves per CU (narrow
+            // 128-joint tree, two / four chains: 727 / 650 us)
+            if (K4 && ((20 * c4 <= 23 * c2 && 4 * c4 <= 3 * c1) || (J > 100 && c4 <= 2 * c2))) use = 4;
             else if (K2 && 4 * c2 <= 3 * c1) use = 2;
         }
         if (use) {
