@@ -274,3 +274,29 @@ def test_fuzz_from_root_positions_reproduces_the_pose(sk_):
     r_or = co.from_root_positions(f64(pos.astype(np.float32)), par, f64(off))
     d = np.minimum(np.abs(r - r_or).max(-1), np.abs(r + r_or).max(-1))
     assert np.median(d) <= 1e-5 and (d > 1e-3).mean() < 0.02, (np.median(d), (d > 1e-3).mean(), d.max())
+
+
+@settings(max_examples=200, deadline=None, derandomize=True)
+@given(skeletons(), st.sampled_from([0.05, 0.9, 1.0, 7.0, 30.0, 4.0e3, 2.5e6]), st.sampled_from([0.0, 3.0, 16.0, 900.0, 1.0e7]), st.booleans())
+def test_fuzz_fk_at_every_magnitude(sk_, bone_scale, root_scale, per_frame_offsets):
+    """the per-tile arithmetic of fk (fp32 walk / float64 rotations + fixed-point chain) over bone and root
+    magnitudes from millimetres to thousands of kilometres, both sides of the decision thresholds, every walk shape:
+    |pos error| <= max(1e-5, 3 ulp of the largest coordinate); rotations <= 2e-6 whatever the positions do"""
+    J, par, lead, rng = sk_
+    rot = rng.standard_normal(lead + (J, 4)).astype(np.float32)
+    gpos = (rng.uniform(-1, 1, lead + (3,)) * root_scale).astype(np.float32)
+    off = (rng.uniform(-1, 1, (lead + (J, 3)) if per_frame_offsets else (J, 3)) * bone_scale).astype(np.float32)
+    pos, rm = sk.fk(rot, gpos, off, par)
+    p_o, r_o = co.fk(f64(rot), f64(gpos), f64(off), par)
+    if pos.size:
+        scale = np.abs(p_o).max()
+        bar = max(1e-5, 3 * 2.0 ** (np.floor(np.log2(scale)) - 23)) if scale > 0 else 1e-5
+        # (depth-129 chains accumulate 129 fp32 rotation products: the rotation term of the position error grows with them)
+        d = np.zeros(J, int)
+        for j in range(1, J):
+            d[j] = d[par[j]] + 1
+        depth = 1 + int(d.max())
+        bar *= max(1.0, depth / 12.0)
+        assert np.abs(pos - p_o).max() <= bar, (np.abs(pos - p_o).max(), bar, scale)
+        assert np.abs(rm - r_o).max() <= 2e-6 * max(1.0, depth / 12.0)
+        np.testing.assert_array_equal(pos[..., 0, :].astype(np.float32), gpos)
