@@ -657,8 +657,13 @@ __global__ __launch_bounds__(PM_WAVE) void fk_kernel(const FkArgs a) {
 // so loads overlap the walk and the stores overlap the next tile's math and walk.  The vmcnt wait in
 // front of math(i+1) only ever covers loads that are a whole walk old (the stores of tile i are issued
 // after it).  The skeleton table is staged once per workgroup.
+// (Second launch bound: at most 128 VGPRs for the four-records-per-lane form, i.e. four waves per SIMD.  Its tiles are small
+// -- 5 to 10 KiB of LDS -- so registers, not LDS, bound residency, and the two arithmetic levels of PREC_DYN in one kernel
+// had pushed the per-frame-offsets variant to 166 VGPRs: 2^20 x 22 with per-frame offsets 416 us, 378 with the bound.  Not for the
+// ortho6d source: its Gram-Schmidt + float64 twins need the registers, and spilling them costs more than the residency buys:
+// fused J = 52 200 -> 223 us, with the quaternion output 268 -> 409 us.)
 template <int FPW, int EPL, bool VEC, int SRC, bool QOUT, bool PAD, bool PFO, int PREC>
-__global__ __launch_bounds__(PM_WAVE) void fk_pipe_kernel(const FkArgs a, const int nt) {
+__global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? 4 : 1) void fk_pipe_kernel(const FkArgs a, const int nt) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool DYN = (PREC & PREC_DYN) != 0;
     constexpr bool QUAD = FPW <= 5;  // records per lane: FPW * J <= 64 * EPL

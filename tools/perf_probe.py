@@ -92,6 +92,15 @@ def main():
         if want("fk"):
             ms, mn = timeit(lambda: _lib.call("pm_fk_f32", p(rot), p(root), p(off), 0, pp, Fj, J, p(pos), p(rm), None))
             report(f"fk J={J} F={Fj}", ms, mn, Fj * (64 * J + 12))
+            offf = (torch.randn((Fj, J, 3), device=dev) * 0.1)
+            ms, mn = timeit(lambda: _lib.call("pm_fk_f32", p(rot), p(root), p(offf), 1, pp, Fj, J, p(pos), p(rm), None))
+            report(f"fk, per-frame offsets J={J}", ms, mn, Fj * (76 * J + 12))
+            del offf
+            off_cm = off * 100.0
+            root_cm = root * 100.0
+            ms, mn = timeit(lambda: _lib.call("pm_fk_f32", p(rot), p(root_cm), p(off_cm), 0, pp, Fj, J, p(pos), p(rm), None))
+            report(f"fk, centimetre-scale data J={J}", ms, mn, Fj * (64 * J + 12))
+            del off_cm, root_cm
         if want("ceiling"):
             rd, wr = 16 * J // 4, 48 * J // 4
             src = rot.view(-1)
@@ -140,6 +149,9 @@ def main():
             ms, mn = timeit(lambda: _lib.call("pm_fk_from_ortho6d_f32", p(x), p(root), p(off), 0, pp, Fj, J, C.c_float(0.0),
                                               p(pos), p(rm), None, None))
             report(f"fk_from_ortho6d J={J} F={Fj}", ms, mn, Fj * (72 * J + 12))
+            ms, mn = timeit(lambda: _lib.call("pm_fk_from_ortho6d_f32", p(x), p(root), p(off), 0, pp, Fj, J, C.c_float(0.0),
+                                              p(pos), p(rm), p(qo), None))
+            report(f"fk_from_ortho6d + quaternions out J={J}", ms, mn, Fj * (88 * J + 12))
         if want("ew") and J == 22:
             N = Fj * J
             q = rotn.view(N, 4)
