@@ -305,8 +305,11 @@ __device__ __forceinline__ v4f load_joint_const(const Parents &parents, const fl
 
 // ortho6d record -> local rotation (and, with QOUT, the quaternion the reference would have produced):
 // rotations/ortho6d.py:50-64 (6D -> matrix -> quaternion, itself normalised), then fk's own normalise and to_matrix.
+template <bool TRANSPOSED>
+__device__ __forceinline__ void put_local(float *slot, const float (&L)[9]);
+
 template <bool QOUT, int M>
-__device__ __forceinline__ void local_from_o6d(const float (&xx)[6], const float eps, float (&L)[9], float (&Q)[4]) {
+__device__ __forceinline__ bool local_from_o6d(const float (&xx)[6], const float eps, float (&L)[9], float (&Q)[4]) {
     bool ill;
     if constexpr (QOUT) {
         float m[9];
@@ -317,21 +320,25 @@ __device__ __forceinline__ void local_from_o6d(const float (&xx)[6], const float
         // Without the quaternion output the trip matrix -> quaternion -> normalise -> matrix is the identity on an
         // orthonormal matrix up to fp32 rounding (~2e-7, two orders inside the parity budget): the Gram-Schmidt
         // result IS the local rotation.  Saves ~80 VALU ops per joint.  It is NOT the identity on what Gram-Schmidt
-        // returns for degenerate columns (zeros, NaN, rounding noise) -- those records take the full chain below.
+        // returns for degenerate columns (zeros, NaN, rounding noise) -- those records are re-done (o6d_redo_ill).
         o6d2m(xx, eps, L, &ill);
     }
-    // Zero / non-finite / (anti-)parallel columns: the reference's answer is decided by its eps floors and NaN rules and,
-    // for near-parallel columns, by digits fp32 does not have -- re-do the record's whole chain in float64 (wave-uniform
-    // branch, ~1e-4 of random records), so that both variants equal ortho6d.to_quat -> fk on EVERY input.
-    if (__builtin_amdgcn_ballot_w64(ill) != 0) {
-        float Ld[9], Qd[4];
-        o6d_chain_f64(xx, eps, Ld, Qd);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) L[k] = ill ? Ld[k] : L[k];
-        if constexpr (QOUT) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) Q[k] = ill ? Qd[k] : Q[k];
-        }
+    return ill;
+}
+
+// Zero / non-finite / (anti-)parallel columns: the reference's answer is decided by its eps floors and NaN rules and, for
+// near-parallel columns, by digits fp32 does not have -- such a record's whole chain is re-done in float64, so that both
+// variants of the fused kernel equal ortho6d.to_quat -> fk on EVERY input.  Called AFTER the tile's local rotations have
+// been parked, on the record's LDS slot: the float64 chain is register-hungry, and inside the conversion loop it would set
+// the register budget of the whole kernel (166 VGPRs = three waves per SIMD) for a branch ~1e-4 of the records take.
+template <bool QOUT, bool TRANSPOSED>
+__device__ __forceinline__ void o6d_redo_ill(const bool ill, const float (&xx)[6], const float eps, float *slot, float *qslot) {
+    if (__builtin_amdgcn_ballot_w64(ill) == 0) return;  // wave-uniform
+    float Ld[9], Qd[4];
+    o6d_chain_f64(xx, eps, Ld, Qd);
+    if (ill) {
+        put_local<TRANSPOSED>(slot, Ld);
+        if (QOUT) lds_put<4>(qslot, 0, Qd);
     }
 }
 
@@ -581,10 +588,11 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
             auto do_batch = [&](const int e0, const v2f (&x)[2][3]) {
                 if (e0 >= n) return;
                 float L[2][9], Q[2][4];
+                bool ill[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const float xx[6] = {x[u][0].x, x[u][0].y, x[u][1].x, x[u][1].y, x[u][2].x, x[u][2].y};
-                    local_from_o6d<QOUT, M>(xx, a.eps, L[u], Q[u]);
+                    ill[u] = local_from_o6d<QOUT, M>(xx, a.eps, L[u], Q[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
@@ -594,6 +602,12 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
                         put_local<QUAD>(sRot + image_slot<PAD>(e, J, invJ, 9, pad), L[u]);
                         if (QOUT) lds_put<4>(sQo, e, Q[u]);
                     }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {  // the rare float64 redo, on the parked slots (in-order DS: after the plain values)
+                    const int e = e0 + u * PM_WAVE + lane, ec = e < n ? e : n - 1;
+                    const float xx[6] = {x[u][0].x, x[u][0].y, x[u][1].x, x[u][1].y, x[u][2].x, x[u][2].y};
+                    o6d_redo_ill<QOUT, QUAD>(ill[u] && e < n, xx, a.eps, sRot + image_slot<PAD>(ec, J, invJ, 9, pad), sQo + 4 * ec);
                 }
             };
             for (int e0 = 0; e0 < n; e0 += 2 * B) {
@@ -659,9 +673,9 @@ __global__ __launch_bounds__(PM_WAVE) void fk_kernel(const FkArgs a) {
 // after it).  The skeleton table is staged once per workgroup.
 // (Second launch bound: at most 128 VGPRs for the four-records-per-lane form, i.e. four waves per SIMD.  Its tiles are small
 // -- 5 to 10 KiB of LDS -- so registers, not LDS, bound residency, and the two arithmetic levels of PREC_DYN in one kernel
-// had pushed the per-frame-offsets variant to 166 VGPRs: 2^20 x 22 with per-frame offsets 416 us, 378 with the bound.  Not for the
-// ortho6d source: its Gram-Schmidt + float64 twins need the registers, and spilling them costs more than the residency buys:
-// fused J = 52 200 -> 223 us, with the quaternion output 268 -> 409 us.)
+// had pushed the per-frame-offsets variant to 166 VGPRs: 2^20 x 22 with per-frame offsets 416 us, 369 with the bound.  The ortho6d
+// source is left alone: bounded, the variant with the quaternion output spills 40-100 registers (268 -> 409 us), and the one
+// without (134 VGPRs once the float64 redo of degenerate records moved behind the parking) gains nothing from a fourth wave.)
 template <int FPW, int EPL, bool VEC, int SRC, bool QOUT, bool PAD, bool PFO, int PREC>
 __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? 4 : 1) void fk_pipe_kernel(const FkArgs a, const int nt) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -777,7 +791,9 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? 4 : 1) voi
         }
         // math of tile i, in registers (phase A of fk_tile)
         float L[EPL][9], Q[EPL][4];
-        bool bad = false;
+        bool bad = false, ill[EPL];
+#pragma unroll
+        for (int u = 0; u < EPL; ++u) ill[u] = false;
         auto math = [&](auto mode) {
             constexpr int M = decltype(mode)::value;
 #pragma unroll
@@ -787,7 +803,7 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? 4 : 1) voi
                     local_from_quat<M>(qi, L[u]);
                 } else {
                     const float xx[6] = {in2[u][0].x, in2[u][0].y, in2[u][1].x, in2[u][1].y, in2[u][2].x, in2[u][2].y};
-                    local_from_o6d<QOUT, M>(xx, a.eps, L[u], Q[u]);
+                    ill[u] = local_from_o6d<QOUT, M>(xx, a.eps, L[u], Q[u]);
                 }
                 if (M & PREC_FX) {  // NaN / Inf input record
                     if constexpr (SRC == SRC_QUAT) bad = bad || !(fabsf(in4[u].x) + fabsf(in4[u].y) + fabsf(in4[u].z) + fabsf(in4[u].w) < 3e38f);
@@ -813,6 +829,14 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? 4 : 1) voi
                     float *o = sOff + image_slot<PAD>(e, J, invJ, 3, pad);
                     o[0] = inO[u].x; o[1] = inO[u].y; o[2] = inO[u].z;
                 }
+            }
+        }
+        if constexpr (SRC == SRC_O6D) {  // the rare float64 redo of degenerate records, on the parked slots, before their inputs are overwritten
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
+                const int e = u * PM_WAVE + lane, ec = e < n ? e : (n > 0 ? n - 1 : 0);
+                const float xx[6] = {in2[u][0].x, in2[u][0].y, in2[u][1].x, in2[u][1].y, in2[u][2].x, in2[u][2].y};
+                o6d_redo_ill<QOUT, QUAD>(ill[u] && e < n, xx, a.eps, sRot + image_slot<PAD>(ec, J, invJ, 9, pad), sQo + 4 * ec);
             }
         }
         f0_prev = f0; nf_prev = nf;
