@@ -59,6 +59,9 @@ def parse():
                     help="launch-path rehearsal on a box with fewer GPUs than ranks: every rank uses cuda:0 and the process group is "
                          "gloo (RCCL refuses two ranks on one device).  Numbers from such a run mean nothing; the JSON says so")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short measurements of BASELINE configs 3 and 4 (N=1)")
+    ap.add_argument("--rccl-debug-file", default="",
+                    help="write RCCL's own log (NCCL_DEBUG=INFO, subsystems INIT,COLL,P2P: topology, channels, the algorithm / protocol "
+                         "each collective ran with) to PATH.<host>.<pid> per rank -- the record of what the reassembly actually did")
     ap.add_argument("--oracle-slice-frames", type=int, default=1 << 16,
                     help="N>1: frames of its own shard every rank checks against the CPU oracle (SURVEY 8d config 5: 2^16)")
     ap.add_argument("--seed", type=int, default=0)
@@ -215,7 +218,7 @@ def gather_report(torch, dist, a, world, rank, F, J, pos, rm, barrier, compute_s
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             sec = float(tt[0])
             rep["methods"][method] = {"ms": sec * 1e3, "first_call_ms": times[0] * 1e3, "xgmi_recv_GBps_per_gpu": recv_bytes / sec / 1e9,
-                                      "frac_of_xgmi_peak": recv_bytes / sec / 1e9 / peak, "own_block_intact": ok}
+                                      "frac_of_xgmi_peak": (recv_bytes / sec / 1e9 / peak) if peak else None, "own_block_intact": ok}
         except Exception as exc:  # noqa: BLE001
             rep["methods"][method] = {"error": repr(exc)[:300]}
     good = {k: v for k, v in rep["methods"].items() if "ms" in v}
@@ -255,14 +258,27 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("PM_BENCH_FORCE_DIST") == "1"
+    if a.rccl_debug_file:
+        os.environ["NCCL_DEBUG"] = "INFO"
+        os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,COLL,P2P"
+        os.environ["NCCL_DEBUG_FILE"] = a.rccl_debug_file + ".%h.%p"
     if use_dist:  # one rank per GPU over RCCL (backend "nccl" on ROCm); also taken by `torchrun --nproc-per-node 1`
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if shared:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        dist.barrier()  # pay RCCL's lazy communicator set-up now, not inside the barrier that opens the timed region
+        # (RCCL prints a version banner on STDOUT when it initialises; stdout carries the one JSON line and nothing else)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if shared:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.barrier()  # pay RCCL's lazy communicator set-up now, not inside the barrier that opens the timed region
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     cdev = torch.device("cpu") if shared else dev  # where the tiny control-plane tensors (timings, errors) live
 
     J = a.joints
@@ -395,7 +411,7 @@ def main():
         line.update(extra)
     else:
         line = None
-    if use_dist and world > 1 and not a.no_gather:
+    if use_dist and (world > 1 or a.rccl_debug_file) and not a.no_gather:
         # The reassembly measurements come LAST and under a watchdog: they are the only part of this script that talks over
         # xGMI peer to peer, nothing measured above depends on them, and a collective that hangs on some node must cost the
         # run its `gather` object, not its bench line.
