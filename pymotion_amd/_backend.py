@@ -233,7 +233,8 @@ class _PinnedPool:
 
 
 _pinned = _PinnedPool()
-_pipe_streams = {}  # device -> (stream0, stream1, event0, event1): created once per device
+_pipe_streams = {}  # device -> ([stream0, stream1], [event0, event1, event2]): created once per device
+_pipe_lock = threading.Lock()  # the streams / events are shared: one pipelined call at a time (they saturate the bus anyway)
 
 
 def _pipe_ctx(dev):
@@ -280,6 +281,11 @@ def pipelined_frames(F, ins, outs, launch):
     Returns the list of result arrays [F, *trailing].
     """
     _lib.require_device()
+    with _pipe_lock:
+        return _pipelined_frames_locked(F, ins, outs, launch)
+
+
+def _pipelined_frames_locked(F, ins, outs, launch):
     dev = _current_device()
     (streams, events) = _pipe_ctx(dev)
     per_in = [int(np.prod(a.shape[1:])) * 4 if pf else 0 for a, pf in ins]

@@ -841,3 +841,41 @@ def test_every_skeleton_kernel_on_views_that_are_only_4_byte_aligned(J, osc):
                     assert np.median(d) <= 1e-6 and (d > 5e-4).mean() <= 2e-3, (k, np.median(d), d.max())
                     continue
                 np.testing.assert_array_equal(t.cpu().numpy(), w, err_msg=f"result {k}")
+
+
+def test_numpy_door_pipeline_from_two_threads_at_once():
+    """the chunked pipeline shares its streams / events per device: concurrent big calls from different Python threads are
+    serialised, small ones run the plain path beside them -- every result equals the single-threaded one"""
+    import threading
+
+    from pymotion_amd import synthetic as syn
+
+    rot, root, off, par = syn.fk_workload(150_000, seed=31)
+    want = sk.fk(rot, root, off, par)
+    small = sk.fk(rot[:500], root[:500], off, par)
+    out, errs = {}, []
+
+    def big(k):
+        try:
+            out[k] = sk.fk(rot, root, off, par)
+        except Exception as exc:  # noqa: BLE001
+            errs.append(exc)
+
+    def little(k):
+        try:
+            for _ in range(20):
+                p, r = sk.fk(rot[:500], root[:500], off, par)
+                np.testing.assert_array_equal(p, small[0])
+            out[k] = True
+        except Exception as exc:  # noqa: BLE001
+            errs.append(exc)
+
+    ths = [threading.Thread(target=big, args=(0,)), threading.Thread(target=big, args=(1,)), threading.Thread(target=little, args=(2,))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for k in (0, 1):
+        np.testing.assert_array_equal(out[k][0], want[0])
+        np.testing.assert_array_equal(out[k][1], want[1])
