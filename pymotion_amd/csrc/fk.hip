@@ -1,6 +1,7 @@
 // fk.hip -- batched forward kinematics for gfx950 (reference: pymotion/ops/skeleton.py:16-61).
 //
-// One wave (= one workgroup) owns a tile of FPW = 20 consecutive frames and a private LDS image of
+// One wave (= one workgroup) owns a tile of FPW consecutive frames (20 / 16 / 12 / 4 by skeleton size, see
+// dispatch_fk; the text below uses 20) and a private LDS image of
 // that tile's OUTPUTS, laid out exactly like HBM (`rotmats` tile then `pos` tile).  Two phases:
 //
 //  A. "local" phase, one lane per (frame, joint) element, 64 elements per pass: the lane loads its
@@ -24,7 +25,7 @@
 //
 // The finished image leaves with contiguous dwordx4 streaming stores.  Algorithmic HBM bytes per
 // frame: 16 J + 12 read, 48 J written -- nothing is read or written twice, and the LDS
-// footprint is just the output tile (48 J B per frame: 21 KiB for J = 22 -> 7 waves per CU).
+// footprint is just the output tile (48 J B per frame: 16.5 KiB for 16 frames of J = 22 -> 9 waves per CU).
 #include <stdlib.h>
 
 #include "common.hpp"
@@ -955,20 +956,31 @@ static int launch_fk(const FkArgs &a, hipStream_t s) {
     return a.pad ? launch_fk_p<FPW, VEC, PFO, SRC, QOUT, true>(a, s) : launch_fk_p<FPW, VEC, PFO, SRC, QOUT, false>(a, s);
 }
 
+#ifdef PM_TUNING
+constexpr bool kAllFkShapes = true;   // PM_FK_FPW can force any shape on any variant
+#else
+constexpr bool kAllFkShapes = false;  // only the (shape, variant) pairs dispatch_fk can pick are compiled
+#endif
+
 template <int FPW, int SRC>
 static int dispatch_fk2(const FkArgs &a, bool vec, bool pfo, hipStream_t s) {
     const bool qout = a.quat_out != nullptr;
 #define PM_FK_CASE(V, P, Q) \
     if (vec == V && pfo == P && qout == Q) return launch_fk<FPW, V, P, SRC, Q>(a, s);
+    constexpr bool WITH_PFO = FPW <= 8 || kAllFkShapes;  // per-frame offsets always take the quad shape (dispatch_fk)
     PM_FK_CASE(true, false, false)
-    PM_FK_CASE(true, true, false)
     PM_FK_CASE(false, false, false)
-    PM_FK_CASE(false, true, false)
+    if constexpr (WITH_PFO) {
+        PM_FK_CASE(true, true, false)
+        PM_FK_CASE(false, true, false)
+    }
     if constexpr (SRC == SRC_O6D) {
         PM_FK_CASE(true, false, true)
-        PM_FK_CASE(true, true, true)
         PM_FK_CASE(false, false, true)
-        PM_FK_CASE(false, true, true)
+        if constexpr (WITH_PFO) {
+            PM_FK_CASE(true, true, true)
+            PM_FK_CASE(false, true, true)
+        }
     }
 #undef PM_FK_CASE
     set_error("fk: no kernel variant");
@@ -977,12 +989,16 @@ static int dispatch_fk2(const FkArgs &a, bool vec, bool pfo, hipStream_t s) {
 
 // Frames per wave (FPW, a multiple of 4 so that every tile base stays 16-byte aligned for any J).
 // The LDS image (48 J B per frame) bounds residency, and with too few waves per CU nothing hides the walk's
-// latency.  Two shapes cover the range (measured, 2^18 frames x 52 joints: FPW 20/16/12/8 with three lanes per
-// frame 376/311/307/253 us, FPW 4 with twelve lanes per frame 178 us; FPW 2 / 5: 227 / 176 us):
-//   FPW 20, 3 lanes per frame  while 6 tiles fit a CU's LDS (J <= 27 without extras; measured at 2^19 frames,
-//           J = 24..28: three lanes 166/161/175/179/209 us, twelve lanes 183/190/184/195/195 us),
-//   FPW 4, 12 lanes per frame (tree_walk_quad) beyond that.
-// Frame padding against LDS bank aliasing (FkArgs::pad) depends on the shape: the 20 frames of the three-lane walk
+// latency; fewer frames per wave leave walk lanes idle.  Four shapes cover the range (measured at 2^19 frames, % of
+// 8 TB/s on the 64 J + 12 B of a frame; at 2^18 x 52: FPW 20/16/12/8 with three lanes per frame 376/311/307/253 us,
+// FPW 4 with twelve lanes per frame 178 us; FPW 2 / 5: 227 / 176 us):
+//   FPW 20, 3 lanes per frame   while 10 tiles fit a CU's LDS (J <= 16;  J = 8 / 12: 64 / 73 % against 60 / 70 % for FPW 16),
+//   FPW 16                      while 7 fit (J <= 29;  J = 20 / 22 / 23 / 24 / 26 / 28: 70 / 72 / 68 / 65 / 70 / 66 % against
+//                               68 / 66 / 65 / 60 / 56 / 51 % for FPW 20; 2^20 x 22: 262.8 us against 270.5 us),
+//   FPW 12                      while 8 fit and the frames do not alias (J <= 34, J != 32;  J = 30 / 31 / 33 / 34:
+//                               65 / 62 / 64 / 64 % against 62 / 61 / 60 / 61 % for the quad shape; J = 36: 58.5 against 60.7 %),
+//   FPW 4, 12 lanes per frame (tree_walk_quad, pipelined tiles) beyond that.
+// Frame padding against LDS bank aliasing (FkArgs::pad) depends on the shape: the frames of the three-lane walk
 // alias when 9 J is a multiple of 8 floats (J % 8 == 0), the 4 frames of the quad walk sit 8 banks apart then and only
 // alias when it is a multiple of 16 (J % 16 == 0; J = 40: 261 us without, 272 us with the padding).
 template <int SRC>
@@ -992,12 +1008,21 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
     auto frame_bytes = [&](const int pad) { return ((size_t)a.J * (12 + extras) + (size_t)pad * nreg) * sizeof(float); };
     const size_t fixed = 4 * ((size_t)a.J + 4) * sizeof(float) + 256;
     const int pad3 = (a.J % 8 == 0) ? 4 : 0, pad12 = (a.J % 16 == 0) ? 4 : 0;
-    int pick = (6 * (20 * frame_bytes(pad3) + fixed) <= kMaxLds) ? 20 : 4;
+    auto tiles = [&](const int fpw) { return kMaxLds / ((size_t)fpw * frame_bytes(pad3) + fixed); };
+    int pick = 4;
+    if constexpr (SRC == SRC_QUAT) {
+        if (tiles(20) >= 10) pick = 20;
+        else if (tiles(16) >= 7) pick = 16;
+        else if (tiles(12) >= 8 && a.J % 8 != 0) pick = 12;
+    } else {
+        if (tiles(20) >= 6) pick = 20;
+    }
     // The variants with a bigger image or a heavier phase A do better on the quad shape earlier (2^20 x 22: per-frame
-    // offsets 422 us three-lane vs 358 us quad; ortho6d source 371 vs 350 us, at J = 24 226 vs 181 us, at J = 16 130 vs 139 us).
+    // offsets 422 us three-lane (434 with FPW 16) vs 358 us quad; ortho6d source 371 vs 350 us, at J = 24 226 vs 181 us,
+    // at J = 16 130 vs 139 us).
     if (pfo || (SRC == SRC_O6D && a.J >= 20)) pick = 4;
-    pick = tune_env("PM_FK_FPW", pick);  // PM_TUNING build only: 20, 8 or 4
-    if (pick != 20 && pick != 8 && pick != 4) { set_error("PM_FK_FPW must be 20, 8 or 4"); return PM_EINVAL; }
+    pick = tune_env("PM_FK_FPW", pick);  // PM_TUNING build only: 20, 16, 12, 8 or 4
+    if (pick != 20 && pick != 16 && pick != 12 && pick != 8 && pick != 4) { set_error("PM_FK_FPW must be 20, 16, 12, 8 or 4"); return PM_EINVAL; }
     if ((size_t)pick * frame_bytes(pad3) + fixed > kMaxLds) pick = 4;
     a.pad = (pick == 4) ? pad12 : pad3;
     const size_t per_frame = frame_bytes(a.pad);
@@ -1008,6 +1033,8 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
         // slower (293 vs 270 us).
         int nt = ((a.F + 3) / 4 >= 16384) ? 2 : 1;
         nt = tune_env("PM_FK_NT", nt);  // PM_TUNING build only: tiles per workgroup, 0 = fk_kernel
+        // (two records per lane cover 4 x 32 joints: J = 28 / 30 / 32 at 2^19 frames 205 / 215 / 230 us with four, 195 / 203 / 209 us with two)
+        if (nt > 0 && a.J <= 32 && tune_env("PM_FK_EPL2", 1)) return dispatch_fk_pipe<4, 2, SRC>(a, vec, pfo, nt, s);
         if (nt > 0) return a.J <= 64 ? dispatch_fk_pipe<4, 4, SRC>(a, vec, pfo, nt, s) : dispatch_fk_pipe<4, 8, SRC>(a, vec, pfo, nt, s);
     }
     // (The pipelined multi-tile structure on the 20-frame three-lane tile, measured again in round 2 with the current kernels:
@@ -1015,7 +1042,9 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
     // per-XCD bandwidth differences the way one-tile workgroups under hardware dispatch do.  Not used.)
     switch (pick) {
         case 20: return dispatch_fk2<20, SRC>(a, vec, pfo, s);
-        case 8: return dispatch_fk2<8, SRC>(a, vec, pfo, s);
+        case 8: if constexpr (kAllFkShapes) return dispatch_fk2<8, SRC>(a, vec, pfo, s); else break;
+        case 16: if constexpr (SRC == SRC_QUAT || kAllFkShapes) return dispatch_fk2<16, SRC>(a, vec, pfo, s); else break;
+        case 12: if constexpr (SRC == SRC_QUAT || kAllFkShapes) return dispatch_fk2<12, SRC>(a, vec, pfo, s); else break;
         case 4: if (4 * per_frame + fixed <= kMaxLds) return dispatch_fk2<4, SRC>(a, vec, pfo, s);
     }
     set_error("fk: J=%d does not fit the LDS tile", a.J);

@@ -25,7 +25,7 @@ def _grid(frames, fpw, nt=1):
 
 
 KNOWN = [
-    ("fk_kernel<20", _grid(F22, 20), "fk_J22", F22 * (64 * 22 + 12)),
+    ("fk_kernel<16", _grid(F22, 16), "fk_J22", F22 * (64 * 22 + 12)),
     ("ceiling_kernel", None, "ceiling", None),
     ("to_root_dq_kernel<16", _grid(F22, 16), "to_root_dq_J22", F22 * (48 * 22 + 12)),
     ("gather_parent_kernel<0", _grid(F22, 8), "from_root_dq_J22", F22 * 60 * 22),
