@@ -639,10 +639,12 @@ extern "C" int pm_to_root_dq_f32(const float *rot, const float *root_pos, const 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t per_frame = (size_t)to_root_frame_stride(J) * sizeof(float), fixed = (13 * (size_t)J + 37) * sizeof(float) + 256;
     int pick = (7 * (16 * per_frame + fixed) <= kMaxLds) ? 16 : 8;  // 4 lanes per frame; keep >= 7 waves per CU if possible
-    // Bigger skeletons: several chains per frame if the tree is wide enough for the shorter walk to pay
-    // (cost of the walk per frame ~ steps x chains / 16; a pure chain stays on the one-chain kernel).
+    // From 20 joints on: several chains per frame if the tree is wide enough for the shorter walk to pay
+    // (cost of the walk per frame ~ steps x chains / 16; a pure chain stays on the one-chain kernel).  Measured at 2^20 / 2^18
+    // frames, one chain (16 frames per wave) against the scheduled walk: J = 16: 142 / 158 us, 20: 195 / 191, 22: 217 / 211,
+    // 24: 238 / 225, 26: 73 / 69, 32: 94 / 87, 36: 115 / 96; four chains only pay from ~36 joints (J = 28: 71 us with two, 76-79 with four).
     int chains = tune_env("PM_DQ_CHAINS", -1);  // PM_TUNING build only: 0 = the one-chain kernel, 2 / 4
-    if ((chains < 0 ? (pick != 16) : (chains == 2 || chains == 4)) && J <= kSchedMaxJoints) {
+    if ((chains < 0 ? (pick != 16 || J >= tune_env("PM_DQ_SCHED_MINJ", 20)) : (chains == 2 || chains == 4)) && J <= kSchedMaxJoints) {
         SchedArgs sa;
         int K2 = 0, K4 = 0;
         uint8_t s2[kSchedMax], s4[kSchedMax];
@@ -657,7 +659,7 @@ extern "C" int pm_to_root_dq_f32(const float *rot, const float *root_pos, const 
             // J = 96 two / four chains 384 / 342 us, J = 65 235 / 228 us; the 52-joint SMPL-H tree, 26 vs 17 steps: 150 / 179 us)
             // ... and so do skeletons whose two-chain tile (8 frames) is too big for more than four waves per CU (narrow
             // 128-joint tree, two / four chains: 727 / 650 us)
-            if (K4 && ((20 * c4 <= 23 * c2 && 4 * c4 <= 3 * c1) || (J > 100 && c4 <= 2 * c2))) use = 4;
+            if (K4 && J >= 36 && ((20 * c4 <= 23 * c2 && 4 * c4 <= 3 * c1) || (J > 100 && c4 <= 2 * c2))) use = 4;
             else if (K2 && 4 * c2 <= 3 * c1) use = 2;
         }
         if (use) {
