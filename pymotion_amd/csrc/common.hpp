@@ -441,9 +441,11 @@ __device__ __forceinline__ void from_to_axis(const float (&v1)[3], const float (
 #ifdef PM_TUNING
 int tune_env(const char *name, int dflt);  // atoi(getenv(name)) or dflt (host.hip)
 #define PM_ABLATED(a, bit) (((a).ablate & (bit)) != 0)
+#define PM_ABLATED_FLAG(f) ((f) != 0)
 #else
 constexpr int tune_env(const char *, int dflt) { return dflt; }
 #define PM_ABLATED(a, bit) false
+#define PM_ABLATED_FLAG(f) false
 #endif
 
 struct Parents {  // passed to kernels BY VALUE (kernarg segment -> s_load_dword, uniform index)

@@ -7,7 +7,10 @@
 // i.e. every frame applies one of three maps to the running sign -- keep, negate, RESET to + -- and maps of that kind
 // compose associatively (affine maps over GF(2): (a, b): s -> a s xor b; keep = (1,0), negate = (1,1), reset = (0,0)).
 // Without resets that is a prefix XOR of the flip bits; a reset (a zero-padded row, an exactly orthogonal step, a NaN)
-// forgets everything before it.  A scan, not a loop:
+// forgets everything before it.  A scan, not a loop.  Two forms:
+//   * at most 64 series (a clip, or a few): ONE kernel, a decoupled look-back scan -- 16 B read and 16 B written per
+//     quaternion, see unroll_onepass_kernel below (2^20 x 22: 173 us; a 65 536-frame clip: 19 us against 79 us);
+//   * wide batches (S > 64), three passes:
 //   pass 1  (unroll_mask_kernel) each wave streams a chunk of 256 consecutive frames (one record per lane, the
 //           predecessor row an L1 / L2 hit), ORs flip / reset bits into per-series LDS masks and turns them into PREFIX
 //           parities relative to the chunk's entry (a shift-XOR ladder per 32 frames); masks + a 2-bit chunk summary
@@ -17,7 +20,7 @@
 // Round 1 staged 64-frame sub-tiles of the rows in LDS in pass 3 and re-derived the flips there with ballots (185 us of
 // the 254 at 2^20 x 22); as a stream it runs at the element-wise kernels' rate.
 // Layout: q [T, S, 4] (unroll axis first; the front-end moves it there), out same.
-// Algorithmic HBM bytes: 16 (pass 1) + 16 + 16 (pass 3) = 48 B per quaternion.
+// Algorithmic HBM bytes: 32 B per quaternion (one pass); the three-pass form moves 16 (pass 1) + 16 + 16 (pass 3) = 48 B.
 #include "common.hpp"
 
 namespace pm {
@@ -249,13 +252,283 @@ __global__ __launch_bounds__(256) void unroll_scan_wide_kernel(int32_t *ws, int 
     }
 }
 
+
+// ---- one pass (S <= 64 series: a clip, or a few) ------------------------------------------------------------------------
+// The three passes above move 48 B per quaternion for a 32 B operation.  With at most 64 series the whole state of the scan
+// at any frame is ONE 64-bit word (the running sign of every series), so the chunks can be chained inside a single kernel
+// (a decoupled look-back scan): a 256-thread workgroup takes the next tile of 256 R consecutive dwordx4 -- the ticket
+// counter hands tiles out in the order workgroups START, so every tile a workgroup may wait for is already running --
+// keeps its records in registers, builds the flip / reset masks of the tile in LDS like the mask pass does, publishes the
+// tile's map {parity it adds per series, series it resets} and then looks back over its predecessors, 64 tiles per
+// load: the nearest tile whose ENTERING + own state is already known ends the search, the maps of the tiles in between
+// compose on top.  Signs are applied to the registers and the tile leaves: 16 B read, 16 B written per dwordx4.
+// Workspace: uint32 ticket (own 64 B line), then per tile one 64-bit status WORD per group of 31 series, zeroed by a memset
+// node ahead of the launch:   bits 0..30 parity, bits 31..61 reset mask, bits 62..63 state -- 0 = nothing yet, 1 = the tile's
+// own map {parity it adds, series it resets}, 2 = parity LEAVING the tile (bits 0..30).  A word is written and read with one
+// relaxed agent-scope atomic and is self-contained, so no fence orders anything (a release / acquire pair at agent scope
+// writes back / invalidates the XCD's L2, per tile).
+constexpr int OP_GROUP = 31;
+
+struct OnePassArgs {
+    const float *q;
+    float *out;
+    uint32_t *ticket;
+    unsigned long long *st;   // [ntiles][ngroups]                level 0: one word per tile
+    unsigned long long *st1;  // [ceil(ntiles / 64)][ngroups]    level 1: one word per aligned block of 64 tiles
+    int64_t nv;        // dwordx4 in all
+    int32_t S, words;  // mask words per series: ceil(rows / 32), rows = frames a tile can touch
+    int32_t ngroups;   // ceil(S / 31)
+    int32_t static_order;  // PM_TUNING build only: tiles by blockIdx (what the ticket costs)
+};
+
+// ---- look-back ----
+// The tiles in flight ahead of a tile publish their own maps long before any of them knows its entering parity, so the
+// nearest tile with a LEAVING parity is typically several hundred tiles back while the chip finishes 40-80 tiles per
+// microsecond: walking back 64 tiles per memory round trip never catches up (measured: 45 of 180 us, and fetching eight
+// windows per round trip instead only adds traffic on the few channels that hold the status words).  So the words form
+// a two-level skip list: the last tile of every aligned block of 64 tiles also publishes the block's map (level 1), and a
+// tile looks at the tiles of its own block before it (<= 63 level-0 words) and at the 64 blocks before that (4096 tiles)
+// in ONE round trip.
+__device__ __forceinline__ unsigned wave_xor(unsigned x) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) x ^= (unsigned)__shfl_xor((int)x, m, 64);
+    return x;
+}
+
+// One window of status words, lane 0 nearest: the map of lanes 0 .. min(L, n - 1), L = nearest lane with a leaving parity
+// (64: none).  Returns false while a needed word is still empty.  (p, r) then (p', r')  =  ((p & ~r') ^ p', r | r').
+__device__ __forceinline__ bool fold_window(const unsigned long long w, const int n, const int lane, unsigned &cp, unsigned &cr, bool &absolute) {
+    const bool in = lane < n;
+    const unsigned long long m_inc = __builtin_amdgcn_ballot_w64(in && (w >> 62) == 2ull), m_zero = __builtin_amdgcn_ballot_w64(in && (w >> 62) == 0ull);
+    const int L = m_inc ? __builtin_ctzll(m_inc) : 64;
+    const unsigned long long near = (L < 64) ? ((1ull << L) - 1ull) : ~0ull;
+    if ((m_zero & near) != 0ull) return false;
+    const unsigned par = (in && lane <= L) ? (unsigned)w & 0x7fffffffu : 0u;  // tiles beyond the leaving parity do not matter
+    const unsigned rst = (in && lane < L) ? (unsigned)(w >> 31) & 0x7fffffffu : 0u;
+    if (__builtin_amdgcn_ballot_w64(rst != 0u) == 0ull) {
+        cp = wave_xor(par);
+        cr = 0u;
+    } else {  // resets among the nearer tiles: in order (rare)
+        const int last = L < 64 ? L : (n < 64 ? n - 1 : 63);
+        cp = (unsigned)__builtin_amdgcn_readlane((int)par, last);
+        cr = (unsigned)__builtin_amdgcn_readlane((int)rst, last);
+        for (int l = last - 1; l >= 0; --l) {
+            const unsigned pl = (unsigned)__builtin_amdgcn_readlane((int)par, l), rl = (unsigned)__builtin_amdgcn_readlane((int)rst, l);
+            cp = (cp & ~rl) ^ pl;
+            cr |= rl;
+        }
+    }
+    absolute = L < 64;
+    if (absolute) cr = 0x7fffffffu;  // a leaving parity is absolute
+    return true;
+}
+
+// Parity of the 31 series of group `grp` ENTERING tile `tile` (wave-uniform; all 64 lanes of one wave call this).  `own_p`,
+// `own_r`: this tile's map; the last tile of a block publishes the block's map on the way.
+__device__ __forceinline__ unsigned unroll_look_back(unsigned long long *st0, unsigned long long *st1, const int ngroups, const int grp, const int64_t tile,
+                                                     const unsigned own_p, const unsigned own_r, const int lane) {
+    constexpr unsigned long long kBefore = 2ull << 62;  // before tile 0: every series enters with +
+    const int pos = (int)(tile & 63);                   // tiles of the own block before this one
+    const int64_t blk = tile >> 6;
+    const unsigned long long *p0 = st0 + (tile - 1 - lane) * ngroups + grp;
+    unsigned long long w0 = 1ull << 62, w1;
+    unsigned c0p = 0u, c0r = 0u;
+    bool abs0 = false;
+    {
+        const int64_t b = blk - 1 - lane;
+        if (lane < pos) w0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w1 = b >= 0 ? __hip_atomic_load(st1 + b * ngroups + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kBefore;
+    }
+    while (!fold_window(w0, pos, lane, c0p, c0r, abs0)) {
+        __builtin_amdgcn_s_sleep(1);
+        if (lane < pos) w0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (pos == 63 && lane == 0) {  // the block's map, for everybody behind: an absolute parity if the walk ended inside the block
+        const unsigned bp = (c0p & ~own_r) ^ own_p, br = c0r | own_r;
+        const unsigned long long word = abs0 ? ((2ull << 62) | bp) : ((1ull << 62) | ((unsigned long long)br << 31) | bp);
+        __hip_atomic_store(st1 + blk * ngroups + grp, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (abs0) return c0p;
+    unsigned acc_par = c0p, acc_rst = c0r;
+    for (int64_t hi = blk - 1;; hi -= 64) {
+        unsigned cp = 0u, cr = 0u;
+        bool abs1 = false;
+        const int64_t b = hi - lane;
+        if (hi != blk - 1) w1 = b >= 0 ? __hip_atomic_load(st1 + b * ngroups + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kBefore;
+        while (!fold_window(w1, 64, lane, cp, cr, abs1)) {
+            __builtin_amdgcn_s_sleep(1);
+            if (b >= 0) w1 = __hip_atomic_load(st1 + b * ngroups + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const unsigned np = (cp & ~acc_rst) ^ acc_par, nr = cr | acc_rst;
+        acc_par = np; acc_rst = nr;
+        if (abs1) return acc_par;
+    }
+}
+
+template <int W, int R, int NT>
+__global__ __launch_bounds__(NT) void unroll_onepass_kernel(const OnePassArgs a) {
+    constexpr int V = W / 4, TILE = NT * R;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ unsigned s_tile;
+    __shared__ unsigned long long s_enter;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int S = a.S, words = a.words;
+    unsigned *flip = reinterpret_cast<unsigned *>(smem);  // [S][words]  flip bits, then prefix parities
+    unsigned *rst = flip + S * words;                      // [S][words]  reset bits, then "a reset at or before"
+    if (tid == 0) s_tile = PM_ABLATED_FLAG(a.static_order & 1) ? blockIdx.x : __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = tid; i < 2 * S * words; i += NT) flip[i] = 0u;
+    __syncthreads();
+    const int64_t tile = s_tile;
+    const int64_t base = tile * TILE;
+    const int64_t rec0 = base / V;          // record of the tile's first dwordx4 -> (tb, sb0), once
+    const int64_t tb = rec0 / S;
+    const int sb0 = (int)(rec0 - tb * S);
+    const float invS = 1.0f / (float)S;
+    const v4f *src = reinterpret_cast<const v4f *>(a.q);
+    v4f *dst = reinterpret_cast<v4f *>(a.out);
+
+    // A wave owns 64 R consecutive dwordx4 of the tile (row u: 64 of them, one per lane), so the record one frame earlier --
+    // D = S V dwordx4 back -- sits in the SAME wave's registers, D lanes to the left in this row or, for the first D lanes, at
+    // the far end of the row before: one select and four ds_bpermute per dwordx4 instead of a second (L2) load of every record
+    // (measured at 2^20 x 22: 57 of 232 us).  Only the first D dwordx4 of a wave's range are fetched again.  (D > 64 --
+    // dual quaternions of more than 32 series -- keeps the second load.)
+    const int D = S * V;
+    const bool shuffled = D <= 64 && !PM_ABLATED_FLAG(a.static_order & 8);
+    const int64_t wbase = base + (int64_t)wave * (64 * R);
+    v4f val[R];
+    int where[R];  // row << 8 | series  (row: frame - tb)
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const int64_t i = wbase + u * 64 + lane;
+        val[u] = __builtin_nontemporal_load(src + (i < a.nv ? i : a.nv - 1));
+    }
+    const int from = ((lane - D) & 63) << 2;  // ds_bpermute address of the lane D to the left
+#pragma unroll
+    for (int u0 = 0; u0 < R; u0 += 4) {
+        v4f prv[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = wbase + (u0 + u) * 64 + lane;
+            const int64_t ic = i < a.nv ? i : a.nv - 1;
+            const int rl = (int)((ic - rec0 * V) / V) + sb0;      // record offset from (tb, 0), < 2^22
+            const int dt = (int)(((float)rl + 0.5f) * invS);       // rl / S
+            const int s_ = rl - dt * S;
+            where[u0 + u] = (dt << 8) | s_;
+            ok[u] = (i < a.nv) && (tb + dt > 0) && (V == 1 || (ic & (V - 1)) == 0);  // the real part decides (dual_quat.py:139-167)
+            const bool outside = !shuffled || (u0 + u == 0 && lane < D);  // the row before lies ahead of this wave's range
+            prv[u] = val[u0 + u];
+            if (outside && ok[u] && !PM_ABLATED_FLAG(a.static_order & 2)) prv[u] = src[ic - D];  // (L1 / L2: fetched 16 S bytes earlier by a neighbour)
+        }
+        if (shuffled) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int uu = u0 + u;
+                // lanes < 64 - D hand their own row to the lane D to the right; the rest hand the previous row to the head of this one
+                const v4f mine = val[uu], before = val[uu > 0 ? uu - 1 : 0];
+                const bool own = lane < 64 - D;
+                v4f give, got;
+                give.x = own ? mine.x : before.x; give.y = own ? mine.y : before.y; give.z = own ? mine.z : before.z; give.w = own ? mine.w : before.w;
+                got.x = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(give.x)));
+                got.y = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(give.y)));
+                got.z = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(give.z)));
+                got.w = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(give.w)));
+                if (!(uu == 0 && lane < D)) prv[u] = got;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const v4f c = val[u0 + u];
+            const float d = c.x * prv[u].x + c.y * prv[u].y + c.z * prv[u].z + c.w * prv[u].w;
+            const bool f = ok[u] && d < 0.0f;
+            const bool z = ok[u] && !(d < 0.0f) && !(d > 0.0f);  // 0, -0 or NaN: reset (see the top of the file)
+            const int dt = where[u0 + u] >> 8, s_ = where[u0 + u] & 255;
+            const int w = s_ * words + (dt >> 5);
+            const unsigned bit = 1u << (dt & 31);
+            if (f) __hip_atomic_fetch_or(flip + w, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (z) __hip_atomic_fetch_or(rst + w, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        int par = 0;
+        unsigned any = 0u;
+        if (lane < S) {  // lane = series: flips -> prefix parities relative to the tile's entry
+            unsigned *fw = flip + lane * words, *rw = rst + lane * words;
+            for (int k = 0; k < words; ++k) any |= rw[k];
+            if (any == 0u) {
+                for (int k = 0; k < words; ++k) {
+                    unsigned x = fw[k];
+                    x ^= x << 1; x ^= x << 2; x ^= x << 4; x ^= x << 8; x ^= x << 16;
+                    x ^= par ? 0xffffffffu : 0u;
+                    fw[k] = x;
+                    par = (int)(x >> 31);
+                }
+            } else {  // resets in this tile: bit-serial (rare)
+                int seen = 0;
+                for (int k = 0; k < words; ++k) {
+                    const unsigned x = fw[k], z = rw[k];
+                    unsigned o = 0u, ab = 0u;
+                    for (int b = 0; b < 32; ++b) {
+                        if ((z >> b) & 1u) { par = 0; seen = 1; }
+                        else par ^= (int)((x >> b) & 1u);
+                        o |= (unsigned)par << b;
+                        ab |= (unsigned)seen << b;
+                    }
+                    fw[k] = o;
+                    rw[k] = ab;
+                }
+            }
+        }
+        const unsigned long long agg_par = __builtin_amdgcn_ballot_w64(par != 0), agg_rst = __builtin_amdgcn_ballot_w64(any != 0u);
+        unsigned long long *me = a.st + tile * a.ngroups;
+        for (int g = 0; g < a.ngroups; ++g) {
+            const unsigned long long p = (agg_par >> (OP_GROUP * g)) & 0x7fffffffull, r = (agg_rst >> (OP_GROUP * g)) & 0x7fffffffull;
+            if (lane == 0) __hip_atomic_store(me + g, (1ull << 62) | (r << 31) | p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        unsigned long long enter = 0ull;
+        for (int g = 0; g < a.ngroups; ++g) {
+            const unsigned long long p = (agg_par >> (OP_GROUP * g)) & 0x7fffffffull, r = (agg_rst >> (OP_GROUP * g)) & 0x7fffffffull;
+            const unsigned long long e = PM_ABLATED_FLAG(a.static_order & 4) ? 0ull : unroll_look_back(a.st, a.st1, a.ngroups, g, tile, (unsigned)p, (unsigned)r, lane);
+            if (lane == 0) {
+                const unsigned long long leaving = (2ull << 62) | ((e & ~r) ^ p);
+                __hip_atomic_store(me + g, leaving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((tile & 63) == 63) __hip_atomic_store(a.st1 + (tile >> 6) * a.ngroups + g, leaving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the block's word becomes absolute
+            }
+            enter |= e << (OP_GROUP * g);
+        }
+        if (lane == 0) s_enter = enter;
+    }
+    __syncthreads();
+    const unsigned long long enter = s_enter;
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const int64_t i = wbase + u * 64 + lane;
+        const int dt = where[u] >> 8, s_ = where[u] & 255;
+        const int w = s_ * words + (dt >> 5);
+        unsigned bit = (flip[w] >> (dt & 31)) & 1u;
+        const unsigned absolute = (rst[w] >> (dt & 31)) & 1u;  // a reset inside the tile came first: the entering parity does not apply
+        bit ^= (unsigned)((enter >> s_) & 1ull) & (absolute ^ 1u);
+        const unsigned sg = bit << 31;
+        if (i < a.nv) {
+            v4f o;
+            o.x = __uint_as_float(__float_as_uint(val[u].x) ^ sg); o.y = __uint_as_float(__float_as_uint(val[u].y) ^ sg);
+            o.z = __uint_as_float(__float_as_uint(val[u].z) ^ sg); o.w = __uint_as_float(__float_as_uint(val[u].w) ^ sg);
+            __builtin_nontemporal_store(o, dst + i);
+        }
+    }
+}
+
 }  // namespace pm
 
 using namespace pm;
 
 extern "C" int64_t pm_quat_unroll_workspace_bytes(int64_t T, int32_t S) {
     if (T <= 0 || S <= 0) return 0;
-    return ((T + UR_CHUNK - 1) / UR_CHUNK) * (int64_t)S * (int64_t)sizeof(int32_t) * (1 + 2 * UR_WORDS);
+    const int64_t three = ((T + UR_CHUNK - 1) / UR_CHUNK) * (int64_t)S * (int64_t)sizeof(int32_t) * (1 + 2 * UR_WORDS);
+    // the one-pass form (S <= 64): ticket line + a status per tile of 1024 dwordx4 (the smaller tile; dual quaternions: 2 per record)
+    const int64_t t1 = (T * S * 2 + 1023) / 1024, one = 64 + (t1 + (t1 + 63) / 64) * (int64_t)sizeof(unsigned long long) * ((S + OP_GROUP - 1) / OP_GROUP);
+    return three > one ? three : one;
 }
 
 template <int W>
@@ -264,6 +537,33 @@ static int unroll_launch(const float *q, int64_t T, int32_t S, float *out, void 
     if (T == 0 || S == 0) return PM_OK;
     PM_CHECK_ARGS(q && out && workspace, "quat_unroll: null pointer");
     PM_CHECK_ARGS(aligned16(q) && aligned16(out), "quat_unroll: q and out must be 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (S <= 64 && tune_env("PM_UNROLL_ONEPASS", 1)) {
+        const int64_t nv = T * (int64_t)S * (W / 4);
+        // tile: 4096 dwordx4 (64 KiB; 16 per thread) from 64 such tiles on, 1024 below.  Measured, S = 22, T = 2^10 / 2^12 / 2^14 /
+        // 2^16 / 2^18 / 2^20 frames: three passes 17 / 20 / 34 / 79 / 60 / 195 us; one pass with 1024-dwordx4 tiles 9 / 8 / 13 / 32 /
+        // 91 / 301 us, with 4096: 12 / 13 / 13 / 19 / 52 / 173 us (512-thread workgroups: 181 us).
+        constexpr int NT = 256;
+        const int R = tune_env("PM_UNROLL_R", nv >= 64 * 4096 ? 16 : 4);
+        if (R != 16 && R != 4) { set_error("PM_UNROLL_R must be 4 or 16"); return PM_EINVAL; }
+        const int64_t tile = NT * (int64_t)R, ntiles = (nv + tile - 1) / tile;
+        if (ntiles > 0x7fffffffLL) { set_error("quat_unroll: problem too large"); return PM_EUNSUPPORTED; }
+        OnePassArgs a;
+        a.q = q; a.out = out; a.nv = nv; a.S = S;
+        a.ticket = static_cast<uint32_t *>(workspace);
+        a.st = reinterpret_cast<unsigned long long *>(static_cast<char *>(workspace) + 64);
+        a.ngroups = (S + OP_GROUP - 1) / OP_GROUP;
+        a.st1 = a.st + ntiles * a.ngroups;
+        a.static_order = tune_env("PM_UNROLL_STATIC", 0);
+        const int64_t rows = (tile / (W / 4) + S - 1) / S + 1;  // frames a tile can touch
+        a.words = (int)((rows + 31) / 32);
+        const size_t lds = 2 * (size_t)S * a.words * sizeof(unsigned);
+        if (int e = check_hip(hipMemsetAsync(workspace, 0, 64 + (size_t)(ntiles + (ntiles + 63) / 64) * a.ngroups * sizeof(unsigned long long), s), "quat_unroll memset")) return e;
+        PM_SET_LDS(lds);
+        if (R == 16) hipLaunchKernelGGL((unroll_onepass_kernel<W, 16, NT>), dim3((unsigned)ntiles), dim3(NT), lds, s, a);
+        else hipLaunchKernelGGL((unroll_onepass_kernel<W, 4, NT>), dim3((unsigned)ntiles), dim3(NT), lds, s, a);
+        return PM_AFTER_LAUNCH("quat_unroll");
+    }
     const int64_t nchunks = (T + UR_CHUNK - 1) / UR_CHUNK;
     // mask pass: series per block from the size of the grid it leaves (>= ~8 K waves if the problem has them)
     int p1_sb = UR_P1_SB;
@@ -276,7 +576,6 @@ static int unroll_launch(const float *q, int64_t T, int32_t S, float *out, void 
     a.sum = static_cast<int32_t *>(workspace);
     a.pre = reinterpret_cast<uint32_t *>(a.sum + nchunks * S);
     a.abs = a.pre + nchunks * S * UR_WORDS;
-    hipStream_t s = static_cast<hipStream_t>(stream);
     {
         const size_t p1_lds = 2 * (size_t)(S < p1_sb ? S : p1_sb) * UR_WORDS * sizeof(unsigned);
         PM_SET_LDS(p1_lds);

@@ -176,3 +176,61 @@ def test_gpu_unroll_with_resets_matches_reference():
     got8 = dq.unroll(i8["dq"], 0)
     assert (np.isnan(got8) == np.isnan(want8)).all()
     np.testing.assert_array_equal(np.nan_to_num(got8).astype(np.float32), np.nan_to_num(want8).astype(np.float32))
+
+
+# ---- the one-pass (look-back) form for clips of at most 64 series, and the three-pass form behind it ----------------------
+
+def _clip_with_flips_and_resets(T, S, W, seed):
+    rng = np.random.default_rng(seed)
+    base = np.cumsum(rng.normal(0, 0.08, (T, S, W)), axis=0) + rng.normal(0, 1, (1, S, W))
+    q = (base * rng.choice([-1.0, 1.0], (T, S, 1))).astype(np.float32)
+    if T > 40:  # resets: zero rows, at tile / word edges too
+        for t in (1, 31, 32, 33, T // 2, T - 2):
+            q[t, rng.integers(0, S)] = 0.0
+    return q
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{}, {"PM_UNROLL_R": "16"}, {"PM_UNROLL_R": "4"}, {"PM_UNROLL_ONEPASS": "0"}])
+def test_gpu_unroll_one_pass_tiles_and_three_pass_agree_with_the_oracle(env, monkeypatch):
+    import pymotion_amd.rotations.dual_quat as dq
+    import pymotion_amd.rotations.quat as quat
+    from pymotion_amd import _lib
+
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    with _lib.variant("tuning" if env else "prod"):
+        for T, S in ((5000, 22), (30_000, 1), (3000, 64), (70_001, 3), (9000, 63), (47, 22), (1, 5), (2, 64)):
+            q = _clip_with_flips_and_resets(T, S, 4, seed=T + S)
+            got = quat.unroll(q, 0)
+            ref = co.quat_unroll(q.astype(np.float64), 0)
+            np.testing.assert_array_equal(got, ref.astype(np.float32), err_msg=f"T={T} S={S} {env}")
+        for T, S in ((6000, 22), (2500, 64), (3, 2)):
+            d8 = _clip_with_flips_and_resets(T, S, 8, seed=T)
+            got = dq.unroll(d8, 0)
+            sref = co.quat_unroll(d8[..., :4].astype(np.float64), 0)
+            flipped = np.signbit(sref[..., 0]) != np.signbit(d8[..., 0])
+            flipped |= (sref[..., 1] != d8[..., 1]) & (d8[..., 0] == 0)
+            want = np.where(flipped[..., None], -d8, d8)
+            np.testing.assert_array_equal(np.abs(got), np.abs(d8))
+            nz = (d8[..., :4] != 0).any(axis=-1)
+            np.testing.assert_array_equal(got[nz], want[nz], err_msg=f"dq T={T} S={S} {env}")
+
+
+@pytest.mark.gpu
+def test_gpu_unroll_full_size_property():
+    """2^20 frames x 22 series through the one-pass kernel (5632 chained tiles): neighbours never end on opposite covers,
+    nothing but signs changes, and the first frame keeps its sign"""
+    import torch
+
+    import pymotion_amd.rotations.quat_torch as quat_t
+
+    g = torch.Generator(device="cuda").manual_seed(5)
+    T, S = 1 << 20, 22
+    q = torch.randn((T, S, 4), device="cuda", generator=g)
+    out = quat_t.unroll(q, 0)
+    assert torch.equal(out.abs(), q.abs())
+    assert torch.equal(out[0], q[0])
+    assert bool(((out[1:] * out[:-1]).sum(-1) >= 0).all())
+    # twice: the workspace (ticket, statuses) is reset by every call
+    assert torch.equal(quat_t.unroll(q, 0), out)

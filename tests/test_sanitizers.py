@@ -32,9 +32,7 @@ def _run(code_or_args, preload, extra_env):
 
 
 def test_oracle_suite_under_asan_ubsan():
-    so = os.path.join(ROOT, "oracle", "_build", "liboracle_asan.so")
-    if not os.path.exists(so):
-        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "asan"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "asan"], check=True, stdout=subprocess.DEVNULL)
     libasan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True, check=True).stdout.strip()
     out = _run(["-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", "tests/test_oracle.py", "tests/test_bvh_unroll.py", "tests/test_ik.py",
                 "tests/test_time.py", "-m", "not gpu"], libasan, {"PM_ORACLE_ASAN": "1"})
@@ -77,6 +75,10 @@ assert h.pm_fk_f32(p, p, p, 0, bad.ctypes.data_as(C.c_void_p), 4, 3, p, p, None)
 assert h.pm_fk_f32(None, p, p, 0, bad.ctypes.data_as(C.c_void_p), 4, 3, p, p, None) == _lib.PM_EINVAL
 assert h.pm_quat_mul_f32(p, p, 10, p, None) in (_lib.PM_EHIP,)
 assert h.pm_quat_unroll_workspace_bytes(1000, 22) > 0
+for T, S in ((1000, 22), (5, 64), (70000, 65), (3, 100000)):  # one-pass and three-pass dispatch, host side
+    assert h.pm_quat_unroll_workspace_bytes(T, S) >= 64
+    assert h.pm_quat_unroll_f32(p, T, S, p, p, None) == _lib.PM_EHIP
+    assert h.pm_dq_unroll_f32(p, T, S, p, p, None) == _lib.PM_EHIP
 print("host paths exercised:", calls)
 """
 
@@ -86,9 +88,8 @@ def test_library_host_side_under_asan_ubsan():
 
     if _lib.device_count() > 0:
         pytest.skip("a GPU is visible: the launches would go through (the sanitizer run is for the host side)")
-    so = _lib.VARIANT_PATHS["asan"]
-    if not os.path.exists(so):
-        subprocess.run(["make", "-C", os.path.join(ROOT, "pymotion_amd", "csrc"), "-j8", "asan"], check=True, stdout=subprocess.DEVNULL)
+    # always through make: a library left over from an older source tree must not be what gets tested
+    subprocess.run(["make", "-C", os.path.join(ROOT, "pymotion_amd", "csrc"), "-j8", "asan"], check=True, stdout=subprocess.DEVNULL)
     rts = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
     assert rts, "clang's ASan runtime not found"
     out = _run(["-c", _HOST_DRIVER], rts[0], {"PMHIP_VARIANT": "asan"})

@@ -134,7 +134,7 @@ def main():
         if want("unroll"):
             ws = torch.empty(int(_lib.lib().pm_quat_unroll_workspace_bytes(Fj, J)) + 16, dtype=torch.uint8, device=dev)
             ms, mn = timeit(lambda: _lib.call("pm_quat_unroll_f32", p(rotn), Fj, J, p(qo), p(ws), None))
-            report(f"quat.unroll axis=0 J={J}", ms, mn, Fj * 48 * J)
+            report(f"quat.unroll axis=0 J={J}", ms, mn, Fj * 32 * J)
         if want("interp") and J == 22:
             Tn, Sn = Fj // 4, Fj // 2                      # 2x up-sampling of a [T, J, 3] clip
             idx = (torch.arange(Sn, device=dev) // 2).clamp(max=Tn - 2).to(torch.int32)
@@ -203,7 +203,7 @@ def main():
                 ("quat.to_scaled_angle_axis", lambda: _lib.call("pm_quat_to_scaled_angle_axis_f32", p(q), N, p(v3b), None), 28),
                 ("quat.from_to_axis", lambda: _lib.call("pm_quat_from_to_axis_f32", p(v3), p(v3b), p(v3), N, 1, p(qo), None), 52),
                 ("from_global_rotations", lambda: _lib.call("pm_from_global_rotations_f32", p(q), pp, Fj, J, p(qo), None), 32),
-                ("dq.unroll axis=0", lambda: _lib.call("pm_dq_unroll_f32", p(d8), Fj, J, p(d8o), p(ws), None), 96),
+                ("dq.unroll axis=0", lambda: _lib.call("pm_dq_unroll_f32", p(d8), Fj, J, p(d8o), p(ws), None), 64),
             ):
                 ms, mn = timeit(fn)
                 report(name, ms, mn, N * nb)
