@@ -9,7 +9,7 @@
 // Without resets that is a prefix XOR of the flip bits; a reset (a zero-padded row, an exactly orthogonal step, a NaN)
 // forgets everything before it.  A scan, not a loop.  Two forms:
 //   * at most 64 series (a clip, or a few): ONE kernel, a decoupled look-back scan -- 16 B read and 16 B written per
-//     quaternion, see unroll_onepass_kernel below (2^20 x 22: 173 us; a 65 536-frame clip: 19 us against 79 us);
+//     quaternion, see unroll_onepass_kernel below (2^20 x 22: 158 us; a 65 536-frame clip: 19 us against 79 us);
 //   * wide batches (S > 64), three passes:
 //   pass 1  (unroll_mask_kernel) each wave streams a chunk of 256 consecutive frames (one record per lane, the
 //           predecessor row an L1 / L2 hit), ORs flip / reset bits into per-series LDS masks and turns them into PREFIX
@@ -268,6 +268,9 @@ __global__ __launch_bounds__(256) void unroll_scan_wide_kernel(int32_t *ws, int 
 // relaxed agent-scope atomic and is self-contained, so no fence orders anything (a release / acquire pair at agent scope
 // writes back / invalidates the XCD's L2, per tile).
 constexpr int OP_GROUP = 31;
+#ifndef PM_OP_MINW
+#define PM_OP_MINW 1  // waves per SIMD the compiler must fit: 164 VGPRs (three workgroups per CU) as it comes; capped at 128 it spills 38 (2^20 x 22: 160 -> 235 us)
+#endif
 
 struct OnePassArgs {
     const float *q;
@@ -366,7 +369,7 @@ __device__ __forceinline__ unsigned unroll_look_back(unsigned long long *st0, un
 }
 
 template <int W, int R, int NT>
-__global__ __launch_bounds__(NT) void unroll_onepass_kernel(const OnePassArgs a) {
+__global__ __launch_bounds__(NT, PM_OP_MINW) void unroll_onepass_kernel(const OnePassArgs a) {
     constexpr int V = W / 4, TILE = NT * R;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ unsigned s_tile;
@@ -394,60 +397,53 @@ __global__ __launch_bounds__(NT) void unroll_onepass_kernel(const OnePassArgs a)
     // dual quaternions of more than 32 series -- keeps the second load.)
     const int D = S * V;
     const bool shuffled = D <= 64 && !PM_ABLATED_FLAG(a.static_order & 8);
+    // (indices inside the wave's range stay 32-bit and nothing per record is kept besides the record itself: with sixteen
+    // records per thread the kernel is register-bound -- 178 VGPRs, two workgroups per CU, before this; see PM_OP_MINW)
     const int64_t wbase = base + (int64_t)wave * (64 * R);
+    const int left = (int)((a.nv - wbase) < (int64_t)(64 * R) ? (a.nv - wbase > 0 ? a.nv - wbase : 0) : (int64_t)(64 * R));  // dwordx4 of this wave's range that exist
+    const v4f *wsrc = src + wbase;
+    const int lastoff = (int)(a.nv - 1 - wbase);  // the array's last dwordx4 seen from this range (negative for a wave past the end): what idle lanes read
+    const int rl0 = (int)((wbase - rec0 * V) / V) + sb0;  // record offset of the range's first dwordx4 from (tb, 0); V divides wbase
+    auto locate = [&](const int li, int &dt, int &s_) {  // dwordx4 li of the range -> (row, series)
+        const int rl = rl0 + (V == 1 ? li : li >> 1);
+        dt = (int)(((float)rl + 0.5f) * invS);  // rl / S, exact below 2^22
+        s_ = rl - dt * S;
+    };
     v4f val[R];
-    int where[R];  // row << 8 | series  (row: frame - tb)
 #pragma unroll
     for (int u = 0; u < R; ++u) {
-        const int64_t i = wbase + u * 64 + lane;
-        val[u] = __builtin_nontemporal_load(src + (i < a.nv ? i : a.nv - 1));
+        const int li = u * 64 + lane;
+        val[u] = __builtin_nontemporal_load(wsrc + (li < left ? li : lastoff));
     }
     const int from = ((lane - D) & 63) << 2;  // ds_bpermute address of the lane D to the left
+    const bool own = lane < 64 - D;           // lanes that hand their own row to the right; the rest hand the previous row to the head of this one
 #pragma unroll
-    for (int u0 = 0; u0 < R; u0 += 4) {
-        v4f prv[4];
-        bool ok[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t i = wbase + (u0 + u) * 64 + lane;
-            const int64_t ic = i < a.nv ? i : a.nv - 1;
-            const int rl = (int)((ic - rec0 * V) / V) + sb0;      // record offset from (tb, 0), < 2^22
-            const int dt = (int)(((float)rl + 0.5f) * invS);       // rl / S
-            const int s_ = rl - dt * S;
-            where[u0 + u] = (dt << 8) | s_;
-            ok[u] = (i < a.nv) && (tb + dt > 0) && (V == 1 || (ic & (V - 1)) == 0);  // the real part decides (dual_quat.py:139-167)
-            const bool outside = !shuffled || (u0 + u == 0 && lane < D);  // the row before lies ahead of this wave's range
-            prv[u] = val[u0 + u];
-            if (outside && ok[u] && !PM_ABLATED_FLAG(a.static_order & 2)) prv[u] = src[ic - D];  // (L1 / L2: fetched 16 S bytes earlier by a neighbour)
-        }
+    for (int u = 0; u < R; ++u) {
+        const int li = u * 64 + lane;
+        int dt, s_;
+        locate(li, dt, s_);
+        const bool ok = (li < left) && (tb + dt > 0) && (V == 1 || (li & 1) == 0);  // the real part decides (dual_quat.py:139-167)
+        const bool outside = !shuffled || (u == 0 && lane < D);  // the row before lies ahead of this wave's range
+        v4f prv = val[u];
+        if (outside && ok && !PM_ABLATED_FLAG(a.static_order & 2)) prv = wsrc[li - D];  // (L1 / L2: fetched 16 S bytes earlier by a neighbour)
         if (shuffled) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int uu = u0 + u;
-                // lanes < 64 - D hand their own row to the lane D to the right; the rest hand the previous row to the head of this one
-                const v4f mine = val[uu], before = val[uu > 0 ? uu - 1 : 0];
-                const bool own = lane < 64 - D;
-                v4f give, got;
-                give.x = own ? mine.x : before.x; give.y = own ? mine.y : before.y; give.z = own ? mine.z : before.z; give.w = own ? mine.w : before.w;
-                got.x = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(give.x)));
-                got.y = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(give.y)));
-                got.z = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(give.z)));
-                got.w = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(give.w)));
-                if (!(uu == 0 && lane < D)) prv[u] = got;
-            }
+            const v4f mine = val[u], before = val[u > 0 ? u - 1 : 0];
+            v4f got;
+            got.x = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(own ? mine.x : before.x)));
+            got.y = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(own ? mine.y : before.y)));
+            got.z = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(own ? mine.z : before.z)));
+            got.w = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(own ? mine.w : before.w)));
+            if (!(u == 0 && lane < D)) prv = got;
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const v4f c = val[u0 + u];
-            const float d = c.x * prv[u].x + c.y * prv[u].y + c.z * prv[u].z + c.w * prv[u].w;
-            const bool f = ok[u] && d < 0.0f;
-            const bool z = ok[u] && !(d < 0.0f) && !(d > 0.0f);  // 0, -0 or NaN: reset (see the top of the file)
-            const int dt = where[u0 + u] >> 8, s_ = where[u0 + u] & 255;
-            const int w = s_ * words + (dt >> 5);
-            const unsigned bit = 1u << (dt & 31);
-            if (f) __hip_atomic_fetch_or(flip + w, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (z) __hip_atomic_fetch_or(rst + w, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        const v4f c = val[u];
+        const float d = c.x * prv.x + c.y * prv.y + c.z * prv.z + c.w * prv.w;
+        const bool f = ok && d < 0.0f;
+        const bool z = ok && !(d < 0.0f) && !(d > 0.0f);  // 0, -0 or NaN: reset (see the top of the file)
+        const int w = s_ * words + (dt >> 5);
+        const unsigned bit = 1u << (dt & 31);
+        if (f) __hip_atomic_fetch_or(flip + w, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (z) __hip_atomic_fetch_or(rst + w, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((u & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // two records in flight, not sixteen (the scheduler would hoist every exchange: 164 VGPRs)
     }
     __syncthreads();
     if (wave == 0) {
@@ -501,21 +497,24 @@ __global__ __launch_bounds__(NT) void unroll_onepass_kernel(const OnePassArgs a)
     }
     __syncthreads();
     const unsigned long long enter = s_enter;
+    v4f *wdst = dst + wbase;
 #pragma unroll
     for (int u = 0; u < R; ++u) {
-        const int64_t i = wbase + u * 64 + lane;
-        const int dt = where[u] >> 8, s_ = where[u] & 255;
+        const int li = u * 64 + lane;
+        int dt, s_;
+        locate(li, dt, s_);
         const int w = s_ * words + (dt >> 5);
         unsigned bit = (flip[w] >> (dt & 31)) & 1u;
         const unsigned absolute = (rst[w] >> (dt & 31)) & 1u;  // a reset inside the tile came first: the entering parity does not apply
         bit ^= (unsigned)((enter >> s_) & 1ull) & (absolute ^ 1u);
         const unsigned sg = bit << 31;
-        if (i < a.nv) {
+        if (li < left) {
             v4f o;
             o.x = __uint_as_float(__float_as_uint(val[u].x) ^ sg); o.y = __uint_as_float(__float_as_uint(val[u].y) ^ sg);
             o.z = __uint_as_float(__float_as_uint(val[u].z) ^ sg); o.w = __uint_as_float(__float_as_uint(val[u].w) ^ sg);
-            __builtin_nontemporal_store(o, dst + i);
+            __builtin_nontemporal_store(o, wdst + li);
         }
+        if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -542,7 +541,7 @@ static int unroll_launch(const float *q, int64_t T, int32_t S, float *out, void 
         const int64_t nv = T * (int64_t)S * (W / 4);
         // tile: 4096 dwordx4 (64 KiB; 16 per thread) from 64 such tiles on, 1024 below.  Measured, S = 22, T = 2^10 / 2^12 / 2^14 /
         // 2^16 / 2^18 / 2^20 frames: three passes 17 / 20 / 34 / 79 / 60 / 195 us; one pass with 1024-dwordx4 tiles 9 / 8 / 13 / 32 /
-        // 91 / 301 us, with 4096: 12 / 13 / 13 / 19 / 52 / 173 us (512-thread workgroups: 181 us).
+        // 91 / 301 us, with 4096: 12 / 13 / 13 / 19 / 52 / 158 us (2048 / 3072 per tile at 2^20: 187 / 166 us; 512-thread workgroups: +5 %).
         constexpr int NT = 256;
         const int R = tune_env("PM_UNROLL_R", nv >= 64 * 4096 ? 16 : 4);
         if (R != 16 && R != 4) { set_error("PM_UNROLL_R must be 4 or 16"); return PM_EINVAL; }
