@@ -20,6 +20,10 @@
 
 namespace pm {
 
+#ifndef PM_IK_MINW
+#define PM_IK_MINW 3
+#endif
+
 struct Topo16 {  // kernarg: parents and children in CSR form
     int16_t parent[PM_MAX_JOINTS];
     int16_t cstart[PM_MAX_JOINTS + 1];
@@ -61,7 +65,7 @@ __host__ __device__ constexpr int ik_frame_stride(const int J) { return 4 * ((J 
 // its parent, or right after it on the parent's own chain, where the parent's quaternion is still in registers), the
 // image and with it the LDS per wave halve, twice as many waves are resident, and a frame's walk is K ~ items / 2 steps.
 template <int FPW, bool VEC, int NL, int C>
-__global__ __launch_bounds__(PM_WAVE) void from_root_positions_kernel(const IkArgs a, const int nt) {
+__global__ __launch_bounds__(PM_WAVE, (NL > 0 && NL <= 12) ? PM_IK_MINW : ((NL > 12 && NL <= 28) ? 2 : 1)) void from_root_positions_kernel(const IkArgs a, const int nt) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
     const int J = a.J;
@@ -95,7 +99,8 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_kernel(const IkAr
         sOff[3 * j] = u[0]; sOff[3 * j + 1] = u[1]; sOff[3 * j + 2] = u[2];
     }
     for (int j = lane; j <= J; j += PM_WAVE) {
-        if (j < J) { sTopo[j] = a.topo.parent[j]; sTopo[2 * J + 1 + j] = a.topo.clist[j]; }
+        // parent | leaf << 16: what the final pass needs about a joint, in one word
+        if (j < J) { sTopo[j] = (int)a.topo.parent[j] | ((a.topo.cstart[j + 1] == a.topo.cstart[j]) ? 0x10000 : 0); sTopo[2 * J + 1 + j] = a.topo.clist[j]; }
         sTopo[J + j] = a.topo.cstart[j];
     }
     if (lane < 3) sOff[3 * J + lane] = 0.0f;
@@ -276,10 +281,11 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_kernel(const IkAr
         const float *fq = sS + fr * FS;
         float gj[4], gp[4], o[4];
         lds_get<4>(fq, j, gj);
-        lds_get<4>(fq, sTopo[j], gp);
+        const int info = sTopo[j];
+        lds_get<4>(fq, info & 0xffff, gp);
         const float inv[4] = {gp[0], -gp[1], -gp[2], -gp[3]};
         qmul(inv, gj, o);
-        const bool leaf = sTopo[J + j + 1] == sTopo[J + j];
+        const bool leaf = (info & 0x10000) != 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = leaf ? (k == 0 ? 1.0f : 0.0f) : ((j == 0) ? gj[k] : o[k]);
         if (valid) {
@@ -335,10 +341,11 @@ static int launch_ik(const IkArgs &a, bool vec, hipStream_t s) {
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
     // records per lane of one tile -> the pipelined instantiation that holds them in registers (3 VGPRs each)
     const int nl = (FPW * a.J + PM_WAVE - 1) / PM_WAVE;
-    int cap = nl <= 24 ? 24 : (nl <= 56 ? 56 : 0);
+    // (the register file bounds residency here: 12 / 24 / 28 / 56 records -> 148 / 246 / ~210 / 415 VGPRs with two chains)
+    int cap = nl <= 12 ? 12 : (nl <= 24 ? 24 : (nl <= 28 ? 28 : (nl <= 56 ? 56 : 0)));
     if (tune_env("PM_IK_PIPE", 1) == 0) cap = 0;  // PM_TUNING build only
-    // (measured, tiles per workgroup 1 / 2 / 4: 2^20 x 22 196 / 191 / 216 us, 2^18 x 128 899 / 863 / 845 us; unpipelined 206 / 992)
-    int nt = cap == 0 ? 1 : (ntiles >= 4096 ? (cap == 24 ? 2 : 4) : 1);
+    // (measured, tiles per workgroup 1 / 2 / 4: 2^18 x 52 with 28 records per lane 165 / 173 / 186 us; 2^20 x 22 196 / 191 / 216 us, 2^18 x 128 899 / 863 / 845 us; unpipelined 206 / 992)
+    int nt = cap == 0 ? 1 : (ntiles >= 4096 ? (cap <= 24 ? 2 : (cap == 28 ? 1 : 4)) : 1);
     nt = tune_env("PM_IK_NT", nt);
     if (nt < 1 || cap == 0) nt = 1;
     const int64_t ngroups = (ntiles + nt - 1) / nt;
@@ -351,8 +358,8 @@ static int launch_ik(const IkArgs &a, bool vec, hipStream_t s) {
         if (int e = allow_lds(k, lds)) return e;                                    \
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a, nt);  \
     }
-    if (vec) { if (cap == 24) PM_IK_LAUNCH(true, 24) else if (cap == 56) PM_IK_LAUNCH(true, 56) else PM_IK_LAUNCH(true, 0) }
-    else { if (cap == 24) PM_IK_LAUNCH(false, 24) else if (cap == 56) PM_IK_LAUNCH(false, 56) else PM_IK_LAUNCH(false, 0) }
+    if (vec) { if (cap == 12) PM_IK_LAUNCH(true, 12) else if (cap == 24) PM_IK_LAUNCH(true, 24) else if (cap == 28) PM_IK_LAUNCH(true, 28) else if (cap == 56) PM_IK_LAUNCH(true, 56) else PM_IK_LAUNCH(true, 0) }
+    else { if (cap == 12) PM_IK_LAUNCH(false, 12) else if (cap == 24) PM_IK_LAUNCH(false, 24) else if (cap == 28) PM_IK_LAUNCH(false, 28) else if (cap == 56) PM_IK_LAUNCH(false, 56) else PM_IK_LAUNCH(false, 0) }
 #undef PM_IK_LAUNCH
     return PM_AFTER_LAUNCH("from_root_positions launch");
 }
