@@ -21,6 +21,7 @@ python $R/tools/perf_probe.py --sustained 100 > $OUT/r${RN}_kernel_probe.txt 2>&
 PM_SWEEP_ALL=1 python $R/tools/jsweep_probe.py 4,8,16,22,23,24,28,32,40,48,52,56,64,65,72,96,128 > $OUT/r${RN}_joint_sweep.txt 2>&1
 python $R/tools/dq_probe.py 22,28,40,48,52,56,64,65,96,128 > $OUT/r${RN}_to_root_dq_sweep.txt 2>&1
 python $R/tools/ik_probe.py 4,22,28,52,96,128 > $OUT/r${RN}_from_root_positions_sweep.txt 2>&1
+python $R/tools/unroll_probe.py > $OUT/r${RN}_unroll_sweep.txt 2>&1
 python $R/tools/prec_probe.py > $OUT/r${RN}_fk_precision_levels.txt 2>&1
 python $R/tools/numpy_door_probe.py > $OUT/r${RN}_numpy_door.txt 2>&1
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
