@@ -588,7 +588,8 @@ extern "C" int pm_stream_ceiling_f32(const float *src, float *dst, int64_t F, in
     PM_CHECK_ARGS(src && dst && F >= 0 && rd >= 4 && wr >= 4 && rd % 4 == 0 && wr % 4 == 0 && aligned16(src) && aligned16(dst),
                   "stream_ceiling: need aligned pointers and rd, wr multiples of 4 floats");
     if (F == 0) return PM_OK;
-    const int fpw = 20;
+    // fk's tile for that frame size: 16 frames while seven tiles fit a CU's LDS (the 22-joint skeleton), 4 beyond (fk.hip: dispatch_fk)
+    const int fpw = tune_env("PM_CEIL_FPW", 7 * 16 * (size_t)wr * sizeof(float) <= kMaxLds ? 16 : 4);
     const size_t lds = (size_t)fpw * (rd > wr ? rd : wr) * sizeof(float);
     if (lds > 64 * 1024) { set_error("stream_ceiling: tile too large"); return PM_EUNSUPPORTED; }
     const int64_t ntiles = (F + fpw - 1) / fpw;
