@@ -262,8 +262,8 @@ __global__ __launch_bounds__(256) void unroll_scan_wide_kernel(int32_t *ws, int 
 // tile's map {parity it adds per series, series it resets} and then looks back over its predecessors, 64 tiles per
 // load: the nearest tile whose ENTERING + own state is already known ends the search, the maps of the tiles in between
 // compose on top.  Signs are applied to the registers and the tile leaves: 16 B read, 16 B written per dwordx4.
-// Workspace: uint32 ticket (own 64 B line), then per tile one 64-bit status WORD per group of 31 series, zeroed by a memset
-// node ahead of the launch:   bits 0..30 parity, bits 31..61 reset mask, bits 62..63 state -- 0 = nothing yet, 1 = the tile's
+// Workspace: uint32 ticket (own 64 B line), then per tile one 64-bit status WORD per group of 31 series, zeroed by a small
+// kernel ahead of the launch:   bits 0..30 parity, bits 31..61 reset mask, bits 62..63 state -- 0 = nothing yet, 1 = the tile's
 // own map {parity it adds, series it resets}, 2 = parity LEAVING the tile (bits 0..30).  A word is written and read with one
 // relaxed agent-scope atomic and is self-contained, so no fence orders anything (a release / acquire pair at agent scope
 // writes back / invalidates the XCD's L2, per tile).
@@ -366,6 +366,13 @@ __device__ __forceinline__ unsigned unroll_look_back(unsigned long long *st0, un
         acc_par = np; acc_rst = nr;
         if (abs1) return acc_par;
     }
+}
+
+// ticket + status words back to zero ahead of every scan (a kernel of our own rather than a memset node: under HIP graph
+// replay the memset node of ROCm 7.0 faulted on the second replay, tests/test_gpu_parity.py)
+__global__ __launch_bounds__(256) void unroll_reset_kernel(unsigned long long *w, const int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) w[i] = 0ull;
 }
 
 template <int W, int R, int NT>
@@ -557,7 +564,8 @@ static int unroll_launch(const float *q, int64_t T, int32_t S, float *out, void 
         const int64_t rows = (tile / (W / 4) + S - 1) / S + 1;  // frames a tile can touch
         a.words = (int)((rows + 31) / 32);
         const size_t lds = 2 * (size_t)S * a.words * sizeof(unsigned);
-        if (int e = check_hip(hipMemsetAsync(workspace, 0, 64 + (size_t)(ntiles + (ntiles + 63) / 64) * a.ngroups * sizeof(unsigned long long), s), "quat_unroll memset")) return e;
+        const int64_t nwords = 8 + (ntiles + (ntiles + 63) / 64) * a.ngroups;  // the ticket's 64-byte line, then the words
+        hipLaunchKernelGGL(unroll_reset_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, s, static_cast<unsigned long long *>(workspace), nwords);
         PM_SET_LDS(lds);
         if (R == 16) hipLaunchKernelGGL((unroll_onepass_kernel<W, 16, NT>), dim3((unsigned)ntiles), dim3(NT), lds, s, a);
         else hipLaunchKernelGGL((unroll_onepass_kernel<W, 4, NT>), dim3((unsigned)ntiles), dim3(NT), lds, s, a);

@@ -693,6 +693,47 @@ def test_fk_is_hip_graph_capturable_and_stream_ordered():
     assert_close(rm.cpu().numpy(), r_o, ATOL, "graph replay rotmats")
 
 
+def test_unroll_one_pass_is_hip_graph_capturable():
+    """the look-back scan resets its ticket / status words with a memset node ahead of the kernel: captured once, the pair
+    replays correctly any number of times on new data"""
+    import ctypes as C
+
+    from pymotion_amd import _lib
+
+    torch = _torch_mods()[0]
+    T, S = 20_000, 22
+    rng = np.random.default_rng(8)
+
+    def clip(seed):
+        r = np.random.default_rng(seed)
+        base = np.cumsum(r.normal(0, 0.08, (T, S, 4)), axis=0) + r.normal(0, 1, (1, S, 4))
+        return (base * r.choice([-1.0, 1.0], (T, S, 1))).astype(np.float32)
+
+    q = torch.from_numpy(clip(1)).cuda()
+    out = torch.empty_like(q)
+    ws = torch.empty(int(_lib.lib().pm_quat_unroll_workspace_bytes(T, S)), dtype=torch.uint8, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+
+    def launch():
+        _lib.call("pm_quat_unroll_f32", p(q), T, S, p(out), p(ws), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        launch()
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        launch()
+    for seed in (2, 3, 4):
+        host = clip(seed)
+        q.copy_(torch.from_numpy(host))
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(out.cpu().numpy(), co.quat_unroll(host.astype(np.float64), 0).astype(np.float32))
+    del rng
+
+
 def test_maximum_joint_count_everywhere():
     """PM_MAX_JOINTS = 512: every skeleton kernel still fits its LDS tile; one more joint is rejected."""
     from pymotion_amd import synthetic as syn
