@@ -236,6 +236,43 @@ def test_fuzz_unroll_any_axis(shape, axis, seed):
     assert (d >= 0).all()
 
 
+@settings(max_examples=150, deadline=None, derandomize=True)
+@given(st.one_of(st.integers(1, 300), st.integers(300, 40_000)), st.integers(1, 64), st.sampled_from([4, 8]), st.integers(0, 2**16))
+def test_fuzz_unroll_clips_one_pass_against_the_sequential_oracle(T, S, W, seed):
+    """clips of 1..64 series (the look-back scan: 1 to ~600 chained tiles, one to three status words per tile), zero rows,
+    NaN rows and exactly orthogonal steps sprinkled in: bit-for-bit the reference's loop"""
+    rng = np.random.default_rng(seed)
+    T = min(T, 2_000_000 // (S * W))
+    base = np.cumsum(rng.normal(0, 0.08, (T, S, W)), axis=0) + rng.normal(0, 1, (1, S, W))
+    q = (base * rng.choice([-1.0, 1.0], (T, S, 1))).astype(np.float32)
+    for _ in range(int(rng.integers(0, 6))):
+        t, s_ = int(rng.integers(0, T)), int(rng.integers(0, S))
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            q[t, s_] = 0.0
+        elif kind == 1:
+            q[t, s_, :4] = np.nan
+        elif t > 0:  # exactly orthogonal to its predecessor: dot == 0
+            q[t - 1, s_, :4] = (1.0, 0.0, 0.0, 0.0)
+            q[t, s_, :4] = (0.0, 1.0, 0.0, 0.0)
+    with np.errstate(all="ignore"):
+        ref = co.quat_unroll(f64(q[..., :4]), 0)
+    if W == 4:
+        got = quat.unroll(q, 0)
+        assert (np.isnan(got) == np.isnan(ref)).all()
+        np.testing.assert_array_equal(np.nan_to_num(got), np.nan_to_num(ref).astype(np.float32))
+    else:
+        import pymotion_amd.rotations.dual_quat as dq
+
+        got = dq.unroll(q, 0)
+        flipped = np.signbit(np.nan_to_num(ref[..., 0])) != np.signbit(np.nan_to_num(q[..., 0]))
+        flipped |= (np.nan_to_num(ref[..., 1]) != np.nan_to_num(q[..., 1]))
+        want = np.where(flipped[..., None], -q, q)
+        ok = ~np.isnan(q[..., :4]).any(axis=-1) & (q[..., :4] != 0).any(axis=-1)
+        np.testing.assert_array_equal(got[ok], want[ok])
+        np.testing.assert_array_equal(np.abs(np.nan_to_num(got)), np.abs(np.nan_to_num(q)))
+
+
 @FUZZ
 @given(st.sampled_from([(3, 3), (50, 22, 3), (2, 9, 5, 3), (40, 4), (17, 1), (6, 2, 2)]), st.integers(0, 3), st.integers(0, 2**16))
 def test_fuzz_interpolate_any_axis(shape, axis, seed):
