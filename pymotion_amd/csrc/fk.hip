@@ -1031,7 +1031,9 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
         // per lane up to 64 joints, 8 up to 128).  Measured at 2^18 x 52: fused ortho6d 224 us (fk_kernel) -> 188 / 183 /
         // 187 / 198 us with 1 / 2 / 4 / 8 tiles per workgroup; the same structure on the 20-frame tile of J = 22 is
         // slower (293 vs 270 us).
-        int nt = ((a.F + 3) / 4 >= 16384) ? 2 : 1;
+        // (beyond 64 joints -- eight records per lane, two waves per SIMD -- four tiles: J = 66 / 96 / 128 at 2^19 frames 589 / 760 / 1209 us
+        // with two, 555 / 725 / 1165 us with four)
+        int nt = ((a.F + 3) / 4 >= 16384) ? (a.J > 64 ? 4 : 2) : 1;
         nt = tune_env("PM_FK_NT", nt);  // PM_TUNING build only: tiles per workgroup, 0 = fk_kernel
         // (two records per lane cover 4 x 32 joints: J = 28 / 30 / 32 at 2^19 frames 205 / 215 / 230 us with four, 195 / 203 / 209 us with two)
         if (nt > 0 && a.J <= 32 && tune_env("PM_FK_EPL2", 1)) return dispatch_fk_pipe<4, 2, SRC>(a, vec, pfo, nt, s);
