@@ -182,9 +182,11 @@ int pm_quat_from_to_axis_f32(const float *v1, const float *v2, const float *axis
                              float *out, pm_stream_t stream);
 
 /* rotations/quat.py:426-462  unroll(quaternions, axis): q is [T, S, 4] with the unroll axis FIRST (the
- * front-end moves it there); frame i is negated when the running sign says so: a prefix XOR of
- * sgn(dot(q_i, q_{i-1})) < 0 along T per series, computed as a three-kernel scan.  `workspace` is a
- * device buffer of pm_quat_unroll_workspace_bytes(T, S) bytes.  pm_dq_unroll_f32 is
+ * front-end moves it there); frame i is negated when the running sign says so: along T per series, a scan over the
+ * maps {keep, negate, reset to +} that sgn(dot(q_i, q_{i-1})) selects (reset: a dot product of exactly 0 or NaN, where the
+ * reference's `d0 < d1` is false whatever came before) -- one look-back kernel for S <= 64, three kernels beyond.
+ * `workspace` is a device buffer of pm_quat_unroll_workspace_bytes(T, S) bytes, 8-byte aligned, contents irrelevant on
+ * entry and on return; a call leaves nothing behind that the next call needs.  q and out 16-byte aligned.  pm_dq_unroll_f32 is
  * rotations/dual_quat.py:139-167: dq [T,S,8], sign decided by the real part, applied to all 8 floats. */
 int64_t pm_quat_unroll_workspace_bytes(int64_t T, int32_t S);
 int pm_quat_unroll_f32(const float *q, int64_t T, int32_t S, float *out, void *workspace, pm_stream_t stream);

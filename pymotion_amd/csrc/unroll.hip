@@ -543,6 +543,7 @@ static int unroll_launch(const float *q, int64_t T, int32_t S, float *out, void 
     if (T == 0 || S == 0) return PM_OK;
     PM_CHECK_ARGS(q && out && workspace, "quat_unroll: null pointer");
     PM_CHECK_ARGS(aligned16(q) && aligned16(out), "quat_unroll: q and out must be 16-byte aligned");
+    PM_CHECK_ARGS((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, "quat_unroll: the workspace must be 8-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (S <= 64 && tune_env("PM_UNROLL_ONEPASS", 1)) {
         const int64_t nv = T * (int64_t)S * (W / 4);
