@@ -191,6 +191,12 @@ int pm_quat_from_to_axis_f32(const float *v1, const float *v2, const float *axis
 int64_t pm_quat_unroll_workspace_bytes(int64_t T, int32_t S);
 int pm_quat_unroll_f32(const float *q, int64_t T, int32_t S, float *out, void *workspace, pm_stream_t stream);
 int pm_dq_unroll_f32(const float *dq, int64_t T, int32_t S, float *out, void *workspace, pm_stream_t stream);
+/* The same for a batch of clips, q [B, T, S, 4]: the layout of unroll(q, axis) whenever the axes in front of `axis` are batch
+ * axes -- B independent scans in one launch, nothing is transposed (S <= 64: one look-back kernel for the whole batch;
+ * beyond: the clips one after the other).  Workspace: pm_quat_unroll_batched_workspace_bytes(B, T, S), same contract. */
+int64_t pm_quat_unroll_batched_workspace_bytes(int64_t B, int64_t T, int32_t S);
+int pm_quat_unroll_batched_f32(const float *q, int64_t B, int64_t T, int32_t S, float *out, void *workspace, pm_stream_t stream);
+int pm_dq_unroll_batched_f32(const float *dq, int64_t B, int64_t T, int32_t S, float *out, void *workspace, pm_stream_t stream);
 
 /* rotations/dual_quat.py:86-136  normalize / is_unit.  The reference picks ONE branch for the whole batch
  * from global `.all()` reductions; the kernels raise three DEVICE ints that the caller zeroes first (pm_memset)

@@ -240,17 +240,30 @@ def _unroll(be, x, axis, width, fname):
     if ax == nd - 1:
         raise ValueError("the unroll axis cannot be the component axis")
     dt = be.result_dtype(x)
+    B, T, S = _prod(shp[:ax]), shp[ax], _prod(shp[ax + 1:-1])
+    if S <= 64:
+        # [B, T, S, W] as it lies: the axes in front of the unroll axis are a batch of independent clips, scanned in one launch --
+        # no transposition (a [B, T, J, 4] batch unrolled along T used to be moved to [T, B J, 4] and back: two more full copies)
+        be.begin(x)
+        try:
+            xp = be.dev_in(x)
+            op, oh = be.dev_out(shp)
+            if B > 0 and T > 0 and S > 0:
+                ws = be.scratch(_lib.lib().pm_quat_unroll_batched_workspace_bytes(B, T, S))
+                _lib.call(fname.replace("_f32", "_batched_f32"), xp, B, T, S, op, ws, be.stream())
+            res = be.result(oh, dt)
+        finally:
+            be.end()
+        return res
     moved = be.moveaxis(x, ax, 0)          # unroll axis first; every other index is an independent series
     mshape = be.shape(moved)
-    T = mshape[0]
-    S = _prod(mshape[1:-1])
     be.begin(x)
     try:
         xp = be.dev_in(moved)
         op, oh = be.dev_out(mshape)
         if T > 0 and S > 0:
-            ws = be.scratch(_lib.lib().pm_quat_unroll_workspace_bytes(T, S))
-            _lib.call(fname, xp, T, S, op, ws, be.stream())
+            ws = be.scratch(_lib.lib().pm_quat_unroll_workspace_bytes(T, B * S))
+            _lib.call(fname, xp, T, B * S, op, ws, be.stream())
         res = be.result(oh, dt)
     finally:
         be.end()

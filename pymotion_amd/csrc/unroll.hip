@@ -9,7 +9,8 @@
 // Without resets that is a prefix XOR of the flip bits; a reset (a zero-padded row, an exactly orthogonal step, a NaN)
 // forgets everything before it.  A scan, not a loop.  Two forms:
 //   * at most 64 series (a clip, or a few): ONE kernel, a decoupled look-back scan -- 16 B read and 16 B written per
-//     quaternion, see unroll_onepass_kernel below (2^20 x 22: 158 us; a 65 536-frame clip: 19 us against 79 us);
+//     quaternion, see unroll_onepass_kernel below (2^20 x 22: 158 us; a 65 536-frame clip: 19 us against 79 us); batches of
+//     clips [B, T, S, 4] are B independent chains in the same launch (16 384 clips of 64 frames x 22: 123 us);
 //   * wide batches (S > 64), three passes:
 //   pass 1  (unroll_mask_kernel) each wave streams a chunk of 256 consecutive frames (one record per lane, the
 //           predecessor row an L1 / L2 hit), ORs flip / reset bits into per-series LDS masks and turns them into PREFIX
@@ -276,12 +277,14 @@ struct OnePassArgs {
     const float *q;
     float *out;
     uint32_t *ticket;
-    unsigned long long *st;   // [ntiles][ngroups]                level 0: one word per tile
-    unsigned long long *st1;  // [ceil(ntiles / 64)][ngroups]    level 1: one word per aligned block of 64 tiles
-    int64_t nv;        // dwordx4 in all
+    unsigned long long *st;   // [nclips][tpc][ngroups]    level 0: one word per tile
+    unsigned long long *st1;  // [nclips][bpc][ngroups]    level 1: one word per aligned block of 64 tiles of a clip
+    int64_t nv;        // dwordx4 per clip
+    int64_t nclips, tpc, bpc;  // clips [B][T][S][W] scanned independently: tiles and 64-tile blocks per clip
     int32_t S, words;  // mask words per series: ceil(rows / 32), rows = frames a tile can touch
     int32_t ngroups;   // ceil(S / 31)
     int32_t static_order;  // PM_TUNING build only: tiles by blockIdx (what the ticket costs)
+    int32_t single;        // every clip is ONE tile: nobody waits for anybody, tiles by blockIdx and no ticket
 };
 
 // ---- look-back ----
@@ -385,17 +388,21 @@ __global__ __launch_bounds__(NT, PM_OP_MINW) void unroll_onepass_kernel(const On
     const int S = a.S, words = a.words;
     unsigned *flip = reinterpret_cast<unsigned *>(smem);  // [S][words]  flip bits, then prefix parities
     unsigned *rst = flip + S * words;                      // [S][words]  reset bits, then "a reset at or before"
-    if (tid == 0) s_tile = PM_ABLATED_FLAG(a.static_order & 1) ? blockIdx.x : __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) s_tile = (a.single || PM_ABLATED_FLAG(a.static_order & 1)) ? blockIdx.x : __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int i = tid; i < 2 * S * words; i += NT) flip[i] = 0u;
     __syncthreads();
-    const int64_t tile = s_tile;
+    // tickets run over (clip, tile of the clip): a tile only ever waits for earlier tiles of its own clip, i.e. lower tickets
+    const int64_t clip = (int64_t)s_tile / a.tpc;
+    if (clip >= a.nclips) return;  // (uniform)
+    const int64_t tile = (int64_t)s_tile - clip * a.tpc;
     const int64_t base = tile * TILE;
     const int64_t rec0 = base / V;          // record of the tile's first dwordx4 -> (tb, sb0), once
     const int64_t tb = rec0 / S;
     const int sb0 = (int)(rec0 - tb * S);
     const float invS = 1.0f / (float)S;
-    const v4f *src = reinterpret_cast<const v4f *>(a.q);
-    v4f *dst = reinterpret_cast<v4f *>(a.out);
+    const v4f *src = reinterpret_cast<const v4f *>(a.q) + clip * a.nv;
+    v4f *dst = reinterpret_cast<v4f *>(a.out) + clip * a.nv;
+    unsigned long long *st0 = a.st + clip * a.tpc * a.ngroups, *st1 = a.st1 + clip * a.bpc * a.ngroups;
 
     // A wave owns 64 R consecutive dwordx4 of the tile (row u: 64 of them, one per lane), so the record one frame earlier --
     // D = S V dwordx4 back -- sits in the SAME wave's registers, D lanes to the left in this row or, for the first D lanes, at
@@ -484,7 +491,7 @@ __global__ __launch_bounds__(NT, PM_OP_MINW) void unroll_onepass_kernel(const On
             }
         }
         const unsigned long long agg_par = __builtin_amdgcn_ballot_w64(par != 0), agg_rst = __builtin_amdgcn_ballot_w64(any != 0u);
-        unsigned long long *me = a.st + tile * a.ngroups;
+        unsigned long long *me = st0 + tile * a.ngroups;
         for (int g = 0; g < a.ngroups; ++g) {
             const unsigned long long p = (agg_par >> (OP_GROUP * g)) & 0x7fffffffull, r = (agg_rst >> (OP_GROUP * g)) & 0x7fffffffull;
             if (lane == 0) __hip_atomic_store(me + g, (1ull << 62) | (r << 31) | p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -492,11 +499,11 @@ __global__ __launch_bounds__(NT, PM_OP_MINW) void unroll_onepass_kernel(const On
         unsigned long long enter = 0ull;
         for (int g = 0; g < a.ngroups; ++g) {
             const unsigned long long p = (agg_par >> (OP_GROUP * g)) & 0x7fffffffull, r = (agg_rst >> (OP_GROUP * g)) & 0x7fffffffull;
-            const unsigned long long e = PM_ABLATED_FLAG(a.static_order & 4) ? 0ull : unroll_look_back(a.st, a.st1, a.ngroups, g, tile, (unsigned)p, (unsigned)r, lane);
+            const unsigned long long e = PM_ABLATED_FLAG(a.static_order & 4) ? 0ull : unroll_look_back(st0, st1, a.ngroups, g, tile, (unsigned)p, (unsigned)r, lane);
             if (lane == 0) {
                 const unsigned long long leaving = (2ull << 62) | ((e & ~r) ^ p);
                 __hip_atomic_store(me + g, leaving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((tile & 63) == 63) __hip_atomic_store(a.st1 + (tile >> 6) * a.ngroups + g, leaving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the block's word becomes absolute
+                if ((tile & 63) == 63) __hip_atomic_store(st1 + (tile >> 6) * a.ngroups + g, leaving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the block's word becomes absolute
             }
             enter |= e << (OP_GROUP * g);
         }
@@ -529,18 +536,21 @@ __global__ __launch_bounds__(NT, PM_OP_MINW) void unroll_onepass_kernel(const On
 
 using namespace pm;
 
-extern "C" int64_t pm_quat_unroll_workspace_bytes(int64_t T, int32_t S) {
-    if (T <= 0 || S <= 0) return 0;
+extern "C" int64_t pm_quat_unroll_batched_workspace_bytes(int64_t B, int64_t T, int32_t S) {
+    if (B <= 0 || T <= 0 || S <= 0) return 0;
+    // three passes (S > 64; clips one after the other through the same workspace)
     const int64_t three = ((T + UR_CHUNK - 1) / UR_CHUNK) * (int64_t)S * (int64_t)sizeof(int32_t) * (1 + 2 * UR_WORDS);
-    // the one-pass form (S <= 64): ticket line + a status per tile of 1024 dwordx4 (the smaller tile; dual quaternions: 2 per record)
-    const int64_t t1 = (T * S * 2 + 1023) / 1024, one = 64 + (t1 + (t1 + 63) / 64) * (int64_t)sizeof(unsigned long long) * ((S + OP_GROUP - 1) / OP_GROUP);
+    // one pass (S <= 64): ticket line + per clip a status word per tile of 1024 dwordx4 (the smaller tile; dual quaternions: 2 per
+    // record) and per block of 64 tiles, for every group of 31 series
+    const int64_t t1 = (T * S * 2 + 1023) / 1024, one = 64 + B * (t1 + (t1 + 63) / 64) * (int64_t)sizeof(unsigned long long) * ((S + OP_GROUP - 1) / OP_GROUP);
     return three > one ? three : one;
 }
+extern "C" int64_t pm_quat_unroll_workspace_bytes(int64_t T, int32_t S) { return pm_quat_unroll_batched_workspace_bytes(1, T, S); }
 
 template <int W>
-static int unroll_launch(const float *q, int64_t T, int32_t S, float *out, void *workspace, pm_stream_t stream) {
-    PM_CHECK_ARGS(T >= 0 && S >= 0, "quat_unroll: negative size");
-    if (T == 0 || S == 0) return PM_OK;
+static int unroll_launch(const float *q, int64_t B, int64_t T, int32_t S, float *out, void *workspace, pm_stream_t stream) {
+    PM_CHECK_ARGS(B >= 0 && T >= 0 && S >= 0, "quat_unroll: negative size");
+    if (B == 0 || T == 0 || S == 0) return PM_OK;
     PM_CHECK_ARGS(q && out && workspace, "quat_unroll: null pointer");
     PM_CHECK_ARGS(aligned16(q) && aligned16(out), "quat_unroll: q and out must be 16-byte aligned");
     PM_CHECK_ARGS((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, "quat_unroll: the workspace must be 8-byte aligned");
@@ -551,24 +561,32 @@ static int unroll_launch(const float *q, int64_t T, int32_t S, float *out, void 
         // 2^16 / 2^18 / 2^20 frames: three passes 17 / 20 / 34 / 79 / 60 / 195 us; one pass with 1024-dwordx4 tiles 9 / 8 / 13 / 32 /
         // 91 / 301 us, with 4096: 12 / 13 / 13 / 19 / 52 / 158 us (2048 / 3072 per tile at 2^20: 187 / 166 us; 512-thread workgroups: +5 %).
         constexpr int NT = 256;
-        const int R = tune_env("PM_UNROLL_R", nv >= 64 * 4096 ? 16 : 4);
-        if (R != 16 && R != 4) { set_error("PM_UNROLL_R must be 4 or 16"); return PM_EINVAL; }
-        const int64_t tile = NT * (int64_t)R, ntiles = (nv + tile - 1) / tile;
+        // Clips of a batch ([B][T][S][W]) are independent chains in one launch.  A clip that fits one tile gets the smallest tile
+        // that holds it (1024 / 2048 / 4096 dwordx4) and no look-back at all; longer clips the big tile once the launch has 64 of them.
+        int Rauto = 16;
+        if (nv <= 1024) Rauto = 4;
+        else if (nv <= 2048) Rauto = 8;
+        else if (nv > 4096 && B * ((nv + 4095) / 4096) < 64) Rauto = 4;
+        const int R = tune_env("PM_UNROLL_R", Rauto);
+        if (R != 16 && R != 8 && R != 4) { set_error("PM_UNROLL_R must be 4, 8 or 16"); return PM_EINVAL; }
+        const int64_t tile = NT * (int64_t)R, tpc = (nv + tile - 1) / tile, bpc = (tpc + 63) / 64, ntiles = B * tpc;
         if (ntiles > 0x7fffffffLL) { set_error("quat_unroll: problem too large"); return PM_EUNSUPPORTED; }
         OnePassArgs a;
-        a.q = q; a.out = out; a.nv = nv; a.S = S;
+        a.q = q; a.out = out; a.nv = nv; a.S = S; a.nclips = B; a.tpc = tpc; a.bpc = bpc;
         a.ticket = static_cast<uint32_t *>(workspace);
         a.st = reinterpret_cast<unsigned long long *>(static_cast<char *>(workspace) + 64);
         a.ngroups = (S + OP_GROUP - 1) / OP_GROUP;
-        a.st1 = a.st + ntiles * a.ngroups;
+        a.st1 = a.st + ntiles * a.ngroups;  // B * bpc blocks
         a.static_order = tune_env("PM_UNROLL_STATIC", 0);
+        a.single = tpc == 1;
         const int64_t rows = (tile / (W / 4) + S - 1) / S + 1;  // frames a tile can touch
         a.words = (int)((rows + 31) / 32);
         const size_t lds = 2 * (size_t)S * a.words * sizeof(unsigned);
-        const int64_t nwords = 8 + (ntiles + (ntiles + 63) / 64) * a.ngroups;  // the ticket's 64-byte line, then the words
+        const int64_t nwords = 8 + (ntiles + B * bpc) * a.ngroups;  // the ticket's 64-byte line, then the words
         hipLaunchKernelGGL(unroll_reset_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, s, static_cast<unsigned long long *>(workspace), nwords);
         PM_SET_LDS(lds);
         if (R == 16) hipLaunchKernelGGL((unroll_onepass_kernel<W, 16, NT>), dim3((unsigned)ntiles), dim3(NT), lds, s, a);
+        else if (R == 8) hipLaunchKernelGGL((unroll_onepass_kernel<W, 8, NT>), dim3((unsigned)ntiles), dim3(NT), lds, s, a);
         else hipLaunchKernelGGL((unroll_onepass_kernel<W, 4, NT>), dim3((unsigned)ntiles), dim3(NT), lds, s, a);
         return PM_AFTER_LAUNCH("quat_unroll");
     }
@@ -580,24 +598,33 @@ static int unroll_launch(const float *q, int64_t T, int32_t S, float *out, void 
     const int64_t nv = T * (int64_t)S * (W / 4), ablocks = (nv + 1023) / 1024;
     if (nchunks * p1_blocks > 0x7fffffffLL || ablocks > 0x7fffffffLL) { set_error("quat_unroll: problem too large"); return PM_EUNSUPPORTED; }
     UnrollArgs a;
-    a.q = q; a.out = out; a.T = T; a.S = S; a.nchunks = (int)nchunks; a.p1_sb = p1_sb; a.p1_blocks = (int)p1_blocks;
+    a.T = T; a.S = S; a.nchunks = (int)nchunks; a.p1_sb = p1_sb; a.p1_blocks = (int)p1_blocks;
     a.sum = static_cast<int32_t *>(workspace);
     a.pre = reinterpret_cast<uint32_t *>(a.sum + nchunks * S);
     a.abs = a.pre + nchunks * S * UR_WORDS;
-    {
-        const size_t p1_lds = 2 * (size_t)(S < p1_sb ? S : p1_sb) * UR_WORDS * sizeof(unsigned);
-        PM_SET_LDS(p1_lds);
-        hipLaunchKernelGGL((unroll_mask_kernel<W>), dim3((unsigned)(nchunks * p1_blocks)), dim3(PM_WAVE), p1_lds, s, a);
+    for (int64_t b = 0; b < B; ++b) {  // wide clips of a batch: one after the other (stream order makes the shared workspace safe)
+        a.q = q + b * T * (int64_t)S * W; a.out = out + b * T * (int64_t)S * W;
+        {
+            const size_t p1_lds = 2 * (size_t)(S < p1_sb ? S : p1_sb) * UR_WORDS * sizeof(unsigned);
+            PM_SET_LDS(p1_lds);
+            hipLaunchKernelGGL((unroll_mask_kernel<W>), dim3((unsigned)(nchunks * p1_blocks)), dim3(PM_WAVE), p1_lds, s, a);
+        }
+        if (nchunks <= 256) hipLaunchKernelGGL(unroll_scan_wide_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, s, a.sum, (int)nchunks, (int)S);
+        else hipLaunchKernelGGL(unroll_scan_kernel, dim3((unsigned)S), dim3(1024), 0, s, a.sum, (int)nchunks, (int)S);
+        hipLaunchKernelGGL((unroll_apply_kernel<W>), dim3((unsigned)ablocks), dim3(256), 0, s, a);
     }
-    if (nchunks <= 256) hipLaunchKernelGGL(unroll_scan_wide_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, s, a.sum, (int)nchunks, (int)S);
-    else hipLaunchKernelGGL(unroll_scan_kernel, dim3((unsigned)S), dim3(1024), 0, s, a.sum, (int)nchunks, (int)S);
-    hipLaunchKernelGGL((unroll_apply_kernel<W>), dim3((unsigned)ablocks), dim3(256), 0, s, a);
     return PM_AFTER_LAUNCH("quat_unroll");
 }
 
 extern "C" int pm_quat_unroll_f32(const float *q, int64_t T, int32_t S, float *out, void *workspace, pm_stream_t stream) {
-    return unroll_launch<4>(q, T, S, out, workspace, stream);
+    return unroll_launch<4>(q, 1, T, S, out, workspace, stream);
 }
 extern "C" int pm_dq_unroll_f32(const float *dq, int64_t T, int32_t S, float *out, void *workspace, pm_stream_t stream) {
-    return unroll_launch<8>(dq, T, S, out, workspace, stream);
+    return unroll_launch<8>(dq, 1, T, S, out, workspace, stream);
+}
+extern "C" int pm_quat_unroll_batched_f32(const float *q, int64_t B, int64_t T, int32_t S, float *out, void *workspace, pm_stream_t stream) {
+    return unroll_launch<4>(q, B, T, S, out, workspace, stream);
+}
+extern "C" int pm_dq_unroll_batched_f32(const float *dq, int64_t B, int64_t T, int32_t S, float *out, void *workspace, pm_stream_t stream) {
+    return unroll_launch<8>(dq, B, T, S, out, workspace, stream);
 }

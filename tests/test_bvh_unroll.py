@@ -234,3 +234,45 @@ def test_gpu_unroll_full_size_property():
     assert bool(((out[1:] * out[:-1]).sum(-1) >= 0).all())
     # twice: the workspace (ticket, statuses) is reset by every call
     assert torch.equal(quat_t.unroll(q, 0), out)
+
+
+@pytest.mark.gpu
+def test_gpu_unroll_batches_of_clips_without_transposing():
+    """[B, T, J, 4] unrolled along T: B independent look-back scans in one launch (short clips: one tile each; long clips:
+    chained tiles per clip), torch and NumPy doors, quaternions and dual quaternions, against the oracle along that axis"""
+    import ctypes as C
+
+    import torch
+
+    import pymotion_amd.rotations.dual_quat as dq
+    import pymotion_amd.rotations.quat as quat
+    import pymotion_amd.rotations.quat_torch as quat_t
+    from pymotion_amd import _lib
+
+    rng = np.random.default_rng(12)
+    for B, T, S in ((1000, 60, 22), (3, 20_000, 22), (7, 513, 64), (2, 1, 5), (40, 300, 1), (5, 4097, 31)):
+        base = np.cumsum(rng.normal(0, 0.08, (B, T, S, 4)), axis=1) + rng.normal(0, 1, (B, 1, S, 4))
+        q = (base * rng.choice([-1.0, 1.0], (B, T, S, 1))).astype(np.float32)
+        if T > 40:
+            q[B // 2, T // 2, 0] = 0.0  # a reset inside one clip only
+        ref = co.quat_unroll(q.astype(np.float64), 1).astype(np.float32)
+        np.testing.assert_array_equal(quat.unroll(q, 1), ref, err_msg=f"B={B} T={T} S={S}")
+        np.testing.assert_array_equal(quat_t.unroll(torch.from_numpy(q).cuda(), 1).cpu().numpy(), ref)
+        np.testing.assert_array_equal(quat.unroll(q, -3), ref)
+    # 5-D: two batch axes in front, two series axes behind
+    q5 = rng.standard_normal((3, 4, 200, 2, 11, 4)).astype(np.float32)
+    np.testing.assert_array_equal(quat.unroll(q5, 2), co.quat_unroll(q5.astype(np.float64), 2).astype(np.float32))
+    # dual quaternions: the real part decides
+    d8 = rng.standard_normal((6, 700, 22, 8)).astype(np.float32)
+    got = dq.unroll(d8, 1)
+    sref = co.quat_unroll(d8[..., :4].astype(np.float64), 1)
+    flipped = np.signbit(sref[..., 0]) != np.signbit(d8[..., 0])
+    np.testing.assert_array_equal(got, np.where(flipped[..., None], -d8, d8))
+    # the C ABI with wide clips in a batch (S > 64: the clips run one after the other through the three-pass scan)
+    B, T, S = 3, 700, 70
+    qw = torch.randn((B, T, S, 4), device="cuda")
+    out = torch.empty_like(qw)
+    ws = torch.empty(int(_lib.lib().pm_quat_unroll_batched_workspace_bytes(B, T, S)), dtype=torch.uint8, device="cuda")
+    _lib.call("pm_quat_unroll_batched_f32", C.c_void_p(qw.data_ptr()), B, T, S, C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), None)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), co.quat_unroll(qw.cpu().numpy().astype(np.float64), 1).astype(np.float32))

@@ -22,3 +22,14 @@ for lg in (10, 12, 14, 16, 18, 20):
     ws = torch.empty(int(_lib.lib().pm_quat_unroll_workspace_bytes(T, S)) + 16, dtype=torch.uint8, device="cuda")
     ms, _ = pp.timeit(lambda: _lib.call("pm_quat_unroll_f32", P(q), T, S, P(out), P(ws), None))
     print(f"[{tag}] T=2^{lg} S={S}: {ms * 1e3:8.1f} us  {T * S * 32 / ms / 1e6 / 80:5.1f}% of 8 TB/s on 32 B/quaternion", flush=True)
+# batches of clips [B, T, S, 4] along T: one launch, nothing transposed (raw ABI), and the torch door end to end
+import pymotion_amd.rotations.quat_torch as quat_t
+
+for B, T in ((16384, 64), (4096, 256), (64, 16384)):
+    q = torch.randn((B, T, S, 4), device="cuda")
+    out = torch.empty_like(q)
+    ws = torch.empty(int(_lib.lib().pm_quat_unroll_batched_workspace_bytes(B, T, S)) + 16, dtype=torch.uint8, device="cuda")
+    ms, _ = pp.timeit(lambda: _lib.call("pm_quat_unroll_batched_f32", P(q), B, T, S, P(out), P(ws), None))
+    ms2, _ = pp.timeit(lambda: quat_t.unroll(q, 1))
+    print(f"[{tag}] batch B={B} T={T} S={S}: {ms * 1e3:8.1f} us  {B * T * S * 32 / ms / 1e6 / 80:5.1f}% of 8 TB/s on 32 B/quaternion;"
+          f" quat_torch.unroll(q, 1) end to end {ms2 * 1e3:8.1f} us", flush=True)
