@@ -79,6 +79,10 @@ for T, S in ((1000, 22), (5, 64), (70000, 65), (3, 100000)):  # one-pass and thr
     assert h.pm_quat_unroll_workspace_bytes(T, S) >= 64
     assert h.pm_quat_unroll_f32(p, T, S, p, p, None) == _lib.PM_EHIP
     assert h.pm_dq_unroll_f32(p, T, S, p, p, None) == _lib.PM_EHIP
+    for B in (1, 3, 5000):  # batches of clips: tile size per clip, single-tile clips, wide clips one after the other
+        assert h.pm_quat_unroll_batched_workspace_bytes(B, T, S) >= h.pm_quat_unroll_workspace_bytes(T, S)
+        assert h.pm_quat_unroll_batched_f32(p, B, T, S, p, p, None) == _lib.PM_EHIP
+        assert h.pm_dq_unroll_batched_f32(p, B, T, S, p, p, None) == _lib.PM_EHIP
 print("host paths exercised:", calls)
 """
 
