@@ -241,7 +241,7 @@ def _unroll(be, x, axis, width, fname):
         raise ValueError("the unroll axis cannot be the component axis")
     dt = be.result_dtype(x)
     B, T, S = _prod(shp[:ax]), shp[ax], _prod(shp[ax + 1:-1])
-    if S <= 64:
+    if S <= 64 and (B == 1 or T * S * (width // 4) >= 512):  # (tiny clips would leave most of a 1024-dwordx4 tile idle: the wide form below)
         # [B, T, S, W] as it lies: the axes in front of the unroll axis are a batch of independent clips, scanned in one launch --
         # no transposition (a [B, T, J, 4] batch unrolled along T used to be moved to [T, B J, 4] and back: two more full copies)
         be.begin(x)

@@ -276,3 +276,17 @@ def test_gpu_unroll_batches_of_clips_without_transposing():
     _lib.call("pm_quat_unroll_batched_f32", C.c_void_p(qw.data_ptr()), B, T, S, C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), None)
     torch.cuda.synchronize()
     np.testing.assert_array_equal(out.cpu().numpy(), co.quat_unroll(qw.cpu().numpy().astype(np.float64), 1).astype(np.float32))
+
+
+@pytest.mark.gpu
+def test_gpu_unroll_many_tiny_clips_take_the_wide_form():
+    """a million two-frame clips: not a workgroup per clip -- the front-end moves the axis and the series-parallel scan runs"""
+    import pymotion_amd.rotations.quat as quat
+
+    rng = np.random.default_rng(4)
+    q = rng.standard_normal((200_000, 2, 3, 4)).astype(np.float32)
+    got = quat.unroll(q, 1)
+    flip = np.sum(q[:, 1] * q[:, 0], axis=-1) < 0
+    want = q.copy()
+    want[:, 1][flip] *= -1
+    np.testing.assert_array_equal(got, want)
