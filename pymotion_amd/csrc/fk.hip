@@ -46,6 +46,7 @@ struct FkArgs {
     float eps;              // ortho6d Gram-Schmidt floor
     int32_t ablate;         // PM_TUNING build only (env PM_FK_ABLATE): 2 = no tree walk; always 0 in production
     int32_t pad;            // floats of padding per frame in each per-frame LDS region (0 or 4), set by dispatch_fk
+    int32_t depth;          // edges on the longest root-to-leaf path: |p_j - root|_1 <= depth max_j |t_j|_1 (fixed-point scale, PREC_FX)
     Parents parents;
 };
 
@@ -364,10 +365,13 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// `tsum` = this lane's share of sum_j |t_j|_1, `rmax` = this lane's |root coordinate| (0 for idle lanes).  NaN / Inf
-// anywhere make the bound non-finite and the tile stays on the plain fp32 path, which propagates them like the reference.
-__device__ __forceinline__ bool fx_scale(const float tsum, const float rmax, FxScale &fx) {
-    const float B = wave_max(rmax) + wave_sum(tsum);
+// `tbound` (wave-uniform) bounds |p_j - root| for every joint of the tile, `rmax` = this lane's |root coordinate| (0 for idle
+// lanes).  NaN / Inf anywhere make the bound non-finite and the tile stays on the plain fp32 path, which propagates them like the
+// reference.  The bound along a path is min(sum over ALL joints of |t_j|_1, depth x max_j |t_j|_1): the first is tight for chains,
+// the second for wide trees (a star of 128 thirty-unit bones: 5760 against 45 -- seven bits of the fixed-point word, which at
+// coordinates of ~46 made its resolution coarser than fp32's; found by a randomised run of the fuzz tests).
+__device__ __forceinline__ bool fx_scale(const float tbound, const float rmax, FxScale &fx) {
+    const float B = wave_max(rmax) + tbound;
     const int e = __builtin_amdgcn_frexp_expf(B);  // B = m 2^e, m in [0.5, 1)
     fx.S = __builtin_ldexpf(1.0f, 30 - e);
     fx.invS = __builtin_ldexpf(1.0f, e - 30);
@@ -534,11 +538,11 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
     if (PFO) image_load<VEC>(a.offsets + f0 * J * 3, sOff, nf, J * 3, pad, lane);
     if (lane <= J) reinterpret_cast<v4f *>(sConst)[lane] = c_first;
     bool tbig = lane < J && const_is_big(c_first);
-    float tsum = lane < J ? const_l1(c_first) : 0.0f;
+    float tsum = lane < J ? const_l1(c_first) : 0.0f, tmx = tsum;
     for (int j = lane + PM_WAVE; j <= J; j += PM_WAVE) {
         const v4f cj = load_const(j);
         reinterpret_cast<v4f *>(sConst)[j] = cj;
-        if (j < J) { tbig = tbig || const_is_big(cj); tsum += const_l1(cj); }
+        if (j < J) { const float l1 = const_l1(cj); tbig = tbig || const_is_big(cj); tsum += l1; tmx = (l1 > tmx || l1 != l1) ? l1 : tmx; }
     }
 
     // ---- PREC_DYN: does this tile need the float64 rotations and the fixed-point chain? ------------------------
@@ -554,8 +558,9 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
         }
         big = __builtin_amdgcn_ballot_w64(mine) != 0 || !DYN;
         if (big) {  // wave-uniform; a non-finite bound (NaN / Inf inputs) keeps the plain path, which propagates them
-            if (PFO) tsum = (lane == 0) ? 3.0f * (float)J * wave_max(tmax) : 0.0f;
-            big = fx_scale(tsum, fabsf(gp), fx);
+            const float bsum = wave_sum(tsum), bmax = (float)a.depth * wave_max(tmx);  // (NaN sticks in both)
+            const float tbound = PFO ? 3.0f * (float)a.depth * wave_max(tmax) : ((bmax < bsum) ? bmax : bsum);
+            big = fx_scale(tbound, fabsf(gp), fx);
         }
     }
 
@@ -700,17 +705,18 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? 4 : 1) voi
     float *sConst = sQo + (QOUT ? FJ * 4 : 0);   // [(J+4)*4]
     // the joint table, and what it says about the arithmetic the tiles need (PREC_DYN, see fk_tile)
     bool tbig_l = false;
-    float tsum_l = 0.0f;
+    float tsum_l = 0.0f, tmx_l = 0.0f;
     for (int j = lane; j <= J; j += PM_WAVE) {
         const v4f cj = load_joint_const<PFO>(a.parents, a.offsets, J, j);
         reinterpret_cast<v4f *>(sConst)[j] = cj;
-        if (j < J) { tbig_l = tbig_l || const_is_big(cj); tsum_l += const_l1(cj); }
+        if (j < J) { const float l1 = const_l1(cj); tbig_l = tbig_l || const_is_big(cj); tsum_l += l1; tmx_l = (l1 > tmx_l || l1 != l1) ? l1 : tmx_l; }
     }
     bool tbig = false;   // wave-uniform
-    float tsum = 0.0f;   // sum_j |t_j|_1 (shared offsets)
+    float tsum = 0.0f;   // bound of |p_j - root| from the joint table (shared offsets), see fx_scale
     if constexpr (!PFO && (DYN || (PREC & PREC_FX))) {
         tbig = __builtin_amdgcn_ballot_w64(tbig_l) != 0;
-        tsum = wave_sum(tsum_l);
+        const float bsum = wave_sum(tsum_l), bmax = (float)a.depth * wave_max(tmx_l);  // (NaN sticks in both)
+        tsum = (bmax < bsum) ? bmax : bsum;
     }
 
     const int wl = lane % ((QUAD ? 12 : 3) * FPW);
@@ -786,8 +792,8 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? 4 : 1) voi
             }
             big = tbig || __builtin_amdgcn_ballot_w64(mine) != 0 || !DYN;
             if (big) {
-                const float bound_t = PFO ? 3.0f * (float)J * wave_max(tmax) : tsum;
-                big = fx_scale((lane == 0) ? bound_t : 0.0f, fabsf(gp_i), fx);
+                const float bound_t = PFO ? 3.0f * (float)a.depth * wave_max(tmax) : tsum;
+                big = fx_scale(bound_t, fabsf(gp_i), fx);
             }
         }
         // math of tile i, in registers (phase A of fk_tile)
@@ -1064,6 +1070,14 @@ static int fk_common(int src_kind, const float *src, const float *root_pos, cons
     a.quat_out = quat_out; a.F = F; a.J = J; a.eps = eps; a.pad = 0;  // set by dispatch_fk, per walk shape
     a.ablate = tune_env("PM_FK_ABLATE", 0);
     if (int e = pack_parents(parents, J, a.parents)) return e;
+    {
+        int dep[PM_MAX_JOINTS];
+        a.depth = 0;
+        for (int32_t j = 0; j < J; ++j) {
+            dep[j] = (j == 0) ? 0 : dep[a.parents.p[j]] + 1;
+            if (dep[j] > a.depth) a.depth = dep[j];
+        }
+    }
     const bool vec = aligned16(src) && aligned16(pos) && aligned16(rotmats) &&
                      (!offsets_per_frame || aligned16(offsets)) && (!quat_out || aligned16(quat_out));
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -3,6 +3,8 @@ dimensions / dtypes / memory layouts through both Python doors against the CPU o
 Complements the fixed-size cases of test_gpu_parity.py; every example is small, the value is in the mix
 (J on both sides of every kernel-shape switch: 23|24 joints, 64|65, odd joint counts, F not a multiple of
 any tile, stars and chains, strided views, per-frame offsets, half / bfloat16 / float64 tensors)."""
+import os
+
 import numpy as np
 import pytest
 from hypothesis import given, settings
@@ -16,7 +18,10 @@ pytestmark = pytest.mark.gpu
 import pymotion_amd.ops.skeleton as sk  # noqa: E402
 import pymotion_amd.rotations.quat as quat  # noqa: E402
 
-FUZZ = settings(max_examples=40, deadline=None, derandomize=True)
+# PM_FUZZ_SCALE=10 PM_FUZZ_RANDOM=1: a one-off long session with fresh examples (the committed runs are derandomised)
+_SCALE = int(os.environ.get("PM_FUZZ_SCALE", "1"))
+_DERAND = os.environ.get("PM_FUZZ_RANDOM") != "1"
+FUZZ = settings(max_examples=40 * _SCALE, deadline=None, derandomize=_DERAND)
 f64 = lambda a: np.asarray(a, dtype=np.float64)  # noqa: E731
 
 
@@ -133,7 +138,7 @@ def test_fuzz_elementwise_broadcasting(shapes, seed):
     assert_close(quat.mul_vec(a, v), want, 1e-5, "mul_vec")
 
 
-@settings(max_examples=24, deadline=None, derandomize=True)
+@settings(max_examples=24 * _SCALE, deadline=None, derandomize=_DERAND)
 @given(skeletons(), st.sampled_from(["float16", "bfloat16", "float32", "float64"]), st.sampled_from(["cuda", "cpu"]))
 def test_fuzz_torch_door_dtypes_and_devices(sk_, dtype, device):
     """the torch door computes in fp32 and returns rot.dtype where the input lives (skeleton_torch.py:45-49)"""
@@ -236,7 +241,7 @@ def test_fuzz_unroll_any_axis(shape, axis, seed):
     assert (d >= 0).all()
 
 
-@settings(max_examples=150, deadline=None, derandomize=True)
+@settings(max_examples=150 * _SCALE, deadline=None, derandomize=_DERAND)
 @given(st.one_of(st.integers(1, 300), st.integers(300, 40_000)), st.integers(1, 64), st.sampled_from([4, 8]), st.integers(0, 2**16))
 def test_fuzz_unroll_clips_one_pass_against_the_sequential_oracle(T, S, W, seed):
     """clips of 1..64 series (the look-back scan: 1 to ~600 chained tiles, one to three status words per tile), zero rows,
@@ -310,15 +315,29 @@ def test_fuzz_from_root_positions_reproduces_the_pose(sk_):
     r = sk.from_root_positions(pos.astype(np.float32), par, off)
     r_or = co.from_root_positions(f64(pos.astype(np.float32)), par, f64(off))
     d = np.minimum(np.abs(r - r_or).max(-1), np.abs(r + r_or).max(-1))
-    assert np.median(d) <= 1e-5 and (d > 1e-3).mean() < 0.02, (np.median(d), (d > 1e-3).mean(), d.max())
+    # quaternion by quaternion against the oracle: equal in bulk; where a further child lies close to the roll axis the roll is
+    # decided by digits fp32 does not have (a tree with five children on one joint: 3 % of its quaternions off by 1e-3..4e-3,
+    # found by a randomised run; a near anti-parallel alignment deep in a 60-chain: one quaternion off by 0.47) -- those may differ
+    assert np.median(d) <= 1e-5 and (d > 1e-3).mean() < 0.06, (np.median(d), (d > 1e-3).mean(), d.max())
+    # Fed back through fk the rotations give the positions back -- on chains.  (Not where a joint has several children: the
+    # reference's roll about the first child's direction does not in general bring the further children home -- its own
+    # result misses them by 0.18 on a three-joint star with these bone lengths, and the kernel reproduces the reference.)
+    if J < 2 or np.bincount(par[1:], minlength=J).max() <= 1:
+        pos2, _ = sk.fk(r, zero, off, par)
+        # (every alignment is good to ~1e-6 rad, and a joint k levels up moves the end of the chain by that times the distance;
+        # a frame with a near anti-parallel alignment somewhere -- axis = a x b with |a x b| ~ 1e-3 -- is off by more: in bulk)
+        e_f = np.abs(pos2 - pos).reshape(-1, J * 3).max(axis=1)
+        bar = 2e-6 * J * max(1.0, float(np.abs(pos).max()))
+        assert np.median(e_f) <= bar and (e_f > bar).mean() <= 0.1 and e_f.max() < 0.05, (np.median(e_f), (e_f > bar).mean(), e_f.max(), bar)
 
 
-@settings(max_examples=200, deadline=None, derandomize=True)
+@settings(max_examples=200 * _SCALE, deadline=None, derandomize=_DERAND)
 @given(skeletons(), st.sampled_from([0.05, 0.9, 1.0, 7.0, 30.0, 4.0e3, 2.5e6]), st.sampled_from([0.0, 3.0, 16.0, 900.0, 1.0e7]), st.booleans())
 def test_fuzz_fk_at_every_magnitude(sk_, bone_scale, root_scale, per_frame_offsets):
     """the per-tile arithmetic of fk (fp32 walk / float64 rotations + fixed-point chain) over bone and root
     magnitudes from millimetres to thousands of kilometres, both sides of the decision thresholds, every walk shape:
-    |pos error| <= max(1e-5, 3 ulp of the largest coordinate); rotations <= 2e-6 whatever the positions do"""
+    rotations <= 2e-6 whatever the positions do; positions within max(1e-5, 3 ulp of the largest coordinate) of what those
+    rotation errors imply (|dR_parent t_j| summed down the chain)"""
     J, par, lead, rng = sk_
     rot = rng.standard_normal(lead + (J, 4)).astype(np.float32)
     gpos = (rng.uniform(-1, 1, lead + (3,)) * root_scale).astype(np.float32)
@@ -327,13 +346,24 @@ def test_fuzz_fk_at_every_magnitude(sk_, bone_scale, root_scale, per_frame_offse
     p_o, r_o = co.fk(f64(rot), f64(gpos), f64(off), par)
     if pos.size:
         scale = np.abs(p_o).max()
-        bar = max(1e-5, 3 * 2.0 ** (np.floor(np.log2(scale)) - 23)) if scale > 0 else 1e-5
-        # (depth-129 chains accumulate 129 fp32 rotation products: the rotation term of the position error grows with them)
+        ulp3 = max(1e-5, 3 * 2.0 ** (np.floor(np.log2(scale)) - 23)) if scale > 0 else 1e-5
         d = np.zeros(J, int)
         for j in range(1, J):
             d[j] = d[par[j]] + 1
         depth = 1 + int(d.max())
-        bar *= max(1.0, depth / 12.0)
-        assert np.abs(pos - p_o).max() <= bar, (np.abs(pos - p_o).max(), bar, scale)
+        # rotations: fp32 products down the chain (129-deep chains accumulate 129 of them)
         assert np.abs(rm - r_o).max() <= 2e-6 * max(1.0, depth / 12.0)
+        # positions: p_j = p_parent + R_parent t_j, so an error dR in the parent's rotation moves the joint by |dR t_j| whatever
+        # the translation chain does.  What is asserted is that the chain adds no more than 3 ulp of the largest coordinate
+        # (max(1e-5, .) at metre scale) on top of what the rotation errors of THIS result imply -- a statement that holds at
+        # every ratio of bone length to root distance (a fixed "n ulp of the largest coordinate" does not: with small roots
+        # the coordinates are all bones, and 4e-7 of rotation error is 3-4 ulp of them).
+        e_rot = np.linalg.norm((rm - r_o).reshape(lead + (J, 9)), axis=-1)          # [..., J]
+        t_len = np.linalg.norm(f64(off), axis=-1) * np.ones(lead + (J,))             # [..., J]
+        implied = np.zeros(lead + (J,))
+        for j in range(1, J):
+            implied[..., j] = implied[..., par[j]] + e_rot[..., par[j]] * t_len[..., j]
+        err = np.linalg.norm(pos - p_o, axis=-1)
+        slack = err - implied
+        assert slack.max() <= ulp3 * np.sqrt(3.0), (slack.max(), ulp3, scale, depth)
         np.testing.assert_array_equal(pos[..., 0, :].astype(np.float32), gpos)
