@@ -278,6 +278,20 @@ def test_fuzz_unroll_clips_one_pass_against_the_sequential_oracle(T, S, W, seed)
         np.testing.assert_array_equal(np.abs(np.nan_to_num(got)), np.abs(np.nan_to_num(q)))
 
 
+@settings(max_examples=60 * _SCALE, deadline=None, derandomize=_DERAND)
+@given(st.integers(1, 300), st.one_of(st.integers(1, 80), st.integers(80, 6000)), st.integers(1, 64), st.integers(0, 2**16))
+def test_fuzz_unroll_batches_of_clips(B, T, S, seed):
+    """[B, T, S, 4] along T: B independent look-back chains in one launch (single-tile clips, chained clips, every tile size
+    the dispatch picks), a few resets sprinkled in -- bit for bit the sequential oracle along that axis"""
+    rng = np.random.default_rng(seed)
+    T = max(1, min(T, 400_000 // (B * S)))
+    base = np.cumsum(rng.normal(0, 0.08, (B, T, S, 4)), axis=1) + rng.normal(0, 1, (B, 1, S, 4))
+    q = (base * rng.choice([-1.0, 1.0], (B, T, S, 1))).astype(np.float32)
+    for _ in range(int(rng.integers(0, 4))):
+        q[int(rng.integers(0, B)), int(rng.integers(0, T)), int(rng.integers(0, S))] = 0.0
+    np.testing.assert_array_equal(quat.unroll(q, 1), co.quat_unroll(f64(q), 1).astype(np.float32))
+
+
 @FUZZ
 @given(st.sampled_from([(3, 3), (50, 22, 3), (2, 9, 5, 3), (40, 4), (17, 1), (6, 2, 2)]), st.integers(0, 3), st.integers(0, 2**16))
 def test_fuzz_interpolate_any_axis(shape, axis, seed):
