@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void unroll_scan_wide_kernel(int32_t *ws, int 
 // writes back / invalidates the XCD's L2, per tile).
 constexpr int OP_GROUP = 31;
 #ifndef PM_OP_MINW
-#define PM_OP_MINW 1  // waves per SIMD the compiler must fit: 164 VGPRs (three workgroups per CU) as it comes; capped at 128 it spills 38 (2^20 x 22: 160 -> 235 us)
+#define PM_OP_MINW 1  // waves per SIMD the compiler must fit (no cap needed: 95 VGPRs once the record indices stopped living across the phases)
 #endif
 
 struct OnePassArgs {
@@ -411,8 +411,8 @@ __global__ __launch_bounds__(NT, PM_OP_MINW) void unroll_onepass_kernel(const On
     // dual quaternions of more than 32 series -- keeps the second load.)
     const int D = S * V;
     const bool shuffled = D <= 64 && !PM_ABLATED_FLAG(a.static_order & 8);
-    // (indices inside the wave's range stay 32-bit and nothing per record is kept besides the record itself: with sixteen
-    // records per thread the kernel is register-bound -- 178 VGPRs, two workgroups per CU, before this; see PM_OP_MINW)
+    // (indices inside the wave's range stay 32-bit and nothing per record is kept besides the record itself: sixteen records
+    // per thread took 178 VGPRs before this, 95 now -- see lane_b / lane_c below)
     const int64_t wbase = base + (int64_t)wave * (64 * R);
     const int left = (int)((a.nv - wbase) < (int64_t)(64 * R) ? (a.nv - wbase > 0 ? a.nv - wbase : 0) : (int64_t)(64 * R));  // dwordx4 of this wave's range that exist
     const v4f *wsrc = src + wbase;
@@ -429,11 +429,15 @@ __global__ __launch_bounds__(NT, PM_OP_MINW) void unroll_onepass_kernel(const On
         const int li = u * 64 + lane;
         val[u] = __builtin_nontemporal_load(wsrc + (li < left ? li : lastoff));
     }
+    // (the lane id through an opaque copy per phase: left to itself the compiler keeps the sixteen record indices of the load
+    // phase -- and their clamps -- alive to the last store, ~30 registers of the 164)
+    int lane_b = lane, lane_c = lane;
+    asm volatile("" : "+v"(lane_b));
     const int from = ((lane - D) & 63) << 2;  // ds_bpermute address of the lane D to the left
     const bool own = lane < 64 - D;           // lanes that hand their own row to the right; the rest hand the previous row to the head of this one
 #pragma unroll
     for (int u = 0; u < R; ++u) {
-        const int li = u * 64 + lane;
+        const int li = u * 64 + lane_b;
         int dt, s_;
         locate(li, dt, s_);
         const bool ok = (li < left) && (tb + dt > 0) && (V == 1 || (li & 1) == 0);  // the real part decides (dual_quat.py:139-167)
@@ -512,9 +516,10 @@ __global__ __launch_bounds__(NT, PM_OP_MINW) void unroll_onepass_kernel(const On
     __syncthreads();
     const unsigned long long enter = s_enter;
     v4f *wdst = dst + wbase;
+    asm volatile("" : "+v"(lane_c));
 #pragma unroll
     for (int u = 0; u < R; ++u) {
-        const int li = u * 64 + lane;
+        const int li = u * 64 + lane_c;
         int dt, s_;
         locate(li, dt, s_);
         const int w = s_ * words + (dt >> 5);
@@ -581,7 +586,13 @@ static int unroll_launch(const float *q, int64_t B, int64_t T, int32_t S, float 
         a.single = tpc == 1;
         const int64_t rows = (tile / (W / 4) + S - 1) / S + 1;  // frames a tile can touch
         a.words = (int)((rows + 31) / 32);
-        const size_t lds = 2 * (size_t)S * a.words * sizeof(unsigned);
+        size_t lds = 2 * (size_t)S * a.words * sizeof(unsigned);
+        // Long chains run best with THREE workgroups per CU: every tile in flight ahead of a tile is a word its look-back has to fold, so
+        // more resident tiles lengthen every walk (2^18 x 22 with 5 / 4 / 3 / 2 workgroups per CU: 60.5 / 56.2 / 51.0 / 53.6 us; batches of
+        // short clips want them all: 4096 clips of 256 frames 145 / 145 / 153 / 187 us).  The kernel needs 95 VGPRs (five workgroups per
+        // CU), so long chains reserve a third of the CU's LDS each.
+        if (tpc > 64 && lds < 52 * 1024) lds = 52 * 1024;
+        lds += (size_t)tune_env("PM_UNROLL_LDS_PAD", 0);  // PM_TUNING build only: more unused LDS
         const int64_t nwords = 8 + (ntiles + B * bpc) * a.ngroups;  // the ticket's 64-byte line, then the words
         hipLaunchKernelGGL(unroll_reset_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, s, static_cast<unsigned long long *>(workspace), nwords);
         PM_SET_LDS(lds);
