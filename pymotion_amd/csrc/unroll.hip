@@ -9,7 +9,7 @@
 // Without resets that is a prefix XOR of the flip bits; a reset (a zero-padded row, an exactly orthogonal step, a NaN)
 // forgets everything before it.  A scan, not a loop.  Two forms:
 //   * at most 64 series (a clip, or a few): ONE kernel, a decoupled look-back scan -- 16 B read and 16 B written per
-//     quaternion, see unroll_onepass_kernel below (2^20 x 22: 158 us; a 65 536-frame clip: 19 us against 79 us); batches of
+//     quaternion, see unroll_onepass_kernel below (2^20 x 22: 151 us; a 65 536-frame clip: 19 us against 79 us); batches of
 //     clips [B, T, S, 4] are B independent chains in the same launch (16 384 clips of 64 frames x 22: 123 us);
 //   * wide batches (S > 64), three passes:
 //   pass 1  (unroll_mask_kernel) each wave streams a chunk of 256 consecutive frames (one record per lane, the
@@ -572,8 +572,9 @@ static int unroll_launch(const float *q, int64_t B, int64_t T, int32_t S, float 
         if (nv <= 1024) Rauto = 4;
         else if (nv <= 2048) Rauto = 8;
         else if (nv > 4096 && B * ((nv + 4095) / 4096) < 64) Rauto = 4;
+        else if (nv >= (int64_t)4 << 20) Rauto = 32;  // very long chains: fewer, bigger tiles (2^18 / 2^20 frames x 22: 51 / 159 -> 46 / 153 us; 2^16: 19.6 -> 21.3)
         const int R = tune_env("PM_UNROLL_R", Rauto);
-        if (R != 16 && R != 8 && R != 4) { set_error("PM_UNROLL_R must be 4, 8 or 16"); return PM_EINVAL; }
+        if (R != 32 && R != 16 && R != 8 && R != 4) { set_error("PM_UNROLL_R must be 4, 8, 16 or 32"); return PM_EINVAL; }
         const int64_t tile = NT * (int64_t)R, tpc = (nv + tile - 1) / tile, bpc = (tpc + 63) / 64, ntiles = B * tpc;
         if (ntiles > 0x7fffffffLL) { set_error("quat_unroll: problem too large"); return PM_EUNSUPPORTED; }
         OnePassArgs a;
@@ -596,7 +597,8 @@ static int unroll_launch(const float *q, int64_t B, int64_t T, int32_t S, float 
         const int64_t nwords = 8 + (ntiles + B * bpc) * a.ngroups;  // the ticket's 64-byte line, then the words
         hipLaunchKernelGGL(unroll_reset_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, s, static_cast<unsigned long long *>(workspace), nwords);
         PM_SET_LDS(lds);
-        if (R == 16) hipLaunchKernelGGL((unroll_onepass_kernel<W, 16, NT>), dim3((unsigned)ntiles), dim3(NT), lds, s, a);
+        if (R == 32) hipLaunchKernelGGL((unroll_onepass_kernel<W, 32, NT>), dim3((unsigned)ntiles), dim3(NT), lds, s, a);
+        else if (R == 16) hipLaunchKernelGGL((unroll_onepass_kernel<W, 16, NT>), dim3((unsigned)ntiles), dim3(NT), lds, s, a);
         else if (R == 8) hipLaunchKernelGGL((unroll_onepass_kernel<W, 8, NT>), dim3((unsigned)ntiles), dim3(NT), lds, s, a);
         else hipLaunchKernelGGL((unroll_onepass_kernel<W, 4, NT>), dim3((unsigned)ntiles), dim3(NT), lds, s, a);
         return PM_AFTER_LAUNCH("quat_unroll");

@@ -191,7 +191,7 @@ def _clip_with_flips_and_resets(T, S, W, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{}, {"PM_UNROLL_R": "16"}, {"PM_UNROLL_R": "4"}, {"PM_UNROLL_ONEPASS": "0"}])
+@pytest.mark.parametrize("env", [{}, {"PM_UNROLL_R": "16"}, {"PM_UNROLL_R": "32"}, {"PM_UNROLL_R": "4"}, {"PM_UNROLL_ONEPASS": "0"}])
 def test_gpu_unroll_one_pass_tiles_and_three_pass_agree_with_the_oracle(env, monkeypatch):
     import pymotion_amd.rotations.dual_quat as dq
     import pymotion_amd.rotations.quat as quat
