@@ -595,7 +595,8 @@ static int unroll_launch(const float *q, int64_t B, int64_t T, int32_t S, float 
         if (tpc > 64 && lds < 52 * 1024) lds = 52 * 1024;
         lds += (size_t)tune_env("PM_UNROLL_LDS_PAD", 0);  // PM_TUNING build only: more unused LDS
         const int64_t nwords = 8 + (ntiles + B * bpc) * a.ngroups;  // the ticket's 64-byte line, then the words
-        hipLaunchKernelGGL(unroll_reset_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, s, static_cast<unsigned long long *>(workspace), nwords);
+        if (!a.single)  // (single-tile clips read neither the ticket nor a status word)
+            hipLaunchKernelGGL(unroll_reset_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, s, static_cast<unsigned long long *>(workspace), nwords);
         PM_SET_LDS(lds);
         if (R == 32) hipLaunchKernelGGL((unroll_onepass_kernel<W, 32, NT>), dim3((unsigned)ntiles), dim3(NT), lds, s, a);
         else if (R == 16) hipLaunchKernelGGL((unroll_onepass_kernel<W, 16, NT>), dim3((unsigned)ntiles), dim3(NT), lds, s, a);
