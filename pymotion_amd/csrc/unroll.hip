@@ -567,10 +567,11 @@ static int unroll_launch(const float *q, int64_t B, int64_t T, int32_t S, float 
         // 91 / 301 us, with 4096: 12 / 13 / 13 / 19 / 52 / 158 us (2048 / 3072 per tile at 2^20: 187 / 166 us; 512-thread workgroups: +5 %).
         constexpr int NT = 256;
         // Clips of a batch ([B][T][S][W]) are independent chains in one launch.  A clip that fits one tile gets the smallest tile
-        // that holds it (1024 / 2048 / 4096 dwordx4) and no look-back at all; longer clips the big tile once the launch has 64 of them.
+        // that holds it (1024 / 2048 / 4096 / 8192 dwordx4) and no look-back at all; longer clips the big tile once the launch has 64 of them.
         int Rauto = 16;
         if (nv <= 1024) Rauto = 4;
         else if (nv <= 2048) Rauto = 8;
+        else if (nv > 4096 && nv <= 8192 && B >= 64) Rauto = 32;  // still one tile per clip (4096 clips of 256 frames x 22: 146 -> 131 us)
         else if (nv > 4096 && B * ((nv + 4095) / 4096) < 64) Rauto = 4;
         else if (nv >= (int64_t)4 << 20) Rauto = 32;  // very long chains: fewer, bigger tiles (2^18 / 2^20 frames x 22: 51 / 159 -> 46 / 153 us; 2^16: 19.6 -> 21.3)
         const int R = tune_env("PM_UNROLL_R", Rauto);
