@@ -154,6 +154,22 @@ def secondary_configs(torch, _lib, syn, dev, rot, root, off, parents, sptr):
 
     out = {}
     rotn = rot / rot.norm(dim=-1, keepdim=True)
+    # configs[1], second half: standalone quat.to_matrix on the normalised [F * 22, 4] (52 B per quaternion)
+    m_out = torch.empty((F * J, 3, 3), device=dev)
+    t_m = timed(lambda: _lib.call("pm_quat_to_matrix_f32", p(rotn), F * J, p(m_out), sptr))
+    out["quat_to_matrix"] = {"quaternions": F * J, "ms": t_m, "quats_per_s": F * J / (t_m * 1e-3),
+                             "hbm_frac": F * J * 52 / (t_m * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    del m_out
+    # the headline kernel on centimetre-scale data (what mocap BVH files hold: bones ~30, roots ~200): those tiles take float64
+    # local rotations and the fixed-point translation chain
+    off_cm = off * 100.0
+    root_cm = root * 100.0
+    pos_c = torch.empty((F, J, 3), device=dev)
+    rm_c = torch.empty((F, J, 3, 3), device=dev)
+    t_cm = timed(lambda: _lib.call("pm_fk_f32", p(rot), p(root_cm), p(off_cm), 0, pp, F, J, p(pos_c), p(rm_c), sptr))
+    out["fk_centimetre_scale_J22"] = {"frames": F, "ms": t_cm, "frames_per_s": F / (t_cm * 1e-3),
+                                      "hbm_frac": F * (64 * J + 12) / (t_cm * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel": _lib.last_kernel_name()}
+    del pos_c, rm_c, off_cm, root_cm
     dq = torch.empty((F, J, 8), device=dev)
     tr = torch.empty((F, J, 3), device=dev)
     qo = torch.empty((F, J, 4), device=dev)
@@ -178,6 +194,94 @@ def secondary_configs(torch, _lib, syn, dev, rot, root, off, parents, sptr):
                                  None, sptr))
     out["fused_ortho6d_fk_J52"] = {"frames": F4, "ms": t4, "frames_per_s": F4 / (t4 * 1e-3),
                                    "hbm_frac": F4 * (72 * 52 + 12) / (t4 * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    q4 = torch.empty((F4, 52, 4), device=dev)
+    t4q = timed(lambda: _lib.call("pm_fk_from_ortho6d_f32", p(x), p(root4), p(off4), 0, pp4, F4, 52, C.c_float(0.0), p(pos4), p(rm4),
+                                  p(q4), sptr))
+    out["fused_ortho6d_fk_J52_quat_out"] = {"frames": F4, "ms": t4q, "frames_per_s": F4 / (t4q * 1e-3),
+                                            "hbm_frac": F4 * (88 * 52 + 12) / (t4q * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    t52 = timed(lambda: _lib.call("pm_fk_f32", p(q4), p(root4), p(off4), 0, pp4, F4, 52, p(pos4), p(rm4), sptr))
+    out["fk_J52"] = {"frames": F4, "ms": t52, "frames_per_s": F4 / (t52 * 1e-3),
+                     "hbm_frac": F4 * (64 * 52 + 12) / (t52 * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    return out
+
+
+def stream_ceilings(torch, _lib, dev, rot, rm, F, J, sptr):
+    """What this chip moves with NO arithmetic, measured in the same process right after the timed region (never inside it):
+    a copy with fk's traffic shape through fk's own tiling (`pm_stream_ceiling_f32`: 16 J B read, 48 J B written per frame;
+    the 12 B root position is left out), and LDS-free grid-stride streams for a pure read, a pure write and the 1:1 / 1:3
+    read:write mixes.  fk_kernel_ms / copy_ceiling_ms says how far the kernel is from what the memory system gives this
+    access pattern; the pure rows say which direction caps it."""
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    ev = [C.c_void_p(), C.c_void_p()]
+    for e in ev:
+        _lib.call("pm_event_create", C.byref(e))
+
+    def timed(fn, n=60, warm=60):
+        for _ in range(warm):
+            fn()
+        _lib.call("pm_event_record", ev[0], sptr)
+        for _ in range(n):
+            fn()
+        _lib.call("pm_event_record", ev[1], sptr)
+        ms = C.c_float()
+        _lib.call("pm_event_elapsed_ms", ev[0], ev[1], C.byref(ms))
+        return ms.value / n
+
+    src, dst = rot.view(-1), rm.view(-1)
+    n4 = F * J                      # dwordx4 in `rot`; `rm` holds 9/4 as many (36 J B per frame), enough for ratios up to 2
+    big = torch.empty(n4 * 12, device=dev)  # 48 J B per frame: fk's output volume
+    out = {}
+    t = timed(lambda: _lib.call("pm_stream_ceiling_f32", p(src), p(big), F, 4 * J, 12 * J, sptr))
+    out["copy_ceiling_ms"] = t
+    out["copy_ceiling_GBps"] = F * 64 * J / (t * 1e-3) / 1e9
+    rates = {}
+    t = timed(lambda: _lib.call("pm_stream_plain_f32", p(big), p(dst), n4 * 3, 0, 8192, sptr))
+    rates["pure_read"] = {"bytes": n4 * 48, "ms": t, "GBps": n4 * 48 / (t * 1e-3) / 1e9}
+    t = timed(lambda: _lib.call("pm_stream_plain_f32", p(src), p(big), n4 * 3, -1, 8192, sptr))
+    rates["pure_write"] = {"bytes": n4 * 48, "ms": t, "GBps": n4 * 48 / (t * 1e-3) / 1e9}
+    t = timed(lambda: _lib.call("pm_stream_plain_f32", p(src), p(big), n4, 1, 8192, sptr))
+    rates["read_write_1_1"] = {"bytes": n4 * 32, "ms": t, "GBps": n4 * 32 / (t * 1e-3) / 1e9}
+    t = timed(lambda: _lib.call("pm_stream_plain_f32", p(src), p(big), n4, 3, 8192, sptr))
+    rates["read_write_1_3"] = {"bytes": n4 * 64, "ms": t, "GBps": n4 * 64 / (t * 1e-3) / 1e9}
+    out["stream_rates"] = rates
+    del big
+    return out
+
+
+def cpu_baseline_extras(np, syn, threads):
+    """Two more CPU lines: config 1 -- the NumPy restatement on a cache-resident 1000-frame clip, where
+    Python overhead is amortised least -- and the oracle's scalar C fk (`oracle/pm_oracle.c`, float64 like the reference)
+    run on every visible core (frame blocks on a thread pool; ctypes releases the GIL), which answers "is the GPU number
+    just Python being slow"."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import c_oracle as co
+    from oracle import numpy_ref as nr
+
+    out = {}
+    rot, root, off, parents = syn.fk_workload(1000, seed=1)
+    nr.fk(rot, root, off, parents)
+    best = 1e9
+    for _ in range(20):
+        t0 = time.perf_counter()
+        nr.fk(rot, root, off, parents)
+        best = min(best, time.perf_counter() - t0)
+    out["config1_numpy_1000_frames"] = {"value": 1000 / best, "unit": "frames/s", "ms": best * 1e3, "kind": "port",
+                                        "sample": "1000 frames x 22 joints, oracle/numpy_ref.fk, best of 20"}
+    F = 1 << 21
+    rot, root, off, parents = syn.fk_workload(F, seed=2)
+    r64, g64, o64 = rot.astype(np.float64), root.astype(np.float64), off.astype(np.float64)
+    blk = 1 << 11
+    spans = [(i, min(i + blk, F)) for i in range(0, F, blk)]
+    co.fk(r64[:blk], g64[:blk], o64, parents)
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(lambda se: co.fk(r64[se[0]:se[1]], g64[se[0]:se[1]], o64, parents), spans[:threads]))  # threads up
+        t0 = time.perf_counter()
+        list(ex.map(lambda se: co.fk(r64[se[0]:se[1]], g64[se[0]:se[1]], o64, parents), spans))
+        wall = time.perf_counter() - t0
+    out["c_oracle_all_cores"] = {"value": F / wall, "unit": "frames/s", "cores": threads, "kind": "port",
+                                 "sample": "%d frames x 22 joints, oracle/pm_oracle.c fk_f64 (scalar C, one frame at a time), %d-frame blocks on "
+                                           "%d threads, %.2f s wall" % (F, blk, threads, wall)}
     return out
 
 
@@ -367,6 +471,11 @@ def main():
         et = torch.tensor([err], device=cdev, dtype=torch.float64)
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
         extra["max_abs_err_vs_oracle_slice"] = {"value": float(et[0]), "frames_per_rank": n_chk}
+    ceil = None
+    if world == 1 and not a.no_secondary:
+        ceil = stream_ceilings(torch, _lib, dev, rot, rm, F, J, sptr)
+        step()  # `rm` served as a scratch destination above: restore the kernel's outputs for the checks below
+        torch.cuda.synchronize()
     if world == 1 and not a.no_secondary and J == 22:
         extra["secondary"] = secondary_configs(torch, _lib, syn, dev, rot, root, off, parents, sptr)
 
@@ -408,6 +517,9 @@ def main():
                          "kernel": kernel_name, "kernel_ms": kern_ms,
                          "bytes_per_frame": bytes_per_frame},
         }
+        if ceil is not None:
+            line["roofline"].update(ceil)
+            line["roofline"]["kernel_over_copy_ceiling"] = kern_ms / ceil["copy_ceiling_ms"]
         line.update(extra)
     else:
         line = None
@@ -441,6 +553,11 @@ def main():
                 "rotmats": float(np.abs(rm[:n].cpu().numpy() - r_cpu).max()),
                 "frames_checked": n,
             }
+            del p_cpu, r_cpu
+            try:
+                line["cpu_baseline_more"] = cpu_baseline_extras(np, syn, len(os.sched_getaffinity(0)))
+            except Exception as exc:  # noqa: BLE001  (extra lines only: never cost the run its bench line)
+                line["cpu_baseline_more"] = {"error": repr(exc)[:200]}
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -228,6 +228,7 @@ int pm_stream_ceiling_f32(const float *src, float *dst, int64_t F, int32_t rd_fl
                           int32_t wr_floats, pm_stream_t stream);
 
 /* LDS-free streaming probe: n4 dwordx4 read, ratio * n4 written, grid-stride with `blocks` 256-thread blocks.
+ * ratio = 0: pure read (n4 dwordx4 read, nothing written); ratio = -1: pure write (n4 dwordx4 written, nothing read).
  * Tells what the memory system sustains for a read:write mix (bench / tuning only). */
 int pm_stream_plain_f32(const float *src, float *dst, int64_t n4, int32_t ratio, int32_t blocks, pm_stream_t stream);
 

@@ -233,20 +233,23 @@ class _PinnedPool:
 
 
 _pinned = _PinnedPool()
-_pipe_streams = {}  # device -> ([stream0, stream1], [event0, event1, event2]): created once per device
-_pipe_lock = threading.Lock()  # the streams / events are shared: one pipelined call at a time (they saturate the bus anyway)
+_pipe_streams = {}  # device -> ([stream0, stream1], [event0, event1, event2], lock): created once per device
+_pipe_ctx_lock = threading.Lock()
 
 
 def _pipe_ctx(dev):
-    ctx = _pipe_streams.get(dev)
-    if ctx is None:
-        hs = [C.c_void_p(), C.c_void_p()]
-        ev = [C.c_void_p(), C.c_void_p(), C.c_void_p()]  # one per staging slot
-        for h in hs:
-            _lib.call("pm_stream_create", C.byref(h))
-        for e in ev:
-            _lib.call("pm_event_create", C.byref(e))
-        ctx = _pipe_streams[dev] = (hs, ev)
+    """streams, events and the lock that serialises pipelined calls ON ONE DEVICE (they share its streams / events and
+    saturate its bus anyway); calls on different GPUs of one process do not wait for each other"""
+    with _pipe_ctx_lock:
+        ctx = _pipe_streams.get(dev)
+        if ctx is None:
+            hs = [C.c_void_p(), C.c_void_p()]
+            ev = [C.c_void_p(), C.c_void_p(), C.c_void_p()]  # one per staging slot
+            for h in hs:
+                _lib.call("pm_stream_create", C.byref(h))
+            for e in ev:
+                _lib.call("pm_event_create", C.byref(e))
+            ctx = _pipe_streams[dev] = (hs, ev, threading.Lock())
     return ctx
 
 
@@ -281,13 +284,14 @@ def pipelined_frames(F, ins, outs, launch):
     Returns the list of result arrays [F, *trailing].
     """
     _lib.require_device()
-    with _pipe_lock:
-        return _pipelined_frames_locked(F, ins, outs, launch)
-
-
-def _pipelined_frames_locked(F, ins, outs, launch):
     dev = _current_device()
-    (streams, events) = _pipe_ctx(dev)
+    ctx = _pipe_ctx(dev)
+    with ctx[2]:
+        return _pipelined_frames_locked(F, ins, outs, launch, dev, ctx)
+
+
+def _pipelined_frames_locked(F, ins, outs, launch, dev, ctx):
+    streams, events = ctx[0], ctx[1]
     per_in = [int(np.prod(a.shape[1:])) * 4 if pf else 0 for a, pf in ins]
     per_out = [_prod(t) * 4 for t, _ in outs]
     per_frame = max(1, sum(per_in) + sum(per_out))

@@ -45,7 +45,11 @@ def ew(be, fname, ins, in_trail, out_trail, out_dtypes, pre=(), mid=()):
             lead = _bshape(*[sh[: len(sh) - len(t)] for sh, t in zip(shapes, in_trail)])
             n = _prod(lead)
             per = 4 * (sum(_prod(t) for t in in_trail) + sum(_prod(t) for t in out_trail))
-            if be.wants_pipeline(n, per):
+            # (an operand that broadcasts over the batch -- one quaternion, one `t` against N records -- would have to be
+            # expanded on the host, staged and sent over the bus N times over: those calls take the plain path, whose
+            # dev_in expands on the way to the device buffer only)
+            full = all(tuple(sh[: len(sh) - len(t)]) == tuple(lead) for sh, t in zip(shapes, in_trail))
+            if full and be.wants_pipeline(n, per):
                 from ._backend import pipelined_frames
 
                 res = pipelined_frames(

@@ -292,27 +292,41 @@ __device__ __forceinline__ void m2q(const float (&m)[9], float (&o)[4]) {
     qnormalize(c, 1e-8f, o);
 }
 
-// rotations/ortho6d.py:67-90 : Gram-Schmidt on the two COLUMNS of x[3][2]; denominators
-// max(norm, eps): eps = 0 -> NumPy path (NaN on a zero column), 1e-12 -> torch twin.
-// `ill` (optional): the record is one where fp32 Gram-Schmidt is not the reference's answer to fp32 accuracy -- a zero or
-// non-finite column (the eps floor / NaN decide the result), or columns closer than ~0.6 degrees to (anti-)parallel
-// (what is left of b after the projection is rounding noise: relative error 6e-8 / sin).  Callers that chain further
-// re-do such records in float64 (o6d_chain_f64).
-__device__ __forceinline__ void o6d2m(const float (&x)[6], float eps, float (&m)[9], bool *ill = nullptr) {
+// rotations/ortho6d.py:67-90 : Gram-Schmidt on the two COLUMNS of x[3][2]  (denominators max(norm, eps): eps = 0 -> NumPy
+// path, NaN on a zero column; 1e-12 -> torch twin, zeros -- both live in the float64 twin below).
+//
+// The reference's projection c2 ~ b - (c1.b) c1 cancels when the columns are close to (anti-)parallel: evaluated in fp32
+// what is left of b is rounding noise amplified by 1 / sin(angle) (1.5e-6 already for ordinary records, 2.5e-4 at half a
+// degree; round 2 re-did everything below 0.6 degrees in float64 and still read 5e-5 down a 52-joint chain).  The SAME
+// frame written without a cancelling step:  c3 = (a x b) / |a x b|,  c2 = c3 x c1  -- identical in exact arithmetic
+// ((a x b) x a = b (a.a) - a (a.b)), and each component of a x b is a difference of two products of fp32 INPUTS, which
+// Kahan's FMA form (w = rn(a2 b1); (fma(a1, b2, -w)) + fma(-a2, b1, w)) returns to 1.5 ulp of the RESULT however
+// much cancels.  Measured against the float64 reference on 2e6 records incl. 2e5 with sin(angle) down to 1e-7:
+// max error 2.8e-7 at every angle (+ 8 instructions per record).
+// `ill`: records whose answer the reference's eps floors / NaN rules / own rounding noise decide -- a column
+// that is zero, non-finite or outside [1e-6, 1e9] in length, or sin(angle) <= 1e-6 (exactly parallel columns included).
+// Callers re-do those in float64 with the reference's own sequence of operations (o6d2m_f64 / o6d_chain_f64).
+__device__ __forceinline__ float diff_of_products(const float a, const float b, const float c, const float d) {  // a b - c d
+    const float w = c * d;
+    const float e = __builtin_fmaf(-c, d, w);  // exact: w - c d
+    const float f = __builtin_fmaf(a, b, -w);
+    return f + e;
+}
+__device__ __forceinline__ void o6d2m(const float (&x)[6], float (&m)[9], bool &ill) {
     const float a0 = x[0], a1 = x[2], a2 = x[4], b0 = x[1], b1 = x[3], b2 = x[5];
-    const float na = fsqrt(a0 * a0 + a1 * a1 + a2 * a2);
-    const float ia = frcp(fmaxf(na, eps));
+    const float na2 = a0 * a0 + a1 * a1 + a2 * a2;
+    const float ia = __builtin_amdgcn_rsqf(na2);
     const float c10 = a0 * ia, c11 = a1 * ia, c12 = a2 * ia;
-    const float d = c10 * b0 + c11 * b1 + c12 * b2;
-    float c20 = b0 - d * c10, c21 = b1 - d * c11, c22 = b2 - d * c12;
-    const float n2c = c20 * c20 + c21 * c21 + c22 * c22;
-    const float ib = frcp(fmaxf(fsqrt(n2c), eps));
-    c20 *= ib; c21 *= ib; c22 *= ib;
-    m[0] = c10; m[1] = c20; m[2] = c11 * c22 - c12 * c21;
-    m[3] = c11; m[4] = c21; m[5] = c12 * c20 - c10 * c22;
-    m[6] = c12; m[7] = c22; m[8] = c10 * c21 - c11 * c20;
-    // sin^2 / cos^2 of the angle between the columns <= 1e-4, a (near-)zero first column, or anything non-finite
-    if (ill) *ill = !(na > 1e-18f && na < 1e18f) || !(n2c > 1.0001e-4f * d * d) || !(n2c < 1e36f);
+    const float n0 = diff_of_products(a1, b2, a2, b1), n1 = diff_of_products(a2, b0, a0, b2), n2 = diff_of_products(a0, b1, a1, b0);
+    const float nn2 = n0 * n0 + n1 * n1 + n2 * n2;
+    const float in = __builtin_amdgcn_rsqf(nn2);
+    const float c30 = n0 * in, c31 = n1 * in, c32 = n2 * in;
+    m[0] = c10; m[1] = c31 * c12 - c32 * c11; m[2] = c30;
+    m[3] = c11; m[4] = c32 * c10 - c30 * c12; m[5] = c31;
+    m[6] = c12; m[7] = c30 * c11 - c31 * c10; m[8] = c32;
+    // (the reference's floors max(norm, eps) only ever decide records that are `ill`)
+    const float nb2 = b0 * b0 + b1 * b1 + b2 * b2;
+    ill = !(na2 > 1e-12f && na2 < 1e18f) || !(nb2 > 1e-12f && nb2 < 1e18f) || !(nn2 > 1e-12f * (na2 * nb2));
 }
 
 // float64 twins for the rare records o6d2m flags.  o6d_chain_f64 = the whole chain ortho6d.to_quat -> fk's local
@@ -431,6 +445,44 @@ __device__ __forceinline__ void from_to_axis(const float (&v1)[3], const float (
     float a[3] = {v1[0], v1[1], v1[2]}, b[3] = {v2[0], v2[1], v2[2]};
     if (normalize_input) { vnormalize(v1, 1e-8f, a); vnormalize(v2, 1e-8f, b); }
     from_to_axis_unit(a, b, axis, o);
+}
+
+// ---- big-magnitude tiles: when fp32 roundings of |p| matter, and the fixed-point translation chain (fk.hip, dq.hip) -------
+// The fp32 walks round every position to an ulp of ITS magnitude once per joint and multiply the rotation error by the bone
+// lengths.  With bones under a metre and roots within 16 m of the origin that stays inside the 1e-5 parity bar with a factor to
+// spare; beyond (centimetre mocap, creatures with metre-long bones, far-away roots) a tile takes more precise rotations and a
+// translation chain in 32-bit FIXED POINT: integer adds do not round.  Both tests are ballots on values a tile loads anyway.
+constexpr float kBigOffset = 1.0f, kBigRoot = 16.0f;
+
+// Scale of the fixed-point positions of one tile: every coordinate is bounded by B = max |root| + (bound of |p_j - root|)
+// (rotations have unit rows), so with B < 2^e the words p * 2^(30-e) stay below 2^30.
+struct FxScale { float S, invS; };
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {  // NaN sticks (fmaxf would drop it)
+        const float o = __shfl_xor(v, m);
+        v = (o > v || o != o) ? o : v;
+    }
+    return v;
+}
+
+// `tbound` (wave-uniform) bounds |p_j - root| for every joint of the tile, `rmax` = this lane's |root coordinate| (0 for idle
+// lanes).  NaN / Inf anywhere make the bound non-finite and the tile stays on the plain fp32 path, which propagates them like the
+// reference.  The bound along a path is min(sum over ALL joints of |t_j|_1, depth x max_j |t_j|_1): the first is tight for chains,
+// the second for wide trees (a star of 128 thirty-unit bones: 5760 against 45 -- seven bits of the fixed-point word, which at
+// coordinates of ~46 made its resolution coarser than fp32's; found by a randomised run of the fuzz tests).
+__device__ __forceinline__ bool fx_scale(const float tbound, const float rmax, FxScale &fx) {
+    const float B = wave_max(rmax) + tbound;
+    const int e = __builtin_amdgcn_frexp_expf(B);  // B = m 2^e, m in [0.5, 1)
+    fx.S = __builtin_ldexpf(1.0f, 30 - e);
+    fx.invS = __builtin_ldexpf(1.0f, e - 30);
+    return B < 1e30f;  // false for NaN / Inf / absurd magnitudes
 }
 
 // ---- host-side helpers -------------------------------------------------------------------------------

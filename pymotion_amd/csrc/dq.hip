@@ -43,8 +43,82 @@ struct ToRootArgs {
     int64_t F;
     int32_t J;
     int32_t ablate;  // PM_TUNING build only (env PM_DQ_ABLATE): 1 = skip the walk, 2 = skip phase C; always 0 in production
+    int32_t depth;   // edges on the longest root-to-leaf path (bound of the fixed-point translations, see fx_scale)
     Parents parents;
 };
+
+// ---------------------------------------------------------------------------------------------------
+// Big-magnitude tiles (centimetre mocap, far-away roots: the test of fk.hip, kBigOffset / kBigRoot) take a PRECISE step.
+// The reference composes in float64 (skeleton.py:230-241 on float64 arrays, dual_quat.py:32) and its output multiplies the
+// running translation (hundreds of units) with the running quaternion: 0.5 (0, T_j) (x) Q_j.  An fp32 quaternion chain is
+// off by ~4e-7 after ten joints, which TIMES |T| = 400 is 4-5 ulp of the largest dual component (measured 4.3 at J = 52;
+// the accumulation of T itself is the smaller term: an emulation with a float64 quaternion chain and an fp32 translation
+// chain reads 1.6 ulp, the other way round 4.4).  So on those tiles
+//   * the quaternion chain runs in float64: lane c keeps component c as a double, the three foreign components of the
+//     parent arrive as two v_mov_b32_dpp each, and the four products are float64 FMAs (fp32 x fp32 is exact there);
+//   * a parent that is not the previous joint is re-read from the image as hi + lo, lo = an 8-bit residual in units of
+//     2^-31 packed four to a word into the slot's spare eighth float (the fp32 image alone would put back 3e-8 per branch
+//     point: 2.2 ulp at J = 52 in the same emulation);
+//   * translations accumulate in 32-bit fixed point like fk's (integer adds do not round; scale from fx_scale), which is
+//     what keeps a 128-joint chain at the bar (fp32 adds: 6.8 ulp there).
+// The step is ~45 instructions against ~32, ~17 of them at the float64 rate: the walk of such a tile takes about twice as
+// long, the tile as a whole ~20 % more.  Metre-scale tiles keep the fp32 step (their error is 6e-7 absolute).
+// ---------------------------------------------------------------------------------------------------
+template <int CTRL>  // CTRL = quad_perm selector byte: a | b << 2 | c << 4 | d << 6
+__device__ __forceinline__ double quad_perm_f64(const double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// component c of pq (x) b with pq distributed over the quad in float64 and sb_k = S[c][k] b_{c xor k} as in dq_step_math
+__device__ __forceinline__ double quad_qmul_f64(const double pq, const float b0, const float sb1, const float sb2, const float sb3) {
+    double q = quad_perm_f64<0x00>(pq) * (double)b0;
+    q = __builtin_fma(quad_perm_f64<0x55>(pq), (double)sb1, q);
+    q = __builtin_fma(quad_perm_f64<0xaa>(pq), (double)sb2, q);
+    return __builtin_fma(quad_perm_f64<0xff>(pq), (double)sb3, q);
+}
+
+// the rotation part of dq_step_math alone: x = pv x tt + pw tt, tt = 2 (pv x v)  (quat.py:320-334; w1 = 2 v_nextnext, w2 = 2 v_next)
+__device__ __forceinline__ float dq_step_rot(const float pq, const float w1, const float w2) {
+    float tt, an, ann, x;
+    asm("s_nop 1\n\t"
+        "v_mul_f32_dpp %0, %4, %5 quad_perm:[0,2,3,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, -%4, %6 quad_perm:[0,3,1,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %1, %4 quad_perm:[0,2,3,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %2, %4 quad_perm:[0,3,1,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %3, %0, %1 quad_perm:[0,3,1,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, -%0, %2 quad_perm:[0,2,3,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %4, %0 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf"
+        : "=&v"(tt), "=&v"(an), "=&v"(ann), "=&v"(x)
+        : "v"(pq), "v"(w1), "v"(w2));
+    return x;
+}
+
+// One PRECISE step for the lane holding component c (see above).  pqd: the parent's component in float64; pti: the parent's
+// fixed-point translation word.  Returns the float64 component; `qh` / `tword` are what goes into the slot: the fp32 head,
+// and the translation word -- or, on lane 0 (whose translation component is the zero scalar part), the four 8-bit residuals.
+__device__ __forceinline__ double dq_step_precise(const double pqd, const int pti, const float b, const float sb1, const float sb2,
+                                                  const float sb3, const float vc, const float w1, const float w2, const float live,
+                                                  const float S, const int c, float &qh, int &ti, int &tword) {
+    const double qd = quad_qmul_f64(pqd, b, sb1, sb2, sb3);
+    const float x = dq_step_rot((float)pqd, w1, w2);
+    ti = pti + (int)__builtin_rintf(__builtin_fmaf(live, x, vc) * S);
+    qh = (float)qd;
+    int k = (int)((qd - (double)qh) * 0x1p31);  // |residual| <= 2^-25 for |q| < 1: |k| <= 64
+    k = k < -128 ? -128 : (k > 127 ? 127 : k);
+    int pk = (k & 0xff) << (8 * c);
+    pk |= __builtin_amdgcn_mov_dpp(pk, 0xb1, 0xf, 0xf, true);  // quad_perm:[1,0,3,2]
+    pk |= __builtin_amdgcn_mov_dpp(pk, 0x4e, 0xf, 0xf, true);  // quad_perm:[2,3,0,1]
+    tword = (c == 0) ? pk : ti;
+    return qd;
+}
+
+// a parent re-read from the image: fp32 head + its 8-bit residual (units of 2^-31) out of the packed word
+__device__ __forceinline__ double dq_parent_f64(const float head, const int packed, const int c) {
+    const int k = (packed << (24 - 8 * c)) >> 24;  // sign-extended byte c
+    return __builtin_fma((double)k, 0x1p-31, (double)head);
+}
 
 // One step of the quad walk for the lane holding component c, as ONE block of 12 VALU instructions
 // with the quad exchanges folded into the DPP operand of the multiplies (these kernels sit near the

@@ -197,7 +197,7 @@ PM_OP(OpDqFromT, 3, 0, 0, 8, 0) {
 // decided by digits fp32 does not have
 PM_OP(OpO6dToMatrix, 6, 0, 0, 9, 0) {
     bool ill;
-    o6d2m(x0, a.eps, y0, &ill);
+    o6d2m(x0, y0, ill);
     if (__builtin_amdgcn_ballot_w64(ill) != 0) {
         double md[9];
         o6d2m_f64(x0, a.eps, md);
@@ -209,7 +209,7 @@ PM_OP(OpO6dToMatrix, 6, 0, 0, 9, 0) {
 PM_OP(OpO6dToQuat, 6, 0, 0, 4, 0) {
     float m[9];
     bool ill;
-    o6d2m(x0, a.eps, m, &ill);
+    o6d2m(x0, m, ill);
     m2q(m, y0);
     if (__builtin_amdgcn_ballot_w64(ill) != 0) {
         double md[9], qd[4];
@@ -499,6 +499,20 @@ template <int MODE>  // bit 0: nontemporal loads, bit 1: nontemporal stores
 __global__ __launch_bounds__(256) void plain_stream_kernel(const v4f *__restrict__ src, v4f *__restrict__ dst, int64_t n4,
                                                            int ratio) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (ratio == 0) {  // pure read: the loads feed a sum that is stored only if it comes out as a value it cannot have
+        v4f acc = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) acc += (MODE & 1) ? __builtin_nontemporal_load(src + i) : src[i];
+        if (acc.x + acc.y + acc.z + acc.w == -1.2345678e37f) dst[threadIdx.x] = acc;
+        return;
+    }
+    if (ratio < 0) {  // pure write: n4 dwordx4 of a pattern, nothing read
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            const v4f v = v4f{(float)(int)i, 1.0f, 2.0f, 3.0f};
+            if (MODE & 2) __builtin_nontemporal_store(v, dst + i);
+            else dst[i] = v;
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         const v4f v = (MODE & 1) ? __builtin_nontemporal_load(src + i) : src[i];
         const int64_t w = i >> 6, l = i & 63;
@@ -639,7 +653,7 @@ extern "C" int pm_dq_unit_flags_f32(const float *dq, int64_t N, float atol, int3
 }
 
 extern "C" int pm_stream_plain_f32(const float *src, float *dst, int64_t n4, int32_t ratio, int32_t blocks, pm_stream_t stream) {
-    PM_CHECK_ARGS(src && dst && n4 >= 0 && ratio >= 1 && blocks >= 1 && aligned16(src) && aligned16(dst), "stream_plain: bad arguments");
+    PM_CHECK_ARGS(src && dst && n4 >= 0 && ratio >= -1 && blocks >= 1 && aligned16(src) && aligned16(dst), "stream_plain: bad arguments");
     if (n4 == 0) return PM_OK;
     const int mode = tune_env("PM_PLAIN_MODE", 3);  // PM_TUNING build only: 0..3 = nontemporal {none, loads, stores, both}
     auto *s4 = reinterpret_cast<const v4f *>(src);

@@ -86,10 +86,6 @@ constexpr int fk_lds_floats() { return 12 + (PFO ? 3 : 0) + (QOUT ? 4 : 0); }
 // chain with its residuals in LDS 310-320 / 252, 0.9 / 1.4 -- but 3/4 of that cost is the LDS (occupancy), not the math.
 enum { PREC_FAST = 0, PREC_RESID = 1, PREC_F64 = 2, PREC_FX = 4, PREC_DYN = 16 };
 
-// Scale of the fixed-point positions of one tile: every coordinate is bounded by B = max |root| + sum_j |t_j|_1
-// (rotations have unit rows), so with B < 2^e the words p * 2^(30-e) stay below 2^30.
-struct FxScale { float S, invS; };
-
 template <int PREC>
 __device__ __forceinline__ void local_from_quat(const float (&qi)[4], float (&L)[9]) {
     if constexpr ((PREC & PREC_F64) != 0) {
@@ -315,7 +311,7 @@ __device__ __forceinline__ bool local_from_o6d(const float (&xx)[6], const float
     bool ill;
     if constexpr (QOUT) {
         float m[9];
-        o6d2m(xx, eps, m, &ill);
+        o6d2m(xx, m, ill);
         m2q(m, Q);
         local_from_quat<M>(Q, L);
     } else {
@@ -323,7 +319,7 @@ __device__ __forceinline__ bool local_from_o6d(const float (&xx)[6], const float
         // orthonormal matrix up to fp32 rounding (~2e-7, two orders inside the parity budget): the Gram-Schmidt
         // result IS the local rotation.  Saves ~80 VALU ops per joint.  It is NOT the identity on what Gram-Schmidt
         // returns for degenerate columns (zeros, NaN, rounding noise) -- those records are re-done (o6d_redo_ill).
-        o6d2m(xx, eps, L, &ill);
+        o6d2m(xx, L, ill);
     }
     return ill;
 }
@@ -344,40 +340,7 @@ __device__ __forceinline__ void o6d_redo_ill(const bool ill, const float (&xx)[6
     }
 }
 
-// ---- PREC_DYN: which arithmetic a tile gets -------------------------------------------------------------------
-// The fp32 walk rounds every position to an ulp of ITS magnitude once per joint, and multiplies the rotation error
-// by the bone lengths.  With bones under a metre and roots within 16 m of the origin (|p| < ~32: ulp 1.9e-6) that stays
-// inside the 1e-5 parity bar with a factor to spare; beyond, the tile takes float64 local rotations and the
-// fixed-point chain.  Both tests are ballots on values the tile has loaded anyway (joint table, root positions).
-constexpr float kBigOffset = 1.0f, kBigRoot = 16.0f;
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {  // NaN sticks (fmaxf would drop it)
-        const float o = __shfl_xor(v, m);
-        v = (o > v || o != o) ? o : v;
-    }
-    return v;
-}
-
-// `tbound` (wave-uniform) bounds |p_j - root| for every joint of the tile, `rmax` = this lane's |root coordinate| (0 for idle
-// lanes).  NaN / Inf anywhere make the bound non-finite and the tile stays on the plain fp32 path, which propagates them like the
-// reference.  The bound along a path is min(sum over ALL joints of |t_j|_1, depth x max_j |t_j|_1): the first is tight for chains,
-// the second for wide trees (a star of 128 thirty-unit bones: 5760 against 45 -- seven bits of the fixed-point word, which at
-// coordinates of ~46 made its resolution coarser than fp32's; found by a randomised run of the fuzz tests).
-__device__ __forceinline__ bool fx_scale(const float tbound, const float rmax, FxScale &fx) {
-    const float B = wave_max(rmax) + tbound;
-    const int e = __builtin_amdgcn_frexp_expf(B);  // B = m 2^e, m in [0.5, 1)
-    fx.S = __builtin_ldexpf(1.0f, 30 - e);
-    fx.invS = __builtin_ldexpf(1.0f, e - 30);
-    return B < 1e30f;  // false for NaN / Inf / absurd magnitudes
-}
-
+// ---- PREC_DYN: which arithmetic a tile gets (kBigOffset / kBigRoot, FxScale, fx_scale: common.hpp) ------------
 // fixed-point words of the position region -> fp32, in place (the region is then the output tile); n4 dwordx4
 __device__ __forceinline__ void fx_to_float(float *sPos, const int n4, const float invS, const int lane) {
     typedef int v4i __attribute__((ext_vector_type(4)));

@@ -51,6 +51,7 @@ struct IkArgs {
 // ~1e-7 by which from_to's output misses unit length) and stores it straight from registers, coalesced.
 // Joints without children keep the exact identity (:126-130).
 __host__ __device__ constexpr int ik_frame_stride(const int J) { return 4 * ((J + 1) | 1); }  // (stride / 4) odd: the lanes (= frames) of a ds_read_b128 spread over all banks
+__host__ __device__ constexpr int ik_tables_floats(const int J) { return (6 * J + 7 + 3) & ~3; }  // sOff [3 J + 3] + sTopo [3 J + 4], padded to 16 bytes
 
 // NL > 0: the pipelined form.  Loading the positions, walking and storing the rotations are three phases of comparable
 // length (2^20 x 22: 47 + 91 + 70 us when run alone) and a wave does them one after the other; with 23 KiB of image only six
@@ -77,7 +78,9 @@ __global__ __launch_bounds__(PM_WAVE, (NL > 0 && NL <= 12) ? PM_IK_MINW : ((NL >
     float *sOff = sS + FPW * FS;              // [(J + 1) * 3]  (entry J: the idle item's zero "rest direction")
     int *sTopo = reinterpret_cast<int *>(sOff + 3 * J + 3);  // [J] parent | [J+1] cstart | [J] clist
     typedef int v4i __attribute__((ext_vector_type(4)));
-    v4i *sItem = reinterpret_cast<v4i *>(sTopo + 3 * J + 4);  // [(J + 2) * C] the walk's program: {joint, parent, first child, first further child | count << 16}
+    // [(J + 2) * C] the walk's program: {joint, parent, first child, first further child | count << 16}; read and written as
+    // 16-byte words, so the tables in front of it (6 J + 7 words, an odd count) are rounded up to a 16-byte boundary
+    v4i *sItem = reinterpret_cast<v4i *>(sOff + ik_tables_floats(J));
     const float invJ = 1.0f / (float)J;
     constexpr int NR = NL > 0 ? NL : 1;
     v3f_a4 pre[NR];  // NL > 0: the next tile's position records, one 12-byte record per lane and load (coalesced dwordx3)
@@ -337,7 +340,7 @@ static int ik_schedule(const Topo16 &t, const int J, uint8_t *sched) {
 
 template <int FPW, int C>
 static int launch_ik(const IkArgs &a, bool vec, hipStream_t s) {
-    const size_t lds = ((size_t)FPW * ik_frame_stride(a.J) + 3 * a.J + 3 + 3 * a.J + 4) * sizeof(float) + (size_t)(a.J + 2) * C * 16;
+    const size_t lds = ((size_t)FPW * ik_frame_stride(a.J) + ik_tables_floats(a.J)) * sizeof(float) + (size_t)(a.J + 2) * C * 16;
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
     // records per lane of one tile -> the pipelined instantiation that holds them in registers (3 VGPRs each)
     const int nl = (FPW * a.J + PM_WAVE - 1) / PM_WAVE;
@@ -387,7 +390,7 @@ extern "C" int pm_from_root_positions_f32(const float *positions, const int32_t 
     for (int32_t j = 1; j < J; ++j) a.topo.clist[fill[p.p[j]]++] = (int16_t)j;
     const bool vec = aligned16(positions) && aligned16(rotations);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t per_frame = (size_t)ik_frame_stride(J) * sizeof(float), fixed = (size_t)(6 * J + 8) * sizeof(float) + (size_t)(J + 2) * 32 + 256;
+    const size_t per_frame = (size_t)ik_frame_stride(J) * sizeof(float), fixed = (size_t)ik_tables_floats(J) * sizeof(float) + (size_t)(J + 2) * 32 + 256;
     {
         const int v = tune_env("PM_IK_FPW", 0);  // PM_TUNING build only
         a.K = 0;

@@ -36,11 +36,16 @@ __host__ __device__ constexpr int mirror_frame_stride(const int J) { return 4 * 
 
 // from_matrix(to_matrix(g)) without the matrices: quat.py:276-317 gives the diagonal, quat.py:85-156 the branch,
 // and each branch's candidate is 4 g[dom] g; then its normalize (:155, quat.py:411-423).
+// The branch predicates are evaluated on the quaternion itself, where nothing cancels against 1 (round 2 formed the diagonal
+// 1 - 2 (yy + zz) ... in fp32 and compared those): with n = |g|^2,
+//     r22 < 0      <=>  1 - 2 (xx + yy) / n < 0          <=>  xx + yy > ww + zz
+//     r00 > r11    <=>  xx > yy                           <=>  |x| > |y|
+//     r00 < -r11   <=>  2 - 2 (xx + yy) / n - 4 zz / n < 0  <=>  ww < zz  <=>  |w| < |z|
+// so the decision is as good as g (exact comparisons of its components) and only flips against the float64 reference where
+// two components of g tie to within g's own chain error.
 __device__ __forceinline__ void canonical_sign(const float (&g)[4], float (&o)[4]) {
-    const float x2 = g[1] + g[1], y2 = g[2] + g[2], z2 = g[3] + g[3];
-    const float xx = g[1] * x2, yy = g[2] * y2, zz = g[3] * z2;
-    const float r00 = 1.0f - (yy + zz), r11 = 1.0f - (xx + zz), r22 = 1.0f - (xx + yy);
-    const float dom = (r22 < 0.0f) ? ((r00 > r11) ? g[1] : g[2]) : ((r00 < -r11) ? g[3] : g[0]);
+    const float ww = g[0] * g[0], xx = g[1] * g[1], yy = g[2] * g[2], zz = g[3] * g[3];
+    const float dom = (xx + yy > ww + zz) ? ((xx > yy) ? g[1] : g[2]) : ((ww < zz) ? g[3] : g[0]);
     const float sg = (dom < 0.0f) ? -1.0f : 1.0f;
     const float c[4] = {sg * g[0], sg * g[1], sg * g[2], sg * g[3]};
     qnormalize(c, 1e-8f, o);

@@ -105,9 +105,13 @@ def all_gather_frames(local, F_total: int, group=None, method=None):
     return _gather_mesh(local, sizes, group) if method == "mesh_send_recv" else _gather_collective(local, sizes, group)
 
 
-def sharded_apply(fn: Callable, frame_args: Sequence, F_total: int, gather: bool = True, group=None, method=None):
-    """Run ``fn(*local_frame_args)`` on this rank's frame block of each ``[F_total, ...]`` argument.
+def sharded_apply(fn: Callable, frame_args: Sequence, F_total: int, gather: bool = True, group=None, method=None,
+                  local: bool = False):
+    """Run ``fn(*local_frame_args)`` on this rank's frame block.
 
+    ``local=False``: every ``[F_total, ...]`` argument is the FULL array (or a view of it) and is sliced here.
+    ``local=True``: the arguments ARE this rank's block already (``shard_bounds(F_total, W, rank)`` frames) -- what a
+    data-parallel producer hands over, and what keeps a rank's resident input at 1/W of the batch.
     ``fn`` returns a tensor or a tuple of tensors with frames on dim 0.  With ``gather`` the
     outputs are reassembled on every rank, otherwise the local shards are returned.
     """
@@ -115,22 +119,35 @@ def sharded_apply(fn: Callable, frame_args: Sequence, F_total: int, gather: bool
 
     W, r = dist.get_world_size(group), dist.get_rank(group)
     s, e = shard_bounds(F_total, W, r)
-    out = fn(*[a[s:e] for a in frame_args])
+    if local:
+        for a in frame_args:
+            if a.shape[0] != e - s:
+                raise ValueError(f"rank {r}: local shard has {a.shape[0]} frames, shard_bounds({F_total}, {W}, {r}) says {e - s}")
+        out = fn(*frame_args)
+    else:
+        out = fn(*[a[s:e] for a in frame_args])
     outs = out if isinstance(out, tuple) else (out,)
     if gather:
         outs = tuple(all_gather_frames(o, F_total, group, method) for o in outs)
     return outs if isinstance(out, tuple) else outs[0]
 
 
-def fk_sharded(rot, global_pos, offsets, parents, gather: bool = True, group=None, fk_fn=None, method=None):
-    """``fk`` over a frame-sharded batch.  ``rot [F, J, 4]`` and ``global_pos [F, 3]`` are the FULL
-    arrays (or views of them); each rank computes only its block with the HIP kernel.
+def fk_sharded(rot, global_pos, offsets, parents, gather: bool = True, group=None, fk_fn=None, method=None, F_total=None):
+    """``fk`` over a frame-sharded batch; each rank computes only its block with the HIP kernel.
+
+    ``F_total=None``: ``rot [F, J, 4]`` and ``global_pos [F, 3]`` (and per-frame ``offsets [F, J, 3]``) are the FULL arrays
+    (or views of them) on every rank and are sliced here.
+    ``F_total=F``: they are this rank's LOCAL block of an ``F``-frame batch (``shard_bounds(F, W, rank)``): nothing but the
+    shard is ever resident on the GPU -- at config 5 (2^24 frames x 22 joints on 8 GPUs) 0.76 GB of inputs and 2.2 GB of
+    outputs per GPU instead of 6.1 GB of inputs on every one of them.
     ``fk_fn`` defaults to ``pymotion_amd.ops.skeleton_torch.fk`` (injectable for CPU/gloo tests).
     Reference semantics: pymotion/ops/skeleton_torch.py:16-66 applied per block.
     """
     if fk_fn is None:
         from .ops.skeleton_torch import fk as fk_fn
+    local = F_total is not None
+    F = int(F_total) if local else rot.shape[0]
     per_frame = offsets.dim() > 2
     if per_frame:
-        return sharded_apply(lambda r_, g_, o_: fk_fn(r_, g_, o_, parents), [rot, global_pos, offsets], rot.shape[0], gather, group, method)
-    return sharded_apply(lambda r_, g_: fk_fn(r_, g_, offsets, parents), [rot, global_pos], rot.shape[0], gather, group, method)
+        return sharded_apply(lambda r_, g_, o_: fk_fn(r_, g_, o_, parents), [rot, global_pos, offsets], F, gather, group, method, local)
+    return sharded_apply(lambda r_, g_: fk_fn(r_, g_, offsets, parents), [rot, global_pos], F, gather, group, method, local)

@@ -1,4 +1,4 @@
-"""CPU-only, world_size 2 over gloo: the frame-sharding + all-gather path of pymotion_amd.parallel.
+"""CPU-only, world sizes 2, 3 and 8 over gloo: the frame-sharding + all-gather path of pymotion_amd.parallel.
 The per-rank compute is injected (the CPU oracle stands in for the HIP kernel, as the checker),
 so what is tested here is exactly the N>1 logic: block bounds, uneven shards, reassembly order."""
 import os
@@ -66,6 +66,16 @@ def _worker(rank, world, port, F, q, method="all_gather_into_tensor"):
         parallel.set_default_gather_method(method)  # ... and the process-wide default is honoured
         p2, _ = parallel.fk_sharded(rot, root, offs, parents, gather=True, fk_fn=_oracle_fk)
         ok = ok and torch.equal(p2, _oracle_fk(rot, root, offs, parents)[0])
+        # a rank that only ever holds ITS block (F_total given): same results, nothing but the shard handed over
+        pl, rl = parallel.fk_sharded(rot[s:e].clone(), root[s:e].clone(), off, parents, gather=True, fk_fn=_oracle_fk, method=method, F_total=F)
+        ok = ok and torch.equal(pl, full_p) and torch.equal(rl, full_r)
+        pl2, _ = parallel.fk_sharded(rot[s:e].clone(), root[s:e].clone(), offs[s:e].clone(), parents, gather=False, fk_fn=_oracle_fk, F_total=F)
+        ok = ok and torch.equal(pl2, p2[s:e])
+        try:
+            parallel.fk_sharded(rot[: (e - s) + 1], root[: (e - s) + 1], off, parents, gather=False, fk_fn=_oracle_fk, F_total=F)
+            ok = False  # a block of the wrong size must be refused, not silently gathered out of place
+        except ValueError:
+            pass
         # both reassemblies give the same tensor, shard by shard
         a1 = parallel.all_gather_frames(lp, F, method="all_gather_into_tensor")
         a2 = parallel.all_gather_frames(lp, F, method="mesh_send_recv")
@@ -99,6 +109,20 @@ def test_fk_sharded_gloo_world3_with_an_empty_shard():
     """F < world: one rank owns no frames; the full-mesh gather must not post zero-size transfers"""
     _run(3, 2, "mesh_send_recv")
     _run(3, 2, "all_gather_into_tensor")
+
+
+@pytest.mark.parametrize("method", parallel.GATHER_METHODS)
+@pytest.mark.parametrize("F", [128, 203])  # even shards / five ranks with one frame more than the other three
+def test_fk_sharded_gloo_world8(F, method):
+    """the world size of the target node: the staggered peer order (r +- step) % 8 of the full-mesh gather, seven
+    sends and seven receives per rank in one group, and the padded collective with uneven shards"""
+    _run(8, F, method)
+
+
+def test_fk_sharded_gloo_world8_with_empty_shards():
+    """F = 5 < world 8: three ranks own nothing; neither method may post a zero-size transfer or wait for one"""
+    _run(8, 5, "mesh_send_recv")
+    _run(8, 5, "all_gather_into_tensor")
 
 
 def test_unknown_gather_method_is_rejected():

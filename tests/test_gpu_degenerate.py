@@ -161,6 +161,7 @@ def test_random_batch_with_sprinkled_degenerate_records_at_config4_size():
     assert bool(torch.equal(p0[clean], p1[clean])) and bool(torch.equal(r0[clean], r1[clean]))
     assert bool(torch.isfinite(r1).all())                 # torch door: zero columns never give NaN
     p2, r2 = skt.fk(o6t.to_quat(x2), root, off, par)      # the two-launch chain on the GPU
-    well = (r1 - r2).abs().amax(dim=(1, 2, 3)) < 5e-5     # (frames with an ill-conditioned record somewhere are compared loosely)
-    assert float(well.float().mean()) > 0.97
-    assert float((p1[well] - p2[well]).abs().max()) < 5e-5
+    # every frame, no conditioning allowance (round 2: 5e-5 on the 97 % best-conditioned frames; Gram-Schmidt no longer
+    # loses accuracy near (anti-)parallel columns -- common.hpp: o6d2m)
+    assert float((r1 - r2).abs().max()) < 1e-5
+    assert float((p1 - p2).abs().max()) < 1e-5

@@ -119,31 +119,32 @@ def test_config4_fused_ortho6d_fk_256k_frames_52_joints():
     off = torch.from_numpy(syn.make_offsets(52, np.random.default_rng(4), 0.15)).cuda()
     par = torch.from_numpy(syn.PARENTS_52)
     pos, rm, q = skt.fk_from_ortho6d(x, root, off, par, return_quat=True)
-    # reference chain on the GPU: ortho6d.to_quat -> fk (two launches, quats through HBM).  Gram-Schmidt
-    # amplifies fp32 rounding by 1/sin(angle between the two columns), and the two code paths contract
-    # FMAs differently: compare on frames whose every joint is reasonably conditioned.
+    # north_star's bar on ALL frames, no conditioning mask: Gram-Schmidt is evaluated as c3 = (a x b) / |a x b|, c2 = c3 x c1
+    # with Kahan's difference of products (common.hpp: o6d2m), whose error does not grow as the two columns approach
+    # (anti-)parallel (round 2 compared at 5e-5 on the frames whose every joint had |cos| < 0.999).
+    def up_to_sign(a_, b_):  # quat.from_matrix picks one of four branches: a record on a branch tie may come out negated
+        return torch.minimum((a_ - b_).abs().amax(-1), (a_ + b_).abs().amax(-1))
+
+    # (i) the reference chain on the GPU: ortho6d.to_quat -> fk (two launches, quaternions through HBM)
     q2 = o6t.to_quat(x)
     p2, r2 = skt.fk(q2, root, off, par)
-    a_, b_ = x[..., 0], x[..., 1]
-    cosang = (a_ * b_).sum(-1).abs() / (a_.norm(dim=-1) * b_.norm(dim=-1))
-    okf = (cosang < 0.99).all(dim=-1)
-    assert float(okf.float().mean()) > 0.4
-    assert float((q - q2)[okf].abs().max()) < 1e-5
-    assert float((pos - p2)[okf].abs().max()) < 1e-5 and float((rm - r2)[okf].abs().max()) < 1e-5
+    assert float(up_to_sign(q, q2).max()) < ATOL
+    assert float(((q - q2).abs().amax(-1) > ATOL).float().mean()) < 1e-5  # sign flips: only ever on branch ties
+    assert float((pos - p2).abs().max()) < ATOL and float((rm - r2).abs().max()) < ATOL
     p3, r3 = skt.fk_from_ortho6d(x, root, off, par)  # without the quaternion output: Gram-Schmidt matrix used directly
-    assert float((p3 - pos)[okf].abs().max()) < 1e-5 and float((r3 - rm)[okf].abs().max()) < 1e-5
-    assert _ortho_err(r3[okf]) < 2e-5
-    # Gram-Schmidt of random gaussians can be ill-conditioned (near-parallel columns): compare with the
-    # oracle where the conditioning is sane, and require orthonormal outputs everywhere
-    sl = slice(777, 777 + 1024)
-    xs = x[sl].cpu().numpy().astype(np.float64)
-    p_o, r_o, q_o = co.fk_from_ortho6d(xs, root[sl].cpu().numpy().astype(np.float64), off.cpu().numpy().astype(np.float64),
-                                       par.numpy(), return_quat=True)
-    a, b = xs[..., 0], xs[..., 1]
-    cosang = np.abs((a * b).sum(-1)) / (np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1))
-    ok = (cosang < 0.999).all(axis=-1)  # frames whose every joint is well conditioned
-    assert ok.mean() > 0.9
-    assert np.abs(pos[sl].cpu().numpy()[ok] - p_o[ok]).max() <= 5e-5  # 52-joint chains, |pos| up to ~3 m
-    assert np.abs(rm[sl].cpu().numpy()[ok] - r_o[ok]).max() <= 5e-5
+    assert float((p3 - pos).abs().max()) < ATOL and float((r3 - rm).abs().max()) < ATOL
+    assert _ortho_err(r3) < 1e-5
+    # (ii) the float64 oracle on slices spread over the batch, every frame of them, both variants
+    for s0 in (0, 777, F // 2 + 13, F - 4096):
+        sl = slice(s0, s0 + 4096)
+        xs = x[sl].cpu().numpy().astype(np.float64)
+        p_o, r_o, q_o = co.fk_from_ortho6d(xs, root[sl].cpu().numpy().astype(np.float64), off.cpu().numpy().astype(np.float64),
+                                           par.numpy(), return_quat=True)
+        for pp_, rr_, what in ((pos, rm, "with quaternions"), (p3, r3, "without")):
+            assert np.abs(pp_[sl].cpu().numpy() - p_o).max() <= ATOL, what
+            assert np.abs(rr_[sl].cpu().numpy() - r_o).max() <= ATOL, what
+        qg = q[sl].cpu().numpy()
+        assert np.minimum(np.abs(qg - q_o).max(-1), np.abs(qg + q_o).max(-1)).max() <= ATOL
+        assert (np.abs(qg - q_o).max(-1) > ATOL).mean() < 1e-4
     assert _ortho_err(rm) < 2e-5
     assert torch.equal(pos[:, 0, :], root)

@@ -1,0 +1,172 @@
+"""GPU: the chunked, double-buffered pipeline of the NumPy door (`_backend.pipelined_frames`).
+
+Every NumPy-door call of 48 MB or more takes it (fk, fk_from_ortho6d, to_root_dual_quat, from_root_dual_quat and every
+element-wise op): two non-blocking streams, a finisher thread, three staging slots with event reuse, pinned and device
+pools, a tapered chunk schedule.  Here the thresholds are patched down so that a small batch is cut into a dozen chunks
+(the ramp at both ends, more than three chunks per staging slot, a ragged last full chunk) and the results are compared
+bit for bit with the plain path and, to 1e-5, with the CPU oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from pymotion_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def be():
+    from pymotion_amd import _backend
+
+    return _backend
+
+
+def _chunks(be, monkeypatch, per_frame_bytes, frames_per_chunk):
+    monkeypatch.setattr(be, "_PIPE_MIN_BYTES", 1)
+    monkeypatch.setattr(be, "_PIPE_CHUNK_BYTES", per_frame_bytes * frames_per_chunk)
+
+
+def _plain(be, monkeypatch):
+    monkeypatch.setattr(be, "_PIPE_MIN_BYTES", 1 << 60)
+
+
+def _spy(be, monkeypatch):
+    """count the chunks pipelined_frames cuts a call into"""
+    seen = []
+    real = be._pipelined_frames_locked
+
+    def wrapped(F, ins, outs, launch, dev, ctx):
+        n = []
+
+        def counting(ip, op, cnt, st):
+            n.append(cnt)
+            return launch(ip, op, cnt, st)
+
+        res = real(F, ins, outs, counting, dev, ctx)
+        seen.append(n)
+        return res
+
+    monkeypatch.setattr(be, "_pipelined_frames_locked", wrapped)
+    return seen
+
+
+@pytest.mark.parametrize("per_frame_offsets", [False, True])
+def test_fk_through_a_dozen_chunks_equals_the_plain_path_bit_for_bit(be, monkeypatch, per_frame_offsets):
+    import pymotion_amd.ops.skeleton as sk
+
+    F, J = 1003, 22
+    rot, root, off, parents = syn.fk_workload(F, seed=31)
+    rot = rot.astype(np.float64)  # a cast on the way in (the reference's usual input dtype), float64 on the way out
+    offs = (off[None] * np.linspace(0.8, 1.2, F, dtype=np.float32)[:, None, None]).astype(np.float32) if per_frame_offsets else off
+    _plain(be, monkeypatch)
+    want = sk.fk(rot, root, offs, parents)
+    seen = _spy(be, monkeypatch)
+    _chunks(be, monkeypatch, 4 * (J * (16 + (3 if per_frame_offsets else 0)) + 3), 100)
+    got = sk.fk(rot, root, offs, parents)
+    assert len(seen) == 1 and len(seen[0]) >= 12 and sum(seen[0]) == F, seen
+    assert min(seen[0]) < max(seen[0]) // 4          # the ramp
+    assert len(set(seen[0])) >= 5                    # ramp sizes, full chunks and a ragged one
+    for g, w in zip(got, want):
+        assert g.dtype == np.float64 and g.shape == w.shape
+        np.testing.assert_array_equal(g, w)
+    p_o, r_o = co.fk(rot, root.astype(np.float64), offs.astype(np.float64), parents)
+    assert np.abs(got[0] - p_o).max() <= 1e-5 and np.abs(got[1] - r_o).max() <= 1e-5
+
+
+@pytest.mark.parametrize("return_quat", [False, True])
+def test_fused_ortho6d_fk_through_the_pipeline(be, monkeypatch, return_quat):
+    import pymotion_amd.ops.skeleton as sk
+
+    F, J = 701, 52
+    rng = np.random.default_rng(32)
+    x = rng.standard_normal((F, J, 3, 2)).astype(np.float32)
+    root = rng.uniform(-2, 2, (F, 3)).astype(np.float32)
+    off = syn.make_offsets(J, rng, 0.15)
+    _plain(be, monkeypatch)
+    want = sk.fk_from_ortho6d(x, root, off, syn.PARENTS_52, return_quat=return_quat)
+    seen = _spy(be, monkeypatch)
+    _chunks(be, monkeypatch, 4 * (J * 24 + 3), 64)
+    got = sk.fk_from_ortho6d(x, root, off, syn.PARENTS_52, return_quat=return_quat)
+    assert len(seen[0]) >= 10 and sum(seen[0]) == F
+    assert len(got) == (3 if return_quat else 2)
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g, w)
+    p_o, r_o, q_o = co.fk_from_ortho6d(x.astype(np.float64), root.astype(np.float64), off.astype(np.float64), syn.PARENTS_52, return_quat=True)
+    assert np.abs(got[0] - p_o).max() <= 1e-5 and np.abs(got[1] - r_o).max() <= 1e-5
+    if return_quat:
+        assert np.minimum(np.abs(got[2] - q_o).max(-1), np.abs(got[2] + q_o).max(-1)).max() <= 1e-5
+
+
+def test_dual_quaternion_encode_and_decode_through_the_pipeline(be, monkeypatch):
+    import pymotion_amd.ops.skeleton as sk
+
+    F, J = 1501, 22
+    rot, root, off, parents = syn.fk_workload(F, seed=33, normalized=True)
+    _plain(be, monkeypatch)
+    d_want = sk.to_root_dual_quat(rot, root, parents, off)
+    t_want, q_want = sk.from_root_dual_quat(d_want.astype(np.float32), parents)
+    seen = _spy(be, monkeypatch)
+    _chunks(be, monkeypatch, 4 * (J * 12 + 3), 128)
+    d = sk.to_root_dual_quat(rot, root, parents, off)
+    _chunks(be, monkeypatch, 4 * J * 15, 128)
+    t, q = sk.from_root_dual_quat(d_want.astype(np.float32), parents)
+    assert len(seen) == 2 and all(len(s) >= 10 for s in seen), seen
+    np.testing.assert_array_equal(d, d_want)
+    np.testing.assert_array_equal(t, t_want)
+    np.testing.assert_array_equal(q, q_want)
+    d_o = co.to_root_dual_quat(rot.astype(np.float64), root.astype(np.float64), parents, off.astype(np.float64))
+    assert np.abs(d - d_o).max() <= 1e-5
+    assert np.abs(q - rot).max() <= 1e-5 and np.abs(t[:, 1:] - off[1:]).max() <= 1e-5
+
+
+def test_two_input_elementwise_op_pipelined_and_a_broadcast_operand_on_the_plain_path(be, monkeypatch):
+    import pymotion_amd.rotations.quat as quat
+
+    n = 5003
+    rng = np.random.default_rng(34)
+    a = rng.standard_normal((n, 4)).astype(np.float32)
+    b = rng.standard_normal((n, 4)).astype(np.float32)
+    one = rng.standard_normal((4,)).astype(np.float32)
+    _plain(be, monkeypatch)
+    want = quat.mul(a, b)
+    want_b = quat.mul(a, one)
+    seen = _spy(be, monkeypatch)
+    _chunks(be, monkeypatch, 48, 500)
+    got = quat.mul(a, b)
+    assert len(seen) == 1 and len(seen[0]) >= 10 and sum(seen[0]) == n
+    np.testing.assert_array_equal(got, want)
+    assert np.abs(got - co.quat_mul(a.astype(np.float64), b.astype(np.float64))).max() <= 1e-5
+    # an operand that broadcasts over the batch is not expanded on the host and shipped N times: plain path, same values
+    got_b = quat.mul(a, one)
+    assert len(seen) == 1
+    np.testing.assert_array_equal(got_b, want_b)
+    np.testing.assert_array_equal(got_b, quat.mul(a, np.broadcast_to(one, a.shape).copy()))
+
+
+def test_a_launch_that_fails_mid_pipeline_gives_everything_back_and_the_next_call_works(be, monkeypatch):
+    import pymotion_amd.ops.skeleton as sk
+    from pymotion_amd import _lib
+
+    F, J = 1003, 22
+    rot, root, off, parents = syn.fk_workload(F, seed=35)
+    _chunks(be, monkeypatch, 1420, 100)
+    sk.fk(rot, root, off, parents)                    # warm: pools hold this call's staging buffers
+    be_dev_cached, be_pin_cached = be._pool.cached, be._pinned.cached
+    calls = []
+    p32 = np.ascontiguousarray(parents, dtype=np.int32)
+
+    def launch(ip, op, n, st):
+        calls.append(n)
+        if len(calls) == 4:
+            raise _lib.PmhipError(-3, "injected failure in chunk 3")
+        _lib.call("pm_fk_f32", ip[0], ip[1], ip[2], 0, p32.ctypes.data_as(C.c_void_p), n, J, op[0], op[1], st)
+
+    with pytest.raises(_lib.PmhipError, match="injected"):
+        be.pipelined_frames(F, [(rot, True), (root, True), (off, False)], [((J, 3), np.dtype(np.float64)), ((J, 3, 3), np.dtype(np.float64))], launch)
+    assert len(calls) == 4                             # nothing was submitted after the failure
+    assert be._pool.cached == be_dev_cached and be._pinned.cached == be_pin_cached   # every block went back to its pool
+    pos, rm = sk.fk(rot, root, off, parents)           # same streams, events and slots: still healthy
+    p_o, r_o = co.fk(rot.astype(np.float64), root.astype(np.float64), off.astype(np.float64), parents)
+    assert np.abs(pos - p_o).max() <= 1e-5 and np.abs(rm - r_o).max() <= 1e-5
