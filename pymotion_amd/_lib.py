@@ -18,6 +18,7 @@ VARIANT_PATHS = {
     "tuning": os.path.join(_HERE, "libpmhip_tuning.so"),
     "debug": os.path.join(_HERE, "libpmhip_debug.so"),
     "asan": os.path.join(_HERE, "libpmhip_asan.so"),  # host code under ASan + UBSan (tests/test_sanitizers.py)
+    "ab": os.path.join(_HERE, "libpmhip_ab.so"),      # scratch build for same-box A/B timing (tools/ab_build.sh); never shipped
 }
 
 PM_OK, PM_EINVAL, PM_ETOPOLOGY, PM_EHIP, PM_EUNSUPPORTED = 0, -1, -2, -3, -4

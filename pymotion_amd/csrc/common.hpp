@@ -313,19 +313,21 @@ __device__ __forceinline__ float diff_of_products(const float a, const float b, 
     return f + e;
 }
 __device__ __forceinline__ void o6d2m(const float (&x)[6], float (&m)[9], bool &ill) {
+    // (every multiply-add is spelled out: with -ffp-contract=fast the compiler fuses a * b + c or not depending on how it packs
+    // the unrolled records of a batch (v_pk_mul + v_pk_add vs v_fma), and a record's result would depend on its place in the batch)
     const float a0 = x[0], a1 = x[2], a2 = x[4], b0 = x[1], b1 = x[3], b2 = x[5];
-    const float na2 = a0 * a0 + a1 * a1 + a2 * a2;
+    const float na2 = __builtin_fmaf(a0, a0, __builtin_fmaf(a1, a1, a2 * a2));
     const float ia = __builtin_amdgcn_rsqf(na2);
     const float c10 = a0 * ia, c11 = a1 * ia, c12 = a2 * ia;
     const float n0 = diff_of_products(a1, b2, a2, b1), n1 = diff_of_products(a2, b0, a0, b2), n2 = diff_of_products(a0, b1, a1, b0);
-    const float nn2 = n0 * n0 + n1 * n1 + n2 * n2;
+    const float nn2 = __builtin_fmaf(n0, n0, __builtin_fmaf(n1, n1, n2 * n2));
     const float in = __builtin_amdgcn_rsqf(nn2);
     const float c30 = n0 * in, c31 = n1 * in, c32 = n2 * in;
-    m[0] = c10; m[1] = c31 * c12 - c32 * c11; m[2] = c30;
-    m[3] = c11; m[4] = c32 * c10 - c30 * c12; m[5] = c31;
-    m[6] = c12; m[7] = c30 * c11 - c31 * c10; m[8] = c32;
+    m[0] = c10; m[1] = __builtin_fmaf(c31, c12, -(c32 * c11)); m[2] = c30;
+    m[3] = c11; m[4] = __builtin_fmaf(c32, c10, -(c30 * c12)); m[5] = c31;
+    m[6] = c12; m[7] = __builtin_fmaf(c30, c11, -(c31 * c10)); m[8] = c32;
     // (the reference's floors max(norm, eps) only ever decide records that are `ill`)
-    const float nb2 = b0 * b0 + b1 * b1 + b2 * b2;
+    const float nb2 = __builtin_fmaf(b0, b0, __builtin_fmaf(b1, b1, b2 * b2));
     ill = !(na2 > 1e-12f && na2 < 1e18f) || !(nb2 > 1e-12f && nb2 < 1e18f) || !(nn2 > 1e-12f * (na2 * nb2));
 }
 
@@ -447,6 +449,9 @@ __device__ __forceinline__ void from_to_axis(const float (&v1)[3], const float (
     from_to_axis_unit(a, b, axis, o);
 }
 
+template <int V>
+struct IntC { static constexpr int value = V; };  // a compile-time int as a function argument (generic lambdas)
+
 // ---- big-magnitude tiles: when fp32 roundings of |p| matter, and the fixed-point translation chain (fk.hip, dq.hip) -------
 // The fp32 walks round every position to an ulp of ITS magnitude once per joint and multiply the rotation error by the bone
 // lengths.  With bones under a metre and roots within 16 m of the origin that stays inside the 1e-5 parity bar with a factor to
@@ -458,19 +463,29 @@ constexpr float kBigOffset = 1.0f, kBigRoot = 16.0f;
 // (rotations have unit rows), so with B < 2^e the words p * 2^(30-e) stay below 2^30.
 struct FxScale { float S, invS; };
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    return v;
+// Wave-wide sum / maximum, the result in a scalar register.  Register-to-register: four DPP steps reduce every row of 16
+// lanes (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror), four v_readlane pick up the rows.  (The __shfl_xor
+// ladder these replace is six dependent ds_bpermute round trips: ~1000 cycles per reduction on a wave that waits for it.)
+template <class Op>
+__device__ __forceinline__ float wave_reduce(float v, Op op) {
+    v = op(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xb1, 0xf, 0xf, true)));
+    v = op(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4e, 0xf, 0xf, true)));
+    v = op(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xf, 0xf, true)));  // row_half_mirror
+    v = op(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xf, 0xf, true)));  // row_mirror
+    const int b = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16)),
+                r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+    return op(op(r0, r1), op(r2, r3));
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {  // NaN sticks (fmaxf would drop it)
-        const float o = __shfl_xor(v, m);
-        v = (o > v || o != o) ? o : v;
-    }
-    return v;
+__device__ __forceinline__ float wave_sum(const float v) {
+    return wave_reduce(v, [](const float a, const float b) { return a + b; });
 }
+__device__ __forceinline__ float wave_max(const float v) {  // NaN sticks (fmaxf would drop it)
+    return wave_reduce(v, [](const float a, const float b) { return (b > a || b != b) ? b : a; });
+}
+
+// a wave-uniform float that the compiler cannot prove uniform (it came out of a cross-lane reduction): into a scalar register
+__device__ __forceinline__ float uniform_f32(const float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
 // `tbound` (wave-uniform) bounds |p_j - root| for every joint of the tile, `rmax` = this lane's |root coordinate| (0 for idle
 // lanes).  NaN / Inf anywhere make the bound non-finite and the tile stays on the plain fp32 path, which propagates them like the

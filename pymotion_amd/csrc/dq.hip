@@ -73,9 +73,14 @@ __device__ __forceinline__ double quad_perm_f64(const double v) {
 
 // component c of pq (x) b with pq distributed over the quad in float64 and sb_k = S[c][k] b_{c xor k} as in dq_step_math
 __device__ __forceinline__ double quad_qmul_f64(const double pq, const float b0, const float sb1, const float sb2, const float sb3) {
+    // (one term at a time: left to itself the compiler moves all eight exchanges and the four conversions to the top, and the
+    // sixteen registers that takes set the budget of the whole kernel)
     double q = quad_perm_f64<0x00>(pq) * (double)b0;
+    asm volatile("" : "+v"(q));
     q = __builtin_fma(quad_perm_f64<0x55>(pq), (double)sb1, q);
+    asm volatile("" : "+v"(q));
     q = __builtin_fma(quad_perm_f64<0xaa>(pq), (double)sb2, q);
+    asm volatile("" : "+v"(q));
     return __builtin_fma(quad_perm_f64<0xff>(pq), (double)sb3, q);
 }
 
@@ -95,9 +100,19 @@ __device__ __forceinline__ float dq_step_rot(const float pq, const float w1, con
     return x;
 }
 
+// What a precise step leaves in the translation word of its slot: the fixed-point translation -- or, on lane 0 (whose
+// translation component is the zero scalar part), the four 8-bit residuals qd - qh of the quad in units of 2^-31.
+__device__ __forceinline__ int dq_pack_residual(const double qd, const float qh, const int ti, const int c) {
+    int k = (int)((qd - (double)qh) * 0x1p31);  // |residual| <= 2^-25 for |q| < 1: |k| <= 64
+    k = k < -128 ? -128 : (k > 127 ? 127 : k);
+    int pk = (k & 0xff) << (8 * c);
+    pk |= __builtin_amdgcn_mov_dpp(pk, 0xb1, 0xf, 0xf, true);  // quad_perm:[1,0,3,2]
+    pk |= __builtin_amdgcn_mov_dpp(pk, 0x4e, 0xf, 0xf, true);  // quad_perm:[2,3,0,1]
+    return (c == 0) ? pk : ti;
+}
+
 // One PRECISE step for the lane holding component c (see above).  pqd: the parent's component in float64; pti: the parent's
-// fixed-point translation word.  Returns the float64 component; `qh` / `tword` are what goes into the slot: the fp32 head,
-// and the translation word -- or, on lane 0 (whose translation component is the zero scalar part), the four 8-bit residuals.
+// fixed-point translation word.  Returns the float64 component; `qh` / `tword` are what goes into the slot.
 __device__ __forceinline__ double dq_step_precise(const double pqd, const int pti, const float b, const float sb1, const float sb2,
                                                   const float sb3, const float vc, const float w1, const float w2, const float live,
                                                   const float S, const int c, float &qh, int &ti, int &tword) {
@@ -105,12 +120,7 @@ __device__ __forceinline__ double dq_step_precise(const double pqd, const int pt
     const float x = dq_step_rot((float)pqd, w1, w2);
     ti = pti + (int)__builtin_rintf(__builtin_fmaf(live, x, vc) * S);
     qh = (float)qd;
-    int k = (int)((qd - (double)qh) * 0x1p31);  // |residual| <= 2^-25 for |q| < 1: |k| <= 64
-    k = k < -128 ? -128 : (k > 127 ? 127 : k);
-    int pk = (k & 0xff) << (8 * c);
-    pk |= __builtin_amdgcn_mov_dpp(pk, 0xb1, 0xf, 0xf, true);  // quad_perm:[1,0,3,2]
-    pk |= __builtin_amdgcn_mov_dpp(pk, 0x4e, 0xf, 0xf, true);  // quad_perm:[2,3,0,1]
-    tword = (c == 0) ? pk : ti;
+    tword = dq_pack_residual(qd, qh, ti, c);
     return qd;
 }
 
@@ -172,6 +182,8 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
     const int wl = lane % (4 * FPW);
     const int fq = wl >> 2, c = wl & 3;
     const float rp = (c > 0 && fq < nf) ? a.root_pos[(f0 + fq) * 3 + c - 1] : 0.0f;  // (0, root_pos) component c
+    bool tbig = false;                 // a bone of a metre or more (or NaN) somewhere in the table: see kBigOffset
+    float tsum = 0.0f, tmx = 0.0f;     // sum / max over the joints of |t_j|_1 (this lane's share; NaN sticks)
     for (int i = lane; i < 4 * (J + 3); i += PM_WAVE) {  // the joint table: offsets in the form each lane column consumes
         const int j = i >> 2, cc = i & 3, jc = j < J ? j : J - 1;
         const float o[3] = {a.offsets[3 * jc], a.offsets[3 * jc + 1], a.offsets[3 * jc + 2]};
@@ -181,6 +193,12 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
             vc = o[cur]; w1 = 2.0f * o[nn]; w2 = 2.0f * o[nx];
         }
         sTab[3 * i] = vc; sTab[3 * i + 1] = w1; sTab[3 * i + 2] = w2;
+        if (cc == 0 && j < J) {
+            const float l1 = fabsf(o[0]) + fabsf(o[1]) + fabsf(o[2]);
+            tbig = tbig || !(fabsf(o[0]) < kBigOffset) || !(fabsf(o[1]) < kBigOffset) || !(fabsf(o[2]) < kBigOffset);
+            tsum += l1;
+            tmx = (l1 > tmx || l1 != l1) ? l1 : tmx;
+        }
     }
     for (int j = lane; j <= J; j += PM_WAVE) {
         // joints hanging off the root stay local (skeleton.py:236-237) = composed with the identity slot;
@@ -241,37 +259,65 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
     struct Regs { float b, vc, w1, w2; };
     Regs A = {oq[0], rp, 0.0f, 0.0f};                     // the root: "offset" = root position (skeleton.py:232)
     Regs B = {oq[8], tb[12], tb[13], tb[14]};
+    // which arithmetic this tile gets (wave-uniform; see "Big-magnitude tiles" above)
+    bool precise = false;
+    FxScale fx = {1.0f, 1.0f};
+    // (a NaN / Inf QUATERNION needs no special case: it makes the float64 chain of its joint and of every descendant NaN in all
+    // four components, and the dual part 0.5 (0,t) (x) q with them, whatever the fixed-point words hold -- the reference's pattern)
+    if (__builtin_amdgcn_ballot_w64(tbig || !(fabsf(rp) < kBigRoot)) != 0) {
+        const float bsum = wave_sum(tsum), bmax = (float)a.depth * wave_max(tmx);  // (NaN sticks in both)
+        precise = fx_scale((bmax < bsum) ? bmax : bsum, fabsf(rp), fx);            // false for a non-finite bound: fp32 step
+    }
     float gq = 0.0f, gt = 0.0f;                           // previous joint, root space
+    double gqd = 0.0;                                     // precise: the same quaternion component in float64
     float peqA = (c == 0) ? 1.0f : 0.0f, petA = 0.0f, peqB = 0.0f, petB = 0.0f;  // the root composes with the identity
+    int pelA = 0, pelB = 0;                               // precise: the parent slot's packed residuals
+    const int *fDl = reinterpret_cast<const int *>(fD + 7);
     int par = J;
-    auto step = [&](const int j, const int o, const int parn, Regs &S, const float peq, const float pet, float &peqn,
-                    float &petn, const bool may_be_dummy) {
+    auto step = [&](auto tag, const int j, const int o, const int parn, Regs &S, const float peq, const float pet, const int pel,
+                    float &peqn, float &petn, int &peln, const bool may_be_dummy) {
+        constexpr bool PRECISE = decltype(tag)::value != 0;
         peqn = fDq[parn * 8];  // parent of joint j+1, if it is not joint j itself (then: a stale value, unused)
         petn = fDt[parn * 8];
+        if (PRECISE) peln = fDl[parn * 8];
         const float sb1 = quad_perm_mul<1, 0, 3, 2>(S.b, s1), sb2 = quad_perm_mul<2, 3, 0, 1>(S.b, s2),
                     sb3 = quad_perm_mul<3, 2, 1, 0>(S.b, s3);
         const bool chain = (par == j - 1);  // wave-uniform
-        const float pq = chain ? gq : peq, pt = chain ? gt : pet;
-        const float s = S.vc + pt;
         float q, t;
-        dq_step_math(pq, s, S.b, sb1, sb2, sb3, S.w1, S.w2, live, q, t);
+        if constexpr (PRECISE) {
+            const double pqd = chain ? gqd : dq_parent_f64(peq, pel, c);
+            const int pti = __float_as_int(chain ? gt : pet);
+            int ti, tw;
+            gqd = dq_step_precise(pqd, pti, S.b, sb1, sb2, sb3, S.vc, S.w1, S.w2, live, fx.S, c, q, ti, tw);
+            gt = __int_as_float(ti);
+            t = __int_as_float(tw);
+        } else {
+            const float pq = chain ? gq : peq, pt = chain ? gt : pet;
+            const float s = S.vc + pt;
+            dq_step_math(pq, s, S.b, sb1, sb2, sb3, S.w1, S.w2, live, q, t);
+            gq = q; gt = t;
+        }
         if (!may_be_dummy || j < J) { oq[o] = q; ot[o] = t; }  // slot <- root-space (q, t, 0)
         S.b = oq[o + 16];                                      // joint j+2: its slot still holds the input quaternion
         S.vc = tb[(o >> 3) * 12 + 24]; S.w1 = tb[(o >> 3) * 12 + 25]; S.w2 = tb[(o >> 3) * 12 + 26];
-        gq = q; gt = t; par = parn;
+        par = parn;
     };
-    for (int jb = PM_ABLATED(a, 1) ? J : 0; jb < J; jb += PM_WAVE) {
-        // effective parents of joints jb+1 .. jb+64 across the lanes: one v_readlane per step
-        const int i0 = jb + 1 + lane;
-        const int pv = sPar[i0 < J ? i0 : J];
-        const int jend = (J - jb) < PM_WAVE ? (J - jb) : PM_WAVE;
-        asm volatile("" ::"v"(pv));  // settle the window load here, not as an lgkmcnt(0) inside the loop
-        for (int jj = 0; jj < jend; jj += 2) {  // pairs; for odd J the very last step is a dummy that stores nothing
-            step(jb + jj, 0, __builtin_amdgcn_readlane(pv, jj), A, peqA, petA, peqB, petB, false);
-            step(jb + jj + 1, 8, __builtin_amdgcn_readlane(pv, jj + 1), B, peqB, petB, peqA, petA, true);
-            oq += 16; ot += 16; tb += 24;
+    auto walk = [&](auto tag) {
+        for (int jb = PM_ABLATED(a, 1) ? J : 0; jb < J; jb += PM_WAVE) {
+            // effective parents of joints jb+1 .. jb+64 across the lanes: one v_readlane per step
+            const int i0 = jb + 1 + lane;
+            const int pv = sPar[i0 < J ? i0 : J];
+            const int jend = (J - jb) < PM_WAVE ? (J - jb) : PM_WAVE;
+            asm volatile("" ::"v"(pv));  // settle the window load here, not as an lgkmcnt(0) inside the loop
+            for (int jj = 0; jj < jend; jj += 2) {  // pairs; for odd J the very last step is a dummy that stores nothing
+                step(tag, jb + jj, 0, __builtin_amdgcn_readlane(pv, jj), A, peqA, petA, pelA, peqB, petB, pelB, false);
+                step(tag, jb + jj + 1, 8, __builtin_amdgcn_readlane(pv, jj + 1), B, peqB, petB, pelB, peqA, petA, pelA, true);
+                oq += 16; ot += 16; tb += 24;
+            }
         }
-    }
+    };
+    if (precise) walk(IntC<1>{});
+    else walk(IntC<0>{});
     wave_sync();
     // phase C, lane per (frame, joint): (q, t) -> [q, 0.5 (0,t) (x) q]  (dual_quat.py:28-36), off the chain
     for_each_slot<2>(PM_ABLATED(a, 2) ? 0 : n, lane, [&](const int e, const bool valid) {
@@ -280,6 +326,10 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
         float *slot = sDq + f * FS + j * 8;
         float qt[8], d[8];
         lds_get<8>(slot, 0, qt);
+        if (precise) {  // wave-uniform: the translation words are fixed point
+#pragma unroll
+            for (int k = 4; k < 7; ++k) qt[k] = (float)__float_as_int(qt[k]) * fx.invS;
+        }
         const float q[4] = {qt[0], qt[1], qt[2], qt[3]}, t[3] = {qt[4], qt[5], qt[6]};
         rt2dq(q, t, d);
         if (valid) *reinterpret_cast<v4f *>(slot + 4) = v4f{d[4], d[5], d[6], d[7]};
@@ -343,6 +393,7 @@ struct SchedArgs {
     int64_t F;
     int32_t J;
     int32_t K;                       // steps
+    int32_t depth;                   // edges on the longest root-to-leaf path (fixed-point bound of the precise step)
     int16_t parent[kSchedMaxJoints + 2];
     uint8_t sched[kSchedMax];        // [K][C]: joint index, 255 = idle
 };
@@ -369,15 +420,30 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_sched_kernel(const SchedAr
     // (Staging the raw constants through LDS first, so that the tile pays one memory latency instead of one per table
     // batch, was measured and is SLOWER -- 150 -> 178 us at J = 52: with ~9 resident waves the latencies are hidden anyway and
     // the kernel is bound by instruction issue, which the extra LDS round trip adds to.)
+    bool tbig_l = false;               // a bone of a metre or more (or NaN) in the table: see kBigOffset
+    float tsum_l = 0.0f, tmx_l = 0.0f; // sum / max over the joints of |t_j|_1 (this lane's share; NaN sticks)
     for (int i = lane; i < 4 * (J + 2); i += PM_WAVE) {  // the joint table, as in to_root_dq_kernel; row 0 is zero (skeleton.py:227)
         const int j = i >> 2, cc = i & 3;
         float vc = 0.0f, w1 = 0.0f, w2 = 0.0f;
-        if (cc > 0 && j > 0 && j < J) {
+        if (j > 0 && j < J) {
             const float o[3] = {a.offsets[3 * j], a.offsets[3 * j + 1], a.offsets[3 * j + 2]};
-            const int cur = cc - 1, nx = cur == 2 ? 0 : cur + 1, nn = nx == 2 ? 0 : nx + 1;
-            vc = o[cur]; w1 = 2.0f * o[nn]; w2 = 2.0f * o[nx];
+            if (cc > 0) {
+                const int cur = cc - 1, nx = cur == 2 ? 0 : cur + 1, nn = nx == 2 ? 0 : nx + 1;
+                vc = o[cur]; w1 = 2.0f * o[nn]; w2 = 2.0f * o[nx];
+            } else {
+                const float l1 = fabsf(o[0]) + fabsf(o[1]) + fabsf(o[2]);
+                tbig_l = tbig_l || !(fabsf(o[0]) < kBigOffset) || !(fabsf(o[1]) < kBigOffset) || !(fabsf(o[2]) < kBigOffset);
+                tsum_l += l1;
+                tmx_l = (l1 > tmx_l || l1 != l1) ? l1 : tmx_l;
+            }
         }
         sTab[3 * i] = vc; sTab[3 * i + 1] = w1; sTab[3 * i + 2] = w2;
+    }
+    const bool tbig = __builtin_amdgcn_ballot_w64(tbig_l) != 0;  // per workgroup: the table is shared by its tiles
+    float tbound;
+    {
+        const float bsum = wave_sum(tsum_l), bmax = (float)a.depth * wave_max(tmx_l);  // (NaN sticks in both)
+        tbound = uniform_f32((bmax < bsum) ? bmax : bsum);  // keep it out of the vector registers
     }
     for (int i = lane; i < (K + 2) * C; i += PM_WAVE) {  // the program; two idle steps of slack for the look-ahead
         const int st = i / C, kk = i - st * C;
@@ -448,8 +514,16 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_sched_kernel(const SchedAr
     const char *bq = reinterpret_cast<const char *>(fD + c), *bt = reinterpret_cast<const char *>(fD + toff);
     const char *btab = reinterpret_cast<const char *>(sTab + 3 * c);
     const v4i *prog = sProg + k;
-    struct In { float b, vc, w1, w2, peq, pet; v4i e; };
-    auto fetch = [&](const v4i e, In &x, const bool root_lane) {
+    // which arithmetic this tile gets (wave-uniform; "Big-magnitude tiles" above)
+    bool precise = false;
+    FxScale fx = {1.0f, 1.0f};
+    if (tbig || __builtin_amdgcn_ballot_w64(!(fabsf(rp) < kBigRoot)) != 0)
+        precise = fx_scale(tbound, (k == 0) ? fabsf(rp) : 0.0f, fx);  // false for a non-finite bound: fp32 step
+    fx.S = uniform_f32(fx.S);
+    fx.invS = uniform_f32(fx.invS);
+    const char *bl = reinterpret_cast<const char *>(fD + 7);  // precise: a slot's packed residuals
+    struct In { float b, vc, w1, w2, peq, pet; int pel; v4i e; };
+    auto fetch = [&](auto tag, const v4i e, In &x, const bool root_lane) {
         x.e = e;
         x.b = *reinterpret_cast<const float *>(bq + e.x);
         const float *row = reinterpret_cast<const float *>(btab + e.z);
@@ -457,35 +531,79 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_sched_kernel(const SchedAr
         if (root_lane) x.vc = rp;  // the root's "offset" is the frame's root position (skeleton.py:232)
         x.peq = *reinterpret_cast<const float *>(bq + e.y);
         x.pet = *reinterpret_cast<const float *>(bt + e.y);
+        if (decltype(tag)::value != 0) x.pel = *reinterpret_cast<const int *>(bl + e.y);
     };
     float gq = 0.0f, gt = 0.0f;  // what this quad produced in the previous step
-    auto step = [&](const In &x) {
+    double gqd = 0.0;            // precise: the same quaternion component in float64
+    auto step = [&](auto tag, const In &x) {
         const float sb1 = quad_perm_mul<1, 0, 3, 2>(x.b, s1), sb2 = quad_perm_mul<2, 3, 0, 1>(x.b, s2),
                     sb3 = quad_perm_mul<3, 2, 1, 0>(x.b, s3);
         const bool chain = x.e.w != 0;
-        const float pq = chain ? gq : x.peq, pt = chain ? gt : x.pet;
-        const float s = x.vc + pt;
         float q, t;
-        dq_step_math(pq, s, x.b, sb1, sb2, sb3, x.w1, x.w2, live, q, t);
+        if constexpr (decltype(tag)::value != 0) {
+            const double pqd = chain ? gqd : dq_parent_f64(x.peq, x.pel, c);
+            const int pti = __float_as_int(chain ? gt : x.pet);
+            int ti, tw;
+            gqd = dq_step_precise(pqd, pti, x.b, sb1, sb2, sb3, x.vc, x.w1, x.w2, live, fx.S, c, q, ti, tw);
+            gt = __int_as_float(ti);
+            t = __int_as_float(tw);
+        } else {
+            const float pq = chain ? gq : x.peq, pt = chain ? gt : x.pet;
+            const float s = x.vc + pt;
+            dq_step_math(pq, s, x.b, sb1, sb2, sb3, x.w1, x.w2, live, q, t);
+            gq = q; gt = t;
+        }
         *reinterpret_cast<float *>(const_cast<char *>(bq) + x.e.x) = q;
         *reinterpret_cast<float *>(const_cast<char *>(bt) + x.e.x) = t;
-        gq = q; gt = t;
     };
     // The root (joint 0) is always the first entry of chain 0 (the scheduler puts it there).
-    In A, B;
-    fetch(prog[0], A, k == 0);
-    v4i en = prog[C];
-    for (int st = 0; st < K; st += 2) {
-        // operands of step st+1 are requested before step st computes: a parent finished at step st-1 or earlier is in its
-        // slot by now (in-order DS), one finished at step st is this quad's own register chain (the scheduler guarantees it)
-        fetch(en, B, false);
-        en = prog[(st + 2) * C];
-        step(A);
-        if (st + 1 >= K) break;
-        fetch(en, A, false);
-        en = prog[(st + 3) * C];
-        step(B);
-    }
+    auto walk = [&](auto tag) {
+        if constexpr (decltype(tag)::value != 0) {
+            // precise: one step at a time, every operand fetched where it is used (quaternion chain first, then the table row
+            // and the translation).  The two-steps-ahead ping-pong of the fp32 walk, in float64, sets the register budget of the
+            // WHOLE kernel: 110 VGPRs = four waves per SIMD instead of five, 210 -> 228 us on metre-scale data that never
+            // takes this path; so does anything over 96 here.
+            int gti = 0;
+#pragma clang loop unroll(disable)
+            for (int st = 0; st < K; ++st) {
+                const v4i e = prog[st * C];
+                const float b = *reinterpret_cast<const float *>(bq + e.x);
+                const float sb1 = quad_perm_mul<1, 0, 3, 2>(b, s1), sb2 = quad_perm_mul<2, 3, 0, 1>(b, s2), sb3 = quad_perm_mul<3, 2, 1, 0>(b, s3);
+                const bool chain = e.w != 0;
+                double pqd = gqd;
+                if (!chain) pqd = dq_parent_f64(*reinterpret_cast<const float *>(bq + e.y), *reinterpret_cast<const int *>(bl + e.y), c);
+                double qd = quad_qmul_f64(pqd, b, sb1, sb2, sb3);
+                float pqf = (float)pqd;
+                asm volatile("" : "+v"(qd), "+v"(pqf));  // the quaternion part is done before the translation's operands are fetched
+                const float *row = reinterpret_cast<const float *>(btab + e.z);
+                const float vc = (st == 0 && k == 0) ? rp : row[0];  // the root's "offset" is the frame's root position (skeleton.py:232)
+                const int pti = chain ? gti : *reinterpret_cast<const int *>(bt + e.y);
+                const float x = dq_step_rot(pqf, row[1], row[2]);
+                const int ti = pti + (int)__builtin_rintf(__builtin_fmaf(live, x, vc) * fx.S);
+                const float qh = (float)qd;
+                *reinterpret_cast<float *>(const_cast<char *>(bq) + e.x) = qh;
+                *reinterpret_cast<int *>(const_cast<char *>(bt) + e.x) = dq_pack_residual(qd, qh, ti, c);
+                gqd = qd; gti = ti;
+            }
+            return;
+        }
+        In A, B;
+        fetch(tag, prog[0], A, k == 0);
+        v4i en = prog[C];
+        for (int st = 0; st < K; st += 2) {
+            // operands of step st+1 are requested before step st computes: a parent finished at step st-1 or earlier is in its
+            // slot by now (in-order DS), one finished at step st is this quad's own register chain (the scheduler guarantees it)
+            fetch(tag, en, B, false);
+            en = prog[(st + 2) * C];
+            step(tag, A);
+            if (st + 1 >= K) break;
+            fetch(tag, en, A, false);
+            en = prog[(st + 3) * C];
+            step(tag, B);
+        }
+    };
+    if (precise) walk(IntC<1>{});
+    else walk(IntC<0>{});
     wave_sync();
     // phase C, lane per (frame, joint): (q, t) -> [q, 0.5 (0,t) (x) q]  (dual_quat.py:28-36), off the chain
     for_each_slot<2>(n, lane, [&](const int e, const bool valid) {
@@ -494,6 +612,10 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_sched_kernel(const SchedAr
         float *slot = sDq + f * FS + j * 8;
         float qt[8], d[8];
         lds_get<8>(slot, 0, qt);
+        if (precise) {  // wave-uniform: the translation words are fixed point
+#pragma unroll
+            for (int kk = 4; kk < 7; ++kk) qt[kk] = (float)__float_as_int(qt[kk]) * fx.invS;
+        }
         const float q[4] = {qt[0], qt[1], qt[2], qt[3]}, t[3] = {qt[4], qt[5], qt[6]};
         rt2dq(q, t, d);
         if (valid) *reinterpret_cast<v4f *>(slot + 4) = v4f{d[4], d[5], d[6], d[7]};
@@ -709,6 +831,14 @@ extern "C" int pm_to_root_dq_f32(const float *rot, const float *root_pos, const 
     a.rot = rot; a.root_pos = root_pos; a.offsets = offsets; a.dq = dq; a.F = F; a.J = J;
     a.ablate = tune_env("PM_DQ_ABLATE", 0);
     if (int e = pack_parents(parents, J, a.parents)) return e;
+    {
+        int dep[PM_MAX_JOINTS];
+        a.depth = 0;
+        for (int32_t j = 0; j < J; ++j) {
+            dep[j] = (j == 0) ? 0 : dep[a.parents.p[j]] + 1;
+            if (dep[j] > a.depth) a.depth = dep[j];
+        }
+    }
     const bool vec = aligned16(rot) && aligned16(dq);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t per_frame = (size_t)to_root_frame_stride(J) * sizeof(float), fixed = (13 * (size_t)J + 37) * sizeof(float) + 256;
@@ -739,6 +869,7 @@ extern "C" int pm_to_root_dq_f32(const float *rot, const float *root_pos, const 
         if (use) {
             sa.rot = rot; sa.root_pos = root_pos; sa.offsets = offsets; sa.dq = dq; sa.F = F; sa.J = J;
             sa.K = use == 2 ? K2 : K4;
+            sa.depth = a.depth;
             memcpy(sa.sched, use == 2 ? s2 : s4, (size_t)sa.K * use);
             for (int j = 0; j < J; ++j) sa.parent[j] = (int16_t)a.parents.p[j];
             if (sched_lds_bytes(J, sa.K, use) <= kMaxLds) return use == 2 ? launch_to_root_sched<2>(sa, vec, s) : launch_to_root_sched<4>(sa, vec, s);

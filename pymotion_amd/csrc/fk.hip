@@ -404,9 +404,6 @@ __device__ __forceinline__ void image_load(const float *__restrict__ g, float *l
     }
 }
 
-template <int V>
-struct IntC { static constexpr int value = V; };
-
 // |t_j|_1 of a joint-table entry (what it adds to the position bound) and whether it trips the "big" test
 __device__ __forceinline__ float const_l1(const v4f c) { return fabsf(c.y) + fabsf(c.z) + fabsf(c.w); }
 __device__ __forceinline__ bool const_is_big(const v4f c) {

@@ -88,11 +88,13 @@ def mirror():
 
 
 def dq():
-    for J in (22, 52, 128):
+    for J in (22, 52, 128, 12, 31, 96):
         parents = {22: syn.PARENTS_22, 52: syn.PARENTS_52}.get(J)
-        if parents is None:
+        if parents is None and J in (128, 12):
             parents = np.arange(-1, J - 1)
             parents[0] = 0
+        elif parents is None:
+            parents = syn.random_parents(J, np.random.default_rng(J))
         for osc, rsc in ((0.3, 2.0), (30.0, 200.0)):
             rng = np.random.default_rng(J)
             F = 6001

@@ -125,6 +125,11 @@ def main():
             report(f"to_root_dq J={J}", ms, mn, Fj * (48 * J + 12))
             ms, mn = timeit(lambda: _lib.call("pm_from_root_dq_f32", p(dq), pp, Fj, J, p(tr), p(qo), None))
             report(f"from_root_dq J={J}", ms, mn, Fj * 60 * J)
+            off_cm = off * 100.0
+            root_cm = root * 100.0
+            ms, mn = timeit(lambda: _lib.call("pm_to_root_dq_f32", p(rotn), p(root_cm), pp, p(off_cm), Fj, J, p(dq), None))
+            report(f"to_root_dq, centimetre-scale J={J}", ms, mn, Fj * (48 * J + 12))
+            del off_cm, root_cm
         if want("mirror"):
             ms, mn = timeit(lambda: _lib.call("pm_mirror_rotations_f32", p(rotn), pp, None, 0, Fj, J, p(qo), None))
             report(f"mirror (all) J={J}", ms, mn, Fj * 32 * J)
