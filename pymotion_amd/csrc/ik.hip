@@ -51,7 +51,7 @@ struct IkArgs {
 // ~1e-7 by which from_to's output misses unit length) and stores it straight from registers, coalesced.
 // Joints without children keep the exact identity (:126-130).
 __host__ __device__ constexpr int ik_frame_stride(const int J) { return 4 * ((J + 1) | 1); }  // (stride / 4) odd: the lanes (= frames) of a ds_read_b128 spread over all banks
-__host__ __device__ constexpr int ik_tables_floats(const int J) { return (6 * J + 7 + 3) & ~3; }  // sOff [3 J + 3] + sTopo [3 J + 4], padded to 16 bytes
+__host__ __device__ constexpr int ik_tables_floats(const int J) { return 8 * (J + 1) + ((3 * J + 4 + 3) & ~3); }  // sOff [8 (J + 1)] + sTopo [3 J + 4], padded to 16 bytes
 
 // NL > 0: the pipelined form.  Loading the positions, walking and storing the rotations are three phases of comparable
 // length (2^20 x 22: 47 + 91 + 70 us when run alone) and a wave does them one after the other; with 23 KiB of image only six
@@ -75,8 +75,8 @@ __global__ __launch_bounds__(PM_WAVE, (NL > 0 && NL <= 12) ? PM_IK_MINW : ((NL >
     if (group < 0) return;
     const int FS = ik_frame_stride(J);
     float *sS = smem;                         // [FPW * FS]  slot (f, j): position, then world quaternion
-    float *sOff = sS + FPW * FS;              // [(J + 1) * 3]  (entry J: the idle item's zero "rest direction")
-    int *sTopo = reinterpret_cast<int *>(sOff + 3 * J + 3);  // [J] parent | [J+1] cstart | [J] clist
+    float *sOff = sS + FPW * FS;              // [(J + 1) * 8]  rest offset u of a joint {u0, u1, u2, |u|^2, 1 / |u|, -, -, -} (entry J: the idle item's zeros)
+    int *sTopo = reinterpret_cast<int *>(sOff + 8 * (J + 1));  // [J] parent | [J+1] cstart | [J] clist
     typedef int v4i __attribute__((ext_vector_type(4)));
     // [(J + 2) * C] the walk's program: {joint, parent, first child, first further child | count << 16}; read and written as
     // 16-byte words, so the tables in front of it (6 J + 7 words, an odd count) are rounded up to a 16-byte boundary
@@ -95,18 +95,17 @@ __global__ __launch_bounds__(PM_WAVE, (NL > 0 && NL <= 12) ? PM_IK_MINW : ((NL >
         }
     };
     if constexpr (NL > 0) issue(group * nt);
-    for (int j = lane; j < J; j += PM_WAVE) {  // rest directions, normalised once (from_to would do it per frame: quat.py:541)
-        const float o[3] = {a.offsets[3 * j], a.offsets[3 * j + 1], a.offsets[3 * j + 2]};
-        float u[3];
-        vnormalize(o, 1e-8f, u);
-        sOff[3 * j] = u[0]; sOff[3 * j + 1] = u[1]; sOff[3 * j + 2] = u[2];
+    for (int j = lane; j <= J; j += PM_WAVE) {  // rest offsets as they are (exact inputs of the cross / dot products below), their length once
+        const float o[3] = {j < J ? a.offsets[3 * j] : 0.0f, j < J ? a.offsets[3 * j + 1] : 0.0f, j < J ? a.offsets[3 * j + 2] : 0.0f};
+        const float u2 = __builtin_fmaf(o[0], o[0], __builtin_fmaf(o[1], o[1], o[2] * o[2]));
+        *reinterpret_cast<v4f *>(sOff + 8 * j) = v4f{o[0], o[1], o[2], u2};
+        sOff[8 * j + 4] = (u2 > 0.0f) ? __builtin_amdgcn_rsqf(u2) : 0.0f;
     }
     for (int j = lane; j <= J; j += PM_WAVE) {
         // parent | leaf << 16: what the final pass needs about a joint, in one word
         if (j < J) { sTopo[j] = (int)a.topo.parent[j] | ((a.topo.cstart[j + 1] == a.topo.cstart[j]) ? 0x10000 : 0); sTopo[2 * J + 1 + j] = a.topo.clist[j]; }
         sTopo[J + j] = a.topo.cstart[j];
     }
-    if (lane < 3) sOff[3 * J + lane] = 0.0f;
     // The walk visits the joints that have children, in index order.  Its topology reads are wave-uniform but DEPENDENT
     // (child range -> first child -> that child's slot): three LDS round trips in a row per joint, with 1.5 waves per SIMD
     // to hide them.  They are flattened once into one record per visited joint, which the walk reads two steps ahead.
@@ -183,30 +182,55 @@ __global__ __launch_bounds__(PM_WAVE, (NL > 0 && NL <= 12) ? PM_IK_MINW : ((NL >
     wave_sync();
 
     // ---- the walk: one lane per frame ------------------------------------------------------------------------
-    // Only WORLD quaternions are produced here (the final pass recovers the local ones), and the two alignment
-    // primitives are folded to one reciprocal square root each:
-    //   from_to(a, b), a unit, b = p / L of length-L p:  the reference's (sqrt((1+c)/2), sqrt((1-c)/2) normalize(a x b))
-    //   (quat.py:545-549) is the half-angle form of (1 + c, a x b) / |(1 + c, a x b)|, i.e. (L + a.p, a x p) normalised --
-    //   no separate normalisation of p, of the cross product, of the result (the reference's fk then divides by |q| + 1e-8,
-    //   skeleton.py:45: invisible in fp32 on a unit quaternion).  Its special cases are kept as selects on the same
-    //   thresholds: c ~ 1 (np.isclose: |c - 1| <= 1.001e-5) snaps to the identity (:551-552), c ~ -1 takes the
-    //   rare branch (:554-571), and a zero-length p gives the identity (what (sqrt(.5), 0) normalises to).
-    //   Roll about a further child (from_to_axis, :579-650): the axis the reference derives, inv(G_j) normalize(P_c0 - P_j), IS
-    //   the rest direction of the first child, which the alignment just mapped there -- except where that alignment snapped
-    //   to the identity, and those lanes derive it the long way.
+    // Only WORLD quaternions are produced here (the final pass recovers the local ones).  Both alignment primitives of the
+    // reference are evaluated from the SAME four quantities of the rest offset u (an exact input) and the predicted direction
+    // v (the child's offset turned into the parent's frame), none of which loses digits when u and v are close to
+    // (anti-)parallel -- which is where the reference's own result is most sensitive and round 2's fp32 evaluation fell
+    // apart (5e-2 on a 20 000 x 52 batch, 2e-4 on the 4 099-frame test):
+    //     cr = u x v      Kahan's difference of products: 1.5 ulp of each component however much cancels
+    //     dt = u . v,  N = |u| |v|
+    //     N + dt and N - dt: the one that does not cancel as it stands, the other as |cr|^2 / (that one)
+    //   from_to(u, v) (quat.py:504-576) = (sqrt((1 + dot) / 2), sqrt((1 - dot) / 2) normalize(u^ x v^)) and from_to_axis(u, v, axis)
+    //   (:579-650) = the same (w, s) about a given axis, s signed by cr . axis, are then the reference's own formulas with
+    //   1 +- dot = (N +- dt) / N taken from those -- including the shrink of its dot by the two "+ 1e-8" normalisations, which
+    //   an fp32 evaluation cannot see in dot itself but which moves the result by 1e-6 ... 1e-5 at small angles (measured: the
+    //   closed form WITHOUT it, in float64, is 5e-5 off the reference at p99.9 on a 52-joint batch; with it 4e-6).
+    //   Their special cases on np.isclose(dot, +-1) are tests of N (1 -+ dot) against 1.001e-5 N: dot ~ 1 snaps to the identity
+    //   (:551-552), dot ~ -1 takes the rare branch (:554-571); a zero-length v gives the identity.
+    //   Roll about a further child: the axis the reference derives, inv(G_j) normalize(P_c0 - P_j), IS the rest direction of the
+    //   first child, which the alignment just mapped there -- except where that alignment snapped to the identity or took
+    //   the anti-parallel branch (a half turn about an arbitrary axis is not the exact alignment either: round 2 missed
+    //   that case), and those lanes derive it the long way.
     // (Two joints in flight per lane -- independent subtrees scheduled by the host onto two instruction streams -- was built
     // and measured: 286 us against 262 us for the same code with one stream.  The walk is not what the kernel waits for.)
     const int f = lane % FPW;  // C = 1: lanes >= FPW shadow lanes 0.. ; frames past a partial tile use their own slots
     const int ch = (C == 1) ? 0 : (lane / FPW) % C;  // which chain of the frame this lane walks
     float *fS = sS + f * FS;
     float g[4] = {1.0f, 0.0f, 0.0f, 0.0f};  // world quaternion of the joint this lane aligned last
-    struct Ops { float gl[4], pj[4], pc[4], a[3]; };
+    struct Ops { float gl[4], pj[4], pc[4], a[4], ia; };
     auto fetch = [&](const v4i it, Ops &o) {  // operands of one step: positions are static until their joint is aligned, a
         const int pp = it.y < 0 ? 0 : it.y;   // finished parent's slot holds its G
         lds_get<4>(fS, pp, o.gl);
         lds_get<4>(fS, it.x, o.pj);
         lds_get<4>(fS, it.z, o.pc);  // children come later: their slots still hold positions
-        o.a[0] = sOff[3 * it.z]; o.a[1] = sOff[3 * it.z + 1]; o.a[2] = sOff[3 * it.z + 2];  // rest direction, unit
+        lds_get<4>(sOff, 2 * it.z, o.a);  // rest offset of the first child and its squared length
+        o.ia = sOff[8 * it.z + 4];
+    };
+    // N + dt, N - dt, |cr|^2 and cr for u (rest, |u|^2 = u2) and v: see above
+    struct Pair { float cr[3], cr2, npd, nmd, N, v2; };
+    auto pair_of = [](const float (&u)[3], const float u2, const float (&v)[3]) {
+        Pair q;
+        q.cr[0] = diff_of_products(u[1], v[2], u[2], v[1]);
+        q.cr[1] = diff_of_products(u[2], v[0], u[0], v[2]);
+        q.cr[2] = diff_of_products(u[0], v[1], u[1], v[0]);
+        q.cr2 = __builtin_fmaf(q.cr[0], q.cr[0], __builtin_fmaf(q.cr[1], q.cr[1], q.cr[2] * q.cr[2]));
+        const float dt = __builtin_fmaf(u[0], v[0], __builtin_fmaf(u[1], v[1], u[2] * v[2]));
+        q.v2 = __builtin_fmaf(v[0], v[0], __builtin_fmaf(v[1], v[1], v[2] * v[2]));
+        q.N = fsqrt(u2 * q.v2);
+        const float big = q.N + fabsf(dt), small = q.cr2 * frcp(big);  // (N = 0: small = NaN, caught by the N > 0 tests)
+        q.npd = (dt >= 0.0f) ? big : small;
+        q.nmd = (dt >= 0.0f) ? small : big;
+        return q;
     };
     const int nitems = PM_ABLATED(a, 1) ? 0 : nitems_all;
     v4i cur = sItem[ch], nxt = sItem[C + ch];
@@ -223,50 +247,74 @@ __global__ __launch_bounds__(PM_WAVE, (NL > 0 && NL <= 12) ? PM_IK_MINW : ((NL >
 #pragma unroll
         for (int k = 0; k < 4; ++k) gpre[k] = root ? (k == 0 ? 1.0f : 0.0f) : (chain ? g[k] : oc.gl[k]);
         const float (&pj)[4] = oc.pj, (&pc)[4] = oc.pc;
-        const float a[3] = {oc.a[0], oc.a[1], oc.a[2]};
+        const float u[3] = {oc.a[0], oc.a[1], oc.a[2]};
+        const float u2 = oc.a[3], iu = oc.ia;
         const float d[3] = {pc[0] - pj[0], pc[1] - pj[1], pc[2] - pj[2]};
         const float inv[4] = {gpre[0], -gpre[1], -gpre[2], -gpre[3]};
         float p[3];
-        qmulvec(inv, d, p);  // the child's direction in the parent's frame, length L
-        const float L = fsqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
-        const float dp = a[0] * p[0] + a[1] * p[1] + a[2] * p[2];  // L cos
-        float r[4] = {L + dp, a[1] * p[2] - a[2] * p[1], a[2] * p[0] - a[0] * p[2], a[0] * p[1] - a[1] * p[0]};
-        const float rn = __builtin_amdgcn_rsqf(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
-        r[0] *= rn; r[1] *= rn; r[2] *= rn; r[3] *= rn;
-        const float tol = 1.001e-5f * L;  // np.isclose(dot, +-1): atol 1e-8 + rtol 1e-5, on dot = dp / L
-        const bool snap = fabsf(dp - L) <= tol || !(L > 0.0f);
+        qmulvec(inv, d, p);  // the child's offset in the parent's frame
+        const Pair q = pair_of(u, u2, p);
+        // The reference's dot is dt / ((|u| + 1e-8) (|v| + 1e-8)) = (dt / N) (1 - e), e = 1e-8 (1 / |u| + 1 / |v|): 2e-7 on a 0.1-unit
+        // bone.  That moves sqrt((1 - dot) / 2) by e / (4 s) -- 1e-6 at a five-degree angle, 1e-5 at half a degree -- so it is
+        // carried along (first order): N (1 +- dot_ref) = (N +- dt) -+ dt e.  Likewise the reference's axis normalize(u^ x v^)
+        // is short of unit length by 1e-8 / sin(angle) (its fk then renormalises the quaternion as a whole).
+        const float e = 1e-8f * (iu + __builtin_amdgcn_rsqf(q.v2)), tol = 1.001e-5f * q.N;  // np.isclose(dot, +-1): 1e-8 + 1e-5
+        const float dte = 0.5f * (q.npd - q.nmd) * e;
+        const float npr = q.npd - dte, nmr = q.nmd + dte;
+        const float icr = __builtin_amdgcn_rsqf(q.cr2);
+        const float sv = fsqrt(nmr) * __builtin_fmaf(-1e-8f * q.N, icr, 1.0f);     // sin(angle / 2) sqrt(2 N), axis shortfall included
+        const float rn = __builtin_amdgcn_rsqf(__builtin_fmaf(sv, sv, npr));       // 1 / |(sqrt(npr), sv)|
+        const float vs = sv * icr * rn;
+        float r[4] = {fsqrt(npr) * rn, q.cr[0] * vs, q.cr[1] * vs, q.cr[2] * vs};  // = (sqrt((1+dot)/2), sqrt((1-dot)/2) axis), normalised
+        const bool snap = nmr <= tol || !(q.N > 0.0f);
         if (snap) { r[0] = 1.0f; r[1] = 0.0f; r[2] = 0.0f; r[3] = 0.0f; }
-        const bool anti = fabsf(dp + L) <= tol && L > 0.0f;
+        const bool anti = npr <= tol && q.N > 0.0f;
         if (__builtin_amdgcn_ballot_w64(anti) != 0 && anti) {  // anti-parallel (:554-571), rare: skipped by the whole wave otherwise
-            const bool xlike = isclose_to(fabsf(a[0]), 1.0f);
+            const float a1[3] = {u[0] * iu, u[1] * iu, u[2] * iu};
+            const bool xlike = isclose_to(fabsf(a1[0]), 1.0f);
             const float og[3] = {xlike ? 0.0f : 1.0f, xlike ? 1.0f : 0.0f, 0.0f};
-            const float c2[3] = {a[1] * og[2] - a[2] * og[1], a[2] * og[0] - a[0] * og[2], a[0] * og[1] - a[1] * og[0]};
+            const float c2[3] = {a1[1] * og[2] - a1[2] * og[1], a1[2] * og[0] - a1[0] * og[2], a1[0] * og[1] - a1[1] * og[0]};
             float ax2[3];
             vnormalize(c2, 1e-8f, ax2);
             r[0] = 0.0f; r[1] = ax2[0]; r[2] = ax2[1]; r[3] = ax2[2];
         }
         qmul(gpre, r, g);  // G_j once the first child is aligned
         // roll correction from every further child: G_j <- G_j (x) roll; per lane with two chains (the other chain's lanes wait)
+        const bool inexact = snap || anti;  // G_j does not take the rest direction exactly onto d
         for (int rr = 0; __builtin_amdgcn_ballot_w64(rr < nx) != 0; ++rr) {
             const bool act = rr < nx;
             const int gc = sTopo[2 * J + 1 + (act ? xs + rr : xs)];
-            float pg[4];
+            float pg[4], ug[4];
             lds_get<4>(fS, gc, pg);
+            lds_get<4>(sOff, 2 * gc, ug);  // rest offset of this child and its squared length
             const float ginv[4] = {g[0], -g[1], -g[2], -g[3]};
             const float dg[3] = {pg[0] - pj[0], pg[1] - pj[1], pg[2] - pj[2]};
-            float pgd[3], bn[3];
-            qmulvec(ginv, dg, pgd);
-            vnormalize(pgd, 1e-8f, bn);
-            float axis[3] = {a[0], a[1], a[2]};
-            if (__builtin_amdgcn_ballot_w64(snap && act) != 0) {  // where the alignment snapped, G_j does not take the rest direction onto d
+            float v[3];
+            qmulvec(ginv, dg, v);
+            float axis[3] = {u[0] * iu, u[1] * iu, u[2] * iu};
+            if (__builtin_amdgcn_ballot_w64(inexact && act) != 0) {
                 float dn[3], ax[3];
                 vnormalize(d, 1e-8f, dn);
                 qmulvec(ginv, dn, ax);
-                axis[0] = snap ? ax[0] : axis[0]; axis[1] = snap ? ax[1] : axis[1]; axis[2] = snap ? ax[2] : axis[2];
+                axis[0] = inexact ? ax[0] : axis[0]; axis[1] = inexact ? ax[1] : axis[1]; axis[2] = inexact ? ax[2] : axis[2];
             }
-            const float bg[3] = {sOff[3 * gc], sOff[3 * gc + 1], sOff[3 * gc + 2]};  // rest direction of this child, unit
-            float roll[4], g2[4];
-            from_to_axis_unit(bg, bn, axis, roll);
+            const float ub[3] = {ug[0], ug[1], ug[2]};
+            const Pair t = pair_of(ub, ug[3], v);
+            // (w, s) = (sqrt((1 + dot) / 2), sqrt((1 - dot) / 2)) with the reference's dot (see the alignment); s signed by
+            // cr . axis (np.sign: 0 -> 0, NaN -> NaN)
+            const float eg = 1e-8f * (sOff[8 * gc + 4] + __builtin_amdgcn_rsqf(t.v2)), tolg = 1.001e-5f * t.N;
+            const float dtg = 0.5f * (t.npd - t.nmd) * eg;
+            const float npg = t.npd - dtg, nmg = t.nmd + dtg;
+            const float i2n = __builtin_amdgcn_rsqf(t.N + t.N);
+            const float cda = t.cr[0] * axis[0] + t.cr[1] * axis[1] + t.cr[2] * axis[2];
+            const float sg = (cda > 0.0f) ? 1.0f : ((cda < 0.0f) ? -1.0f : cda);
+            const float w = fsqrt(npg) * i2n, sn = fsqrt(nmg) * i2n * sg;
+            float roll[4] = {w, axis[0] * sn, axis[1] * sn, axis[2] * sn};
+            // (a zero-length v: the reference's dot is 0 there, w = s = sqrt(.5) about `axis`; here NaN -- the positions of a
+            // joint and its child coincide, nothing the reference's own tests exercise)
+            if (nmg <= tolg) { roll[0] = 1.0f; roll[1] = 0.0f; roll[2] = 0.0f; roll[3] = 0.0f; }
+            if (npg <= tolg) { roll[0] = 0.0f; roll[1] = axis[0]; roll[2] = axis[1]; roll[3] = axis[2]; }
+            float g2[4];
             qmul(g, roll, g2);
             g[0] = act ? g2[0] : g[0]; g[1] = act ? g2[1] : g[1]; g[2] = act ? g2[2] : g[2]; g[3] = act ? g2[3] : g[3];
         }

@@ -76,34 +76,65 @@ def test_gpu_from_root_positions(case):
     i, want = g.get(case, "in"), g.get(case, "out64")["rot"]
     got = sk.from_root_positions(i["pos"], i["parents"], i["off"])
     assert got.shape == want.shape and got.dtype == np.float64
-    # the reference's own twin test uses 1e-2 here (test_skeleton.py:225); fp32 vs its f64 path is much closer
-    assert _same_rotation_err(got, want) <= 2e-4, _same_rotation_err(got, want)
+    # the reference's own twin test uses 1e-2 here (test_skeleton.py:225); measured 3.6e-6 / 1.9e-6 / 1.4e-6 / 1.6e-7 (round 2
+    # asserted 2e-4: its alignment lost digits near (anti-)parallel directions and ignored the reference's "+ 1e-8"s, ik.hip)
+    assert _same_rotation_err(got, want) <= 2e-5, _same_rotation_err(got, want)
     # the recovered pose is the reference's pose (the algorithm itself only matches the input positions
     # approximately: roll is fixed from one extra child at a time; the reference tests it at 1e-2)
     pos, _ = sk.fk(got, np.zeros((got.shape[0], 3)), i["off"], i["parents"])
     pos_ref, _ = co.fk(want, np.zeros((got.shape[0], 3)), i["off"].astype(np.float64), i["parents"])
-    assert np.abs(pos - pos_ref).max() <= 1e-4
+    assert np.abs(pos - pos_ref).max() <= 1e-5
     got_t = skt.from_root_positions(torch.from_numpy(i["pos"]).cuda(), torch.from_numpy(i["parents"]), torch.from_numpy(i["off"]).cuda())
-    assert _same_rotation_err(got_t.cpu().numpy(), want) <= 2e-4
+    assert _same_rotation_err(got_t.cpu().numpy(), want) <= 2e-5
+
+
+def _reference_sensitivity(pos, par, off, ref, draws=3):
+    """How far the REFERENCE's own (float64) answer moves when its fp32 inputs move by one ulp: from_to is ill-conditioned where a
+    bone has to turn by nearly 180 degrees (the axis of a half turn is any direction perpendicular to the bone), and everything
+    below such a joint inherits the twist.  Max over a few random one-ulp perturbations, per (frame, joint)."""
+    s = np.zeros(ref.shape[:2])
+    for k in range(draws):
+        up = np.random.default_rng(k + 1).random(pos.shape) < 0.5
+        pos2 = np.nextafter(pos, np.where(up, np.inf, -np.inf).astype(np.float32))
+        ref2 = co.from_root_positions(pos2.astype(np.float64), par, off.astype(np.float64))
+        s = np.maximum(s, np.minimum(np.abs(ref2 - ref).max(-1), np.abs(ref2 + ref).max(-1)))
+    return s
 
 
 @pytest.mark.gpu
-def test_gpu_from_root_positions_large_vs_oracle_and_mirror_positions():
+@pytest.mark.parametrize("J,F", [(22, 4099), (52, 3001)])
+def test_gpu_from_root_positions_large_vs_oracle(J, F):
+    """Random poses at test size.  The bar per record: 2e-5, plus -- on the handful of records where the reference's answer is
+    itself decided by the last bit of its fp32 inputs -- a small multiple of how far one ulp of input moves THE REFERENCE
+    (measured at 4099 x 22: 6 of 90 178 records above 2e-5, the worst 3.8e-5, all within 1.5x the reference's own movement;
+    round 2 asserted 2e-4 on everything)."""
     import pymotion_amd.ops.skeleton as sk
     from pymotion_amd import synthetic as syn
 
-    rot, root, off, par = syn.fk_workload(4099, seed=9, normalized=True)
-    pos, _ = sk.fk(rot, np.zeros_like(root), off, par)
+    par = syn.PARENTS_22 if J == 22 else syn.PARENTS_52
+    rot, root, off, par = syn.fk_workload(F, parents=par, seed=9, normalized=True, offset_scale=0.3 if J == 22 else 0.15)
+    pos, _ = co.fk(rot.astype(np.float64), np.zeros((F, 3)), off.astype(np.float64), par)
     pos = pos.astype(np.float32)
     got = sk.from_root_positions(pos, par, off)
     ref = co.from_root_positions(pos.astype(np.float64), par, off.astype(np.float64))
-    assert _same_rotation_err(got, ref) <= 2e-4
+    err = np.minimum(np.abs(got - ref).max(-1), np.abs(got + ref).max(-1))
+    sens = _reference_sensitivity(pos, par, off, ref)
+    over = err > 2e-5
+    assert over.mean() <= 5e-4, int(over.sum())
+    assert (err <= 2e-5 + 8.0 * sens).all(), (float(err.max()), float(((err - 2e-5) / np.maximum(sens, 1e-12))[over].max()))
+    assert np.quantile(err, 0.999) <= 2e-5
     p2, _ = sk.fk(got, np.zeros_like(root), off, par)
-    p_ref, _ = co.fk(ref, np.zeros((4099, 3)), off.astype(np.float64), par)
-    assert np.abs(p2 - p_ref).max() <= 1e-4
+    p_ref, _ = co.fk(ref, np.zeros((F, 3)), off.astype(np.float64), par)
+    assert np.abs(p2 - p_ref).max() <= 2e-5
+
+
+@pytest.mark.gpu
+def test_gpu_mirror_positions_vs_reference_golden():
+    import pymotion_amd.ops.skeleton as sk
+
     g = golden("ik.npz")
     i, want = g.get("mirror_positions_X", "in"), g.get("mirror_positions_X", "out64")
     r, gt, o, _ = sk.mirror(i["rot"], i["root"], i["parents"], i["off"], None, None, "positions", "X")
-    assert _same_rotation_err(r, want["rot"]) <= 5e-4
+    assert _same_rotation_err(r, want["rot"]) <= 2e-5   # true mirror -> fk -> from_root_positions (measured 3.5e-6; round 2: 5e-4)
     assert_close(gt, want["gt"], 1e-7, "mirrored translation")
     assert_close(o, want["off"], 1e-7, "offsets unchanged in mode 'positions'")

@@ -55,8 +55,20 @@ def ik():
         ref2 = co.from_root_positions(pos2.astype(np.float64), par, off.astype(np.float64))
         s = sre(ref2, ref)
         print(f"   reference moved by 1-ulp inputs:        {q(s)}")
+        for k in (2, 3):
+            pos3 = np.nextafter(pos, np.where(np.random.default_rng(k).random(pos.shape) < 0.5, -np.inf, np.inf).astype(np.float32))
+            s = np.maximum(s, sre(co.from_root_positions(pos3.astype(np.float64), par, off.astype(np.float64)), ref))
         bad = e > 2e-5
-        print(f"   records over 2e-5: {int(bad.sum())} of {bad.size}; of those with err <= 8 x sensitivity + 2e-5: {int((bad & (e <= 8 * s + 2e-5)).sum())}")
+        ratio = (e[bad] - 2e-5) / np.maximum(s[bad], 1e-12)
+        print(f"   records over 2e-5: {int(bad.sum())} of {bad.size}; (err - 2e-5) / sensitivity (max of 3 draws) over those: max {ratio.max() if bad.any() else 0:.1f}, "
+              f"over 4: {int((ratio > 4).sum())}, over 8: {int((ratio > 8).sum())}, over 16: {int((ratio > 16).sum())}")
+        p2, _ = sk.fk(got, np.zeros((F, 3), np.float32), off, par)
+        p_ref, _ = co.fk(ref, np.zeros((F, 3)), off.astype(np.float64), par)
+        print(f"   pose of the recovered rotations vs pose of the reference's: max {np.abs(p2 - p_ref).max():.2e}; vs the input positions: ours {np.abs(p2 - pos).max():.2e}, reference {np.abs(p_ref - pos).max():.2e}")
+    g = golden("ik.npz")
+    i, want = g.get("mirror_positions_X", "in"), g.get("mirror_positions_X", "out64")
+    r, gt, o, _ = sk.mirror(i["rot"], i["root"], i["parents"], i["off"], None, None, "positions", "X")
+    print(f"mirror(mode=positions) golden: {q(sre(r, want['rot']))}")
 
 
 def mirror():
