@@ -308,19 +308,14 @@ __device__ __forceinline__ void put_local(float *slot, const float (&L)[9]);
 
 template <bool QOUT, int M>
 __device__ __forceinline__ bool local_from_o6d(const float (&xx)[6], const float eps, float (&L)[9], float (&Q)[4]) {
+    // The trip matrix -> quaternion -> normalise -> matrix is the identity on an orthonormal matrix up to fp32 rounding (~2e-7, two
+    // orders inside the parity budget): the Gram-Schmidt result IS the local rotation, with or without the quaternion output
+    // (round 2 went through the quaternion when it was asked for: ~80 more VALU operations per joint and 40 more live registers,
+    // 57.9 % against 61.8 %).  The quaternion, when wanted, is from_matrix of it (ortho6d.py:50-64).  None of this holds for what
+    // Gram-Schmidt returns on degenerate columns (zeros, NaN, rounding noise): those records are re-done (o6d_redo_ill).
     bool ill;
-    if constexpr (QOUT) {
-        float m[9];
-        o6d2m(xx, m, ill);
-        m2q(m, Q);
-        local_from_quat<M>(Q, L);
-    } else {
-        // Without the quaternion output the trip matrix -> quaternion -> normalise -> matrix is the identity on an
-        // orthonormal matrix up to fp32 rounding (~2e-7, two orders inside the parity budget): the Gram-Schmidt
-        // result IS the local rotation.  Saves ~80 VALU ops per joint.  It is NOT the identity on what Gram-Schmidt
-        // returns for degenerate columns (zeros, NaN, rounding noise) -- those records are re-done (o6d_redo_ill).
-        o6d2m(xx, L, ill);
-    }
+    o6d2m(xx, L, ill);
+    if constexpr (QOUT) m2q(L, Q);
     return ill;
 }
 
@@ -336,7 +331,9 @@ __device__ __forceinline__ void o6d_redo_ill(const bool ill, const float (&xx)[6
     o6d_chain_f64(xx, eps, Ld, Qd);
     if (ill) {
         put_local<TRANSPOSED>(slot, Ld);
-        if (QOUT) lds_put<4>(qslot, 0, Qd);
+        // qslot: the record's LDS slot (fk_tile) or its place in HBM (fk_pipe_kernel: a second store of this lane to the address
+        // it has already written -- same-address stores of one wave land in program order)
+        if (QOUT) { qslot[0] = Qd[0]; qslot[1] = Qd[1]; qslot[2] = Qd[2]; qslot[3] = Qd[3]; }
     }
 }
 
@@ -643,7 +640,7 @@ __global__ __launch_bounds__(PM_WAVE) void fk_kernel(const FkArgs a) {
 // source is left alone: bounded, the variant with the quaternion output spills 40-100 registers (268 -> 409 us), and the one
 // without (134 VGPRs once the float64 redo of degenerate records moved behind the parking) gains nothing from a fourth wave.)
 template <int FPW, int EPL, bool VEC, int SRC, bool QOUT, bool PAD, bool PFO, int PREC>
-__global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? 4 : 1) void fk_pipe_kernel(const FkArgs a, const int nt) {
+__global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? 4 : ((EPL <= 4 && QOUT && !PFO) ? 3 : 1)) void fk_pipe_kernel(const FkArgs a, const int nt) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool DYN = (PREC & PREC_DYN) != 0;
     constexpr bool QUAD = FPW <= 5;  // records per lane: FPW * J <= 64 * EPL
@@ -661,8 +658,10 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? 4 : 1) voi
     float *sRot = smem;                          // [FPW*(J*9+pad)]
     float *sPos = sRot + FJ * 9 + FPW * pad;     // [FPW*(J*3+pad)]
     float *sOff = sPos + FJ * 3 + FPW * pad;     // [FPW*(J*3+pad)]  (PFO: per-frame offsets)
-    float *sQo = sOff + (PFO ? FJ * 3 + FPW * pad : 0);  // [FJ*4]  (QOUT)
-    float *sConst = sQo + (QOUT ? FJ * 4 : 0);   // [(J+4)*4]
+    float *sConst = sOff + (PFO ? FJ * 3 + FPW * pad : 0);  // [(J+4)*4]
+    // (QOUT: the quaternions are one 16-byte record per lane with consecutive lanes on consecutive records -- a contiguous stream
+    // as they stand -- and leave straight from the conversion's registers.  Round 2 parked them in a fourth LDS region and copied
+    // that out: 16 J B more image per frame and 16 more live registers across the walk, 57.9 % against 61.8 % without the output.)
     // the joint table, and what it says about the arithmetic the tiles need (PREC_DYN, see fk_tile)
     bool tbig_l = false;
     float tsum_l = 0.0f, tmx_l = 0.0f;
@@ -725,7 +724,6 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? 4 : 1) voi
     auto copy_out = [&](const int64_t f0, const int nfr) {
         image_store<VEC>(a.rotmats + f0 * J * 9, sRot, nfr, J * 9, pad, lane);
         image_store<VEC>(a.pos + f0 * J * 3, sPos, nfr, J * 3, pad, lane);
-        if (QOUT) tile_store<VEC>(a.quat_out + f0 * J * 4, sQo, nfr * J * 4, lane);
     };
 
     int64_t f0 = t0 * FPW, f0_prev = 0;
@@ -757,7 +755,8 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? 4 : 1) voi
             }
         }
         // math of tile i, in registers (phase A of fk_tile)
-        float L[EPL][9], Q[EPL][4];
+        float L[EPL][9];
+        float *gq = QOUT ? a.quat_out + f0 * J * 4 : nullptr;  // this tile's quaternion records
         bool bad = false, ill[EPL];
 #pragma unroll
         for (int u = 0; u < EPL; ++u) ill[u] = false;
@@ -770,7 +769,15 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? 4 : 1) voi
                     local_from_quat<M>(qi, L[u]);
                 } else {
                     const float xx[6] = {in2[u][0].x, in2[u][0].y, in2[u][1].x, in2[u][1].y, in2[u][2].x, in2[u][2].y};
-                    ill[u] = local_from_o6d<QOUT, M>(xx, a.eps, L[u], Q[u]);
+                    float Q[4];
+                    ill[u] = local_from_o6d<QOUT, M>(xx, a.eps, L[u], Q);
+                    if constexpr (QOUT) {
+                        const int e = u * PM_WAVE + lane;
+                        if (e < n) {
+                            if (VEC) __builtin_nontemporal_store(v4f{Q[0], Q[1], Q[2], Q[3]}, reinterpret_cast<v4f *>(gq) + e);
+                            else { gq[4 * e] = Q[0]; gq[4 * e + 1] = Q[1]; gq[4 * e + 2] = Q[2]; gq[4 * e + 3] = Q[3]; }
+                        }
+                    }
                 }
                 if (M & PREC_FX) {  // NaN / Inf input record
                     if constexpr (SRC == SRC_QUAT) bad = bad || !(fabsf(in4[u].x) + fabsf(in4[u].y) + fabsf(in4[u].z) + fabsf(in4[u].w) < 3e38f);
@@ -791,7 +798,6 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? 4 : 1) voi
             const int e = u * PM_WAVE + lane;
             if (e < n) {
                 put_local<QUAD>(sRot + image_slot<PAD>(e, J, invJ, 9, pad), L[u]);
-                if (QOUT) lds_put<4>(sQo, e, Q[u]);
                 if constexpr (PFO) {
                     float *o = sOff + image_slot<PAD>(e, J, invJ, 3, pad);
                     o[0] = inO[u].x; o[1] = inO[u].y; o[2] = inO[u].z;
@@ -803,7 +809,7 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? 4 : 1) voi
             for (int u = 0; u < EPL; ++u) {
                 const int e = u * PM_WAVE + lane, ec = e < n ? e : (n > 0 ? n - 1 : 0);
                 const float xx[6] = {in2[u][0].x, in2[u][0].y, in2[u][1].x, in2[u][1].y, in2[u][2].x, in2[u][2].y};
-                o6d_redo_ill<QOUT, QUAD>(ill[u] && e < n, xx, a.eps, sRot + image_slot<PAD>(ec, J, invJ, 9, pad), sQo + 4 * ec);
+                o6d_redo_ill<QOUT, QUAD>(ill[u] && e < n, xx, a.eps, sRot + image_slot<PAD>(ec, J, invJ, 9, pad), QOUT ? gq + 4 * ec : nullptr);
             }
         }
         f0_prev = f0; nf_prev = nf;
@@ -875,7 +881,7 @@ static int launch_fk_p(const FkArgs &a, hipStream_t s) {
 
 template <int FPW, int EPL, bool VEC, int SRC, bool QOUT, bool PAD, bool PFO, int PREC>
 static int launch_fk_pipe_pp(const FkArgs &a, const int nt, hipStream_t s) {
-    const size_t lds = ((size_t)FPW * (a.J * (12 + (PFO ? 3 : 0) + (QOUT ? 4 : 0)) + (PFO ? 3 : 2) * a.pad) + 4 * (a.J + 4)) * sizeof(float);
+    const size_t lds = ((size_t)FPW * (a.J * (12 + (PFO ? 3 : 0)) + (PFO ? 3 : 2) * a.pad) + 4 * (a.J + 4)) * sizeof(float);
     auto k = fk_pipe_kernel<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, PREC>;
     if (int e = allow_lds(k, lds)) return e;
     const int64_t ntiles = (a.F + FPW - 1) / FPW, ngroups = (ntiles + nt - 1) / nt;
