@@ -421,30 +421,30 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_sched_kernel(const SchedAr
     // batch, was measured and is SLOWER -- 150 -> 178 us at J = 52: with ~9 resident waves the latencies are hidden anyway and
     // the kernel is bound by instruction issue, which the extra LDS round trip adds to.)
     bool tbig_l = false;               // a bone of a metre or more (or NaN) in the table: see kBigOffset
-    float tsum_l = 0.0f, tmx_l = 0.0f; // sum / max over the joints of |t_j|_1 (this lane's share; NaN sticks)
     for (int i = lane; i < 4 * (J + 2); i += PM_WAVE) {  // the joint table, as in to_root_dq_kernel; row 0 is zero (skeleton.py:227)
         const int j = i >> 2, cc = i & 3;
         float vc = 0.0f, w1 = 0.0f, w2 = 0.0f;
-        if (j > 0 && j < J) {
+        if (cc > 0 && j > 0 && j < J) {
             const float o[3] = {a.offsets[3 * j], a.offsets[3 * j + 1], a.offsets[3 * j + 2]};
-            if (cc > 0) {
-                const int cur = cc - 1, nx = cur == 2 ? 0 : cur + 1, nn = nx == 2 ? 0 : nx + 1;
-                vc = o[cur]; w1 = 2.0f * o[nn]; w2 = 2.0f * o[nx];
-            } else {
-                const float l1 = fabsf(o[0]) + fabsf(o[1]) + fabsf(o[2]);
-                tbig_l = tbig_l || !(fabsf(o[0]) < kBigOffset) || !(fabsf(o[1]) < kBigOffset) || !(fabsf(o[2]) < kBigOffset);
-                tsum_l += l1;
-                tmx_l = (l1 > tmx_l || l1 != l1) ? l1 : tmx_l;
-            }
+            const int cur = cc - 1, nx = cur == 2 ? 0 : cur + 1, nn = nx == 2 ? 0 : nx + 1;
+            vc = o[cur]; w1 = 2.0f * o[nn]; w2 = 2.0f * o[nx];
+            tbig_l = tbig_l || !(fabsf(vc) < kBigOffset);
         }
         sTab[3 * i] = vc; sTab[3 * i + 1] = w1; sTab[3 * i + 2] = w2;
     }
     const bool tbig = __builtin_amdgcn_ballot_w64(tbig_l) != 0;  // per workgroup: the table is shared by its tiles
-    float tbound;
-    {
+    // bound of |t_j - t_(depth-1 ancestor)| for the fixed-point scale, from the table in LDS: only tiles that take the precise
+    // step pay for it (round-3 note: gathering these sums in the loop above for every workgroup cost metre-scale data 4 %)
+    auto table_bound = [&]() {
+        float tsum_l = 0.0f, tmx_l = 0.0f;  // sum / max over the joints of |t_j|_1 (this lane's share; NaN sticks)
+        for (int j = 1 + lane; j < J; j += PM_WAVE) {
+            const float l1 = fabsf(sTab[12 * j + 3]) + fabsf(sTab[12 * j + 6]) + fabsf(sTab[12 * j + 9]);
+            tsum_l += l1;
+            tmx_l = (l1 > tmx_l || l1 != l1) ? l1 : tmx_l;
+        }
         const float bsum = wave_sum(tsum_l), bmax = (float)a.depth * wave_max(tmx_l);  // (NaN sticks in both)
-        tbound = uniform_f32((bmax < bsum) ? bmax : bsum);  // keep it out of the vector registers
-    }
+        return (bmax < bsum) ? bmax : bsum;
+    };
     for (int i = lane; i < (K + 2) * C; i += PM_WAVE) {  // the program; two idle steps of slack for the look-ahead
         const int st = i / C, kk = i - st * C;
         int j = (st < K) ? a.sched[i] : 255;
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_sched_kernel(const SchedAr
     bool precise = false;
     FxScale fx = {1.0f, 1.0f};
     if (tbig || __builtin_amdgcn_ballot_w64(!(fabsf(rp) < kBigRoot)) != 0)
-        precise = fx_scale(tbound, (k == 0) ? fabsf(rp) : 0.0f, fx);  // false for a non-finite bound: fp32 step
+        precise = fx_scale(table_bound(), (k == 0) ? fabsf(rp) : 0.0f, fx);  // false for a non-finite bound: fp32 step
     fx.S = uniform_f32(fx.S);
     fx.invS = uniform_f32(fx.invS);
     const char *bl = reinterpret_cast<const char *>(fD + 7);  // precise: a slot's packed residuals
@@ -564,10 +564,11 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_sched_kernel(const SchedAr
             // WHOLE kernel: 110 VGPRs = four waves per SIMD instead of five, 210 -> 228 us on metre-scale data that never
             // takes this path; so does anything over 96 here.
             int gti = 0;
+            v4i e = prog[0];
+            float b = *reinterpret_cast<const float *>(bq + e.x);
 #pragma clang loop unroll(disable)
             for (int st = 0; st < K; ++st) {
-                const v4i e = prog[st * C];
-                const float b = *reinterpret_cast<const float *>(bq + e.x);
+                const v4i en = prog[(st + 1) * C];  // (the program has two idle steps of slack)
                 const float sb1 = quad_perm_mul<1, 0, 3, 2>(b, s1), sb2 = quad_perm_mul<2, 3, 0, 1>(b, s2), sb3 = quad_perm_mul<3, 2, 1, 0>(b, s3);
                 const bool chain = e.w != 0;
                 double pqd = gqd;
@@ -575,6 +576,7 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_sched_kernel(const SchedAr
                 double qd = quad_qmul_f64(pqd, b, sb1, sb2, sb3);
                 float pqf = (float)pqd;
                 asm volatile("" : "+v"(qd), "+v"(pqf));  // the quaternion part is done before the translation's operands are fetched
+                const float bn = *reinterpret_cast<const float *>(bq + en.x);  // next joint's input quaternion: its slot is untouched until its own step
                 const float *row = reinterpret_cast<const float *>(btab + e.z);
                 const float vc = (st == 0 && k == 0) ? rp : row[0];  // the root's "offset" is the frame's root position (skeleton.py:232)
                 const int pti = chain ? gti : *reinterpret_cast<const int *>(bt + e.y);
@@ -584,6 +586,7 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_sched_kernel(const SchedAr
                 *reinterpret_cast<float *>(const_cast<char *>(bq) + e.x) = qh;
                 *reinterpret_cast<int *>(const_cast<char *>(bt) + e.x) = dq_pack_residual(qd, qh, ti, c);
                 gqd = qd; gti = ti;
+                e = en; b = bn;
             }
             return;
         }
