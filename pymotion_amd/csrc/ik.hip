@@ -194,7 +194,9 @@ __global__ __launch_bounds__(PM_WAVE, (NL > 0 && NL <= 12) ? PM_IK_MINW : ((NL >
     //   (:579-650) = the same (w, s) about a given axis, s signed by cr . axis, are then the reference's own formulas with
     //   1 +- dot = (N +- dt) / N taken from those -- including the shrink of its dot by the two "+ 1e-8" normalisations, which
     //   an fp32 evaluation cannot see in dot itself but which moves the result by 1e-6 ... 1e-5 at small angles (measured: the
-    //   closed form WITHOUT it, in float64, is 5e-5 off the reference at p99.9 on a 52-joint batch; with it 4e-6).
+    //   closed form WITHOUT it, in float64, is 5e-5 off the reference at p99.9 on a 52-joint batch; with it 4e-6).  (What is NOT
+    //   carried: the reference's axis normalize(u^ x v^) being short of unit length by 1e-8 / sin(angle) -- 1e-5 only within
+    //   0.06 degrees of anti-parallel, where the answer moves by more than that with the last bit of the input.)
     //   Their special cases on np.isclose(dot, +-1) are tests of N (1 -+ dot) against 1.001e-5 N: dot ~ 1 snaps to the identity
     //   (:551-552), dot ~ -1 takes the rare branch (:554-571); a zero-length v gives the identity.
     //   Roll about a further child: the axis the reference derives, inv(G_j) normalize(P_c0 - P_j), IS the rest direction of the
@@ -236,16 +238,16 @@ __global__ __launch_bounds__(PM_WAVE, (NL > 0 && NL <= 12) ? PM_IK_MINW : ((NL >
     v4i cur = sItem[ch], nxt = sItem[C + ch];
     Ops oc, on;
     fetch(cur, oc);
-    int prevj = -2;
+    int prevj = -1;
     for (int st = 0; st < nitems; ++st) {
         const v4i nn = sItem[(st + 2) * C + ch];
         fetch(nxt, on);  // issued before this step computes; if next's parent is THIS lane's joint its gl is stale, and unused (register chain)
         const int j = cur.x, par = cur.y;
         const int xs = cur.w & 0xffff, nx = cur.w >> 16;
         float gpre[4];
-        const bool chain = par == prevj, root = par < 0;
+        const bool chain = par == prevj;  // (the root, par = -1, is "chained" to the identity g starts as)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) gpre[k] = root ? (k == 0 ? 1.0f : 0.0f) : (chain ? g[k] : oc.gl[k]);
+        for (int k = 0; k < 4; ++k) gpre[k] = chain ? g[k] : oc.gl[k];
         const float (&pj)[4] = oc.pj, (&pc)[4] = oc.pc;
         const float u[3] = {oc.a[0], oc.a[1], oc.a[2]};
         const float u2 = oc.a[3], iu = oc.ia;
@@ -256,16 +258,15 @@ __global__ __launch_bounds__(PM_WAVE, (NL > 0 && NL <= 12) ? PM_IK_MINW : ((NL >
         const Pair q = pair_of(u, u2, p);
         // The reference's dot is dt / ((|u| + 1e-8) (|v| + 1e-8)) = (dt / N) (1 - e), e = 1e-8 (1 / |u| + 1 / |v|): 2e-7 on a 0.1-unit
         // bone.  That moves sqrt((1 - dot) / 2) by e / (4 s) -- 1e-6 at a five-degree angle, 1e-5 at half a degree -- so it is
-        // carried along (first order): N (1 +- dot_ref) = (N +- dt) -+ dt e.  Likewise the reference's axis normalize(u^ x v^)
-        // is short of unit length by 1e-8 / sin(angle) (its fk then renormalises the quaternion as a whole).
+        // carried along (first order): N (1 +- dot_ref) = (N +- dt) -+ dt e.
         const float e = 1e-8f * (iu + __builtin_amdgcn_rsqf(q.v2)), tol = 1.001e-5f * q.N;  // np.isclose(dot, +-1): 1e-8 + 1e-5
-        const float dte = 0.5f * (q.npd - q.nmd) * e;
-        const float npr = q.npd - dte, nmr = q.nmd + dte;
-        const float icr = __builtin_amdgcn_rsqf(q.cr2);
-        const float sv = fsqrt(nmr) * __builtin_fmaf(-1e-8f * q.N, icr, 1.0f);     // sin(angle / 2) sqrt(2 N), axis shortfall included
-        const float rn = __builtin_amdgcn_rsqf(__builtin_fmaf(sv, sv, npr));       // 1 / |(sqrt(npr), sv)|
-        const float vs = sv * icr * rn;
-        float r[4] = {fsqrt(npr) * rn, q.cr[0] * vs, q.cr[1] * vs, q.cr[2] * vs};  // = (sqrt((1+dot)/2), sqrt((1-dot)/2) axis), normalised
+        const float dte = 0.5f * (q.npd - q.nmd) * e;                                       // dt e
+        const float npr = q.npd - dte, nmr = q.nmd + dte;                                   // N (1 +- dot_ref)
+        // (sqrt(npr), sqrt(nmr) cr / |cr|) / sqrt(2 N) with |cr|^2 = npd nmd, expanded to first order in dte: ONE reciprocal square
+        // root and one reciprocal (the literal form: two square roots and two reciprocal square roots), unit to O(e^2)
+        const float A = __builtin_amdgcn_rsqf((q.N + q.N) * q.npd);
+        const float vs = A * __builtin_fmaf(0.5f * dte, frcp(q.nmd), 1.0f);
+        float r[4] = {A * __builtin_fmaf(-0.5f, dte, q.npd), q.cr[0] * vs, q.cr[1] * vs, q.cr[2] * vs};
         const bool snap = nmr <= tol || !(q.N > 0.0f);
         if (snap) { r[0] = 1.0f; r[1] = 0.0f; r[2] = 0.0f; r[3] = 0.0f; }
         const bool anti = npr <= tol && q.N > 0.0f;
