@@ -236,9 +236,20 @@ PM_OP(OpO6dFromMatrix, 9, 0, 0, 6, 0) {
 // any |x| < 1e8 with no Cody-Waite constant juggling and no Payne-Hanek), then the Cephes minimax polynomials
 // on [-pi/4, pi/4] (|error| < 2^-24) and the quadrant fix-up.  Beyond 1e8 rad (nobody's Euler angle) libm takes over.
 __device__ __forceinline__ void sincos_rr(const float x, float &s, float &c) {
-    const double xd = (double)x, kd = rint(xd * 0.6366197723675814);
-    const float r = (float)fma(kd, -1.5707963267948966, xd);
-    const int k = (int)kd;
+    // Ordinary angles (|x| < 4096: every Euler angle, every half angle of a rotation): k = rint(x 2/pi) and two FMAs against
+    // pi/2 = 1.5707963705062866 (its fp32 value) - 4.3711390e-8: the first is exact or rounds a value of magnitude < 1 once, the
+    // split is good to 2e-15 k.  Six fp32 instructions; the float64 reduction (convert, multiply, rint, fma, two converts at
+    // the float64 rate) was 30 of the 190 instructions from_euler spent per element.  Larger arguments keep it (a branch the
+    // wave takes only if a lane needs it).
+    float kf = __builtin_rintf(x * 0.6366197723675814f);
+    float r = __builtin_fmaf(kf, 4.3711390001862412e-08f, __builtin_fmaf(kf, -1.5707963705062866f, x));
+    int k = (int)kf;
+    if (__builtin_amdgcn_ballot_w64(!(fabsf(x) < 4096.0f)) != 0) {  // valid for any |x| < 1e8 with no constant juggling and no Payne-Hanek
+        const double xd = (double)x, kd = rint(xd * 0.6366197723675814);
+        const bool far = !(fabsf(x) < 4096.0f);
+        r = far ? (float)fma(kd, -1.5707963267948966, xd) : r;
+        k = far ? (int)kd : k;
+    }
     const float r2 = r * r;
     const float sp = r + r * r2 * (-1.6666654611e-1f + r2 * (8.3321608736e-3f + r2 * -1.9515295891e-4f));
     const float cp = 1.0f - 0.5f * r2 + r2 * r2 * (4.166664568298827e-2f + r2 * (-1.388731625493765e-3f + r2 * 2.443315711809948e-5f));
@@ -257,9 +268,10 @@ __device__ __forceinline__ void sincos_rr(const float x, float &s, float &c) {
 __device__ __forceinline__ float atan2_rr(const float y, const float x) {
     const float ay = fabsf(y), ax = fabsf(x);
     const float hi = fmaxf(ay, ax), lo = fminf(ay, ax);
-    const float t = lo * frcp(hi);                         // in [0, 1]
-    const bool mid = t > 0.4142135623730950f;
-    const float u = mid ? (t - 1.0f) * frcp(t + 1.0f) : t;
+    // t = lo / hi in [0, 1], reduced at tan(pi / 8): u = (t - 1) / (t + 1) = (lo - hi) / (lo + hi) -- decided and formed
+    // before the division, so there is ONE reciprocal (round 2: lo rcp(hi), then rcp(t + 1))
+    const bool mid = lo > 0.4142135623730950f * hi;
+    const float u = (mid ? lo - hi : lo) * frcp(mid ? lo + hi : hi);
     const float z = u * u;
     float a = (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * u + u;
     a += mid ? 0.7853981633974483f : 0.0f;
@@ -327,13 +339,39 @@ __device__ __forceinline__ void load_order(const EwArgs &a, int64_t elem, int (&
 // rotations/quat.py:43-82 : q = q0 (x) (q1 (x) q2), each an axis rotation about order[k]
 PM_OP(OpFromEuler, 3, 0, 0, 4, 0) {
     int o[3]; load_order(a, elem, o);
-    float q[3][4];
+    float sn[3], cs[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-        aa2q(x0[k], o[k] == 0 ? 1.0f : 0.0f, o[k] == 1 ? 1.0f : 0.0f, o[k] == 2 ? 1.0f : 0.0f, q[k]);
-    float t[4];
-    qmul(q[1], q[2], t);
-    qmul(q[0], t, y0);
+    for (int k = 0; k < 3; ++k) sincos_rr(x0[k] / 2.0f, sn[k], cs[k]);  // quat.py:38: half angles
+    // Three DISTINCT axes (a, b, c) -- every Tait-Bryan order, the only ones the reference documents -- have a closed form: with
+    // sigma = +1 for a cyclic order (xyz, yzx, zxy) and -1 otherwise,
+    //     w = c0 c1 c2 - sigma s0 s1 s2      v[a] = s0 c1 c2 + sigma c0 s1 s2
+    //     v[b] = c0 s1 c2 - sigma s0 c1 s2   v[c] = c0 c1 s2 + sigma s0 s1 c2
+    // 13 multiply-adds and six selects for what two general Hamilton products of axis quaternions (two non-zeros each) spend
+    // 41 instructions on.  Anything else (a repeated axis) takes the general products, a branch the wave skips otherwise.
+    const int ia = o[0], ib = o[1], ic = o[2];
+    const bool distinct = ia != ib && ib != ic && ia != ic;
+    const float sg = ((ib - ia + 3) % 3 == 1) ? 1.0f : -1.0f;
+    const float cc = cs[1] * cs[2], ss = sn[1] * sn[2], csn = cs[1] * sn[2], scn = sn[1] * cs[2];
+    const float s0 = sg * sn[0];
+    const float w = __builtin_fmaf(cs[0], cc, -(s0 * ss));
+    const float va = __builtin_fmaf(sn[0], cc, sg * cs[0] * ss);
+    const float vb = __builtin_fmaf(cs[0], scn, -(s0 * csn));
+    const float vc = __builtin_fmaf(cs[0], csn, s0 * scn);
+    y0[0] = w;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) y0[1 + m] = (ia == m) ? va : ((ib == m) ? vb : vc);
+    if (__builtin_amdgcn_ballot_w64(!distinct) != 0) {
+        float q[3][4];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            q[k][0] = cs[k]; q[k][1] = o[k] == 0 ? sn[k] : 0.0f; q[k][2] = o[k] == 1 ? sn[k] : 0.0f; q[k][3] = o[k] == 2 ? sn[k] : 0.0f;
+        }
+        float t[4], g[4];
+        qmul(q[1], q[2], t);
+        qmul(q[0], t, g);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) y0[m] = distinct ? y0[m] : g[m];
+    }
 } PM_OP_END
 // rotations/quat.py:159-227
 PM_OP(OpToEuler, 4, 0, 0, 3, 0) {
@@ -344,10 +382,10 @@ PM_OP(OpToEuler, 4, 0, 0, 3, 0) {
     const float qi = (i == 0) ? x0[1] : (i == 1 ? x0[2] : x0[3]);
     const float qj = (j == 0) ? x0[1] : (j == 1 ? x0[2] : x0[3]);
     const float qk = (k == 0) ? x0[1] : (k == 1 ? x0[2] : x0[3]);
-    // sums / differences of two fp32 components cancel (w ~ q_j: near gimbal lock both operands of an atan2 are small and
-    // its argument takes their RELATIVE error): formed in float64, where they are exact, and rounded once
-    const double wd = x0[0], qid = qi, qjd = qj, qks = (double)(qk * sg);  // sg = +-1: exact
-    const float aa = (float)(wd - qjd), bb = (float)(qid + qks), cc = (float)(qjd + wd), dd = (float)(qks - qid);
+    // (these are correctly rounded differences and sums of two fp32 numbers: exactly what forming them in float64 and rounding
+    // once gives, bit for bit -- round 2 went through float64 for them, twelve instructions at its rate)
+    const float qks = qk * sg;  // sg = +-1: exact
+    const float aa = x0[0] - qj, bb = qi + qks, cc = qj + x0[0], dd = qks - qi;
     const float two_pi = 6.283185307179586f;
     float e[3];
     // (np.hypot on quaternion-sized operands: no overflow to guard against, plain sqrt of the sum of squares)
@@ -355,13 +393,15 @@ PM_OP(OpToEuler, 4, 0, 0, 3, 0) {
     const float hs = atan2_rr(bb, aa), hd = atan2_rr(dd, cc);
     e[2] = hs - hd;
     e[0] = (hs + hd) * sg;
+    // np.mod(e, 2pi): the result carries the divisor's sign.  The half sums lie in [-pi, pi], so e[0], e[2] in [-2pi, 2pi] and the
+    // middle angle in [-pi/2, pi/2]: one conditional addition, and for the outer angles one conditional subtraction
+    // (-2pi itself: + 2pi = 0, like np.mod)
+    y0[1] = (e[1] < 0.0f) ? e[1] + two_pi : e[1];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {  // np.mod(e, 2pi): result carries the divisor's sign.  |e| < 4 pi here, so fmod is
-        float r = e[c];            // at most one exact subtraction (Sterbenz), no division loop
-        r = (r >= two_pi) ? r - two_pi : r;
-        r = (r <= -two_pi) ? r + two_pi : r;
-        if (r < 0.0f) r += two_pi;
-        y0[c] = r;
+    for (int c = 0; c < 3; c += 2) {
+        float r = e[c];
+        r = (r < 0.0f) ? r + two_pi : r;
+        y0[c] = (r >= two_pi) ? r - two_pi : r;
     }
 } PM_OP_END
 // rotations/quat.py:465-501
