@@ -25,10 +25,14 @@ for J in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "22,
     rot = torch.randn((Fj, J, 4), device="cuda")
     rot /= rot.norm(dim=-1, keepdim=True)
     root = torch.randn((Fj, 3), device="cuda")
-    off = torch.randn((J, 3), device="cuda")
-    off[0] = 0
+    # metre-scale bones (|t| < 1: the fp32 step) and the same skeleton in centimetres (the precise step, dq.hip)
+    off = torch.from_numpy(syn.make_offsets(J, np.random.default_rng(J), 0.3)).cuda()
     dq = torch.empty((Fj, J, 8), device="cuda")
     pp_ = par.ctypes.data_as(C.c_void_p)
     ms, _ = pp.timeit(lambda: _lib.call("pm_to_root_dq_f32", P(rot), P(root), pp_, P(off), Fj, J, P(dq), None))
-    print(f"[{tag}] J={J:3d} depth={int(syn.depth_of(par).max()):2d}: to_root {ms * 1e3:7.1f} us {Fj * (48 * J + 12) / ms / 1e6 / 80:5.1f}%  {_lib.last_kernel_name().split('(')[0][8:]}", flush=True)
+    off_cm, root_cm = off * 100.0, root * 100.0
+    ms_cm, _ = pp.timeit(lambda: _lib.call("pm_to_root_dq_f32", P(rot), P(root_cm), pp_, P(off_cm), Fj, J, P(dq), None))
+    pct = lambda t: Fj * (48 * J + 12) / t / 1e6 / 80  # noqa: E731
+    print(f"[{tag}] J={J:3d} depth={int(syn.depth_of(par).max()):2d}: to_root {ms * 1e3:7.1f} us {pct(ms):5.1f}%   centimetre data {ms_cm * 1e3:7.1f} us {pct(ms_cm):5.1f}%  "
+          f"{_lib.last_kernel_name().split('(')[0][8:]}", flush=True)
     del rot, dq
