@@ -80,6 +80,59 @@ __global__ __launch_bounds__(256) void interp_linear_kernel(const InterpArgs a) 
     }
 }
 
+// Rows whose length is not a multiple of four floats (66 = 22 joints x 3, 63, ...): a lane still moves dwordx4 -- gfx9 global
+// loads and stores only need 4-byte alignment -- counted per row, the last one of a row holding its B % 4 floats (per-float
+// accesses, one lane in ceil(B / 4)).  Round 2 fell back to dwordx2 / single floats per lane there: 58 % / 40 % of the HBM spec
+// against 78-82 % for rows of 72 / 156 floats.
+typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+__global__ __launch_bounds__(256) void interp_linear_flat_kernel(const InterpArgs a) {
+    // lane-elements are dwordx4 counted PER ROW: V = ceil(B / 4) to a row, the last one of a row holding B % 4 floats
+    const int64_t B = a.B, V = (B + 3) >> 2, nv = a.A * a.S * V;
+    const int64_t base = (int64_t)blockIdx.x * IP_BLOCK;
+    const int64_t row0 = base / V;                              // one 64-bit divide per wave (uniform)
+    const int v0 = (int)(base - row0 * V);
+    const int64_t a0 = row0 / a.S;
+    const int64_t s0 = row0 - a0 * a.S;
+    const float invV = 1.0f / (float)V, invS = 1.0f / (float)a.S;
+    const bool narrow = V < (1 << 21), short_s = a.S < (1 << 21);
+    const int tail = (int)(B & 3);                              // floats of a row's last vector (0: full)
+#pragma unroll
+    for (int k = 0; k < IP_PER_THREAD; ++k) {
+        const int o = k * 256 + threadIdx.x;
+        if (base + o >= nv) break;
+        int dr;
+        int64_t v;
+        if (narrow) {
+            const int e = v0 + o;
+            dr = (int)(((float)e + 0.5f) * invV);
+            v = e - dr * (int)V;
+        } else {
+            const int64_t e = (int64_t)v0 + o;
+            dr = e >= V ? 1 : 0;
+            v = e >= V ? e - V : e;
+        }
+        int64_t aa, s;
+        if (short_s) {
+            const int t = (int)s0 + dr, q = (int)(((float)t + 0.5f) * invS);
+            aa = a0 + q; s = t - q * (int)a.S;
+        } else {
+            const int64_t t = s0 + dr;
+            aa = a0 + (t >= a.S ? 1 : 0); s = t >= a.S ? t - a.S : t;
+        }
+        const int32_t i0 = a.idx[s];
+        const float w = a.w[s], u = 1.0f - w;                  // time.py:61-64
+        const float *p0 = a.pos + ((aa * a.T + i0) * B) + 4 * v;
+        float *o_ = a.out + (row0 + dr) * B + 4 * v;
+        if (tail == 0 || v != V - 1) {
+            const v4f_a4 x = *reinterpret_cast<const v4f_a4 *>(p0), y = *reinterpret_cast<const v4f_a4 *>(p0 + B);
+            *reinterpret_cast<v4f_a4 *>(o_) = v4f_a4{u * x.x + w * y.x, u * x.y + w * y.y, u * x.z + w * y.z, u * x.w + w * y.w};
+        } else {
+            for (int j = 0; j < tail; ++j) o_[j] = u * p0[j] + w * p0[B + j];
+        }
+    }
+}
+
 }  // namespace pm
 
 extern "C" int pm_interpolate_linear_f32(const float *positions, const int32_t *idx, const float *weights, int64_t A,
@@ -96,6 +149,13 @@ extern "C" int pm_interpolate_linear_f32(const float *positions, const int32_t *
     const int64_t grid = (nv + IP_BLOCK - 1) / IP_BLOCK;
     if (grid > 0x7fffffffLL) { set_error("interpolate_linear: grid too large"); return PM_EUNSUPPORTED; }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (vw != 4 && B >= 4) {  // any row length: dword-aligned dwordx4 per row (see interp_linear_flat_kernel)
+        const int64_t n4 = A * S * ((B + 3) >> 2);
+        const int64_t gridf = (n4 + IP_BLOCK - 1) / IP_BLOCK;
+        if (gridf > 0x7fffffffLL) { set_error("interpolate_linear: grid too large"); return PM_EUNSUPPORTED; }
+        hipLaunchKernelGGL(interp_linear_flat_kernel, dim3((unsigned)gridf), dim3(256), 0, s, a);
+        return PM_AFTER_LAUNCH("interpolate_linear launch");
+    }
     if (vw == 4) hipLaunchKernelGGL(interp_linear_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, a);
     else if (vw == 2) hipLaunchKernelGGL(interp_linear_kernel<2>, dim3((unsigned)grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(interp_linear_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, a);
