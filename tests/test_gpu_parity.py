@@ -186,6 +186,25 @@ def test_euler_with_one_order_per_joint_tiled_over_the_frames(F, J):
     assert np.minimum(np.abs(back - q).max(-1), np.abs(back + q).max(-1)).max() < 2e-5
 
 
+def test_from_euler_every_order_triple_and_both_angle_ranges():
+    """from_euler takes a closed form for three distinct axes and the general Hamilton products for a repeated axis (a branch per
+    wave), and its sin / cos an fp32 reduction below 4096 rad and the float64 one above: all 27 triples, alone and mixed inside
+    one wave, on small and large angles, against the oracle (quat.py:43-82 is defined for any triple)"""
+    rng = np.random.default_rng(27)
+    axes = np.array(list("xyz"))
+    triples = np.array([[a, b, c] for a in range(3) for b in range(3) for c in range(3)])
+    n = 1000
+    for scale in (3.2, 3000.0, 5000.0, 2.0e5):
+        e = rng.uniform(-scale, scale, (n, 3)).astype(np.float32)
+        e[::7, 1] = 0.0
+        for t in triples:                                   # one order for the whole batch
+            order = np.tile(axes[t], (n, 1))
+            got = quat.from_euler(e, order)
+            assert_close(got, co.quat_from_euler(e.astype(np.float64), order), 2e-6 if scale < 1e4 else ATOL, f"order {''.join(axes[t])} scale {scale}")
+        order = axes[triples[rng.integers(0, 27, n)]]      # an order per element: distinct and repeated axes in the same wave
+        assert_close(quat.from_euler(e, order), co.quat_from_euler(e.astype(np.float64), order), 2e-6 if scale < 1e4 else ATOL, f"mixed orders, scale {scale}")
+
+
 def test_to_euler_on_quadrant_boundaries_and_identity():
     """the library's own atan2 must keep np.arctan2's conventions where they matter: axis-aligned rotations
     (operands exactly 0), the identity (atan2(0, 0) family) and every quadrant"""

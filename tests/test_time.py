@@ -72,7 +72,9 @@ def test_gpu_interpolate_vs_reference_golden(case):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape,axis", [((1000, 22, 3), 0), ((7, 1000, 22, 3), 1), ((22, 257, 3), -2), ((3, 64, 5), 1),
-                                        ((100_003, 4), 0), ((2, 2, 7), 1), ((5, 0, 3), 0)])
+                                        ((100_003, 4), 0), ((2, 2, 7), 1), ((5, 0, 3), 0),
+                                        # rows of 63 / 6 / 9 floats: dword-aligned dwordx4 per row with a 3 / 2 / 1-float tail
+                                        ((333, 21, 3), 0), ((3, 500, 21, 3), 1), ((5000, 6), 0), ((4, 77, 3, 3), 1)])
 def test_gpu_interpolate_vs_oracle_shapes(shape, axis):
     """every time axis, row lengths that are / are not multiples of 4 floats, an empty axis after the time axis"""
     import pymotion_amd.ops.time as tm
