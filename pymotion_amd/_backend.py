@@ -269,9 +269,32 @@ def _big_empty(shape, dtype):
             n = (out.ctypes.data + out.nbytes - a0) & ~((1 << 21) - 1)
             if n > 0:
                 _libc.madvise(C.c_void_p(a0), C.c_size_t(n), 14)  # MADV_HUGEPAGE
+            _prefault(out)
         except Exception:  # noqa: BLE001  (a hint, never an error)
             pass
     return out
+
+
+_prefault_pool = None
+
+
+def _prefault(arr):
+    """First-touch the pages of a fresh result array from a few helper threads (MADV_POPULATE_WRITE, Linux >= 5.14; EINVAL on an
+    older kernel is ignored) while the pipeline stages and transfers its first chunks: the finisher's casts then write
+    into pages that exist instead of faulting them in one by one on the critical path."""
+    global _prefault_pool
+    if os.environ.get("PM_NO_PREFAULT") == "1":
+        return
+    if _prefault_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        _prefault_pool = ThreadPoolExecutor(4, thread_name_prefix="pm-prefault")
+    page = 4096
+    a0 = (arr.ctypes.data + page - 1) & ~(page - 1)
+    n = (arr.ctypes.data + arr.nbytes - a0) & ~(page - 1)
+    step = max(64 << 20, ((n // 8) + page - 1) & ~(page - 1))
+    for off in range(0, n, step):
+        _prefault_pool.submit(_libc.madvise, C.c_void_p(a0 + off), C.c_size_t(min(step, n - off)), 23)  # MADV_POPULATE_WRITE
 
 
 def pipelined_frames(F, ins, outs, launch):
