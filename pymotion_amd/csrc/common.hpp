@@ -244,25 +244,27 @@ __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x)
 
 // rotations/quat.py:337-361
 __device__ __forceinline__ void qmul(const float (&a)[4], const float (&b)[4], float (&o)[4]) {
-    o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
-    o[1] = a[0] * b[1] + b[0] * a[1] + a[2] * b[3] - a[3] * b[2];
-    o[2] = a[0] * b[2] + b[0] * a[2] + a[3] * b[1] - a[1] * b[3];
-    o[3] = a[0] * b[3] + b[0] * a[3] + a[1] * b[2] - a[2] * b[1];
+    // the FMAs are spelled out: left to -ffp-contract the pairing differs from one kernel instance to the next, and the
+    // same record would round differently depending on which kernel (tile size, tail, pipeline chunk) it lands in
+    o[0] = __builtin_fmaf(-a[3], b[3], __builtin_fmaf(-a[2], b[2], __builtin_fmaf(-a[1], b[1], a[0] * b[0])));
+    o[1] = __builtin_fmaf(-a[3], b[2], __builtin_fmaf(a[2], b[3], __builtin_fmaf(b[0], a[1], a[0] * b[1])));
+    o[2] = __builtin_fmaf(-a[1], b[3], __builtin_fmaf(a[3], b[1], __builtin_fmaf(b[0], a[2], a[0] * b[2])));
+    o[3] = __builtin_fmaf(-a[2], b[1], __builtin_fmaf(a[1], b[2], __builtin_fmaf(b[0], a[3], a[0] * b[3])));
 }
 
 // rotations/quat.py:320-334 : t = 2 (qv x v); v' = v + w t + qv x t
 __device__ __forceinline__ void qmulvec(const float (&q)[4], const float (&v)[3], float (&o)[3]) {
-    const float t0 = 2.0f * (q[2] * v[2] - q[3] * v[1]);
-    const float t1 = 2.0f * (q[3] * v[0] - q[1] * v[2]);
-    const float t2 = 2.0f * (q[1] * v[1] - q[2] * v[0]);
-    o[0] = v[0] + q[0] * t0 + (q[2] * t2 - q[3] * t1);
-    o[1] = v[1] + q[0] * t1 + (q[3] * t0 - q[1] * t2);
-    o[2] = v[2] + q[0] * t2 + (q[1] * t1 - q[2] * t0);
+    const float t0 = 2.0f * __builtin_fmaf(q[2], v[2], -(q[3] * v[1]));
+    const float t1 = 2.0f * __builtin_fmaf(q[3], v[0], -(q[1] * v[2]));
+    const float t2 = 2.0f * __builtin_fmaf(q[1], v[1], -(q[2] * v[0]));
+    o[0] = __builtin_fmaf(q[0], t0, v[0]) + __builtin_fmaf(q[2], t2, -(q[3] * t1));
+    o[1] = __builtin_fmaf(q[0], t1, v[1]) + __builtin_fmaf(q[3], t0, -(q[1] * t2));
+    o[2] = __builtin_fmaf(q[0], t2, v[2]) + __builtin_fmaf(q[1], t1, -(q[2] * t0));
 }
 
 // rotations/quat.py:364-376, 411-423 : q / (|q| + eps)  (eps ADDED TO THE NORM)
 __device__ __forceinline__ void qnormalize(const float (&q)[4], float eps, float (&o)[4]) {
-    const float n = fsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const float n = fsqrt(__builtin_fmaf(q[3], q[3], __builtin_fmaf(q[2], q[2], __builtin_fmaf(q[1], q[1], q[0] * q[0]))));
     const float inv = frcp(n + eps);
     o[0] = q[0] * inv; o[1] = q[1] * inv; o[2] = q[2] * inv; o[3] = q[3] * inv;
 }
@@ -270,12 +272,11 @@ __device__ __forceinline__ void qnormalize(const float (&q)[4], float eps, float
 // rotations/quat.py:276-317
 __device__ __forceinline__ void q2m(const float (&q)[4], float (&m)[9]) {
     const float x2 = q[1] + q[1], y2 = q[2] + q[2], z2 = q[3] + q[3];
-    const float xx = q[1] * x2, yy = q[2] * y2, wx = q[0] * x2;
-    const float xy = q[1] * y2, yz = q[2] * z2, wy = q[0] * y2;
-    const float xz = q[1] * z2, zz = q[3] * z2, wz = q[0] * z2;
-    m[0] = 1.0f - (yy + zz); m[1] = xy - wz;          m[2] = xz + wy;
-    m[3] = xy + wz;          m[4] = 1.0f - (xx + zz); m[5] = yz - wx;
-    m[6] = xz - wy;          m[7] = yz + wx;          m[8] = 1.0f - (xx + yy);
+    const float yy = q[2] * y2, zz = q[3] * z2;
+    const float wx = q[0] * x2, wy = q[0] * y2, wz = q[0] * z2;
+    m[0] = 1.0f - __builtin_fmaf(q[2], y2, zz); m[1] = __builtin_fmaf(q[1], y2, -wz);       m[2] = __builtin_fmaf(q[1], z2, wy);
+    m[3] = __builtin_fmaf(q[1], y2, wz);        m[4] = 1.0f - __builtin_fmaf(q[1], x2, zz); m[5] = __builtin_fmaf(q[2], z2, -wx);
+    m[6] = __builtin_fmaf(q[1], z2, -wy);       m[7] = __builtin_fmaf(q[2], z2, wx);        m[8] = 1.0f - __builtin_fmaf(q[1], x2, yy);
 }
 
 // rotations/quat.py:85-156 : same predicates and candidates, then normalize(eps = 1e-8).

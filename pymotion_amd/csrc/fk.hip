@@ -116,7 +116,7 @@ __device__ __forceinline__ void local_from_quat(const float (&qi)[4], float (&L)
         }
     } else if constexpr ((PREC & PREC_RESID) != 0) {
         float q[4];
-        const float n = fsqrt(qi[0] * qi[0] + qi[1] * qi[1] + qi[2] * qi[2] + qi[3] * qi[3]);
+        const float n = fsqrt(__builtin_fmaf(qi[3], qi[3], __builtin_fmaf(qi[2], qi[2], __builtin_fmaf(qi[1], qi[1], qi[0] * qi[0]))));
         const float inv = frcp(n + 1e-8f);
         q[0] = qi[0] * inv; q[1] = qi[1] * inv; q[2] = qi[2] * inv; q[3] = qi[3] * inv;
         const float w = q[0], x = q[1], y = q[2], z = q[3];
@@ -167,13 +167,15 @@ __device__ __forceinline__ void tree_walk(float *sRot, float *sPos, const float 
             pt = fPos[par * 3];
         }
         if (PFO && j > 0) { t0 = fOff[3 * j]; t1 = fOff[3 * j + 1]; t2 = fOff[3 * j + 2]; }
-        g0 = p0 * L[0] + p1 * L[3] + p2 * L[6];
-        g1 = p0 * L[1] + p1 * L[4] + p2 * L[7];
-        g2 = p0 * L[2] + p1 * L[5] + p2 * L[8];
+        // FMAs spelled out: the same frame must round the same way in every instance of the kernel (tile sizes, tails)
+        g0 = __builtin_fmaf(p2, L[6], __builtin_fmaf(p1, L[3], p0 * L[0]));
+        g1 = __builtin_fmaf(p2, L[7], __builtin_fmaf(p1, L[4], p0 * L[1]));
+        g2 = __builtin_fmaf(p2, L[8], __builtin_fmaf(p1, L[5], p0 * L[2]));
+        const float dt = __builtin_fmaf(p2, t2, __builtin_fmaf(p1, t1, p0 * t0));
         if (FX) {
-            gt = __int_as_float(__float_as_int(pt) + (int)__builtin_rintf((p0 * t0 + p1 * t1 + p2 * t2) * S));
+            gt = __int_as_float(__float_as_int(pt) + (int)__builtin_rintf(dt * S));
         } else {
-            gt = p0 * t0 + p1 * t1 + p2 * t2 + pt;
+            gt = dt + pt;
         }
         // all three lanes of the frame have read slot j (in-order DS) -> overwrite in place
         fRot[j * 9] = g0; fRot[j * 9 + 1] = g1; fRot[j * 9 + 2] = g2;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B library for same-box comparisons: pymotion_amd/libpmhip_ab.so = the current production objects, with the listed
 # translation units taken from another git ref.  Run the probes with PMHIP_VARIANT=ab (tools only; never the product).
-#   tools/ab_build.sh HEAD~1 dq.hip [fk.hip ...]
+#   tools/ab_build.sh HEAD~1 dq.hip [fk.hip ...]        (AB_FLAGS="" builds them without -fno-slp-vectorize)
 set -e
 ref=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
@@ -11,7 +11,7 @@ git -C "$root" archive "$ref" pymotion_amd/csrc include | tar -x -C "$tmp"
 objs=""
 for f in fk dq mirror elementwise unroll ik interp host; do
   if [[ " $* " == *" $f.hip "* ]]; then
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -c "$tmp/pymotion_amd/csrc/$f.hip" -o "$tmp/$f.o"
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC ${AB_FLAGS--fno-slp-vectorize} --offload-arch=gfx950 -c "$tmp/pymotion_amd/csrc/$f.hip" -o "$tmp/$f.o"
     objs="$objs $tmp/$f.o"
   else
     objs="$objs $root/pymotion_amd/csrc/build/prod/$f.o"
