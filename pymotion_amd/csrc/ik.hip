@@ -21,7 +21,7 @@
 namespace pm {
 
 #ifndef PM_IK_MINW
-#define PM_IK_MINW 3
+#define PM_IK_MINW 4
 #endif
 
 struct Topo16 {  // kernarg: parents and children in CSR form
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(PM_WAVE, (NL > 0 && NL <= 12) ? PM_IK_MINW : ((NL >
     if (group < 0) return;
     const int FS = ik_frame_stride(J);
     float *sS = smem;                         // [FPW * FS]  slot (f, j): position, then world quaternion
-    float *sOff = sS + FPW * FS;              // [(J + 1) * 8]  rest offset u of a joint {u0, u1, u2, |u|^2, 1 / |u|, -, -, -} (entry J: the idle item's zeros)
+    float *sOff = sS + FPW * FS;              // [(J + 1) * 8]  rest offset u of a joint {u0, u1, u2, 1 / |u| | u / |u|, |u|} (entry J: the idle item's zeros)
     int *sTopo = reinterpret_cast<int *>(sOff + 8 * (J + 1));  // [J] parent | [J+1] cstart | [J] clist
     typedef int v4i __attribute__((ext_vector_type(4)));
     // [(J + 2) * C] the walk's program: {joint, parent, first child, first further child | count << 16}; read and written as
@@ -98,8 +98,9 @@ __global__ __launch_bounds__(PM_WAVE, (NL > 0 && NL <= 12) ? PM_IK_MINW : ((NL >
     for (int j = lane; j <= J; j += PM_WAVE) {  // rest offsets as they are (exact inputs of the cross / dot products below), their length once
         const float o[3] = {j < J ? a.offsets[3 * j] : 0.0f, j < J ? a.offsets[3 * j + 1] : 0.0f, j < J ? a.offsets[3 * j + 2] : 0.0f};
         const float u2 = __builtin_fmaf(o[0], o[0], __builtin_fmaf(o[1], o[1], o[2] * o[2]));
-        *reinterpret_cast<v4f *>(sOff + 8 * j) = v4f{o[0], o[1], o[2], u2};
-        sOff[8 * j + 4] = (u2 > 0.0f) ? __builtin_amdgcn_rsqf(u2) : 0.0f;
+        const float iu = (u2 > 0.0f) ? __builtin_amdgcn_rsqf(u2) : 0.0f;
+        *reinterpret_cast<v4f *>(sOff + 8 * j) = v4f{o[0], o[1], o[2], iu};
+        *reinterpret_cast<v4f *>(sOff + 8 * j + 4) = v4f{o[0] * iu, o[1] * iu, o[2] * iu, fsqrt(u2)};
     }
     for (int j = lane; j <= J; j += PM_WAVE) {
         // parent | leaf << 16: what the final pass needs about a joint, in one word
@@ -209,57 +210,70 @@ __global__ __launch_bounds__(PM_WAVE, (NL > 0 && NL <= 12) ? PM_IK_MINW : ((NL >
     const int ch = (C == 1) ? 0 : (lane / FPW) % C;  // which chain of the frame this lane walks
     float *fS = sS + f * FS;
     float g[4] = {1.0f, 0.0f, 0.0f, 0.0f};  // world quaternion of the joint this lane aligned last
-    struct Ops { float gl[4], pj[4], pc[4], a[4], ia; };
+    struct Ops { float gl[4], pj[4], pc[4], a[4], b[4]; };
     auto fetch = [&](const v4i it, Ops &o) {  // operands of one step: positions are static until their joint is aligned, a
         const int pp = it.y < 0 ? 0 : it.y;   // finished parent's slot holds its G
         lds_get<4>(fS, pp, o.gl);
         lds_get<4>(fS, it.x, o.pj);
         lds_get<4>(fS, it.z, o.pc);  // children come later: their slots still hold positions
-        lds_get<4>(sOff, 2 * it.z, o.a);  // rest offset of the first child and its squared length
-        o.ia = sOff[8 * it.z + 4];
+        lds_get<4>(sOff, 2 * it.z, o.a);      // rest offset u of the first child, 1 / |u|
+        lds_get<4>(sOff, 2 * it.z + 1, o.b);  // u / |u|, |u|
+    };
+    // v turned by the INVERSE of the unit quaternion g:  v + 2 (w c + qv x c), c = qv x v, qv = -g.xyz  (18 instructions; the
+    // reference's own order of terms, quat.py:320-334 / qmulvec, takes 21)
+    auto unrotate = [](const float (&g)[4], const float (&v)[3], float (&o)[3]) {
+        const float c0 = __builtin_fmaf(g[3], v[1], -(g[2] * v[2]));
+        const float c1 = __builtin_fmaf(g[1], v[2], -(g[3] * v[0]));
+        const float c2 = __builtin_fmaf(g[2], v[0], -(g[1] * v[1]));
+        const float s0 = __builtin_fmaf(g[0], c0, __builtin_fmaf(g[3], c1, -(g[2] * c2)));
+        const float s1 = __builtin_fmaf(g[0], c1, __builtin_fmaf(g[1], c2, -(g[3] * c0)));
+        const float s2 = __builtin_fmaf(g[0], c2, __builtin_fmaf(g[2], c0, -(g[1] * c1)));
+        o[0] = __builtin_fmaf(2.0f, s0, v[0]); o[1] = __builtin_fmaf(2.0f, s1, v[1]); o[2] = __builtin_fmaf(2.0f, s2, v[2]);
     };
     // N + dt, N - dt, |cr|^2 and cr for u (rest, |u|^2 = u2) and v: see above
-    struct Pair { float cr[3], cr2, npd, nmd, N, v2; };
-    auto pair_of = [](const float (&u)[3], const float u2, const float (&v)[3]) {
+    struct Pair { float cr[3], cr2, npd, nmd, N, iv; };
+    auto pair_of = [](const float (&u)[3], const float lu, const float (&v)[3]) {
         Pair q;
         q.cr[0] = diff_of_products(u[1], v[2], u[2], v[1]);
         q.cr[1] = diff_of_products(u[2], v[0], u[0], v[2]);
         q.cr[2] = diff_of_products(u[0], v[1], u[1], v[0]);
         q.cr2 = __builtin_fmaf(q.cr[0], q.cr[0], __builtin_fmaf(q.cr[1], q.cr[1], q.cr[2] * q.cr[2]));
         const float dt = __builtin_fmaf(u[0], v[0], __builtin_fmaf(u[1], v[1], u[2] * v[2]));
-        q.v2 = __builtin_fmaf(v[0], v[0], __builtin_fmaf(v[1], v[1], v[2] * v[2]));
-        q.N = fsqrt(u2 * q.v2);
-        const float big = q.N + fabsf(dt), small = q.cr2 * frcp(big);  // (N = 0: small = NaN, caught by the N > 0 tests)
+        const float v2 = __builtin_fmaf(v[0], v[0], __builtin_fmaf(v[1], v[1], v[2] * v[2]));
+        q.iv = __builtin_amdgcn_rsqf(v2);  // 1 / |v|: the eps term needs it anyway, and |v| = v2 / |v| saves the square root of N
+        q.N = lu * (v2 * q.iv);            // (v = 0: NaN, caught by the N > 0 tests like the N = 0 it replaces)
+        const float big = q.N + fabsf(dt), small = q.cr2 * frcp(big);
         q.npd = (dt >= 0.0f) ? big : small;
         q.nmd = (dt >= 0.0f) ? small : big;
         return q;
     };
     const int nitems = PM_ABLATED(a, 1) ? 0 : nitems_all;
-    v4i cur = sItem[ch], nxt = sItem[C + ch];
-    Ops oc, on;
-    fetch(cur, oc);
+    // Two steps per trip with ping-pong operand sets (A, B): the look-ahead costs no register moves (a single set copied
+    // per step was 20 v_mov of ~170 instructions).  A step's item is consumed into scalars first and its registers are
+    // refilled with the item two steps on; the other set's operands are requested before this step computes (if the next
+    // item's parent is THIS lane's joint its gl is stale, and unused: register chain).
     int prevj = -1;
-    for (int st = 0; st < nitems; ++st) {
-        const v4i nn = sItem[(st + 2) * C + ch];
-        fetch(nxt, on);  // issued before this step computes; if next's parent is THIS lane's joint its gl is stale, and unused (register chain)
+    auto step = [&](const int st, v4i &cur, const Ops &oc, const v4i &nxt, Ops &on) {
         const int j = cur.x, par = cur.y;
         const int xs = cur.w & 0xffff, nx = cur.w >> 16;
+        cur = sItem[(st + 2) * C + ch];
+        fetch(nxt, on);
         float gpre[4];
         const bool chain = par == prevj;  // (the root, par = -1, is "chained" to the identity g starts as)
 #pragma unroll
         for (int k = 0; k < 4; ++k) gpre[k] = chain ? g[k] : oc.gl[k];
         const float (&pj)[4] = oc.pj, (&pc)[4] = oc.pc;
         const float u[3] = {oc.a[0], oc.a[1], oc.a[2]};
-        const float u2 = oc.a[3], iu = oc.ia;
+        const float iu = oc.a[3], lu = oc.b[3];
+        const float (&un)[3] = reinterpret_cast<const float (&)[3]>(oc.b);  // u / |u|
         const float d[3] = {pc[0] - pj[0], pc[1] - pj[1], pc[2] - pj[2]};
-        const float inv[4] = {gpre[0], -gpre[1], -gpre[2], -gpre[3]};
         float p[3];
-        qmulvec(inv, d, p);  // the child's offset in the parent's frame
-        const Pair q = pair_of(u, u2, p);
+        unrotate(gpre, d, p);  // the child's offset in the parent's frame
+        const Pair q = pair_of(u, lu, p);
         // The reference's dot is dt / ((|u| + 1e-8) (|v| + 1e-8)) = (dt / N) (1 - e), e = 1e-8 (1 / |u| + 1 / |v|): 2e-7 on a 0.1-unit
         // bone.  That moves sqrt((1 - dot) / 2) by e / (4 s) -- 1e-6 at a five-degree angle, 1e-5 at half a degree -- so it is
         // carried along (first order): N (1 +- dot_ref) = (N +- dt) -+ dt e.
-        const float e = 1e-8f * (iu + __builtin_amdgcn_rsqf(q.v2)), tol = 1.001e-5f * q.N;  // np.isclose(dot, +-1): 1e-8 + 1e-5
+        const float e = 1e-8f * (iu + q.iv), tol = 1.001e-5f * q.N;  // np.isclose(dot, +-1): 1e-8 + 1e-5
         const float dte = 0.5f * (q.npd - q.nmd) * e;                                       // dt e
         const float npr = q.npd - dte, nmr = q.nmd + dte;                                   // N (1 +- dot_ref)
         // (sqrt(npr), sqrt(nmr) cr / |cr|) / sqrt(2 N) with |cr|^2 = npd nmd, expanded to first order in dte: ONE reciprocal square
@@ -271,7 +285,7 @@ __global__ __launch_bounds__(PM_WAVE, (NL > 0 && NL <= 12) ? PM_IK_MINW : ((NL >
         if (snap) { r[0] = 1.0f; r[1] = 0.0f; r[2] = 0.0f; r[3] = 0.0f; }
         const bool anti = npr <= tol && q.N > 0.0f;
         if (__builtin_amdgcn_ballot_w64(anti) != 0 && anti) {  // anti-parallel (:554-571), rare: skipped by the whole wave otherwise
-            const float a1[3] = {u[0] * iu, u[1] * iu, u[2] * iu};
+            const float a1[3] = {un[0], un[1], un[2]};
             const bool xlike = isclose_to(fabsf(a1[0]), 1.0f);
             const float og[3] = {xlike ? 0.0f : 1.0f, xlike ? 1.0f : 0.0f, 0.0f};
             const float c2[3] = {a1[1] * og[2] - a1[2] * og[1], a1[2] * og[0] - a1[0] * og[2], a1[0] * og[1] - a1[1] * og[0]};
@@ -287,23 +301,24 @@ __global__ __launch_bounds__(PM_WAVE, (NL > 0 && NL <= 12) ? PM_IK_MINW : ((NL >
             const int gc = sTopo[2 * J + 1 + (act ? xs + rr : xs)];
             float pg[4], ug[4];
             lds_get<4>(fS, gc, pg);
-            lds_get<4>(sOff, 2 * gc, ug);  // rest offset of this child and its squared length
-            const float ginv[4] = {g[0], -g[1], -g[2], -g[3]};
+            lds_get<4>(sOff, 2 * gc, ug);  // rest offset of this child, 1 / its length
+            const float lug = sOff[8 * gc + 7];
             const float dg[3] = {pg[0] - pj[0], pg[1] - pj[1], pg[2] - pj[2]};
             float v[3];
-            qmulvec(ginv, dg, v);
-            float axis[3] = {u[0] * iu, u[1] * iu, u[2] * iu};
+            unrotate(g, dg, v);
+            float axis[3] = {un[0], un[1], un[2]};
             if (__builtin_amdgcn_ballot_w64(inexact && act) != 0) {
-                float dn[3], ax[3];
-                vnormalize(d, 1e-8f, dn);
-                qmulvec(ginv, dn, ax);
+                float dd[3] = {d[0], d[1], d[2]}, dn[3], ax[3];
+                asm volatile("" : "+v"(dd[0]), "+v"(dd[1]), "+v"(dd[2]));  // or the normalisation (a square root and a reciprocal) is hoisted in front of the loop and paid by every step
+                vnormalize(dd, 1e-8f, dn);
+                unrotate(g, dn, ax);
                 axis[0] = inexact ? ax[0] : axis[0]; axis[1] = inexact ? ax[1] : axis[1]; axis[2] = inexact ? ax[2] : axis[2];
             }
             const float ub[3] = {ug[0], ug[1], ug[2]};
-            const Pair t = pair_of(ub, ug[3], v);
+            const Pair t = pair_of(ub, lug, v);
             // (w, s) = (sqrt((1 + dot) / 2), sqrt((1 - dot) / 2)) with the reference's dot (see the alignment); s signed by
             // cr . axis (np.sign: 0 -> 0, NaN -> NaN)
-            const float eg = 1e-8f * (sOff[8 * gc + 4] + __builtin_amdgcn_rsqf(t.v2)), tolg = 1.001e-5f * t.N;
+            const float eg = 1e-8f * (ug[3] + t.iv), tolg = 1.001e-5f * t.N;
             const float dtg = 0.5f * (t.npd - t.nmd) * eg;
             const float npg = t.npd - dtg, nmg = t.nmd + dtg;
             const float i2n = __builtin_amdgcn_rsqf(t.N + t.N);
@@ -321,7 +336,14 @@ __global__ __launch_bounds__(PM_WAVE, (NL > 0 && NL <= 12) ? PM_IK_MINW : ((NL >
         }
         lds_put<4>(fS, j, g);  // P_j is dead from here on
         prevj = j;
-        cur = nxt; nxt = nn; oc = on;
+    };
+    v4i iA = sItem[ch], iB = sItem[C + ch];
+    Ops oA, oB;
+    fetch(iA, oA);
+    for (int st = 0; st < nitems; st += 2) {
+        step(st, iA, oA, iB, oB);
+        if (st + 1 >= nitems) break;
+        step(st + 1, iB, oB, iA, oA);
     }
     wave_sync();
 
