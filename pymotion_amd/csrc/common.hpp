@@ -566,6 +566,18 @@ int allow_lds(K kernel, size_t bytes) {
 
 constexpr size_t kMaxLds = 160 * 1024;
 
+// ---- deep.hip: lane-per-frame walks for long skeletons -------------------------------------------------------------
+constexpr int kDeepM = 8;      // joints per chunk
+constexpr int kDeepSlots = 4;  // parent states kept in registers for children that do not follow their parent directly
+enum : uint8_t { DEEP_CHAIN = 0xff, DEEP_LOCAL = 0xfe, DEEP_ROOT = 0xfd, DEEP_NONE = 0xff };
+struct DeepTopo {                    // by value in the kernarg segment: one s_load_dword per joint (a byte table would be read with
+    int32_t code[PM_MAX_JOINTS];     // global_load_ubyte, whose wait is a wait for every prefetch and store in flight): load | save << 8
+};                                   // load: where joint j's parent state comes from -- a slot, DEEP_CHAIN (the previous joint), DEEP_LOCAL /
+                                     // DEEP_ROOT (none); save: the slot joint j's state is kept in for later children, or DEEP_NONE
+int deep_plan(const Parents &par, int J, bool root_is_identity, DeepTopo &t);
+int launch_to_root_deep(const float *rot, const float *root_pos, const float *offsets, float *dq, int64_t F, int32_t J,
+                        const DeepTopo &topo, hipStream_t s);
+
 }  // namespace pm
 
 #define PM_CHECK_ARGS(cond, msg)       \

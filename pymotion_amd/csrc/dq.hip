@@ -382,6 +382,7 @@ static int launch_to_root(const ToRootArgs &a, bool vec, hipStream_t s) {
 // Everything else (image = output tile + identity slot, phase A / C, copy-out, the 12-instruction DPP step) is the
 // kernel above.
 // ---------------------------------------------------------------------------------------------------
+constexpr int kDeepDqMinJ = 56;  // from here on the lane-per-frame kernels of deep.hip (2^19 frames, chain-like skeleton, deep / scheduled walk: J = 40 202 / 206 us, 48 246 / 256, 56 284 / 309, 64 315 / 383; the 52-joint SMPL-H tree 149 / 146)
 constexpr int kSchedMax = 768;  // bytes of schedule in the kernarg segment (steps x chains)
 constexpr int kSchedMaxJoints = 250;
 
@@ -844,6 +845,12 @@ extern "C" int pm_to_root_dq_f32(const float *rot, const float *root_pos, const 
     }
     const bool vec = aligned16(rot) && aligned16(dq);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // Long skeletons: one lane per frame, the joints streamed through LDS in chunks (deep.hip) -- if the topology's open
+    // branch points fit its register slots.  PM_DQ_DEEP (PM_TUNING build only): 0 never, 1 whenever eligible.
+    if (const int deep = tune_env("PM_DQ_DEEP", -1); vec && deep != 0 && (deep == 1 || J >= kDeepDqMinJ)) {
+        DeepTopo topo;
+        if (deep_plan(a.parents, J, true, topo) >= 0) return launch_to_root_deep(rot, root_pos, offsets, dq, F, J, topo, s);
+    }
     const size_t per_frame = (size_t)to_root_frame_stride(J) * sizeof(float), fixed = (13 * (size_t)J + 37) * sizeof(float) + 256;
     int pick = (7 * (16 * per_frame + fixed) <= kMaxLds) ? 16 : 8;  // 4 lanes per frame; keep >= 7 waves per CU if possible
     // From 20 joints on: several chains per frame if the tree is wide enough for the shorter walk to pay

@@ -1,0 +1,163 @@
+"""GPU: the lane-per-frame kernels of deep.hip (to_root_dual_quat and fk for long skeletons).
+
+From 56 joints on, a skeleton whose open branch points fit four register slots is walked one LANE per frame with the joints
+streamed through LDS in chunks of eight (J a multiple of 8) or in line-aligned groups of four (any other J: the ring kernel).
+Checked here: which kernel a call dispatched to, parity with the float64 C oracle at the float32-rounding level (the state is
+float64: the data's magnitude does not matter), partial tiles and single frames, every residue of J mod 8, topologies that
+need 1, 4 and 5 slots (the last one must fall back), NaN / Inf staying in their frame."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from pymotion_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _ulp_of(x):
+    return 2.0 ** (np.floor(np.log2(np.abs(x).max())) - 23)
+
+
+def chain_like(J):
+    """the joint sweep's skeleton: one chain, a second one off the root at J / 2, a third off joint J / 4 at 3 J / 4"""
+    p = np.maximum(np.arange(J) - 1, 0).astype(np.int32)
+    p[J // 2] = 0
+    p[3 * J // 4] = J // 4
+    return p
+
+
+def humanoid_with_hands(J):
+    """spine of 6, head chain of 3, two legs of 5 off the root, two arms of 4 off the last spine joint, and fingers of 3 off the
+    wrists for as many joints as are left (parents before children, children of one joint NOT contiguous)"""
+    p = [0]
+    def chain(start, n):
+        first = len(p)
+        for i in range(n):
+            p.append(start if i == 0 else len(p) - 1)
+        return first, len(p) - 1
+    _, spine_end = chain(0, 6)
+    chain(spine_end, 3)
+    chain(0, 5)
+    chain(0, 5)
+    _, lw = chain(spine_end, 4)
+    _, rw = chain(spine_end, 4)
+    side = 0
+    while len(p) + 3 <= J:
+        chain(lw if side == 0 else rw, 3)
+        side ^= 1
+    while len(p) < J:
+        p.append(len(p) - 1)
+    return np.asarray(p[:J], dtype=np.int32)
+
+
+def nested_branches(J, n):
+    """n branch points open at once: joints 1..n form a chain, each gets a second child AFTER joint n's own chain, innermost first"""
+    p = [0] + list(range(0, n))          # 1..n: chain off the root
+    tail = (J - 1 - n) // (n + 1)
+    for k in range(tail):                # the chain continues below joint n
+        p.append(len(p) - 1)
+    for b in range(n, 0, -1):            # far children of n, n-1, ..., 1, each with a short chain
+        p.append(b)
+        for k in range(tail - 1):
+            p.append(len(p) - 1)
+    while len(p) < J:
+        p.append(len(p) - 1)
+    return np.asarray(p[:J], dtype=np.int32)
+
+
+def _batch(F, J, seed, osc, rsc):
+    rng = np.random.default_rng(seed)
+    rot = rng.standard_normal((F, J, 4))
+    rot = (rot / np.linalg.norm(rot, axis=-1, keepdims=True)).astype(np.float32)
+    root = rng.uniform(-rsc, rsc, (F, 3)).astype(np.float32)
+    off = rng.uniform(-osc, osc, (J, 3)).astype(np.float32)
+    off[0] = 0
+    return rot, root, off
+
+
+CASES = [
+    (56, "chain_like", "deep"), (57, "chain_like", "ring"), (58, "chain_like", "ring"), (59, "humanoid", "ring"), (60, "chain_like", "ring"),
+    (61, "humanoid", "ring"), (62, "chain_like", "ring"), (63, "chain_like", "ring"), (64, "humanoid", "deep"), (65, "chain_like", "ring"),
+    (96, "chain_like", "deep"), (127, "humanoid", "ring"), (128, "chain_like", "deep"), (130, "chain_like", "ring"), (250, "humanoid", "ring"),
+    (72, "nested4", "deep"), (75, "nested4", "ring"), (72, "nested5", "fallback"), (300, "chain_like", "ring"), (512, "chain_like", "deep"),
+]
+
+
+def _parents(kind, J):
+    return {"chain_like": chain_like, "humanoid": humanoid_with_hands, "nested4": lambda j: nested_branches(j, 4),
+            "nested5": lambda j: nested_branches(j, 5)}[kind](J)
+
+
+@pytest.mark.parametrize("J,kind,expect", CASES)
+def test_to_root_dual_quat_lane_per_frame_against_the_oracle(J, kind, expect):
+    import pymotion_amd.ops.skeleton as sk
+
+    parents = _parents(kind, J)
+    assert (parents[1:] < np.arange(1, J)).all()
+    for F, osc, rsc in ((1, 0.3, 2.0), (63, 0.3, 2.0), (64, 30.0, 200.0), (65, 0.3, 2.0), (333, 30.0, 200.0)):
+        rot, root, off = _batch(F, J, 1000 * J + F, osc, rsc)
+        d = sk.to_root_dual_quat(rot, root, parents, off)
+        name = _lib.last_kernel_name()
+        if expect == "fallback":
+            assert "deep_kernel" not in name and "ring_kernel" not in name, name
+        else:
+            assert ("to_root_dq_%s_kernel" % expect) in name, (name, expect)
+        d_o = co.to_root_dual_quat(rot.astype(np.float64), root.astype(np.float64), parents, off.astype(np.float64))
+        err = np.abs(d - d_o).max()
+        if expect != "fallback":
+            # float64 state: the output is the oracle's value rounded once (0.5 ulp of each component, bounded here by 1 ulp of the largest)
+            assert err <= _ulp_of(d_o), (F, err / _ulp_of(d_o), "ulp")
+            assert np.abs(d[..., :4] - d_o[..., :4]).max() <= 6.1e-8
+        else:
+            assert err <= max(1e-5, 3 * _ulp_of(d_o))
+        t, q = sk.from_root_dual_quat(d, parents)
+        assert np.abs(q - rot).max() <= 4e-6
+        assert np.abs(t[:, 1:] - off[1:]).max() <= 4e-6 * max(1.0, np.abs(d_o).max())
+
+
+@pytest.mark.parametrize("J", [64, 77])
+def test_to_root_dual_quat_lane_per_frame_keeps_nan_and_inf_in_their_frame(J):
+    import pymotion_amd.ops.skeleton as sk
+    from pymotion_amd import synthetic as syn
+
+    parents = humanoid_with_hands(J)
+    F = 200
+    rot, root, off = _batch(F, J, 5, 0.3, 2.0)
+    deep = [j for j in range(J) if syn.depth_of(parents)[j] >= 2]
+    rot[70, deep[3], 2] = np.nan
+    rot[71, deep[10], 0] = np.inf
+    root[150, 1] = np.nan
+    with np.errstate(all="ignore"):
+        d_o = co.to_root_dual_quat(rot.astype(np.float64), root.astype(np.float64), parents, off.astype(np.float64))
+    d = sk.to_root_dual_quat(rot, root, parents, off)
+    assert "ring_kernel" in _lib.last_kernel_name() or "deep_kernel" in _lib.last_kernel_name()
+    assert (np.isnan(d) == np.isnan(d_o)).all()
+    assert (np.isinf(d) == np.isinf(d_o)).all()
+    fin = np.isfinite(d_o)
+    assert np.abs(d[fin] - d_o[fin]).max() <= _ulp_of(d_o[fin])
+    clean = np.ones(F, bool)
+    clean[[70, 71, 150]] = False
+    assert np.isfinite(d[clean]).all()
+
+
+def test_to_root_dual_quat_lane_per_frame_through_the_torch_door_and_an_unaligned_view():
+    """device tensors in, no host copy; a view that starts 4 bytes into its storage is not 16-byte aligned: the tile kernels' scalar path"""
+    import torch
+
+    import pymotion_amd.ops.skeleton_torch as skt
+
+    J, F = 80, 300
+    parents = chain_like(J)
+    rot, root, off = _batch(F, J, 9, 0.3, 2.0)
+    d_o = co.to_root_dual_quat(rot.astype(np.float64), root.astype(np.float64), parents, off.astype(np.float64))
+    dev = torch.device("cuda:0")
+    tr, tp, to = torch.from_numpy(rot).to(dev), torch.from_numpy(root).to(dev), torch.from_numpy(off).to(dev)
+    d = skt.to_root_dual_quat(tr, tp, parents, to)
+    assert "to_root_dq_deep_kernel" in _lib.last_kernel_name()
+    assert np.abs(d.cpu().numpy() - d_o).max() <= _ulp_of(d_o)
+    buf = torch.empty(F * J * 4 + 1, device=dev)
+    view = buf[1:].view(F, J, 4)
+    view.copy_(tr)
+    d2 = skt.to_root_dual_quat(view, tp, parents, to)
+    assert "deep" not in _lib.last_kernel_name() and "ring" not in _lib.last_kernel_name()
+    assert np.abs(d2.cpu().numpy() - d_o).max() <= 1e-5

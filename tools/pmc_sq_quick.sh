@@ -1,8 +1,9 @@
 #!/bin/bash
 # SQ counters of the kernels one perf_probe selection launches (own rocprofv3 pass, no trace domains):  tools/pmc_sq_quick.sh ew euler
+#   PMC_CMD="python tools/deep_sweep.py 64,65" tools/pmc_sq_quick.sh - deep     (any other command instead of perf_probe)
 R=$(pwd); only=$1; match=${2:-pm::}
-cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/pq
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_WAVES -d /tmp/pq -o q --output-format csv -- python $R/tools/perf_probe.py --only $only --sustained 5 > /tmp/pq.log 2>&1
+export PYTHONPATH=$R; cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/pq
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_WAVES -d /tmp/pq -o q --output-format csv -- ${PMC_CMD:-python $R/tools/perf_probe.py --only $only --sustained 5} > /tmp/pq.log 2>&1
 python - "$match" <<'PY'
 import csv,glob,collections,statistics,sys
 rows=collections.defaultdict(lambda: collections.defaultdict(list))
