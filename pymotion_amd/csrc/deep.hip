@@ -415,4 +415,10 @@ int launch_to_root_deep(const float *rot, const float *root_pos, const float *of
     return PM_AFTER_LAUNCH("to_root_dq (deep) launch");
 }
 
+// (fk in the same shape was built and measured in round 3, and removed: its 12- and 36-byte records leave a chunk of eight joints as
+// 96- and 288-byte PIECES of cache lines -- no joint count aligns them -- and the chip writes such pieces at 1.7-2.7 TB/s: 2^19 x 128
+// frames 1438 us against 1163 us for the pipelined tile kernel, 367 us with the stores ablated.  Line-sized pieces need 32 records of
+// a frame in LDS at once: 1.5 KB per frame, the tile kernels' problem again.  fk beyond 64 joints got a six-records-per-lane
+// variant of the pipelined tile kernel instead, fk.hip.)
+
 }  // namespace pm

@@ -84,59 +84,7 @@ constexpr int fk_lds_floats() { return 12 + (PFO ? 3 : 0) + (QOUT ? 4 : 0); }
 // Measured at 2^20 x 22 / 2^18 x 52 (sustained, us) and, on offsets +-30 / root +-200, max |pos error| in ulps of the
 // largest coordinate: FAST 267 / 175, 4.3 / 6.3 ulp; RESID 266 / 172, 2.2 / 2.9; F64 273 / 179, 2.0 / 3.0; a float64
 // chain with its residuals in LDS 310-320 / 252, 0.9 / 1.4 -- but 3/4 of that cost is the LDS (occupancy), not the math.
-enum { PREC_FAST = 0, PREC_RESID = 1, PREC_F64 = 2, PREC_FX = 4, PREC_DYN = 16 };
-
-template <int PREC>
-__device__ __forceinline__ void local_from_quat(const float (&qi)[4], float (&L)[9]) {
-    if constexpr ((PREC & PREC_F64) != 0) {
-        const double w = qi[0], x = qi[1], y = qi[2], z = qi[3];
-        const double xx = x * x, yy = y * y, zz = z * z;
-        const double n2 = __builtin_fma(w, w, xx + (yy + zz));
-        const float n2f = (float)n2;
-        // 1 / |q|: hardware rsq (1 ulp) + one Newton step in float64 -> relative error ~1e-14
-        double yd = (double)__builtin_amdgcn_rsqf(n2f);
-        const double e = __builtin_fma(-n2 * yd, yd, 1.0);
-        yd = __builtin_fma(yd * e, 0.5, yd);
-        // 1 / (|q| + eps) = yd / (1 + eps yd) = yd (1 - eps yd) up to (eps yd)^2 < 1e-12 for |q| > 1e-2
-        const double inv = __builtin_fma(-1e-8 * yd, yd, yd);
-        const double s = 2.0 * inv * inv;
-        const double wz = w * z, wy = w * y, wx = w * x;
-        L[0] = (float)__builtin_fma(-s, yy + zz, 1.0); L[1] = (float)(s * __builtin_fma(x, y, -wz)); L[2] = (float)(s * __builtin_fma(x, z, wy));
-        L[3] = (float)(s * __builtin_fma(x, y, wz));   L[4] = (float)__builtin_fma(-s, xx + zz, 1.0); L[5] = (float)(s * __builtin_fma(y, z, -wx));
-        L[6] = (float)(s * __builtin_fma(x, z, -wy));  L[7] = (float)(s * __builtin_fma(y, z, wx));   L[8] = (float)__builtin_fma(-s, xx + yy, 1.0);
-        // tiny or zero quaternions (|q| < 1e-2: eps is no longer a perturbation; zero -> identity, skeleton.py:45): fp32 path
-        // non-finite ones too: the reference's NaN PATTERN (e.g. (inf,0,0,0) -> NaN off the diagonal, 1 on it) comes out of its formula
-        const bool tiny = !(n2f >= 1e-4f && n2f < 3e38f);
-        if (__builtin_amdgcn_ballot_w64(tiny) != 0) {  // wave-uniform, practically never taken
-            float q[4], Lf[9];
-            qnormalize(qi, 1e-8f, q);
-            q2m(q, Lf);
-#pragma unroll
-            for (int k = 0; k < 9; ++k) L[k] = tiny ? Lf[k] : L[k];
-        }
-    } else if constexpr ((PREC & PREC_RESID) != 0) {
-        float q[4];
-        const float n = fsqrt(__builtin_fmaf(qi[3], qi[3], __builtin_fmaf(qi[2], qi[2], __builtin_fmaf(qi[1], qi[1], qi[0] * qi[0]))));
-        const float inv = frcp(n + 1e-8f);
-        q[0] = qi[0] * inv; q[1] = qi[1] * inv; q[2] = qi[2] * inv; q[3] = qi[3] * inv;
-        const float w = q[0], x = q[1], y = q[2], z = q[3];
-        // |q^|^2 - 1 as the fp32 arithmetic left it; the reference's q^ has |q^| = |q| / (|q| + eps) = 1 - eps inv, so the
-        // scale that reproduces ITS matrix is 2 (1 - eps inv)^2 / |q^|^2 = 2 (1 - r - 2 eps inv) to first order.
-        const float r = __builtin_fmaf(w, w, __builtin_fmaf(x, x, __builtin_fmaf(y, y, __builtin_fmaf(z, z, -1.0f))));
-        float s = __builtin_fmaf(-2.0f, __builtin_fmaf(2e-8f, inv, r), 2.0f);
-        s = (n >= 1e-2f && n < 3e38f) ? s : 2.0f;  // tiny / zero / non-finite quaternions: the reference's formula as it is (L = I + 2 M(q^))
-        const float zz = z * z, yy = y * y;
-        const float wz = w * z, wy = w * y, wx = w * x;
-        L[0] = __builtin_fmaf(-s, __builtin_fmaf(y, y, zz), 1.0f); L[1] = s * __builtin_fmaf(x, y, -wz); L[2] = s * __builtin_fmaf(x, z, wy);
-        L[3] = s * __builtin_fmaf(x, y, wz); L[4] = __builtin_fmaf(-s, __builtin_fmaf(x, x, zz), 1.0f); L[5] = s * __builtin_fmaf(y, z, -wx);
-        L[6] = s * __builtin_fmaf(x, z, -wy); L[7] = s * __builtin_fmaf(y, z, wx); L[8] = __builtin_fmaf(-s, __builtin_fmaf(x, x, yy), 1.0f);
-    } else {
-        float q[4];
-        qnormalize(qi, 1e-8f, q);
-        q2m(q, L);
-    }
-}
-
+// (enum PREC_* and local_from_quat: common.hpp)
 
 // ---- phase B: row-parallel tree walk over one LDS tile ----------------------------------------------
 // sRot slot (f, j) holds the local rotation L_j on entry and row-by-row the world rotation on exit;
@@ -1011,7 +959,11 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
         nt = tune_env("PM_FK_NT", nt);  // PM_TUNING build only: tiles per workgroup, 0 = fk_kernel
         // (two records per lane cover 4 x 32 joints: J = 28 / 30 / 32 at 2^19 frames 205 / 215 / 230 us with four, 195 / 203 / 209 us with two)
         if (nt > 0 && a.J <= 32 && tune_env("PM_FK_EPL2", 1)) return dispatch_fk_pipe<4, 2, SRC>(a, vec, pfo, nt, s);
-        if (nt > 0) return a.J <= 64 ? dispatch_fk_pipe<4, 4, SRC>(a, vec, pfo, nt, s) : dispatch_fk_pipe<4, 8, SRC>(a, vec, pfo, nt, s);
+        if (nt > 0 && a.J <= 64) return dispatch_fk_pipe<4, 4, SRC>(a, vec, pfo, nt, s);
+        // (six records per lane cover 4 x 96 joints in 142-150 VGPRs -- three waves per SIMD -- where eight take 214-222: chain-like
+        // skeletons at 2^19 frames, eight / six records: J = 65 549 / 457 us, 72 592 / 507, 80 634 / 585, 88 - / 667, 96 718 / 732)
+        if (nt > 0 && a.J <= 92 && tune_env("PM_FK_EPL6", 1)) return dispatch_fk_pipe<4, 6, SRC>(a, vec, pfo, nt, s);
+        if (nt > 0) return dispatch_fk_pipe<4, 8, SRC>(a, vec, pfo, nt, s);
     }
     // (The pipelined multi-tile structure on the 20-frame three-lane tile, measured again in round 2 with the current kernels:
     // 257 us against 270 us on one box, 295-310 us against 271 us on the next -- fewer, longer workgroups cannot absorb

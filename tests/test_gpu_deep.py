@@ -1,4 +1,4 @@
-"""GPU: the lane-per-frame kernels of deep.hip (to_root_dual_quat and fk for long skeletons).
+"""GPU: the lane-per-frame kernels of deep.hip (to_root_dual_quat for long skeletons).
 
 From 56 joints on, a skeleton whose open branch points fit four register slots is walked one LANE per frame with the joints
 streamed through LDS in chunks of eight (J a multiple of 8) or in line-aligned groups of four (any other J: the ring kernel).
@@ -161,3 +161,4 @@ def test_to_root_dual_quat_lane_per_frame_through_the_torch_door_and_an_unaligne
     d2 = skt.to_root_dual_quat(view, tp, parents, to)
     assert "deep" not in _lib.last_kernel_name() and "ring" not in _lib.last_kernel_name()
     assert np.abs(d2.cpu().numpy() - d_o).max() <= 1e-5
+

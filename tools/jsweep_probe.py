@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """fk over a sweep of joint counts (chains with two branch points, 2^19 frames): where the kernel shapes switch
-(23|24 joints, 64|65) and what multiples of 8 joints -- frame strides that alias in LDS -- cost.  Tuning aid."""
+(23|24 joints, 64|65) and what multiples of 8 joints -- frame strides that alias in LDS -- cost.  Tuning aid.
+PM_SWEEP_TOPO=bushy: random trees (parents[i] uniform in [0, i): depth ~ 2 ln J) instead of the chain-like skeleton."""
 import ctypes as C
 import os
 import sys
@@ -19,6 +20,9 @@ for J in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "8,1
     par = np.maximum(np.arange(J) - 1, 0).astype(np.int32)
     par[J // 2] = 0
     par[3 * J // 4] = J // 4
+    if os.environ.get("PM_SWEEP_TOPO") == "bushy":
+        from pymotion_amd import synthetic as syn
+        par = syn.random_parents(J, np.random.default_rng(J))
     rot = torch.randn((F, J, 4), device="cuda")
     root = torch.randn((F, 3), device="cuda")
     off = torch.randn((J, 3), device="cuda") * 0.15  # human-scale bones in metres: the fp32 walk (bones >= 1 m take the fixed-point one, see fk.hip PREC_DYN)
@@ -27,7 +31,7 @@ for J in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "8,1
     pp_ = par.ctypes.data_as(C.c_void_p)
     ms, _ = pp.timeit(lambda: _lib.call("pm_fk_f32", P(rot), P(root), P(off), 0, pp_, F, J, P(pos), P(rm), None))
     gb = F * (64 * J + 12) / ms / 1e6
-    line = f"FPW={os.environ.get('PM_FK_FPW', 'auto'):>4} J={J:3d}: fk {ms * 1e3:7.1f} us {gb / 80:5.1f}%"
+    line = f"{os.environ.get('PM_SWEEP_TOPO', 'chain-like'):>10} J={J:3d}: fk {ms * 1e3:7.1f} us {gb / 80:5.1f}%"
     if os.environ.get("PM_SWEEP_ALL"):
         off[0] = 0
         dq = torch.empty((F, J, 8), device="cuda")
