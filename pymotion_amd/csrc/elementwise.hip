@@ -34,6 +34,7 @@ struct EwArgs {
                // of P orders, element e using row e % P (one order per joint of a [F, J, 3] clip)
     int64_t tile_e0;   // filled by the kernel: first element of the wave's tile ...
     int order_r0;      // ... and its row in the order table (tile_e0 % P), so that a row index is a 32-bit affair
+    int order_pk;      // ... and, per element, its order as three packed bytes (fetched BEFORE the tile's operands: see ew_kernel)
 };
 
 // Records of 4 (dwordx4), 3 (dwordx3) or 1 float: one record per lane with consecutive lanes on consecutive
@@ -91,6 +92,7 @@ __device__ __forceinline__ void ew_put(float *g, float *s, const int64_t e0, con
 // Op concept: static constexpr int I0,I1,I2,O0,O1 (0 = absent);
 //   static __device__ void apply(const float(&)[I0|1], const float(&)[I1|1], const float(&)[I2|1],
 //                                float(&)[O0|1], float(&)[O1|1], const EwArgs&, int64_t elem)
+struct OpToEuler;
 template <class Op, bool VEC>
 __global__ __launch_bounds__(PM_WAVE) void ew_kernel(const EwArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -111,6 +113,23 @@ __global__ __launch_bounds__(PM_WAVE) void ew_kernel(const EwArgs a) {
     EwArgs b = a;
     b.tile_e0 = e0;
     b.order_r0 = (a.order != nullptr && a.flag >= 2) ? (int)(e0 % a.flag) : 0;  // wave-uniform, once per tile
+    // Euler orders: three bytes per element from a side table.  Requested here, ahead of the operands -- inside the op they were a
+    // second, dependent trip to memory per tile (to_euler: waves waiting 77 % of their time, 51 % of the HBM spec).
+    // (to_euler needs its order first thing; from_euler only after three sincos, which hide the trip -- fetched early it was 3.5 % slower)
+    int opk[EW_PER_LANE];
+#pragma unroll
+    for (int m = 0; m < EW_PER_LANE; ++m) opk[m] = 0;
+    if constexpr (__is_same(Op, OpToEuler)) {
+#pragma unroll
+        for (int m = 0; m < EW_PER_LANE; ++m) {
+            const int idx = m * PM_WAVE + lane, ic = idx < n ? idx : n - 1;
+            int64_t row = 0;
+            if (a.flag == 1) row = e0 + ic;
+            else if (a.flag >= 2) row = (unsigned)(b.order_r0 + ic) % (unsigned)a.flag;  // < P + EW_TILE: 32-bit
+            const uint8_t *p = a.order + row * 3;
+            opk[m] = (int)p[0] | ((int)p[1] << 8) | ((int)p[2] << 16);
+        }
+    }
     ew_stage_in<I0, VEC>(a.in0, s0, e0, n, lane);
     ew_stage_in<I1, VEC>(a.in1, s1, e0, n, lane);
     ew_stage_in<I2, VEC>(a.in2, s2, e0, n, lane);
@@ -130,7 +149,8 @@ __global__ __launch_bounds__(PM_WAVE) void ew_kernel(const EwArgs a) {
     for (int m = 0; m < EW_PER_LANE; ++m) {
         const int idx = m * PM_WAVE + lane, ic = idx < n ? idx : n - 1;
         float y0[O0 ? O0 : 1], y1[O1 ? O1 : 1];
-        Op::apply(x0[m], x1[m], x2[m], y0, y1, b, e0 + ic);  // (ops that index global side tables stay in bounds)
+        b.order_pk = opk[m];
+        Op::apply(x0[m], x1[m], x2[m], y0, y1, b, e0 + ic);
         if (idx < n) {
             ew_put<O0, VEC>(a.out0, t0, e0, idx, y0);
             ew_put<O1, VEC>(a.out1, t1, e0, idx, y1);
@@ -329,12 +349,15 @@ PM_OP(OpToScaledAA, 4, 0, 0, 3, 0) {
     y0[0] = ang * ax[0]; y0[1] = ang * ax[1]; y0[2] = ang * ax[2];
 } PM_OP_END
 
-__device__ __forceinline__ void load_order(const EwArgs &a, int64_t elem, int (&o)[3]) {
+__device__ __forceinline__ void load_order(const EwArgs &a, int64_t elem, int (&o)[3]) {  // from the side table
     int64_t row = 0;
     if (a.flag == 1) row = elem;
     else if (a.flag >= 2) row = (unsigned)(a.order_r0 + (int)(elem - a.tile_e0)) % (unsigned)a.flag;  // < P + EW_TILE: 32-bit
     const uint8_t *p = a.order + row * 3;
     o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+}
+__device__ __forceinline__ void unpack_order(const EwArgs &a, int (&o)[3]) {  // fetched by the kernel ahead of the operands
+    o[0] = a.order_pk & 0xff; o[1] = (a.order_pk >> 8) & 0xff; o[2] = (a.order_pk >> 16) & 0xff;
 }
 // rotations/quat.py:43-82 : q = q0 (x) (q1 (x) q2), each an axis rotation about order[k]
 PM_OP(OpFromEuler, 3, 0, 0, 4, 0) {
@@ -375,13 +398,17 @@ PM_OP(OpFromEuler, 3, 0, 0, 4, 0) {
 } PM_OP_END
 // rotations/quat.py:159-227
 PM_OP(OpToEuler, 4, 0, 0, 3, 0) {
-    int o[3]; load_order(a, elem, o);
+    int o[3]; unpack_order(a, o);
     const int i = o[2], j = o[1], k = o[0];
     const int prod = (i - j) * (j - k) * (k - i);
     const float sg = (float)(prod >= 0 ? prod / 2 : -((-prod + 1) / 2));  // python floor division
-    const float qi = (i == 0) ? x0[1] : (i == 1 ? x0[2] : x0[3]);
-    const float qj = (j == 0) ? x0[1] : (j == 1 ? x0[2] : x0[3]);
-    const float qk = (k == 0) ? x0[1] : (k == 1 ? x0[2] : x0[3]);
+    // (opaque copies: left as array elements, the three selects become x0[i + 1] -- a dynamically indexed array, i.e. 48 bytes of
+    // scratch memory per lane and a trip to it per element: the kernel ran at 51 % with its waves waiting 77 % of the time)
+    float vx = x0[1], vy = x0[2], vz = x0[3];
+    asm volatile("" : "+v"(vx), "+v"(vy), "+v"(vz));
+    const float qi = (i == 0) ? vx : (i == 1 ? vy : vz);
+    const float qj = (j == 0) ? vx : (j == 1 ? vy : vz);
+    const float qk = (k == 0) ? vx : (k == 1 ? vy : vz);
     // (these are correctly rounded differences and sums of two fp32 numbers: exactly what forming them in float64 and rounding
     // once gives, bit for bit -- round 2 went through float64 for them, twelve instructions at its rate)
     const float qks = qk * sg;  // sg = +-1: exact
@@ -429,7 +456,7 @@ static EwArgs mk(const float *i0, const float *i1, const float *i2, float *o0, f
                  int flag = 0, const uint8_t *order = nullptr) {
     EwArgs a;
     a.in0 = i0; a.in1 = i1; a.in2 = i2; a.out0 = o0; a.out1 = o1; a.order = order; a.N = N; a.eps = eps; a.flag = flag;
-    a.tile_e0 = 0; a.order_r0 = 0;
+    a.tile_e0 = 0; a.order_r0 = 0; a.order_pk = 0;
     return a;
 }
 

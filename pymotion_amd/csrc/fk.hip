@@ -590,7 +590,7 @@ __global__ __launch_bounds__(PM_WAVE) void fk_kernel(const FkArgs a) {
 // source is left alone: bounded, the variant with the quaternion output spills 40-100 registers (268 -> 409 us), and the one
 // without (134 VGPRs once the float64 redo of degenerate records moved behind the parking) gains nothing from a fourth wave.)
 template <int FPW, int EPL, bool VEC, int SRC, bool QOUT, bool PAD, bool PFO, int PREC>
-__global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? 4 : ((EPL <= 4 && QOUT && !PFO) ? 3 : 1)) void fk_pipe_kernel(const FkArgs a, const int nt) {
+__global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? ((PFO && EPL == 4) ? 3 : 4) : ((EPL <= 4 && QOUT && !PFO) ? 3 : 1)) void fk_pipe_kernel(const FkArgs a, const int nt) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool DYN = (PREC & PREC_DYN) != 0;
     constexpr bool QUAD = FPW <= 5;  // records per lane: FPW * J <= 64 * EPL

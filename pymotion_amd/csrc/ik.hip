@@ -140,16 +140,19 @@ __global__ __launch_bounds__(PM_WAVE, (NL > 0 && NL <= 12) ? PM_IK_MINW : ((NL >
     const int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
     const int n = nf * J;
     // positions -> the 16-byte slots of the image
-    auto park = [&](const int e, const v3f_a4 pv) {
+    int lane_park = lane;
+    auto park = [&](const int e0, const v3f_a4 pv) {  // record e0 + lane
+        const int e = e0 + lane_park;
         const int f = (int)(((float)e + 0.5f) * invJ);  // e / J, exact for e < 2^22
         const int j = e - f * J;
-        if (e < n) { float *sl = sS + f * FS + 4 * j; sl[0] = pv.x; sl[1] = pv.y; sl[2] = pv.z; }
+        if (lane_park < n - e0) { float *sl = sS + f * FS + 4 * j; sl[0] = pv.x; sl[1] = pv.y; sl[2] = pv.z; }  // (lane against a scalar: no threshold register per record)
     };
     if constexpr (NL > 0) {
         if (!PM_ABLATED(a, 4)) {
+            asm volatile("" : "+v"(lane_park));  // the records' slots are recomputed per tile (six instructions each): held across the walk, NL addresses cost the register that spills
 #pragma unroll
             for (int u = 0; u < NR; ++u)
-                if (u * PM_WAVE < n) park(u * PM_WAVE + lane, pre[u]);
+                if (u * PM_WAVE < n) park(u * PM_WAVE, pre[u]);
         }
         if (tile + 1 < ntiles && tile + 1 < (group + 1) * nt) issue(tile + 1);  // in flight during this tile's walk
     } else {
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(PM_WAVE, (NL > 0 && NL <= 12) ? PM_IK_MINW : ((NL >
         auto park_b = [&](const int e0, const v3f_a4 (&pv)[NB]) {
             if (e0 >= n) return;
 #pragma unroll
-            for (int u = 0; u < NB; ++u) park(e0 + u * PM_WAVE + lane, pv[u]);
+            for (int u = 0; u < NB; ++u) park(e0 + u * PM_WAVE, pv[u]);
         };
         v3f_a4 pa[NB], pb[NB];
         load_b(0, pa);
