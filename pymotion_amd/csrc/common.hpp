@@ -622,6 +622,11 @@ int allow_lds(K kernel, size_t bytes) {
 
 constexpr size_t kMaxLds = 160 * 1024;
 
+// ---- dq.hip / mirror.hip: joints list-scheduled onto C chains per frame ---------------------------------------------------
+constexpr int kSchedMax = 768;  // bytes of schedule in the kernarg segment (steps x chains)
+constexpr int kSchedMaxJoints = 250;
+int schedule_chains(const Parents &par, int J, int C, uint8_t *sched, bool root_local);
+
 // ---- deep.hip: lane-per-frame walks for long skeletons -------------------------------------------------------------
 constexpr int kDeepM = 8;      // joints per chunk
 constexpr int kDeepSlots = 4;  // parent states kept in registers for children that do not follow their parent directly

@@ -383,8 +383,7 @@ static int launch_to_root(const ToRootArgs &a, bool vec, hipStream_t s) {
 // kernel above.
 // ---------------------------------------------------------------------------------------------------
 constexpr int kDeepDqMinJ = 56;  // from here on the lane-per-frame kernels of deep.hip (2^19 frames, chain-like skeleton, deep / scheduled walk: J = 40 202 / 206 us, 48 246 / 256, 56 284 / 309, 64 315 / 383; the 52-joint SMPL-H tree 149 / 146)
-constexpr int kSchedMax = 768;  // bytes of schedule in the kernarg segment (steps x chains)
-constexpr int kSchedMaxJoints = 250;
+// (kSchedMax, kSchedMaxJoints: common.hpp -- mirror.hip schedules its walk the same way)
 
 struct SchedArgs {
     const float *rot;
@@ -645,13 +644,14 @@ static size_t sched_lds_bytes(const int J, const int K, const int C) {
 }
 
 // List scheduling of the joints onto C chains (see above).  Returns the number of steps K, or 0 if the schedule does
-// not fit the kernarg table.  sched[st * C + k] = joint or 255.
-static int schedule_chains(const Parents &par, const int J, const int C, uint8_t *sched) {
+// not fit the kernarg table.  sched[st * C + k] = joint or 255.  root_local: to_root_dual_quat's convention -- joints hanging
+// off the root do not wait for it (they stay local); mirror's world rotations do (root_local = false).
+int schedule_chains(const Parents &par, const int J, const int C, uint8_t *sched, const bool root_local) {
     int height[PM_MAX_JOINTS], done_step[PM_MAX_JOINTS], done_chain[PM_MAX_JOINTS];
     for (int j = 0; j < J; ++j) { height[j] = 1; done_step[j] = -1; done_chain[j] = -1; }
-    for (int j = J - 1; j >= 1; --j) {  // joints hanging off the root do not wait for it (they stay local)
+    for (int j = J - 1; j >= 1; --j) {
         const int p = par.p[j];
-        if (p != 0 && height[p] < height[j] + 1) height[p] = height[j] + 1;
+        if ((p != 0 || !root_local) && height[p] < height[j] + 1) height[p] = height[j] + 1;
     }
     int left = J, K = 0;
     for (int st = 0; left > 0; ++st) {
@@ -665,7 +665,7 @@ static int schedule_chains(const Parents &par, const int J, const int C, uint8_t
                     if (done_step[j] >= 0) continue;
                     const int p = par.p[j];
                     int on_chain = 0;
-                    if (p != 0) {
+                    if (p != 0 || !root_local) {
                         if (done_step[p] < 0 || done_step[p] == st) continue;             // parent not done (or done in this very step)
                         if (done_step[p] == st - 1) { if (done_chain[p] != k) continue; on_chain = 1; }  // only on the parent's chain
                     }
@@ -862,8 +862,8 @@ extern "C" int pm_to_root_dq_f32(const float *rot, const float *root_pos, const 
         SchedArgs sa;
         int K2 = 0, K4 = 0;
         uint8_t s2[kSchedMax], s4[kSchedMax];
-        if (chains != 4) K2 = schedule_chains(a.parents, J, 2, s2);
-        if (chains != 2) K4 = schedule_chains(a.parents, J, 4, s4);
+        if (chains != 4) K2 = schedule_chains(a.parents, J, 2, s2, true);
+        if (chains != 2) K4 = schedule_chains(a.parents, J, 4, s4, true);
         int use = 0;
         if (chains == 2) use = K2 ? 2 : 0;
         else if (chains == 4) use = K4 ? 4 : 0;

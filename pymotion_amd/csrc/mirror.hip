@@ -14,12 +14,14 @@
 //            components, local'_j = conj(g'_parent(j)) (x) g'_j (skeleton.py:322-331 / :410-416), stored
 //            straight from registers (one record per lane = a contiguous dwordx4 stream).
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.hpp"
 
 namespace pm {
 
 struct Map16 { int16_t m[PM_MAX_JOINTS]; };
+constexpr int kMirrorSchedMinJ = 40;  // from here on the scheduled walk is considered (measured: see pm_mirror_rotations_f32)
 
 struct MirrorArgs {
     const float *rot;   // [F,J,4] local rotations
@@ -27,12 +29,15 @@ struct MirrorArgs {
     int64_t F;
     int32_t J;
     int32_t c0, c1;     // quaternion components to negate (X: 2,3  Y: 1,3  Z: 1,2)
+    int32_t K;          // C > 1 chains per frame: steps of the schedule
     Parents parents;
     Map16 mapping;      // identity for mode 'all'
+    uint8_t sched[kSchedMax];  // [K][C]: joint index, 255 = idle (C > 1)
 };
 
-// J slots + the identity slot, padded so that (stride / 4) is odd: the quads of 8 frames hit 8 distinct bank groups
-__host__ __device__ constexpr int mirror_frame_stride(const int J) { return 4 * ((J + 1) | 1); }
+// J slots + the identity slot (+ an idle slot for the scheduled walk), padded so that (stride / 4) is odd: the quads of 8 frames
+// hit 8 distinct bank groups
+__host__ __device__ constexpr int mirror_frame_stride(const int J, const int C) { return 4 * ((J + (C > 1 ? 2 : 1)) | 1); }
 
 // from_matrix(to_matrix(g)) without the matrices: quat.py:276-317 gives the diagonal, quat.py:85-156 the branch,
 // and each branch's candidate is 4 g[dom] g; then its normalize (:155, quat.py:411-423).
@@ -51,7 +56,11 @@ __device__ __forceinline__ void canonical_sign(const float (&g)[4], float (&o)[4
     qnormalize(c, 1e-8f, o);
 }
 
-template <int FPW, bool VEC>
+// C = chains per frame.  C = 1: 4 lanes per frame walk the joints in index order (below).  C = 2 / 4: the joints are list-scheduled
+// onto C quads per frame as in to_root_dq_sched_kernel (dq.hip) -- subtrees are independent once their common ancestor is done, so
+// the walk is K ~ max(J / C, depth) steps instead of J, at 16 / C frames per wave: the 52-joint SMPL-H tree walks 27 steps with
+// two chains, 17 with four.  FPW = 16 / C there.
+template <int FPW, bool VEC, int C>
 __global__ __launch_bounds__(PM_WAVE) void mirror_kernel(const MirrorArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
@@ -62,11 +71,26 @@ __global__ __launch_bounds__(PM_WAVE) void mirror_kernel(const MirrorArgs a) {
     const int64_t f0 = tile * FPW;
     const int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
     const int n = nf * J;
-    const int FS = mirror_frame_stride(J);
+    const int FS = mirror_frame_stride(J, C);
     float *sQ = smem;                                          // [FPW * FS]
     int *sPar = reinterpret_cast<int *>(sQ + FPW * FS);        // [J+1]  walk parent (the root: the identity slot J); entry J repeats
     int *sMap = sPar + (J + 1);                                // [2J]   {mapping[j], mapping[parents[j]]}
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    v2i *sProg = reinterpret_cast<v2i *>(sMap + 2 * J + ((J & 1) ^ 1));  // C > 1: [(K + 2) * C] {own slot | on-chain << 31, parent slot} in bytes; 8-byte aligned
     const float invJ = 1.0f / (float)J;
+    if constexpr (C > 1) {
+        for (int i = lane; i < (a.K + 2) * C; i += PM_WAVE) {  // two idle steps of slack for the look-ahead
+            const int st = i / C, kk = i - st * C;
+            const int j = (st < a.K) ? a.sched[i] : 255;
+            v2i e = v2i{(J + 1) * 16, J * 16};  // idle: the scratch slot, composed with the identity
+            if (j != 255) {
+                const int p = (j == 0) ? J : a.parents.p[j];
+                const int prev = (st > 0) ? a.sched[(st - 1) * C + kk] : 255;
+                e = v2i{j * 16 | ((p != J && prev == p) ? (int)0x80000000 : 0), p * 16};
+            }
+            sProg[i] = e;
+        }
+    }
 
     for (int j = lane; j <= J; j += PM_WAVE) {
         const int jc = j < J ? j : J - 1;
@@ -81,6 +105,7 @@ __global__ __launch_bounds__(PM_WAVE) void mirror_kernel(const MirrorArgs a) {
         const int j = e - f * J;
         if (valid) *reinterpret_cast<v4f *>(sQ + f * FS + j * 4) = v4f{u[0], u[1], u[2], u[3]};
     });
+  if constexpr (C == 1) {
     const int wl = lane % (4 * FPW);  // lanes >= 4*FPW shadow lanes 0..; frames past a partial tile walk their own slots
     const int fq = wl >> 2, c = wl & 3;
     float *fD = sQ + fq * FS;
@@ -119,6 +144,33 @@ __global__ __launch_bounds__(PM_WAVE) void mirror_kernel(const MirrorArgs a) {
     }
     wave_sync();
 
+  } else {
+    // ---- the scheduled walk: quad (frame fq, chain k) runs its column of the program ---------------------------------------
+    const int fq = lane / (4 * C), k = (lane >> 2) % C, c = lane & 3;
+    float *fD = sQ + fq * FS;
+    if (k == 0) { fD[J * 4 + c] = (c == 0) ? 1.0f : 0.0f; fD[(J + 1) * 4 + c] = (c == 0) ? 1.0f : 0.0f; }  // identity and idle slots
+    wave_sync();
+    const float s1 = (c == 0 || c == 2) ? -1.0f : 1.0f, s2 = (c == 0 || c == 3) ? -1.0f : 1.0f, s3 = (c == 0 || c == 1) ? -1.0f : 1.0f;
+    const char *bq = reinterpret_cast<const char *>(fD + c);
+    const v2i *prog = sProg + k;
+    // operands of step st + 1 are requested before step st computes: a parent finished at step st - 1 or earlier is in its slot
+    // by now (in-order DS), one finished at step st is this quad's own register chain (the scheduler guarantees it)
+    v2i e = prog[0], en = prog[C];
+    float b = *reinterpret_cast<const float *>(bq + (e.x & 0x7fffffff)), pe = *reinterpret_cast<const float *>(bq + e.y);
+    float gq = 0.0f;
+    for (int st = 0; st < a.K; ++st) {
+        const v2i enn = prog[(st + 2) * C];
+        const float bn = *reinterpret_cast<const float *>(bq + (en.x & 0x7fffffff));  // its slot holds the local quaternion until its own step
+        const float pen = *reinterpret_cast<const float *>(bq + en.y);
+        const float sb1 = quad_perm_mul<1, 0, 3, 2>(b, s1), sb2 = quad_perm_mul<2, 3, 0, 1>(b, s2), sb3 = quad_perm_mul<3, 2, 1, 0>(b, s3);
+        const float pq = (e.x < 0) ? gq : pe;  // uniform within the quad
+        const float q = quad_qmul(pq, b, sb1, sb2, sb3);
+        *reinterpret_cast<float *>(const_cast<char *>(bq) + (e.x & 0x7fffffff)) = q;
+        gq = q; e = en; en = enn; b = bn; pe = pen;
+    }
+    wave_sync();
+  }
+
     // ---- finish, lane per (frame, joint) --------------------------------------------------------------------
     // (this kernel is VALU-bound -- SQ_ACTIVE_INST_VALU accounts for every SIMD cycle -- so each world quaternion
     // gets the reference's sign and normalisation ONCE, in place, not once as a child and once per child it has)
@@ -154,18 +206,22 @@ __global__ __launch_bounds__(PM_WAVE) void mirror_kernel(const MirrorArgs a) {
     });
 }
 
-template <int FPW>
+static size_t mirror_lds_bytes(const int FPW, const int J, const int K, const int C) {
+    return ((size_t)FPW * mirror_frame_stride(J, C) + 3 * (size_t)J + 1 + 8) * sizeof(float) + (C > 1 ? (size_t)(K + 2) * C * 8 + 8 : 0);  // + slack for the walk's look-ahead
+}
+
+template <int FPW, int C = 1>
 static int launch_mirror(const MirrorArgs &a, bool vec, hipStream_t s) {
-    const size_t lds = ((size_t)FPW * mirror_frame_stride(a.J) + 3 * (size_t)a.J + 1 + 8) * sizeof(float);  // + slack for the walk's look-ahead
+    const size_t lds = mirror_lds_bytes(FPW, a.J, a.K, C);
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
     const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
     if (grid > 0x7fffffffLL) { set_error("mirror: grid too large"); return PM_EUNSUPPORTED; }
     if (vec) {
-        auto k = mirror_kernel<FPW, true>;
+        auto k = mirror_kernel<FPW, true, C>;
         if (int e = allow_lds(k, lds)) return e;
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
     } else {
-        auto k = mirror_kernel<FPW, false>;
+        auto k = mirror_kernel<FPW, false, C>;
         if (int e = allow_lds(k, lds)) return e;
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
     }
@@ -193,8 +249,33 @@ extern "C" int pm_mirror_rotations_f32(const float *rot, const int32_t *parents,
     }
     const bool vec = aligned16(rot) && aligned16(out);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t per_frame = (size_t)mirror_frame_stride(J) * sizeof(float), fixed = (3 * (size_t)J + 9) * sizeof(float) + 256;
+    const size_t per_frame = (size_t)mirror_frame_stride(J, 1) * sizeof(float), fixed = (3 * (size_t)J + 9) * sizeof(float) + 256;
     int pick = (7 * (16 * per_frame + fixed) <= kMaxLds) ? 16 : 8;  // 4 lanes per frame; keep >= 7 waves per CU if possible
+    // Several chains per frame where the tree is wide enough for the shorter walk to pay (walk cost per frame ~ steps x chains / 16),
+    // the rule of to_root_dual_quat (dq.hip).  PM_MIRROR_CHAINS (PM_TUNING build only): 0 = one chain, 2 / 4.
+    a.K = 0;
+    if (const int chains = tune_env("PM_MIRROR_CHAINS", -1); (chains < 0 ? J >= kMirrorSchedMinJ : (chains == 2 || chains == 4)) && J <= kSchedMaxJoints) {
+        uint8_t s2[kSchedMax], s4[kSchedMax];
+        const int K2 = chains == 4 ? 0 : schedule_chains(a.parents, J, 2, s2, false), K4 = chains == 2 ? 0 : schedule_chains(a.parents, J, 4, s4, false);
+        int use = 0;
+        if (chains == 2) use = K2 ? 2 : 0;
+        else if (chains == 4) use = K4 ? 4 : 0;
+        else {
+            const int c1 = 2 * J, c2 = K2 ? 2 * K2 : 1 << 30, c4 = K4 ? 4 * K4 : 1 << 30;
+            // measured at 2^19 frames, one / two / four chains (% of the HBM spec): chain-like skeletons J = 36 66 / 63 / 47, 40 64 / 66.5 / 50,
+            // 52 57 / 63 / 53, 64 55 / 62 / 53, 72 49 / 58 / 48, 96 50 / 53 / 47, 128 40 / 45 / 43; bushy random trees J = 40 64 / 66 / 58,
+            // 52 57 / 63 / 62, 64 55 / 62 / 62, 72 49 / 57 / 56, 96 50 / 53 / 59, 128 41 / 46 / 58: two chains from 40 joints on, four
+            // only for big trees wide enough to halve the walk again
+            if (K4 && J >= 80 && 10 * c4 <= 12 * c2) use = 4;
+            else if (K2 && 4 * c2 <= 3 * c1) use = 2;
+        }
+        if (use) {
+            a.K = use == 2 ? K2 : K4;
+            memcpy(a.sched, use == 2 ? s2 : s4, (size_t)a.K * use);
+            if (mirror_lds_bytes(16 / use, J, a.K, use) <= kMaxLds) return use == 2 ? launch_mirror<8, 2>(a, vec, s) : launch_mirror<4, 4>(a, vec, s);
+            a.K = 0;
+        }
+    }
     if (const int v = tune_env("PM_MIRROR_FPW", 0); v == 16 || v == 8 || v == 4) pick = v;  // PM_TUNING build only
     while (pick > 4 && pick * per_frame + fixed > kMaxLds) pick >>= 1;
     if (pick * per_frame + fixed <= kMaxLds) {

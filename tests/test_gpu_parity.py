@@ -693,14 +693,20 @@ def test_mirror_argument_errors():
         sk.mirror(*args, axis="W")
 
 
-@pytest.mark.parametrize("J", [52, 31, 130])
-def test_mirror_big_skeletons_vs_oracle_composition(J):
-    """Bigger skeletons (8 / 4 frames per wave, odd joint counts, several 64-joint windows of the walk):
-    check against the reference's chain rebuilt from oracle pieces (fk -> from_matrix -> negate -> from_global_rotations)."""
+@pytest.mark.parametrize("J,kind", [(52, "body"), (31, "random"), (130, "random"), (40, "random"), (41, "chain"), (64, "chain"), (65, "random"),
+                                    (96, "random"), (96, "chain"), (250, "random"), (251, "random"), (300, "chain")])
+def test_mirror_big_skeletons_vs_oracle_composition(J, kind):
+    """Bigger skeletons (8 / 4 frames per wave, odd joint counts, several 64-joint windows of the walk; from 40 joints on two or
+    four list-scheduled chains per frame, up to 250 joints): check against the reference's chain rebuilt from oracle pieces
+    (fk -> from_matrix -> negate -> from_global_rotations)."""
     from pymotion_amd import synthetic as syn
 
     rng = np.random.default_rng(J)
-    parents = syn.PARENTS_52 if J == 52 else syn.random_parents(J, rng)
+    parents = {"body": syn.PARENTS_52, "random": syn.random_parents(J, rng)}.get(kind)
+    if parents is None:  # a chain with two branch points
+        parents = np.maximum(np.arange(J) - 1, 0).astype(np.int32)
+        parents[J // 2] = 0
+        parents[3 * J // 4] = J // 4
     F = 257
     rot = rng.standard_normal((F, J, 4)).astype(np.float32)
     rot /= np.linalg.norm(rot, axis=-1, keepdims=True)
@@ -719,6 +725,32 @@ def test_mirror_big_skeletons_vs_oracle_composition(J):
     assert same[~tie_el].all() and tie_el.mean() < 0.01, (int((~same[~tie_el]).sum()), float(tie_el.mean()))
     assert_close(gt, root * np.array([1, -1, 1], np.float32), 0, "translation")
     assert_close(o2, off * np.array([1, -1, 1], np.float32), 0, "offsets")
+
+
+@pytest.mark.parametrize("J", [52, 97])
+def test_mirror_symmetry_mapping_on_the_scheduled_walk(J):
+    """mode='symmetry' permutes the joints' world rotations before they are made local again (skeleton.py:322-331); on skeletons
+    that take the multi-chain walk, against the same composition of oracle pieces (up to the sign of each quaternion)"""
+    from pymotion_amd import synthetic as syn
+
+    rng = np.random.default_rng(7 * J)
+    parents = syn.PARENTS_52 if J == 52 else syn.random_parents(J, rng)
+    mapping = np.arange(J)
+    pairs = rng.permutation(np.arange(1, J))[: 2 * ((J - 1) // 3)].reshape(-1, 2)
+    mapping[pairs[:, 0]], mapping[pairs[:, 1]] = pairs[:, 1], pairs[:, 0]  # an involution, root fixed
+    F = 130
+    rot = rng.standard_normal((F, J, 4)).astype(np.float32)
+    rot /= np.linalg.norm(rot, axis=-1, keepdims=True)
+    root = rng.uniform(-1, 1, (F, 3)).astype(np.float32)
+    off = syn.make_offsets(J, rng, 0.1)
+    got, *_ = sk.mirror(rot, root, parents, off, None, mapping, "symmetry", "X")
+    _, rm = co.fk(rot.astype(np.float64), np.zeros((F, 3)), off.astype(np.float64), parents)
+    g = co.quat_from_matrix(rm)[:, mapping]
+    g[..., 2] *= -1  # axis X -> components (2, 3)  (skeleton.py:310-312)
+    g[..., 3] *= -1
+    want = co.from_global_rotations(g, parents)
+    err = np.minimum(np.abs(got - want).max(-1), np.abs(got + want).max(-1)).max()
+    assert err <= ATOL, err
 
 
 def test_fk_is_hip_graph_capturable_and_stream_ordered():
