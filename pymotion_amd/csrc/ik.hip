@@ -15,10 +15,13 @@
 //     quaternions);  joints without children keep the identity (:126-130).
 // HBM traffic: 12 J B/frame in, 16 J out, both as coalesced one-record-per-lane streams.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.hpp"
 
 namespace pm {
+
+constexpr int kIkFourChainsMinJ = 56;
 
 #ifndef PM_IK_MINW
 #define PM_IK_MINW 4
@@ -39,7 +42,7 @@ struct IkArgs {
     int32_t ablate;  // PM_TUNING build only (env PM_IK_ABLATE): 1 = no walk, 2 = no final pass, 4 = no position staging
     int32_t K;       // two chains per frame: steps of the schedule (0: one chain, every joint with children in index order)
     Topo16 topo;
-    uint8_t sched[512];  // [K][2] joint aligned at step st by chain c, 255 = idle
+    uint8_t sched[512];  // [K][C] joint aligned at step st by chain c, 255 = idle
 };
 
 // LDS image: ONE 16-byte slot per (frame, joint).  It holds the joint's position until the joint has been
@@ -378,7 +381,7 @@ __global__ __launch_bounds__(PM_WAVE, (NL > 0 && NL <= 12) ? PM_IK_MINW : ((NL >
 // right after it on the parent's own chain (its quaternion is still in that lane's registers; the look-ahead fetch of the
 // next step is issued before the current one stores).  Longest remaining path first, a further child counting like an
 // alignment.  Returns the number of steps; 0 if it does not fit or the tree is too narrow to pay.
-static int ik_schedule(const Topo16 &t, const int J, uint8_t *sched) {
+static int ik_schedule(const Topo16 &t, const int J, uint8_t *sched, const int C = 2) {
     int height[PM_MAX_JOINTS], done_step[PM_MAX_JOINTS], done_chain[PM_MAX_JOINTS], items = 0;
     for (int j = 0; j < J; ++j) { height[j] = 0; done_step[j] = -1; done_chain[j] = -1; }
     for (int j = J - 1; j >= 0; --j) {
@@ -391,8 +394,8 @@ static int ik_schedule(const Topo16 &t, const int J, uint8_t *sched) {
     }
     int left = items, K = 0;
     for (int st = 0; left > 0; ++st) {
-        if (2 * (st + 1) > 512) return 0;
-        for (int k = 0; k < 2; ++k) {
+        if (C * (st + 1) > 512) return 0;
+        for (int k = 0; k < C; ++k) {
             int best = -1, best_on = 0;
             for (int j = 0; j < J; ++j) {
                 if (done_step[j] >= 0 || t.cstart[j + 1] <= t.cstart[j]) continue;
@@ -404,12 +407,12 @@ static int ik_schedule(const Topo16 &t, const int J, uint8_t *sched) {
                 }
                 if (best < 0 || on > best_on || (on == best_on && height[j] > height[best])) { best = j; best_on = on; }
             }
-            sched[2 * st + k] = (uint8_t)(best < 0 ? 255 : best);
+            sched[C * st + k] = (uint8_t)(best < 0 ? 255 : best);
             if (best >= 0) { done_step[best] = st; done_chain[best] = k; --left; }
         }
         K = st + 1;
     }
-    return (4 * K <= 3 * items) ? K : 0;
+    return (C > 2 || 4 * K <= 3 * items) ? K : 0;
 }
 
 template <int FPW, int C>
@@ -473,7 +476,19 @@ extern "C" int pm_from_root_positions_f32(const float *positions, const int32_t 
         if (v == 16) return launch_ik<16, 1>(a, vec, s);
     }
     // two chains per frame when the tree is wide enough for the schedule to pay (PM_IK_CHAINS=1 in the tuning build: never)
-    a.K = (J <= 254 && tune_env("PM_IK_CHAINS", 2) == 2) ? ik_schedule(a.topo, J, a.sched) : 0;
+    const int chains = tune_env("PM_IK_CHAINS", 0);  // PM_TUNING build only: 1 = never several, 2 / 4 = that many if the schedule exists
+    a.K = (J <= 254 && chains != 1 && chains != 4) ? ik_schedule(a.topo, J, a.sched) : 0;
+    // FOUR chains (16 frames per wave) for long skeletons whose tree is wide enough to shorten the walk again: beyond ~56 joints the
+    // 32-frame image leaves room for two to four waves per CU and the walk is all the kernel waits for
+    if (J <= 254 && (chains == 4 || (chains == 0 && J > kIkFourChainsMinJ))) {
+        uint8_t s4[512];
+        const int K4 = ik_schedule(a.topo, J, s4, 4);
+        if (K4 > 0 && (chains == 4 || a.K == 0 || 10 * K4 <= 7 * a.K) && 2 * (16 * per_frame + fixed + (size_t)(J + 2) * 32) <= kMaxLds) {
+            a.K = K4;
+            memcpy(a.sched, s4, sizeof(s4));
+            return launch_ik<16, 4>(a, vec, s);
+        }
+    }
     if (a.K > 0 && 2 * (32 * per_frame + fixed) <= kMaxLds) return launch_ik<32, 2>(a, vec, s);
     a.K = 0;
     if (4 * (64 * per_frame + fixed) <= kMaxLds) return launch_ik<64, 1>(a, vec, s);  // every lane busy, >= 4 waves per CU

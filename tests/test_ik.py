@@ -129,6 +129,32 @@ def test_gpu_from_root_positions_large_vs_oracle(J, F):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("J,F,four", [(57, 700, None), (72, 700, None), (96, 520, True), (130, 300, True), (250, 130, None), (300, 70, False)])
+def test_gpu_from_root_positions_long_bushy_skeletons_on_four_chains(J, F, four):
+    """beyond 56 joints a tree wide enough to shorten the walk again is scheduled onto FOUR chains per frame (16 frames per wave)"""
+    import pymotion_amd.ops.skeleton as sk
+    from pymotion_amd import _lib
+    from pymotion_amd import synthetic as syn
+
+    par = syn.random_parents(J, np.random.default_rng(J))
+    rot, root, off, par = syn.fk_workload(F, parents=par, seed=J, normalized=True, offset_scale=0.1)
+    pos, _ = co.fk(rot.astype(np.float64), np.zeros((F, 3)), off.astype(np.float64), par)
+    pos = pos.astype(np.float32)
+    got = sk.from_root_positions(pos, par, off)
+    name = _lib.last_kernel_name()
+    assert four is None or name.endswith(", 4>(pm::IkArgs, int)") == four, name  # (None: whichever the schedules of this tree favour)
+    ref = co.from_root_positions(pos.astype(np.float64), par, off.astype(np.float64))
+    err = np.minimum(np.abs(got - ref).max(-1), np.abs(got + ref).max(-1))
+    # (2e-5 on 99.9 % of the records; the rest -- alignments within a hair of a half turn, whose twist every joint below inherits,
+    # see _reference_sensitivity -- within 1e-4: measured worst 4e-5 at 700 x 72)
+    assert np.quantile(err, 0.999) <= 2e-5, float(np.quantile(err, 0.999))
+    assert err.max() <= 1e-4, float(err.max())
+    p2, _ = sk.fk(got, np.zeros_like(root), off, par)
+    p_ref, _ = co.fk(ref, np.zeros((F, 3)), off.astype(np.float64), par)
+    assert np.abs(p2 - p_ref).max() <= 2e-5
+
+
+@pytest.mark.gpu
 def test_gpu_mirror_positions_vs_reference_golden():
     import pymotion_amd.ops.skeleton as sk
 
