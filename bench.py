@@ -202,6 +202,30 @@ def secondary_configs(torch, _lib, syn, dev, rot, root, off, parents, sptr):
     t52 = timed(lambda: _lib.call("pm_fk_f32", p(q4), p(root4), p(off4), 0, pp4, F4, 52, p(pos4), p(rm4), sptr))
     out["fk_J52"] = {"frames": F4, "ms": t52, "frames_per_s": F4 / (t52 * 1e-3),
                      "hbm_frac": F4 * (64 * 52 + 12) / (t52 * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    del x, root4, off4, pos4, rm4, q4
+    # a LONG, chain-like skeleton (128 joints: one chain, a second one off the root, a third off joint 32; 2^18 frames): what the
+    # tile kernels are worst at (round 2: to_root_dual_quat 31 %, fk 46 %).  to_root_dual_quat: the lane-per-frame kernel of deep.hip.
+    F5, J5 = 1 << 18, 128
+    par5 = np.maximum(np.arange(J5) - 1, 0).astype(np.int32)
+    par5[J5 // 2] = 0
+    par5[3 * J5 // 4] = J5 // 4
+    pp5 = par5.ctypes.data_as(C.c_void_p)
+    rot5 = torch.randn((F5, J5, 4), device=dev)
+    rot5 /= rot5.norm(dim=-1, keepdim=True)
+    root5 = torch.rand((F5, 3), device=dev) * 4 - 2
+    off5 = torch.randn((J5, 3), device=dev) * 0.15
+    off5[0] = 0
+    dq5 = torch.empty((F5, J5, 8), device=dev)
+    t5 = timed(lambda: _lib.call("pm_to_root_dq_f32", p(rot5), p(root5), pp5, p(off5), F5, J5, p(dq5), sptr), n=40)
+    k5 = _lib.last_kernel_name()
+    del dq5
+    pos5 = torch.empty((F5, J5, 3), device=dev)
+    rm5 = torch.empty((F5, J5, 3, 3), device=dev)
+    t5f = timed(lambda: _lib.call("pm_fk_f32", p(rot5), p(root5), p(off5), 0, pp5, F5, J5, p(pos5), p(rm5), sptr), n=40)
+    out["long_chain_like_skeleton_J128"] = {
+        "frames": F5, "to_root_dual_quat_ms": t5, "to_root_dual_quat_hbm_frac": F5 * (48 * J5 + 12) / (t5 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        "to_root_dual_quat_kernel": k5, "fk_ms": t5f, "fk_hbm_frac": F5 * (64 * J5 + 12) / (t5f * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        "fk_kernel": _lib.last_kernel_name()}
     return out
 
 
@@ -241,6 +265,8 @@ def stream_ceilings(torch, _lib, dev, rot, rm, F, J, sptr):
     rates["pure_write"] = {"bytes": n4 * 48, "ms": t, "GBps": n4 * 48 / (t * 1e-3) / 1e9}
     t = timed(lambda: _lib.call("pm_stream_plain_f32", p(src), p(big), n4, 1, 8192, sptr))
     rates["read_write_1_1"] = {"bytes": n4 * 32, "ms": t, "GBps": n4 * 32 / (t * 1e-3) / 1e9}
+    t = timed(lambda: _lib.call("pm_stream_plain_f32", p(src), p(big), n4, 2, 8192, sptr))
+    rates["read_write_1_2"] = {"bytes": n4 * 48, "ms": t, "GBps": n4 * 48 / (t * 1e-3) / 1e9}
     t = timed(lambda: _lib.call("pm_stream_plain_f32", p(src), p(big), n4, 3, 8192, sptr))
     rates["read_write_1_3"] = {"bytes": n4 * 64, "ms": t, "GBps": n4 * 64 / (t * 1e-3) / 1e9}
     out["stream_rates"] = rates
