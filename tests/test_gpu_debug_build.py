@@ -68,16 +68,25 @@ def _same(torch, x, y):
 
 
 CASES = [(22, 61, 0.3, 2.0), (22, 20 * 7 + 3, 30.0, 200.0), (52, 4 * 9 + 1, 0.15, 2.0), (52, 70_003, 30.0, 200.0), (24, 45, 0.3, 2.0),
-         (64, 13, 0.3, 2.0), (100, 21, 0.2, 2.0), (130, 9, 0.2, 2.0), (3, 1000, 0.3, 2.0), (1, 65, 0.3, 2.0)]
+         (64, 13, 0.3, 2.0), (100, 21, 0.2, 2.0), (130, 9, 0.2, 2.0), (3, 1000, 0.3, 2.0), (1, 65, 0.3, 2.0),
+         # chain-like skeletons (negative J): to_root_dual_quat's lane-per-frame kernels (chunks of eight / the line-aligned ring), full and
+         # partial tiles of 64 frames, the guard words right behind every frame row they store
+         (-56, 64, 0.3, 2.0), (-57, 130, 0.3, 2.0), (-63, 65, 30.0, 200.0), (-66, 1, 0.3, 2.0), (-72, 193, 0.3, 2.0), (-129, 67, 0.2, 2.0)]
 
 
 @pytest.mark.parametrize("J,F,osc,rsc", CASES)
 def test_skeleton_kernels_under_the_debug_build(J, F, osc, rsc):
     import torch
 
+    chain_like = J < 0
+    J = abs(J)
     rng = np.random.default_rng(J * 1000 + F)
     parents = {22: syn.PARENTS_22, 52: syn.PARENTS_52}.get(J)
-    if parents is None:
+    if chain_like:
+        parents = np.maximum(np.arange(J) - 1, 0).astype(np.int32)
+        parents[J // 2] = 0
+        parents[3 * J // 4] = J // 4
+    elif parents is None:
         parents = syn.random_parents(J, rng)
     pp = parents.ctypes.data_as(C.c_void_p)
     rot_h = rng.standard_normal((F, J, 4)).astype(np.float32)
