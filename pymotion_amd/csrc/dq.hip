@@ -382,7 +382,7 @@ static int launch_to_root(const ToRootArgs &a, bool vec, hipStream_t s) {
 // Everything else (image = output tile + identity slot, phase A / C, copy-out, the 12-instruction DPP step) is the
 // kernel above.
 // ---------------------------------------------------------------------------------------------------
-constexpr int kDeepDqMinJ = 56;  // from here on the lane-per-frame kernels of deep.hip (2^19 frames, chain-like skeleton, deep / scheduled walk: J = 40 202 / 206 us, 48 246 / 256, 56 284 / 309, 64 315 / 383; the 52-joint SMPL-H tree 149 / 146)
+constexpr int kDeepDqMinJ = 40;  // from here on the lane-per-frame kernels of deep.hip where the topology allows (2^19 frames, chain-like skeleton, deep / scheduled walk: J = 32 159 / 152 us, 40 202 / 206, 48 246 / 256, 56 284 / 309, 64 315 / 383; the 52-joint SMPL-H tree at 2^18: 149 / 146 us on metre data, 148 / 196 us on centimetre data -- the float64 state does not know the difference)
 // (kSchedMax, kSchedMaxJoints: common.hpp -- mirror.hip schedules its walk the same way)
 
 struct SchedArgs {

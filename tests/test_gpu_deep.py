@@ -1,6 +1,6 @@
 """GPU: the lane-per-frame kernels of deep.hip (to_root_dual_quat for long skeletons).
 
-From 56 joints on, a skeleton whose open branch points fit four register slots is walked one LANE per frame with the joints
+From 40 joints on, a skeleton whose open branch points fit four register slots is walked one LANE per frame with the joints
 streamed through LDS in chunks of eight (J a multiple of 8) or in line-aligned groups of four (any other J: the ring kernel).
 Checked here: which kernel a call dispatched to, parity with the float64 C oracle at the float32-rounding level (the state is
 float64: the data's magnitude does not matter), partial tiles and single frames, every residue of J mod 8, topologies that
@@ -76,6 +76,7 @@ def _batch(F, J, seed, osc, rsc):
 
 
 CASES = [
+    (40, "chain_like", "deep"), (41, "humanoid", "ring"), (52, "smplh", "ring"), (39, "chain_like", "fallback"),
     (56, "chain_like", "deep"), (57, "chain_like", "ring"), (58, "chain_like", "ring"), (59, "humanoid", "ring"), (60, "chain_like", "ring"),
     (61, "humanoid", "ring"), (62, "chain_like", "ring"), (63, "chain_like", "ring"), (64, "humanoid", "deep"), (65, "chain_like", "ring"),
     (96, "chain_like", "deep"), (127, "humanoid", "ring"), (128, "chain_like", "deep"), (130, "chain_like", "ring"), (250, "humanoid", "ring"),
@@ -84,6 +85,10 @@ CASES = [
 
 
 def _parents(kind, J):
+    from pymotion_amd import synthetic as syn
+
+    if kind == "smplh":
+        return syn.PARENTS_52
     return {"chain_like": chain_like, "humanoid": humanoid_with_hands, "nested4": lambda j: nested_branches(j, 4),
             "nested5": lambda j: nested_branches(j, 5)}[kind](J)
 

@@ -979,6 +979,13 @@ def test_every_skeleton_kernel_on_views_that_are_only_4_byte_aligned(J, osc):
                     d = np.minimum(np.abs(t.cpu().numpy() - w).max(-1), np.abs(t.cpu().numpy() + w).max(-1))
                     assert np.median(d) <= 1e-6 and (d > 5e-4).mean() <= 2e-3, (k, np.median(d), d.max())
                     continue
+                if 7 <= k <= 9 and J >= 40:
+                    # to_root_dual_quat: the aligned call walks one lane per frame in float64 (deep.hip), the 4-byte-aligned view stays on
+                    # the tile kernel -- both within 2 ulp of the largest component of the float64 oracle, not bit-identical
+                    # (8, 9: the decode of either result)
+                    tn = t.cpu().numpy()
+                    assert np.abs(tn - w).max() <= max(2e-6, 3 * 2.0 ** (np.floor(np.log2(np.abs(w).max())) - 23)), (k, np.abs(tn - w).max())
+                    continue
                 np.testing.assert_array_equal(t.cpu().numpy(), w, err_msg=f"result {k}")
 
 
