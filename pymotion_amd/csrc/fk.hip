@@ -589,7 +589,8 @@ __global__ __launch_bounds__(PM_WAVE) void fk_kernel(const FkArgs a) {
 // had pushed the per-frame-offsets variant to 166 VGPRs: 2^20 x 22 with per-frame offsets 416 us, 369 with the bound.  The ortho6d
 // source is left alone: bounded, the variant with the quaternion output spills 40-100 registers (268 -> 409 us), and the one
 // without (134 VGPRs once the float64 redo of degenerate records moved behind the parking) gains nothing from a fourth wave.)
-template <int FPW, int EPL, bool VEC, int SRC, bool QOUT, bool PAD, bool PFO, int PREC>
+// FIXED (J a multiple of 4, 16-byte aligned linear image): the copy-out is a fixed number of unconditional dwordx4 stores, see copy_out.
+template <int FPW, int EPL, bool VEC, int SRC, bool QOUT, bool PAD, bool PFO, int PREC, bool FIXED = false>
 __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? ((PFO && EPL == 4) ? 3 : 4) : ((EPL <= 4 && QOUT && !PFO) ? 3 : 1)) void fk_pipe_kernel(const FkArgs a, const int nt) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool DYN = (PREC & PREC_DYN) != 0;
@@ -672,6 +673,22 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? ((PFO && E
         }
     };
     auto copy_out = [&](const int64_t f0, const int nfr) {
+        // A FIXED number of unconditional dwordx4 stores (lanes past the tile's end repeat its last vector): behind store loops of
+        // unknown length every later wait on a load -- the next tile's records are in flight by then -- is a vmcnt(0), i.e. a wait for
+        // these stores to be acknowledged; counted, they drain under the next tile's math and walk.
+        if constexpr (FIXED) {
+            constexpr int NR = (EPL * 9 + 3) / 4, NP = (EPL * 3 + 3) / 4;
+            const int n4r = (nfr * J * 9) >> 2, n4p = (nfr * J * 3) >> 2;
+            v4f *gr = reinterpret_cast<v4f *>(a.rotmats + f0 * J * 9), *gp4 = reinterpret_cast<v4f *>(a.pos + f0 * J * 3);
+            const v4f *lr = reinterpret_cast<const v4f *>(sRot), *lp = reinterpret_cast<const v4f *>(sPos);
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+#pragma unroll
+            for (int u = 0; u < NR; ++u) { const int i = u * PM_WAVE + ln, ic = i < n4r ? i : n4r - 1; __builtin_nontemporal_store(lr[ic], gr + ic); }
+#pragma unroll
+            for (int u = 0; u < NP; ++u) { const int i = u * PM_WAVE + ln, ic = i < n4p ? i : n4p - 1; __builtin_nontemporal_store(lp[ic], gp4 + ic); }
+            return;
+        }
         image_store<VEC>(a.rotmats + f0 * J * 9, sRot, nfr, J * 9, pad, lane);
         image_store<VEC>(a.pos + f0 * J * 3, sPos, nfr, J * 3, pad, lane);
     };
@@ -832,11 +849,20 @@ static int launch_fk_p(const FkArgs &a, hipStream_t s) {
 template <int FPW, int EPL, bool VEC, int SRC, bool QOUT, bool PAD, bool PFO, int PREC>
 static int launch_fk_pipe_pp(const FkArgs &a, const int nt, hipStream_t s) {
     const size_t lds = ((size_t)FPW * (a.J * (12 + (PFO ? 3 : 0)) + (PFO ? 3 : 2) * a.pad) + 4 * (a.J + 4)) * sizeof(float);
-    auto k = fk_pipe_kernel<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, PREC>;
-    if (int e = allow_lds(k, lds)) return e;
     const int64_t ntiles = (a.F + FPW - 1) / FPW, ngroups = (ntiles + nt - 1) / nt;
     const int64_t grid = ((ngroups + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
     if (grid > 0x7fffffffLL) { set_error("fk: grid too large"); return PM_EUNSUPPORTED; }
+    if constexpr (VEC && !PAD && !QOUT) {
+        if (a.J % 4 == 0 && tune_env("PM_FK_FIXED_STORES", 1)) {  // every tile, full or partial, is whole dwordx4: fixed-count copy-out
+            auto kf = fk_pipe_kernel<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, PREC, true>;
+            if (int e = allow_lds(kf, lds)) return e;
+            set_kernel_name("void pm::fk_pipe_kernel<%d, %d, %s, %d, %s, %s, %s, %d, true>(pm::FkArgs, int)", FPW, EPL, tf(VEC), SRC, tf(QOUT), tf(PAD), tf(PFO), PREC);
+            hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a, nt);
+            return PM_AFTER_LAUNCH("fk launch");
+        }
+    }
+    auto k = fk_pipe_kernel<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, PREC>;
+    if (int e = allow_lds(k, lds)) return e;
     set_kernel_name("void pm::fk_pipe_kernel<%d, %d, %s, %d, %s, %s, %s, %d>(pm::FkArgs, int)", FPW, EPL, tf(VEC), SRC, tf(QOUT), tf(PAD), tf(PFO), PREC);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a, nt);
     return PM_AFTER_LAUNCH("fk launch");
