@@ -53,6 +53,13 @@ def trees(J):
     yield np.maximum(np.arange(J) - 1, 0).astype(np.int32)          # chain
     yield np.zeros(J, np.int32)                                      # star
     yield ((np.arange(J) - 1) // 2).clip(0).astype(np.int32)         # heap
+    c = np.maximum(np.arange(J) - 1, 0).astype(np.int32)             # a chain with two branch points (deep.hip's register slots)
+    c[J // 2] = 0; c[3 * J // 4] = J // 4
+    yield c
+    n = np.maximum(np.arange(J) - 1, 0).astype(np.int32)             # branch points nested deeper than the slots go: the fallback
+    for k in range(1, min(7, J // 8)):
+        n[J - k] = k
+    yield n
     for _ in range(3):
         yield syn.random_parents(J, rng)
 for J in (1, 2, 3, 22, 27, 28, 52, 64, 65, 128, 250, 251, 254, 255, 512):
