@@ -377,6 +377,356 @@ __global__ __launch_bounds__(PM_WAVE, (NL > 0 && NL <= 12) ? PM_IK_MINW : ((NL >
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// ONE LANE PER FRAME, the joints streamed through LDS (the shape of deep.hip) -- for skeletons stored depth first, which is how
+// every BVH hierarchy and every SMPL-style table comes: the FIRST child of a joint is the next joint.
+// The kernel above keeps a frame's 16 J bytes in LDS for the whole walk, which is what bounds it: 32 frames x 2 chains per wave
+// at 11 waves per CU (J = 22), half the lane-steps of its two-chain schedule idle, a final lane-per-record pass to turn world
+// quaternions back into local ones; five 31 KB images per CU at J = 52.  Here
+//   * a lane walks ITS frame's joints in index order -- 64 frames per wave, no idle chains, no schedule;
+//   * joint p is finished when its first child p + 1 arrives: d = P_(p+1) - P_p with P_p still in registers, the parent's world
+//     quaternion the lane's own registers (parent = previous joint) or one of four saved register sets (ik_deep_plan colours the
+//     open branch points like deep_plan);
+//   * the positions of FURTHER children, which the reference consumes at the same moment (skeleton.py:147-168) and which lie
+//     further down the stream, are fetched per lane when the tile starts (<= kIkFar of them: 4 on the 22-joint body, 12 on
+//     SMPL-H) and wait in registers as a queue;
+//   * the LOCAL rotation is what the alignment and the rolls produce (r (x) roll (x) ...): no world -> local pass;
+//   * LDS is a ring of sixteen 16-byte slots per frame -- a joint's position comes in (cut at the output's 128-byte lines:
+//     groups of eight records g = f J + j, as in to_root_dq_ring_kernel), is read once, and the joint's rotation goes out
+//     through the same slot: 17 KB per wave, nine waves = 576 frames in flight per CU.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int kIkFar = 12;
+constexpr int kIkDeepMinJ = 24;  // (chain-like skeletons at 2^19 frames, lane per frame / tile kernel: J = 16 58.5 / 56.7 us, 22 80.5 / 80.3, 24 85 / 91, 32 109 / 132,
+                                 // 40 138 / 186, 64 232 / 365, 96 327 / 1026, 128 450 / 1400)
+
+struct IkDeepArgs {
+    const float *pos;      // [F,J,3]
+    const float *offsets;  // [J,3]
+    float *out;            // [F,J,4]
+    int64_t F;
+    int32_t J;
+    int32_t nfar;
+    int32_t far_joint[kIkFar];     // the further children, in the order the walk consumes them (dwords: s_load, not a vector-memory byte load)
+    int32_t code[PM_MAX_JOINTS];   // step j: load_p | save_p << 8 | nroll_p << 16 | fin << 24 | leaf << 25   (p = j - 1, the joint finished at step j)
+};
+
+__device__ __forceinline__ void ik_unrotate(const float (&g)[4], const float (&v)[3], float (&o)[3]) {  // v turned by the inverse of unit g
+    const float c0 = __builtin_fmaf(g[3], v[1], -(g[2] * v[2]));
+    const float c1 = __builtin_fmaf(g[1], v[2], -(g[3] * v[0]));
+    const float c2 = __builtin_fmaf(g[2], v[0], -(g[1] * v[1]));
+    const float s0 = __builtin_fmaf(g[0], c0, __builtin_fmaf(g[3], c1, -(g[2] * c2)));
+    const float s1 = __builtin_fmaf(g[0], c1, __builtin_fmaf(g[1], c2, -(g[3] * c0)));
+    const float s2 = __builtin_fmaf(g[0], c2, __builtin_fmaf(g[2], c0, -(g[1] * c1)));
+    o[0] = __builtin_fmaf(2.0f, s0, v[0]); o[1] = __builtin_fmaf(2.0f, s1, v[1]); o[2] = __builtin_fmaf(2.0f, s2, v[2]);
+}
+struct IkPair { float cr[3], cr2, npd, nmd, N, iv; };
+__device__ __forceinline__ IkPair ik_pair_of(const float (&u)[3], const float lu, const float (&v)[3]) {  // see the walk of the tile kernel
+    IkPair q;
+    q.cr[0] = diff_of_products(u[1], v[2], u[2], v[1]);
+    q.cr[1] = diff_of_products(u[2], v[0], u[0], v[2]);
+    q.cr[2] = diff_of_products(u[0], v[1], u[1], v[0]);
+    q.cr2 = __builtin_fmaf(q.cr[0], q.cr[0], __builtin_fmaf(q.cr[1], q.cr[1], q.cr[2] * q.cr[2]));
+    const float dt = __builtin_fmaf(u[0], v[0], __builtin_fmaf(u[1], v[1], u[2] * v[2]));
+    const float v2 = __builtin_fmaf(v[0], v[0], __builtin_fmaf(v[1], v[1], v[2] * v[2]));
+    q.iv = __builtin_amdgcn_rsqf(v2);
+    q.N = lu * (v2 * q.iv);
+    const float big = q.N + fabsf(dt), small = q.cr2 * frcp(big);
+    q.npd = (dt >= 0.0f) ? big : small;
+    q.nmd = (dt >= 0.0f) ? small : big;
+    return q;
+}
+// from_to(u, inv(gpre) d) with the reference's eps terms and special cases (the alignment of the tile kernel's walk, same formulas);
+// `inexact`: the result does not take the rest direction exactly onto d (snapped to the identity, or the anti-parallel branch)
+__device__ __forceinline__ void ik_align(const float (&gpre)[4], const float (&d)[3], const float (&ta)[4], const float (&tb)[4], float (&r)[4], bool &inexact) {
+    const float u[3] = {ta[0], ta[1], ta[2]};
+    const float iu = ta[3], lu = tb[3];
+    float p[3];
+    ik_unrotate(gpre, d, p);
+    const IkPair q = ik_pair_of(u, lu, p);
+    const float e = 1e-8f * (iu + q.iv), tol = 1.001e-5f * q.N;
+    const float dte = 0.5f * (q.npd - q.nmd) * e;
+    const float npr = q.npd - dte, nmr = q.nmd + dte;
+    const float A = __builtin_amdgcn_rsqf((q.N + q.N) * q.npd);
+    const float vs = A * __builtin_fmaf(0.5f * dte, frcp(q.nmd), 1.0f);
+    r[0] = A * __builtin_fmaf(-0.5f, dte, q.npd); r[1] = q.cr[0] * vs; r[2] = q.cr[1] * vs; r[3] = q.cr[2] * vs;
+    const bool snap = nmr <= tol || !(q.N > 0.0f);
+    if (snap) { r[0] = 1.0f; r[1] = 0.0f; r[2] = 0.0f; r[3] = 0.0f; }
+    const bool anti = npr <= tol && q.N > 0.0f;
+    if (__builtin_amdgcn_ballot_w64(anti) != 0 && anti) {  // anti-parallel (quat.py:554-571), rare: skipped by the whole wave otherwise
+        const float a1[3] = {tb[0], tb[1], tb[2]};
+        const bool xlike = isclose_to(fabsf(a1[0]), 1.0f);
+        const float og[3] = {xlike ? 0.0f : 1.0f, xlike ? 1.0f : 0.0f, 0.0f};
+        const float c2[3] = {a1[1] * og[2] - a1[2] * og[1], a1[2] * og[0] - a1[0] * og[2], a1[0] * og[1] - a1[1] * og[0]};
+        float ax2[3];
+        vnormalize(c2, 1e-8f, ax2);
+        r[0] = 0.0f; r[1] = ax2[0]; r[2] = ax2[1]; r[3] = ax2[2];
+    }
+    inexact = snap || anti;
+}
+// from_to_axis(offsets[gc], inv(g) dg, axis) (quat.py:579-650) as the tile kernel's walk evaluates it; tg = {u_gc, 1 / |u_gc|}, lug = |u_gc|
+__device__ __forceinline__ void ik_roll(const float (&g)[4], const float (&dg)[3], const float (&d)[3], const float (&un)[3], const bool inexact,
+                                        const float (&tg)[4], const float lug, float (&roll)[4]) {
+    float v[3];
+    ik_unrotate(g, dg, v);
+    float axis[3] = {un[0], un[1], un[2]};
+    if (__builtin_amdgcn_ballot_w64(inexact) != 0) {
+        float dd[3] = {d[0], d[1], d[2]}, dn[3], ax[3];
+        asm volatile("" : "+v"(dd[0]), "+v"(dd[1]), "+v"(dd[2]));
+        vnormalize(dd, 1e-8f, dn);
+        ik_unrotate(g, dn, ax);
+        axis[0] = inexact ? ax[0] : axis[0]; axis[1] = inexact ? ax[1] : axis[1]; axis[2] = inexact ? ax[2] : axis[2];
+    }
+    const float ub[3] = {tg[0], tg[1], tg[2]};
+    const IkPair t = ik_pair_of(ub, lug, v);
+    const float eg = 1e-8f * (tg[3] + t.iv), tolg = 1.001e-5f * t.N;
+    const float dtg = 0.5f * (t.npd - t.nmd) * eg;
+    const float npg = t.npd - dtg, nmg = t.nmd + dtg;
+    const float i2n = __builtin_amdgcn_rsqf(t.N + t.N);
+    const float cda = t.cr[0] * axis[0] + t.cr[1] * axis[1] + t.cr[2] * axis[2];
+    const float sg = (cda > 0.0f) ? 1.0f : ((cda < 0.0f) ? -1.0f : cda);
+    const float w = fsqrt(npg) * i2n, sn = fsqrt(nmg) * i2n * sg;
+    roll[0] = w; roll[1] = axis[0] * sn; roll[2] = axis[1] * sn; roll[3] = axis[2] * sn;
+    if (nmg <= tolg) { roll[0] = 1.0f; roll[1] = 0.0f; roll[2] = 0.0f; roll[3] = 0.0f; }
+    if (npg <= tolg) { roll[0] = 0.0f; roll[1] = axis[0]; roll[2] = axis[1]; roll[3] = axis[2]; }
+}
+
+struct IkSaves { float g[kDeepSlots][4]; };
+template <int K>
+__device__ __forceinline__ void ik_slot_load(const int ld, const IkSaves &sv, float (&g)[4]) {
+    if constexpr (K < kDeepSlots) {
+        int code = ld;
+        asm volatile("" : "+s"(code));  // an opaque copy per test (see deep.hip: an indexed array would live in scratch memory)
+        if (code == K) { g[0] = sv.g[K][0]; g[1] = sv.g[K][1]; g[2] = sv.g[K][2]; g[3] = sv.g[K][3]; }
+        ik_slot_load<K + 1>(ld, sv, g);
+    }
+}
+template <int K>
+__device__ __forceinline__ void ik_slot_save(const int st, IkSaves &sv, const float (&g)[4]) {
+    if constexpr (K < kDeepSlots) {
+        int code = st;
+        asm volatile("" : "+s"(code));
+        if (code == K) { sv.g[K][0] = g[0]; sv.g[K][1] = g[1]; sv.g[K][2] = g[2]; sv.g[K][3] = g[3]; }
+        ik_slot_save<K + 1>(st, sv, g);
+    }
+}
+
+constexpr int kIkDeepRow = 16 * 4 + 4;  // sixteen 16-byte slots + 16 bytes: (row / 4) odd
+
+__global__ __launch_bounds__(PM_WAVE) void from_root_positions_deep_kernel(const IkDeepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int G = 8, RS = kIkDeepRow;
+    const int lane = threadIdx.x;
+    const int J = a.J;
+    const int64_t tile = xcd_tile((a.F + PM_WAVE - 1) / PM_WAVE);
+    if (tile < 0) return;
+    float *sImg = smem;                 // [64][RS]
+    float *sOff = smem + PM_WAVE * RS;  // [J][4]  {u, 1 / |u|} of every joint's rest offset ...
+    float *sLen = sOff + 4 * J;         // [J]     ... and |u|
+    for (int j = lane; j < J; j += PM_WAVE) {
+        const float o[3] = {a.offsets[3 * j], a.offsets[3 * j + 1], a.offsets[3 * j + 2]};
+        const float u2 = __builtin_fmaf(o[0], o[0], __builtin_fmaf(o[1], o[1], o[2] * o[2]));
+        const float iu = (u2 > 0.0f) ? __builtin_amdgcn_rsqf(u2) : 0.0f;
+        float *t = sOff + 4 * j;
+        if (PM_LDS_OK(t, 16u)) *reinterpret_cast<v4f *>(t) = v4f{o[0], o[1], o[2], iu};
+        if (PM_LDS_OK(sLen + j, 4u)) sLen[j] = fsqrt(u2);
+    }
+    const int64_t f0 = tile * PM_WAVE;  // a multiple of 64: (f0 + fr) J & 7 == fr J & 7
+    const int nf = (int)((a.F - f0) < PM_WAVE ? (a.F - f0) : PM_WAVE);
+    const int ngroups = ((J + 6) >> 3) + 1;
+    const float *gpos = a.pos + f0 * J * 3;
+    float *gout = a.out + f0 * J * 4;
+    const int fl = lane < nf ? lane : nf - 1;
+
+    // the further children's positions of this lane's frame, in the order they are consumed
+    v3f_a4 farq[kIkFar];
+#pragma unroll
+    for (int k = 0; k < kIkFar; ++k) {
+        farq[k] = v3f_a4{0.0f, 0.0f, 0.0f};
+        if (k < a.nfar) farq[k] = *reinterpret_cast<const v3f_a4 *>(gpos + ((int64_t)fl * J + a.far_joint[k]) * 3);
+    }
+
+    // loads: lane = (frl, jj) = (lane >> 3, lane & 7); load u covers frame 8 u + frl, whose shift is that of frl (8 J = 0 mod 8)
+    const int l_frl = lane >> 3, l_d = (lane & 7) - ((l_frl * J) & 7);  // joint of this lane's place in group c: 8 c + l_d
+    v3f_a4 pre[G], pre1[G];
+    auto issue = [&](const int c, v3f_a4 (&pre)[G]) {
+        int j = 8 * c + l_d;
+        j = j < 0 ? 0 : (j > J - 1 ? J - 1 : j);  // outside the frame: a valid record again, parked where nobody reads
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const int fr = 8 * u + l_frl, fc = fr < nf ? fr : nf - 1;
+            pre[u] = *reinterpret_cast<const v3f_a4 *>(gpos + ((int64_t)fc * J + j) * 3);  // (not nontemporal: the rest of the line is the next group's)
+        }
+    };
+    issue(0, pre);
+    if (ngroups > 1) issue(1, pre1);  // the far positions and the first TWO groups are in flight together: one exposed latency per tile
+    auto park = [&](const int c, const v3f_a4 (&pre)[G]) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            float *p = sImg + (8 * u + l_frl) * RS + ((c & 1) * G + (lane & 7)) * 4;
+            if (PM_LDS_OK(p, 16u)) { p[0] = pre[u].x; p[1] = pre[u].y; p[2] = pre[u].z; }
+        }
+    };
+    float *row = sImg + lane * RS;
+    const int sf = (lane * J) & 7;
+    float g[4] = {1.0f, 0.0f, 0.0f, 0.0f};   // world quaternion of the joint finished last
+    float pp[3] = {0.0f, 0.0f, 0.0f};        // position of the previous joint (finished when its first child arrives)
+    IkSaves sv = {};
+    int fi = 0;                              // next entry of the far list (wave-uniform)
+    wave_sync();
+    auto walk = [&](const int c) {
+        const int jlo = 8 * c - 7 < 0 ? 0 : 8 * c - 7, jhi = 8 * c > J - 1 ? J - 1 : 8 * c;
+        // a joint's operands (its position, the table rows of its rest offset) are requested while the joint before it computes
+        float pjn[4], tan[4], tbn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (jlo <= jhi) {
+            lds_get<4>(row + ((jlo + sf) & 15) * 4, 0, pjn);
+            lds_get<4>(sOff, jlo, tan);
+            tbn[3] = sLen[jlo];
+        }
+#pragma unroll 1
+        for (int j = jlo; j <= jhi; ++j) {
+            const int code = __builtin_amdgcn_readfirstlane(a.code[j]);  // wave-uniform (kernarg)
+            float *slot = row + ((j + sf) & 15) * 4;
+            float pj[4], ta[4], tb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { pj[k] = pjn[k]; ta[k] = tan[k]; }
+            tb[0] = ta[0] * ta[3]; tb[1] = ta[1] * ta[3]; tb[2] = ta[2] * ta[3]; tb[3] = tbn[3];  // u / |u|, |u|
+            if (j < jhi) {  // (the step's last joint: the next one's slot may not be parked yet)
+                lds_get<4>(row + ((j + 1 + sf) & 15) * 4, 0, pjn);
+                lds_get<4>(sOff, j + 1, tan);
+                tbn[3] = sLen[j + 1];
+            }
+            if (code & (1 << 24)) {  // joint j is the first child of p = j - 1: p is finished now
+                const int p = j - 1, ld = code & 0xff, st = (code >> 8) & 0xff, nroll = (code >> 16) & 0xff;
+                float gpre[4] = {g[0], g[1], g[2], g[3]};
+                ik_slot_load<0>(ld, sv, gpre);
+                if (ld == DEEP_ROOT) { gpre[0] = 1.0f; gpre[1] = 0.0f; gpre[2] = 0.0f; gpre[3] = 0.0f; }
+                const float d[3] = {pj[0] - pp[0], pj[1] - pp[1], pj[2] - pp[2]};
+                float r[4];
+                bool inexact;
+                ik_align(gpre, d, ta, tb, r, inexact);
+                qmul(gpre, r, g);
+                const float un[3] = {tb[0], tb[1], tb[2]};
+                for (int rr = 0; rr < nroll; ++rr) {  // further children: wave-uniform here (every lane walks the same skeleton)
+                    const int gc = __builtin_amdgcn_readfirstlane(a.far_joint[fi]);
+                    ++fi;
+                    float tg[4];
+                    lds_get<4>(sOff, gc, tg);
+                    const float lug = sLen[gc];
+                    const float dg[3] = {farq[0].x - pp[0], farq[0].y - pp[1], farq[0].z - pp[2]};
+#pragma unroll
+                    for (int k = 0; k + 1 < kIkFar; ++k) farq[k] = farq[k + 1];
+                    float roll[4], g2[4], r2[4];
+                    ik_roll(g, dg, d, un, inexact, tg, lug, roll);
+                    qmul(g, roll, g2);
+                    qmul(r, roll, r2);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { g[k] = g2[k]; r[k] = r2[k]; }
+                }
+                ik_slot_save<0>(st, sv, g);
+                lds_put<4>(row + ((p + sf) & 15) * 4, 0, r);  // the local rotation of p, through the slot its position came in by
+            }
+            if (code & (1 << 25)) {  // a joint without children keeps the identity (skeleton.py:126-130)
+                const float id[4] = {1.0f, 0.0f, 0.0f, 0.0f};
+                lds_put<4>(slot, 0, id);
+            }
+            pp[0] = pj[0]; pp[1] = pj[1]; pp[2] = pj[2];
+        }
+    };
+    // group k leaves: lane (frl, place) of store u writes the 16-byte record of frame 8 u + frl.  Its slots are READ into registers,
+    // then the next group's positions are parked over them, then the stores go out: no store sits between the request for a
+    // group's positions and the wait for them, so that wait is never a wait for stores (half of a 22-joint frame's groups are
+    // partial ones whose stores are predicated and cannot be counted past -- see deep.hip).
+    const int s_d = (lane & 7) - ((l_frl * J) & 7);
+    v4f outr[G];
+    auto read_group = [&](const int k) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const float *p = sImg + (8 * u + l_frl) * RS + ((k & 1) * G + (lane & 7)) * 4;
+            outr[u] = PM_LDS_OK(p, 16u) ? *reinterpret_cast<const v4f *>(p) : v4f{0, 0, 0, 0};
+        }
+    };
+    auto store_group = [&](const int k) {
+        const int j = 8 * k + s_d;
+        const bool jok = j >= 0 && j < J;
+        float *g0 = gout + (l_frl * J + (jok ? j : 0)) * 4;
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+            if (jok && 8 * u + l_frl < nf) __builtin_nontemporal_store(outr[u], reinterpret_cast<v4f *>(g0 + 8 * u * J * 4));
+    };
+    park(0, pre);
+    if (ngroups > 1) park(1, pre1);
+#pragma unroll
+    for (int k = 0; k < kIkFar; ++k) asm volatile("" : "+v"(farq[k]));  // settled HERE (everything requested so far has arrived): their first use is inside the walk
+    if (ngroups > 2) issue(2, pre);
+    for (int c = 0; c <= ngroups; ++c) {
+        wave_sync();
+        walk(c);
+        wave_sync();
+        if (c >= 1) {
+            read_group(c - 1);
+            wave_sync();
+            if (c + 1 < ngroups) park(c + 1, pre);          // over the slots just read; requested a whole step ago
+            if (c + 2 < ngroups) issue(c + 2, pre);         // in flight during the next step
+            store_group(c - 1);
+        }
+    }
+}
+
+// Host plan of the lane-per-frame kernel.  Eligible: every joint with children has joint + 1 as its first child (depth-first
+// storage), at most kIkFar further children in all, at most kDeepSlots branch points open at once.  Returns false otherwise.
+static bool ik_deep_plan(const Topo16 &t, const int J, IkDeepArgs &a) {
+    int nfar = 0, last_use[PM_MAX_JOINTS], slot_of[PM_MAX_JOINTS], busy_until[kDeepSlots];
+    for (int j = 0; j < J; ++j) {
+        const int cs = t.cstart[j], ce = t.cstart[j + 1];
+        if (ce > cs && t.clist[cs] != j + 1) return false;
+        for (int k = cs + 1; k < ce; ++k) {
+            if (nfar == kIkFar) return false;
+            a.far_joint[nfar++] = t.clist[k];
+        }
+        last_use[j] = -1; slot_of[j] = -1;
+    }
+    for (int k = nfar; k < kIkFar; ++k) a.far_joint[k] = 0;
+    a.nfar = nfar;
+    // a joint WITH children whose parent is not the previous joint reads the parent's world quaternion from a slot
+    for (int j = 1; j < J; ++j)
+        if (t.cstart[j + 1] > t.cstart[j] && t.parent[j] != j - 1 && last_use[t.parent[j]] < j) last_use[t.parent[j]] = j;
+    for (int k = 0; k < kDeepSlots; ++k) busy_until[k] = -1;
+    int load_of[PM_MAX_JOINTS], save_of[PM_MAX_JOINTS];
+    for (int j = 0; j < J; ++j) {
+        load_of[j] = (j == 0) ? DEEP_ROOT : ((t.parent[j] == j - 1) ? DEEP_CHAIN : slot_of[t.parent[j]]);
+        save_of[j] = DEEP_NONE;
+        if (t.cstart[j + 1] > t.cstart[j] && load_of[j] < 0) return false;  // (cannot happen: parents come first)
+        if (last_use[j] >= 0) {
+            int k = 0;
+            while (k < kDeepSlots && busy_until[k] > j) ++k;
+            if (k == kDeepSlots) return false;
+            busy_until[k] = last_use[j];
+            slot_of[j] = k;
+            save_of[j] = k;
+        }
+    }
+    for (int j = 0; j < J; ++j) {
+        const bool leaf = t.cstart[j + 1] == t.cstart[j];
+        const int p = j - 1;
+        const bool fin = j >= 1 && t.cstart[p + 1] > t.cstart[p];  // p has children, so j = p + 1 is its first
+        int code = (leaf ? 1 << 25 : 0);
+        if (fin) code |= (load_of[p] & 0xff) | ((save_of[p] & 0xff) << 8) | ((t.cstart[p + 1] - t.cstart[p] - 1) << 16) | (1 << 24);
+        a.code[j] = code;
+    }
+    return true;
+}
+
+static int launch_ik_deep(const IkDeepArgs &a, hipStream_t s) {
+    const size_t lds = ((size_t)PM_WAVE * kIkDeepRow + 5 * (size_t)a.J) * sizeof(float);
+    const int64_t ntiles = (a.F + PM_WAVE - 1) / PM_WAVE;
+    const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
+    if (grid > 0x7fffffffLL) { set_error("from_root_positions: grid too large"); return PM_EUNSUPPORTED; }
+    set_kernel_name("pm::from_root_positions_deep_kernel(pm::IkDeepArgs)");
+    if (int e = allow_lds(from_root_positions_deep_kernel, lds)) return e;
+    hipLaunchKernelGGL(from_root_positions_deep_kernel, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
+    return PM_AFTER_LAUNCH("from_root_positions (lane per frame) launch");
+}
+
 // Joints with children onto two chains, one item per chain and step.  A joint is ready two steps after its parent, or
 // right after it on the parent's own chain (its quaternion is still in that lane's registers; the look-ahead fetch of the
 // next step is issued before the current one stores).  Longest remaining path first, a further child counting like an
@@ -467,6 +817,15 @@ extern "C" int pm_from_root_positions_f32(const float *positions, const int32_t 
     for (int32_t j = 1; j < J; ++j) a.topo.clist[fill[p.p[j]]++] = (int16_t)j;
     const bool vec = aligned16(positions) && aligned16(rotations);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // depth-first skeletons from 24 joints on: one lane per frame, joints streamed (see from_root_positions_deep_kernel).
+    // PM_IK_DEEP (PM_TUNING build only): 0 = never, 1 = whenever eligible
+    if (const int deep = tune_env("PM_IK_DEEP", -1); aligned16(rotations) && J >= 2 && deep != 0 && (deep == 1 || J >= kIkDeepMinJ)) {
+        IkDeepArgs da;
+        if (ik_deep_plan(a.topo, J, da)) {
+            da.pos = positions; da.offsets = offsets; da.out = rotations; da.F = F; da.J = J;
+            return launch_ik_deep(da, s);
+        }
+    }
     const size_t per_frame = (size_t)ik_frame_stride(J) * sizeof(float), fixed = (size_t)ik_tables_floats(J) * sizeof(float) + (size_t)(J + 2) * 32 + 256;
     {
         const int v = tune_env("PM_IK_FPW", 0);  // PM_TUNING build only

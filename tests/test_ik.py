@@ -154,6 +154,71 @@ def test_gpu_from_root_positions_long_bushy_skeletons_on_four_chains(J, F, four)
     assert np.abs(p2 - p_ref).max() <= 2e-5
 
 
+def _dfs_humanoid(J, fingers=5):
+    """a humanoid stored DEPTH FIRST (the order of a BVH file): hips -> spine (4) -> [neck, head | left arm (4) -> `fingers` x 3 |
+    right arm likewise] | left leg (4) | right leg (4); joints left over lengthen the tail of the last finger"""
+    par = [0]
+
+    def chain(p, n):
+        for _ in range(n):
+            par.append(p)
+            p = len(par) - 1
+        return p
+
+    chest = chain(0, 4)
+    chain(chest, 2)
+    for _ in range(2):
+        wrist = chain(chest, 4)
+        for _ in range(fingers):
+            chain(wrist, 3)
+    chain(0, 4)
+    chain(0, 4)
+    par = par[:J]
+    while len(par) < J:
+        par.append(len(par) - 1)
+    return np.asarray(par, dtype=np.int32)
+
+
+def _chain_like(J):
+    p = np.maximum(np.arange(J) - 1, 0).astype(np.int32)
+    p[J // 2] = 0
+    p[3 * J // 4] = J // 4
+    return p
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("J,kind,deep", [(24, "chain", True), (31, "chain", True), (23, "chain", False), (53, "body5", True), (47, "body4", True), (64, "chain", True),
+                                         (65, "body5", True), (128, "chain", True), (250, "body5", True), (512, "chain", True), (59, "body6", False),
+                                         (52, "smplh", False)])
+def test_gpu_from_root_positions_lane_per_frame_on_depth_first_skeletons(J, kind, deep):
+    """skeletons stored depth first (every BVH hierarchy) take from_root_positions_deep_kernel from 24 joints on: one lane per frame,
+    joints streamed through a ring of LDS slots, further children prefetched (at most 12: six fingers a hand are one too many),
+    full and partial tiles of 64 frames; a breadth-first table like SMPL-H's stays on the tile kernel"""
+    import pymotion_amd.ops.skeleton as sk
+    from pymotion_amd import _lib
+    from pymotion_amd import synthetic as syn
+
+    par = {"chain": lambda: _chain_like(J), "smplh": lambda: syn.PARENTS_52}.get(kind, lambda: _dfs_humanoid(J, int(kind[-1])))()
+    for F in (1, 63, 64, 65, 400):
+        rot, root, off, par = syn.fk_workload(F, parents=par, seed=J + F, normalized=True, offset_scale=0.1)
+        pos, _ = co.fk(rot.astype(np.float64), np.zeros((F, 3)), off.astype(np.float64), par)
+        pos = pos.astype(np.float32)
+        got = sk.from_root_positions(pos, par, off)
+        assert ("from_root_positions_deep_kernel" in _lib.last_kernel_name()) == deep, _lib.last_kernel_name()
+        ref = co.from_root_positions(pos.astype(np.float64), par, off.astype(np.float64))
+        err = np.minimum(np.abs(got - ref).max(-1), np.abs(got + ref).max(-1))
+        # (2e-5 on 99 % of the records of these small batches; an alignment within a hair of a half turn is decided by the last bit
+        # of its input -- see _reference_sensitivity -- and every joint below inherits the twist: the POSE is the firm check)
+        if J <= 128:  # (longer chains: a twist anywhere is inherited by hundreds of joints below it, in the reference as here)
+            assert np.quantile(err, 0.99) <= 2e-5, (F, float(np.quantile(err, 0.99)))
+        assert np.median(err) <= (1e-6 if J <= 128 else 1e-5) and (J > 128 or err.max() <= 5e-3), (F, float(np.median(err)), float(err.max()))
+        leaves = np.setdiff1d(np.arange(J), par[1:])
+        assert (got[:, leaves] == np.array([1, 0, 0, 0], np.float32)).all()   # joints without children keep the exact identity
+        p2, _ = sk.fk(got, np.zeros_like(root), off, par)
+        p_ref, _ = co.fk(ref, np.zeros((F, 3)), off.astype(np.float64), par)
+        assert np.abs(p2 - p_ref).max() <= (2e-5 if J <= 128 else 1e-4), float(np.abs(p2 - p_ref).max())
+
+
 @pytest.mark.gpu
 def test_gpu_mirror_positions_vs_reference_golden():
     import pymotion_amd.ops.skeleton as sk
