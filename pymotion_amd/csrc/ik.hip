@@ -510,11 +510,16 @@ __device__ __forceinline__ void ik_slot_save(const int st, IkSaves &sv, const fl
     }
 }
 
-constexpr int kIkDeepRow = 16 * 4 + 4;  // sixteen 16-byte slots + 16 bytes: (row / 4) odd
+// G = records per group.  8: whole 128-byte lines of output, 96 bytes of input, 17 KB of LDS per wave (eight waves per CU).  The kernel
+// is a latency chain per lane and lives on occupancy (2^20 x 22 with 8 / 7 / 5 / 4 waves per CU: 158 / 174 / 193 / 267 us), but G = 4 --
+// half the ring, sixteen waves per CU -- moves HALF lines and is slower for it (240 us; J = 128 at 2^19: 615 against 444 us): not instantiated.
+__host__ __device__ constexpr int ik_deep_row(const int G) { return 2 * G * 4 + 4; }  // 2 G 16-byte slots + 16 bytes: (row / 4) odd
 
+template <int G>
 __global__ __launch_bounds__(PM_WAVE) void from_root_positions_deep_kernel(const IkDeepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int G = 8, RS = kIkDeepRow;
+    constexpr int RS = ik_deep_row(G), FPI = PM_WAVE / G, LG = (G == 8) ? 3 : 2, SM = 2 * G - 1;  // frames per load / store instruction, log2 G, slot mask
+    static_assert(G == 8 || G == 4, "groups of eight or four records");
     const int lane = threadIdx.x;
     const int J = a.J;
     const int64_t tile = xcd_tile((a.F + PM_WAVE - 1) / PM_WAVE);
@@ -530,9 +535,9 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_deep_kernel(const
         if (PM_LDS_OK(t, 16u)) *reinterpret_cast<v4f *>(t) = v4f{o[0], o[1], o[2], iu};
         if (PM_LDS_OK(sLen + j, 4u)) sLen[j] = fsqrt(u2);
     }
-    const int64_t f0 = tile * PM_WAVE;  // a multiple of 64: (f0 + fr) J & 7 == fr J & 7
+    const int64_t f0 = tile * PM_WAVE;  // a multiple of 64: (f0 + fr) J & (G - 1) == fr J & (G - 1)
     const int nf = (int)((a.F - f0) < PM_WAVE ? (a.F - f0) : PM_WAVE);
-    const int ngroups = ((J + 6) >> 3) + 1;
+    const int ngroups = ((J + G - 2) >> LG) + 1;
     const float *gpos = a.pos + f0 * J * 3;
     float *gout = a.out + f0 * J * 4;
     const int fl = lane < nf ? lane : nf - 1;
@@ -545,15 +550,15 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_deep_kernel(const
         if (k < a.nfar) farq[k] = *reinterpret_cast<const v3f_a4 *>(gpos + ((int64_t)fl * J + a.far_joint[k]) * 3);
     }
 
-    // loads: lane = (frl, jj) = (lane >> 3, lane & 7); load u covers frame 8 u + frl, whose shift is that of frl (8 J = 0 mod 8)
-    const int l_frl = lane >> 3, l_d = (lane & 7) - ((l_frl * J) & 7);  // joint of this lane's place in group c: 8 c + l_d
+    // loads: lane = (frl, jj) = (lane / G, lane % G); load u covers frame FPI u + frl, whose shift is that of frl (FPI J = 0 mod G)
+    const int l_frl = lane >> LG, l_d = (lane & (G - 1)) - ((l_frl * J) & (G - 1));  // joint of this lane's place in group c: G c + l_d
     v3f_a4 pre[G], pre1[G];
     auto issue = [&](const int c, v3f_a4 (&pre)[G]) {
-        int j = 8 * c + l_d;
+        int j = G * c + l_d;
         j = j < 0 ? 0 : (j > J - 1 ? J - 1 : j);  // outside the frame: a valid record again, parked where nobody reads
 #pragma unroll
         for (int u = 0; u < G; ++u) {
-            const int fr = 8 * u + l_frl, fc = fr < nf ? fr : nf - 1;
+            const int fr = FPI * u + l_frl, fc = fr < nf ? fr : nf - 1;
             pre[u] = *reinterpret_cast<const v3f_a4 *>(gpos + ((int64_t)fc * J + j) * 3);  // (not nontemporal: the rest of the line is the next group's)
         }
     };
@@ -562,36 +567,36 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_deep_kernel(const
     auto park = [&](const int c, const v3f_a4 (&pre)[G]) {
 #pragma unroll
         for (int u = 0; u < G; ++u) {
-            float *p = sImg + (8 * u + l_frl) * RS + ((c & 1) * G + (lane & 7)) * 4;
+            float *p = sImg + (FPI * u + l_frl) * RS + ((c & 1) * G + (lane & (G - 1))) * 4;
             if (PM_LDS_OK(p, 16u)) { p[0] = pre[u].x; p[1] = pre[u].y; p[2] = pre[u].z; }
         }
     };
     float *row = sImg + lane * RS;
-    const int sf = (lane * J) & 7;
+    const int sf = (lane * J) & (G - 1);
     float g[4] = {1.0f, 0.0f, 0.0f, 0.0f};   // world quaternion of the joint finished last
     float pp[3] = {0.0f, 0.0f, 0.0f};        // position of the previous joint (finished when its first child arrives)
     IkSaves sv = {};
     int fi = 0;                              // next entry of the far list (wave-uniform)
     wave_sync();
     auto walk = [&](const int c) {
-        const int jlo = 8 * c - 7 < 0 ? 0 : 8 * c - 7, jhi = 8 * c > J - 1 ? J - 1 : 8 * c;
+        const int jlo = G * c - (G - 1) < 0 ? 0 : G * c - (G - 1), jhi = G * c > J - 1 ? J - 1 : G * c;
         // a joint's operands (its position, the table rows of its rest offset) are requested while the joint before it computes
         float pjn[4], tan[4], tbn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (jlo <= jhi) {
-            lds_get<4>(row + ((jlo + sf) & 15) * 4, 0, pjn);
+            lds_get<4>(row + ((jlo + sf) & SM) * 4, 0, pjn);
             lds_get<4>(sOff, jlo, tan);
             tbn[3] = sLen[jlo];
         }
 #pragma unroll 1
         for (int j = jlo; j <= jhi; ++j) {
             const int code = __builtin_amdgcn_readfirstlane(a.code[j]);  // wave-uniform (kernarg)
-            float *slot = row + ((j + sf) & 15) * 4;
+            float *slot = row + ((j + sf) & SM) * 4;
             float pj[4], ta[4], tb[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { pj[k] = pjn[k]; ta[k] = tan[k]; }
             tb[0] = ta[0] * ta[3]; tb[1] = ta[1] * ta[3]; tb[2] = ta[2] * ta[3]; tb[3] = tbn[3];  // u / |u|, |u|
             if (j < jhi) {  // (the step's last joint: the next one's slot may not be parked yet)
-                lds_get<4>(row + ((j + 1 + sf) & 15) * 4, 0, pjn);
+                lds_get<4>(row + ((j + 1 + sf) & SM) * 4, 0, pjn);
                 lds_get<4>(sOff, j + 1, tan);
                 tbn[3] = sLen[j + 1];
             }
@@ -623,7 +628,7 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_deep_kernel(const
                     for (int k = 0; k < 4; ++k) { g[k] = g2[k]; r[k] = r2[k]; }
                 }
                 ik_slot_save<0>(st, sv, g);
-                lds_put<4>(row + ((p + sf) & 15) * 4, 0, r);  // the local rotation of p, through the slot its position came in by
+                lds_put<4>(row + ((p + sf) & SM) * 4, 0, r);  // the local rotation of p, through the slot its position came in by
             }
             if (code & (1 << 25)) {  // a joint without children keeps the identity (skeleton.py:126-130)
                 const float id[4] = {1.0f, 0.0f, 0.0f, 0.0f};
@@ -636,22 +641,25 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_deep_kernel(const
     // then the next group's positions are parked over them, then the stores go out: no store sits between the request for a
     // group's positions and the wait for them, so that wait is never a wait for stores (half of a 22-joint frame's groups are
     // partial ones whose stores are predicated and cannot be counted past -- see deep.hip).
-    const int s_d = (lane & 7) - ((l_frl * J) & 7);
+    const int s_d = l_d;
     v4f outr[G];
     auto read_group = [&](const int k) {
 #pragma unroll
         for (int u = 0; u < G; ++u) {
-            const float *p = sImg + (8 * u + l_frl) * RS + ((k & 1) * G + (lane & 7)) * 4;
+            const float *p = sImg + (FPI * u + l_frl) * RS + ((k & 1) * G + (lane & (G - 1))) * 4;
             outr[u] = PM_LDS_OK(p, 16u) ? *reinterpret_cast<const v4f *>(p) : v4f{0, 0, 0, 0};
         }
     };
     auto store_group = [&](const int k) {
-        const int j = 8 * k + s_d;
+        const int j = G * k + s_d;
         const bool jok = j >= 0 && j < J;
         float *g0 = gout + (l_frl * J + (jok ? j : 0)) * 4;
 #pragma unroll
         for (int u = 0; u < G; ++u)
-            if (jok && 8 * u + l_frl < nf) __builtin_nontemporal_store(outr[u], reinterpret_cast<v4f *>(g0 + 8 * u * J * 4));
+            if (jok && FPI * u + l_frl < nf) {
+                if (G == 8) __builtin_nontemporal_store(outr[u], reinterpret_cast<v4f *>(g0 + FPI * u * J * 4));
+                else *reinterpret_cast<v4f *>(g0 + FPI * u * J * 4) = outr[u];  // half lines: the other half is the next step's, merged in L2
+            }
     };
     park(0, pre);
     if (ngroups > 1) park(1, pre1);
@@ -716,14 +724,15 @@ static bool ik_deep_plan(const Topo16 &t, const int J, IkDeepArgs &a) {
     return true;
 }
 
+template <int G>
 static int launch_ik_deep(const IkDeepArgs &a, hipStream_t s) {
-    const size_t lds = ((size_t)PM_WAVE * kIkDeepRow + 5 * (size_t)a.J) * sizeof(float);
+    const size_t lds = ((size_t)PM_WAVE * ik_deep_row(G) + 5 * (size_t)a.J) * sizeof(float);
     const int64_t ntiles = (a.F + PM_WAVE - 1) / PM_WAVE;
     const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
     if (grid > 0x7fffffffLL) { set_error("from_root_positions: grid too large"); return PM_EUNSUPPORTED; }
-    set_kernel_name("pm::from_root_positions_deep_kernel(pm::IkDeepArgs)");
-    if (int e = allow_lds(from_root_positions_deep_kernel, lds)) return e;
-    hipLaunchKernelGGL(from_root_positions_deep_kernel, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
+    set_kernel_name("void pm::from_root_positions_deep_kernel<%d>(pm::IkDeepArgs)", G);
+    if (int e = allow_lds(from_root_positions_deep_kernel<G>, lds)) return e;
+    hipLaunchKernelGGL(from_root_positions_deep_kernel<G>, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
     return PM_AFTER_LAUNCH("from_root_positions (lane per frame) launch");
 }
 
@@ -823,7 +832,7 @@ extern "C" int pm_from_root_positions_f32(const float *positions, const int32_t 
         IkDeepArgs da;
         if (ik_deep_plan(a.topo, J, da)) {
             da.pos = positions; da.offsets = offsets; da.out = rotations; da.F = F; da.J = J;
-            return launch_ik_deep(da, s);
+            return launch_ik_deep<8>(da, s);
         }
     }
     const size_t per_frame = (size_t)ik_frame_stride(J) * sizeof(float), fixed = (size_t)ik_tables_floats(J) * sizeof(float) + (size_t)(J + 2) * 32 + 256;
