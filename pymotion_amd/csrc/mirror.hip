@@ -21,6 +21,9 @@
 namespace pm {
 
 struct Map16 { int16_t m[PM_MAX_JOINTS]; };
+constexpr int kMirrorDeepMinJ = 66;   // from here on mode 'all' walks one lane per frame where the topology allows (chain-like skeletons at 2^19 frames, lane per
+                                      // frame / scheduled walk, % of the HBM spec: J = 32 75 / 69, 44 69 / 64, 48 67 / 67, 50 56 / 62, 56 61 / 65, 64 60 / 63,
+                                      // 65 54 / 58, 66 57 / 55, 72 60 / 58, 80 60 / 55.5, 96 60 / 53, 128 61 / 45; the SMPL-H tree at 2^18: 68 / 60)
 constexpr int kMirrorSchedMinJ = 40;  // from here on the scheduled walk is considered (measured: see pm_mirror_rotations_f32)
 
 struct MirrorArgs {
@@ -206,6 +209,161 @@ __global__ __launch_bounds__(PM_WAVE) void mirror_kernel(const MirrorArgs a) {
     });
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Mode 'all' (no joint permutation) on skeletons whose open branch points fit deep.hip's four register slots: ONE LANE PER FRAME,
+// the joints streamed through a ring of sixteen 16-byte LDS slots per frame (a quaternion comes in, the mirrored local rotation goes
+// out through the same slot; groups of eight records cut at the 128-byte lines of both arrays, a group's slots read into registers
+// before the next group is parked over them and stored after: the structure of from_root_positions_deep_kernel, ik.hip).  A lane's
+// state is the world quaternion of the joint before and its mirrored, sign-fixed form; a parent that is not the previous joint
+// comes from a saved register set.  Nothing grows with J, and a chain-like skeleton -- where the scheduled walk has nothing to
+// schedule -- costs what a bushy one costs.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct MirrorDeepArgs {
+    const float *rot;
+    float *out;
+    int64_t F;
+    int32_t J;
+    int32_t c0, c1;
+    DeepTopo topo;
+};
+struct MirrorSaves { float g[kDeepSlots][4], c[kDeepSlots][4]; };
+template <int K>
+__device__ __forceinline__ void mirror_slot_load(const int ld, const MirrorSaves &sv, float (&g)[4], float (&c)[4]) {
+    if constexpr (K < kDeepSlots) {
+        int code = ld;
+        asm volatile("" : "+s"(code));  // an opaque copy per test (deep.hip: an indexed array would live in scratch memory)
+        if (code == K) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { g[i] = sv.g[K][i]; c[i] = sv.c[K][i]; }
+        }
+        mirror_slot_load<K + 1>(ld, sv, g, c);
+    }
+}
+template <int K>
+__device__ __forceinline__ void mirror_slot_save(const int st, MirrorSaves &sv, const float (&g)[4], const float (&c)[4]) {
+    if constexpr (K < kDeepSlots) {
+        int code = st;
+        asm volatile("" : "+s"(code));
+        if (code == K) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { sv.g[K][i] = g[i]; sv.c[K][i] = c[i]; }
+        }
+        mirror_slot_save<K + 1>(st, sv, g, c);
+    }
+}
+
+constexpr int kMirrorDeepRow = 16 * 4 + 4;  // sixteen 16-byte slots + 16 bytes: (row / 4) odd
+
+__global__ __launch_bounds__(PM_WAVE) void mirror_deep_kernel(const MirrorDeepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int G = 8, RS = kMirrorDeepRow;
+    const int lane = threadIdx.x;
+    const int J = a.J;
+    const int64_t tile = xcd_tile((a.F + PM_WAVE - 1) / PM_WAVE);
+    if (tile < 0) return;
+    float *sImg = smem;  // [64][RS]
+    const int64_t f0 = tile * PM_WAVE;  // a multiple of 64: (f0 + fr) J & 7 == fr J & 7
+    const int nf = (int)((a.F - f0) < PM_WAVE ? (a.F - f0) : PM_WAVE);
+    const int ngroups = ((J + 6) >> 3) + 1;
+    const float *gin = a.rot + f0 * J * 4;
+    float *gout = a.out + f0 * J * 4;
+    const float f1 = (a.c0 == 1 || a.c1 == 1) ? -1.0f : 1.0f, f2 = (a.c0 == 2 || a.c1 == 2) ? -1.0f : 1.0f, f3 = (a.c0 == 3 || a.c1 == 3) ? -1.0f : 1.0f;
+
+    // lane = (frl, place) = (lane >> 3, lane & 7) for loads and stores; instruction u covers frame 8 u + frl, whose shift is that of frl
+    const int l_frl = lane >> 3, l_d = (lane & 7) - ((l_frl * J) & 7);  // joint of this lane's place in group c: 8 c + l_d
+    v4f pre[G], pre1[G];
+    auto issue = [&](const int c, v4f (&pre)[G]) {
+        int j = 8 * c + l_d;
+        j = j < 0 ? 0 : (j > J - 1 ? J - 1 : j);  // outside the frame: a valid record again, parked where nobody reads
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const int fr = 8 * u + l_frl, fc = fr < nf ? fr : nf - 1;
+            pre[u] = *reinterpret_cast<const v4f *>(gin + ((int64_t)fc * J + j) * 4);  // (not nontemporal: a misaligned frame's line is shared with the next group)
+        }
+    };
+    auto park = [&](const int c, const v4f (&pre)[G]) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            float *p = sImg + (8 * u + l_frl) * RS + ((c & 1) * G + (lane & 7)) * 4;
+            if (PM_LDS_OK(p, 16u)) *reinterpret_cast<v4f *>(p) = pre[u];
+        }
+    };
+    issue(0, pre);
+    if (ngroups > 1) issue(1, pre1);
+    float *row = sImg + lane * RS;
+    const int sf = (lane * J) & 7;
+    float g[4] = {1.0f, 0.0f, 0.0f, 0.0f}, cm[4] = {1.0f, 0.0f, 0.0f, 0.0f};  // world quaternion of the previous joint; its mirrored, sign-fixed form
+    MirrorSaves sv = {};
+    auto walk = [&](const int c) {
+        const int jlo = 8 * c - 7 < 0 ? 0 : 8 * c - 7, jhi = 8 * c > J - 1 ? J - 1 : 8 * c;
+#pragma unroll 1
+        for (int j = jlo; j <= jhi; ++j) {
+            const int code = __builtin_amdgcn_readfirstlane(a.topo.code[j]), ld = code & 0xff, st = code >> 8;  // wave-uniform (kernarg)
+            float *slot = row + ((j + sf) & 15) * 4;
+            float qi[4], q[4];
+            lds_get<4>(slot, 0, qi);
+            qnormalize(qi, 1e-8f, q);  // skeleton.py:45
+            float gp[4] = {g[0], g[1], g[2], g[3]}, cp[4] = {cm[0], cm[1], cm[2], cm[3]};
+            mirror_slot_load<0>(ld, sv, gp, cp);
+            if (ld == DEEP_ROOT) { gp[0] = 1.0f; gp[1] = 0.0f; gp[2] = 0.0f; gp[3] = 0.0f; }
+            qmul(gp, q, g);
+            float cg[4];
+            canonical_sign(g, cg);
+            cm[0] = cg[0]; cm[1] = cg[1] * f1; cm[2] = cg[2] * f2; cm[3] = cg[3] * f3;  // skeleton.py:310-318
+            const float inv[4] = {cp[0], -cp[1], -cp[2], -cp[3]};
+            float o[4];
+            qmul(inv, cm, o);                                                          // skeleton.py:85-91 on the mirrored world rotations
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (ld == DEEP_ROOT) ? cm[k] : o[k];       // the root has no parent
+            lds_put<4>(slot, 0, o);
+            mirror_slot_save<0>(st, sv, g, cm);
+        }
+    };
+    v4f outr[G];
+    auto read_group = [&](const int k) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const float *p = sImg + (8 * u + l_frl) * RS + ((k & 1) * G + (lane & 7)) * 4;
+            outr[u] = PM_LDS_OK(p, 16u) ? *reinterpret_cast<const v4f *>(p) : v4f{0, 0, 0, 0};
+        }
+    };
+    auto store_group = [&](const int k) {
+        const int j = 8 * k + l_d;
+        const bool jok = j >= 0 && j < J;
+        float *g0 = gout + (l_frl * J + (jok ? j : 0)) * 4;
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+            if (jok && 8 * u + l_frl < nf) __builtin_nontemporal_store(outr[u], reinterpret_cast<v4f *>(g0 + 8 * u * J * 4));
+    };
+    park(0, pre);
+    if (ngroups > 1) park(1, pre1);
+    if (ngroups > 2) issue(2, pre);
+    for (int c = 0; c <= ngroups; ++c) {
+        wave_sync();
+        walk(c);
+        wave_sync();
+        if (c >= 1) {
+            read_group(c - 1);
+            wave_sync();
+            if (c + 1 < ngroups) park(c + 1, pre);   // over the slots just read; requested a whole step ago
+            if (c + 2 < ngroups) issue(c + 2, pre);  // in flight during the next step
+            store_group(c - 1);
+        }
+    }
+}
+
+static int launch_mirror_deep(const MirrorDeepArgs &a, hipStream_t s) {
+    const size_t lds = (size_t)PM_WAVE * kMirrorDeepRow * sizeof(float);
+    const int64_t ntiles = (a.F + PM_WAVE - 1) / PM_WAVE;
+    const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
+    if (grid > 0x7fffffffLL) { set_error("mirror: grid too large"); return PM_EUNSUPPORTED; }
+    set_kernel_name("pm::mirror_deep_kernel(pm::MirrorDeepArgs)");
+    if (int e = allow_lds(mirror_deep_kernel, lds)) return e;
+    hipLaunchKernelGGL(mirror_deep_kernel, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
+    return PM_AFTER_LAUNCH("mirror (lane per frame) launch");
+}
+
 static size_t mirror_lds_bytes(const int FPW, const int J, const int K, const int C) {
     return ((size_t)FPW * mirror_frame_stride(J, C) + 3 * (size_t)J + 1 + 8) * sizeof(float) + (C > 1 ? (size_t)(K + 2) * C * 8 + 8 : 0);  // + slack for the walk's look-ahead
 }
@@ -216,6 +374,7 @@ static int launch_mirror(const MirrorArgs &a, bool vec, hipStream_t s) {
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
     const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
     if (grid > 0x7fffffffLL) { set_error("mirror: grid too large"); return PM_EUNSUPPORTED; }
+    set_kernel_name("void pm::mirror_kernel<%d, %s, %d>(pm::MirrorArgs)", FPW, tf(vec), C);
     if (vec) {
         auto k = mirror_kernel<FPW, true, C>;
         if (int e = allow_lds(k, lds)) return e;
@@ -249,6 +408,15 @@ extern "C" int pm_mirror_rotations_f32(const float *rot, const int32_t *parents,
     }
     const bool vec = aligned16(rot) && aligned16(out);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // mode 'all' on long skeletons: one lane per frame, joints streamed (mirror_deep_kernel).  PM_MIRROR_DEEP (PM_TUNING build only):
+    // 0 = never, 1 = whenever eligible
+    if (const int deep = tune_env("PM_MIRROR_DEEP", -1); vec && mapping == nullptr && deep != 0 && (deep == 1 || J >= kMirrorDeepMinJ)) {
+        MirrorDeepArgs da;
+        if (deep_plan(a.parents, J, false, da.topo) >= 0) {
+            da.rot = rot; da.out = out; da.F = F; da.J = J; da.c0 = a.c0; da.c1 = a.c1;
+            return launch_mirror_deep(da, s);
+        }
+    }
     const size_t per_frame = (size_t)mirror_frame_stride(J, 1) * sizeof(float), fixed = (3 * (size_t)J + 9) * sizeof(float) + 256;
     int pick = (7 * (16 * per_frame + fixed) <= kMaxLds) ? 16 : 8;  // 4 lanes per frame; keep >= 7 waves per CU if possible
     // Several chains per frame where the tree is wide enough for the shorter walk to pay (walk cost per frame ~ steps x chains / 16),

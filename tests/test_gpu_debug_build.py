@@ -71,7 +71,7 @@ CASES = [(22, 61, 0.3, 2.0), (22, 20 * 7 + 3, 30.0, 200.0), (52, 4 * 9 + 1, 0.15
          (64, 13, 0.3, 2.0), (100, 21, 0.2, 2.0), (130, 9, 0.2, 2.0), (3, 1000, 0.3, 2.0), (1, 65, 0.3, 2.0),
          # chain-like skeletons (negative J): to_root_dual_quat's lane-per-frame kernels (chunks of eight / the line-aligned ring), full and
          # partial tiles of 64 frames, the guard words right behind every frame row they store
-         (-56, 64, 0.3, 2.0), (-57, 130, 0.3, 2.0), (-63, 65, 30.0, 200.0), (-66, 1, 0.3, 2.0), (-72, 193, 0.3, 2.0), (-129, 67, 0.2, 2.0)]
+         (-56, 64, 0.3, 2.0), (-57, 130, 0.3, 2.0), (-63, 65, 30.0, 200.0), (-66, 1, 0.3, 2.0), (-72, 193, 0.3, 2.0), (-129, 67, 0.2, 2.0), (-96, 64, 0.2, 2.0)]
 
 
 @pytest.mark.parametrize("J,F,osc,rsc", CASES)

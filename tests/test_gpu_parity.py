@@ -694,7 +694,7 @@ def test_mirror_argument_errors():
 
 
 @pytest.mark.parametrize("J,kind", [(52, "body"), (31, "random"), (130, "random"), (40, "random"), (41, "chain"), (64, "chain"), (65, "random"),
-                                    (96, "random"), (96, "chain"), (250, "random"), (251, "random"), (300, "chain")])
+                                    (96, "random"), (96, "chain"), (250, "random"), (251, "random"), (300, "chain"), (66, "chain"), (71, "chain"), (128, "chain"), (512, "chain")])
 def test_mirror_big_skeletons_vs_oracle_composition(J, kind):
     """Bigger skeletons (8 / 4 frames per wave, odd joint counts, several 64-joint windows of the walk; from 40 joints on two or
     four list-scheduled chains per frame, up to 250 joints): check against the reference's chain rebuilt from oracle pieces
@@ -713,6 +713,8 @@ def test_mirror_big_skeletons_vs_oracle_composition(J, kind):
     root = rng.uniform(-1, 1, (F, 3)).astype(np.float32)
     off = syn.make_offsets(J, rng, 0.1)
     got, gt, o2, _ = sk.mirror(rot, root, parents, off, None, None, "all", "Y")
+    from pymotion_amd import _lib
+    assert ("mirror_deep_kernel" in _lib.last_kernel_name()) == (kind == "chain" and J >= 66), _lib.last_kernel_name()  # mode 'all', long, few open branch points
     _, rm = co.fk(rot.astype(np.float64), np.zeros((F, 3)), off.astype(np.float64), parents)
     g = co.quat_from_matrix(rm)
     g[..., 1] *= -1  # axis Y -> components (1, 3)  (skeleton.py:313-315)
