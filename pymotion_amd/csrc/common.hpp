@@ -629,7 +629,7 @@ int schedule_chains(const Parents &par, int J, int C, uint8_t *sched, bool root_
 
 // ---- deep.hip: lane-per-frame walks for long skeletons -------------------------------------------------------------
 constexpr int kDeepM = 8;      // joints per chunk
-constexpr int kDeepSlots = 4;  // parent states kept in registers for children that do not follow their parent directly
+constexpr int kDeepSlots = 6;  // parent states kept in registers for children that do not follow their parent directly (the kernels are LDS-bound at two waves per SIMD: the registers are there)
 enum : uint8_t { DEEP_CHAIN = 0xff, DEEP_LOCAL = 0xfe, DEEP_ROOT = 0xfd, DEEP_NONE = 0xff };
 struct DeepTopo {                    // by value in the kernarg segment: one s_load_dword per joint (a byte table would be read with
     int32_t code[PM_MAX_JOINTS];     // global_load_ubyte, whose wait is a wait for every prefetch and store in flight): load | save << 8

@@ -1,10 +1,10 @@
 """GPU: the lane-per-frame kernels of deep.hip (to_root_dual_quat for long skeletons).
 
-From 40 joints on, a skeleton whose open branch points fit four register slots is walked one LANE per frame with the joints
+From 40 joints on, a skeleton whose open branch points fit six register slots is walked one LANE per frame with the joints
 streamed through LDS in chunks of eight (J a multiple of 8) or in line-aligned groups of four (any other J: the ring kernel).
 Checked here: which kernel a call dispatched to, parity with the float64 C oracle at the float32-rounding level (the state is
 float64: the data's magnitude does not matter), partial tiles and single frames, every residue of J mod 8, topologies that
-need 1, 4 and 5 slots (the last one must fall back), NaN / Inf staying in their frame."""
+need 1, 4, 6 and 7 slots (the last one must fall back), NaN / Inf staying in their frame."""
 import numpy as np
 import pytest
 
@@ -80,7 +80,7 @@ CASES = [
     (56, "chain_like", "deep"), (57, "chain_like", "ring"), (58, "chain_like", "ring"), (59, "humanoid", "ring"), (60, "chain_like", "ring"),
     (61, "humanoid", "ring"), (62, "chain_like", "ring"), (63, "chain_like", "ring"), (64, "humanoid", "deep"), (65, "chain_like", "ring"),
     (96, "chain_like", "deep"), (127, "humanoid", "ring"), (128, "chain_like", "deep"), (130, "chain_like", "ring"), (250, "humanoid", "ring"),
-    (72, "nested4", "deep"), (75, "nested4", "ring"), (72, "nested5", "fallback"), (300, "chain_like", "ring"), (512, "chain_like", "deep"),
+    (72, "nested4", "deep"), (75, "nested6", "ring"), (72, "nested6", "deep"), (72, "nested7", "fallback"), (300, "chain_like", "ring"), (512, "chain_like", "deep"),
 ]
 
 
@@ -89,8 +89,9 @@ def _parents(kind, J):
 
     if kind == "smplh":
         return syn.PARENTS_52
-    return {"chain_like": chain_like, "humanoid": humanoid_with_hands, "nested4": lambda j: nested_branches(j, 4),
-            "nested5": lambda j: nested_branches(j, 5)}[kind](J)
+    if kind.startswith("nested"):
+        return nested_branches(J, int(kind[6:]))
+    return {"chain_like": chain_like, "humanoid": humanoid_with_hands}[kind](J)
 
 
 @pytest.mark.parametrize("J,kind,expect", CASES)
