@@ -385,7 +385,7 @@ __global__ __launch_bounds__(PM_WAVE, (NL > 0 && NL <= 12) ? PM_IK_MINW : ((NL >
 // quaternions back into local ones; five 31 KB images per CU at J = 52.  Here
 //   * a lane walks ITS frame's joints in index order -- 64 frames per wave, no idle chains, no schedule;
 //   * joint p is finished when its first child p + 1 arrives: d = P_(p+1) - P_p with P_p still in registers, the parent's world
-//     quaternion the lane's own registers (parent = previous joint) or one of four saved register sets (ik_deep_plan colours the
+//     quaternion the lane's own registers (parent = previous joint) or one of six saved register sets (ik_deep_plan colours the
 //     open branch points like deep_plan);
 //   * the positions of FURTHER children, which the reference consumes at the same moment (skeleton.py:147-168) and which lie
 //     further down the stream, are fetched per lane when the tile starts (<= kIkFar of them: 4 on the 22-joint body, 12 on
