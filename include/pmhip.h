@@ -232,6 +232,17 @@ int pm_stream_ceiling_f32(const float *src, float *dst, int64_t F, int32_t rd_fl
  * Tells what the memory system sustains for a read:write mix (bench / tuning only). */
 int pm_stream_plain_f32(const float *src, float *dst, int64_t n4, int32_t ratio, int32_t blocks, pm_stream_t stream);
 
+/* Store-pattern probe (tools/store_probe.py -> profiles/r04_store_patterns.txt): n4 dwordx4 written in per-wave chunks under
+ * the knobs of cfg, 12 HOST ints: [0] burst KiB per wave and chunk (1, 2, 3, 4, 6, 8, 12, 16, 24, 32), [1] dwordx4 per lane READ in front of a
+ * chunk's stores (src must then hold n4 * cfg[1] / cfg[0] dwordx4), [2] store cache policy (0 plain, 1 nt, 2 sc1, 3 sc0 sc1,
+ * 4 sc0 sc1 nt, 5 sc0, 6 sc1 nt, 10 / 11 buffer_store plain / nt, -1 hipMemsetD32Async instead of a kernel), [3] chunk -> address
+ * placement (0 linear, 1 one contiguous range per XCD, 2 XCD-interleaved runs of cfg[4] block-chunks), [5] threads per workgroup
+ * (64 / 256), [6] grid (0 = one block-chunk per workgroup), [7] 0 one output array, 1 two (3/4 + 1/4 of every chunk, fk's
+ * rotmats + pos), 2 the two arrays one after the other, [8] what is stored (0 a per-chunk pattern plus what was read, 1 one constant, 2 random
+ * bits), [9] 1 = plain instead of nt loads, [10] 1 = one load in flight per wave instead of all of a chunk's loads up front,
+ * [11] bytes of unused LDS per workgroup (bounds the resident workgroups per CU like a kernel's LDS tile).  Bench / tuning only. */
+int pm_store_probe_f32(const float *src, float *dst, int64_t n4, const int32_t *cfg, pm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,6 +92,7 @@ SIGNATURES = {
     # measurement helper
     "pm_stream_ceiling_f32": [_f, _f, _i64, _i32, _i32, _strm],
     "pm_stream_plain_f32": [_f, _f, _i64, _i32, _i32, _strm],
+    "pm_store_probe_f32": [_f, _f, _i64, C.c_void_p, _strm],
 }
 
 _lib = None

@@ -349,6 +349,33 @@ __device__ __forceinline__ void o6d2m_f64(const float (&x)[6], const float eps_f
     r[6] = c12; r[7] = c22; r[8] = c10 * c21 - c11 * c20;
 }
 
+// Gram-Schmidt of a big-magnitude tile (fk.hip: PREC_F64): the reference's own sequence (ortho6d.py:67-90) in float64, where its
+// cancelling projection b - (c1.b) c1 keeps 1e-16 / sin(angle) -- nothing at the angles that are not `ill` -- and one rounding to
+// fp32 per matrix entry (3e-8 against the 2.8e-7 of o6d2m: down a chain of 30-unit bones that is the difference between 2 and 16
+// ulp of the positions).  Reciprocal square roots: hardware rsq (1 ulp of fp32) + one Newton step in float64 (relative error 5e-15).
+// `ill` as in o6d2m (|b - (c1.b) c1|^2 = |a x b|^2 / |a|^2); those records are re-done by the caller with the eps floors.
+__device__ __forceinline__ double rsqrt_newton_f64(const double n2) {
+    const double y = (double)__builtin_amdgcn_rsqf((float)n2);
+    const double e = __builtin_fma(-n2 * y, y, 1.0);
+    return __builtin_fma(y * e, 0.5, y);
+}
+__device__ __forceinline__ void o6d2m_precise(const float (&x)[6], float (&m)[9], bool &ill) {
+    const double a0 = x[0], a1 = x[2], a2 = x[4], b0 = x[1], b1 = x[3], b2 = x[5];
+    const double na2 = __builtin_fma(a0, a0, __builtin_fma(a1, a1, a2 * a2));
+    const double ia = rsqrt_newton_f64(na2);
+    const double c10 = a0 * ia, c11 = a1 * ia, c12 = a2 * ia;
+    const double d = __builtin_fma(c10, b0, __builtin_fma(c11, b1, c12 * b2));
+    double c20 = __builtin_fma(-d, c10, b0), c21 = __builtin_fma(-d, c11, b1), c22 = __builtin_fma(-d, c12, b2);
+    const double np2 = __builtin_fma(c20, c20, __builtin_fma(c21, c21, c22 * c22));
+    const double ib = rsqrt_newton_f64(np2);
+    c20 *= ib; c21 *= ib; c22 *= ib;
+    m[0] = (float)c10; m[1] = (float)c20; m[2] = (float)__builtin_fma(c11, c22, -(c12 * c21));
+    m[3] = (float)c11; m[4] = (float)c21; m[5] = (float)__builtin_fma(c12, c20, -(c10 * c22));
+    m[6] = (float)c12; m[7] = (float)c22; m[8] = (float)__builtin_fma(c10, c21, -(c11 * c20));
+    const float na2f = (float)na2, nb2f = (float)__builtin_fma(b0, b0, __builtin_fma(b1, b1, b2 * b2)), np2f = (float)np2;
+    ill = !(na2f > 1e-12f && na2f < 1e18f) || !(nb2f > 1e-12f && nb2f < 1e18f) || !(np2f > 1e-12f * nb2f);
+}
+
 // quat.py:85-156 in float64, incl. its normalize(eps = 1e-8)
 __device__ __forceinline__ void m2q_f64(const double (&m)[9], double (&q)[4]) {
     const double r00 = m[0], r01 = m[1], r02 = m[2], r10 = m[3], r11 = m[4], r12 = m[5], r20 = m[6], r21 = m[7], r22 = m[8];

@@ -263,8 +263,11 @@ __device__ __forceinline__ bool local_from_o6d(const float (&xx)[6], const float
     // (round 2 went through the quaternion when it was asked for: ~80 more VALU operations per joint and 40 more live registers,
     // 57.9 % against 61.8 %).  The quaternion, when wanted, is from_matrix of it (ortho6d.py:50-64).  None of this holds for what
     // Gram-Schmidt returns on degenerate columns (zeros, NaN, rounding noise): those records are re-done (o6d_redo_ill).
+    // M & PREC_F64 (big-magnitude tiles: centimetre mocap, far-away roots): Gram-Schmidt in float64 like the reference's chain, as
+    // local_from_quat does for the quaternion source -- the rotation error is multiplied by the bone lengths down the chain.
     bool ill;
-    o6d2m(xx, L, ill);
+    if constexpr ((M & PREC_F64) != 0) o6d2m_precise(xx, L, ill);
+    else o6d2m(xx, L, ill);
     if constexpr (QOUT) m2q(L, Q);
     return ill;
 }
@@ -567,7 +570,7 @@ template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT, bool PAD, int PREC>
 __global__ __launch_bounds__(PM_WAVE) void fk_kernel(const FkArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
-    const int64_t tile = xcd_tile(ntiles);
+    const int64_t tile = PM_ABLATED(a, 4) ? ((int64_t)blockIdx.x < ntiles ? (int64_t)blockIdx.x : -1) : xcd_tile(ntiles);  // tuning: linear tile order
     if (tile < 0) return;
     const int64_t f0 = tile * FPW;
     const int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
@@ -970,6 +973,17 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
     // at J = 16 130 vs 139 us).
     if (pfo || (SRC == SRC_O6D && a.J >= 20)) pick = 4;
     pick = tune_env("PM_FK_FPW", pick);  // PM_TUNING build only: 20, 16, 12, 8 or 4
+#ifdef PM_TUNING
+    if constexpr (SRC == SRC_QUAT) {  // the three-lane tile, several tiles per workgroup with the next tile's records prefetched into registers
+        const int pnt = tune_env("PM_FK_PIPE3", 0);
+        if (pnt > 0 && !pfo && a.J == 22) {
+            a.pad = pad3;
+            if (pick == 20) return dispatch_fk_pipe<20, 7, SRC>(a, vec, pfo, pnt, s);
+            if (pick == 16) return dispatch_fk_pipe<16, 6, SRC>(a, vec, pfo, pnt, s);
+            if (pick == 12) return dispatch_fk_pipe<12, 5, SRC>(a, vec, pfo, pnt, s);
+        }
+    }
+#endif
     if (pick != 20 && pick != 16 && pick != 12 && pick != 8 && pick != 4) { set_error("PM_FK_FPW must be 20, 16, 12, 8 or 4"); return PM_EINVAL; }
     if ((size_t)pick * frame_bytes(pad3) + fixed > kMaxLds) pick = 4;
     a.pad = (pick == 4) ? pad12 : pad3;
