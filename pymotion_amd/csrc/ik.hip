@@ -300,8 +300,8 @@ __global__ __launch_bounds__(PM_WAVE, (NL > 0 && NL <= 12) ? PM_IK_MINW : ((NL >
             r[0] = 0.0f; r[1] = ax2[0]; r[2] = ax2[1]; r[3] = ax2[2];
         }
         qmul(gpre, r, g);  // G_j once the first child is aligned
+        const bool inexact = snap || anti;  // G_j does not take the rest direction onto d (not even approximately)
         // roll correction from every further child: G_j <- G_j (x) roll; per lane with two chains (the other chain's lanes wait)
-        const bool inexact = snap || anti;  // G_j does not take the rest direction exactly onto d
         for (int rr = 0; __builtin_amdgcn_ballot_w64(rr < nx) != 0; ++rr) {
             const bool act = rr < nx;
             const int gc = sTopo[2 * J + 1 + (act ? xs + rr : xs)];
@@ -312,7 +312,23 @@ __global__ __launch_bounds__(PM_WAVE, (NL > 0 && NL <= 12) ? PM_IK_MINW : ((NL >
             const float dg[3] = {pg[0] - pj[0], pg[1] - pj[1], pg[2] - pj[2]};
             float v[3];
             unrotate(g, dg, v);
-            float axis[3] = {un[0], un[1], un[2]};
+            // The roll axis the reference derives, inv(G_j) normalize(P_c0 - P_j), is NOT quite the first child's rest direction: its
+            // alignment turns by acos(dot (1 - e)), e = 1e-8 (1 / |u| + 1 / |v|), not by the angle between the two directions, so G_j
+            // leaves the rest direction e cot(angle) short of d -- 1e-4 rad on a 3 cm bone turned by a third of a degree (or by
+            // 179.7), and the roll quaternion inherits that times sin(roll / 2): round 3, which used the rest direction as it stands,
+            // read 1e-4 there (3e-5 at one degree) where one ulp of the inputs moves the reference's answer by 3e-8.  To first order
+            // in e the axis is  un + e (dt N / |cr|^2) ((dt / N) un - p / |p|)  -- from exact table values and the step's own
+            // quantities, i.e. without the rounding noise of deriving it the long way (measured: the long way in fp32 is worse than
+            // no correction on trees, 2e-4 against 6e-5 at 3001 x 52).  Lanes whose alignment snapped to the identity or took the
+            // anti-parallel branch derive it the long way as before (a half turn about an arbitrary axis is no alignment at all).
+            float axis[3];
+            {
+                float kk = dte * q.N;
+                asm volatile("" : "+v"(kk));  // or all of this is hoisted in front of the loop and paid by every step
+                kk *= frcp(q.cr2);
+                const float cs = 0.5f * (q.npd - q.nmd) * frcp(q.N), ks = 1.0f + kk * cs, kp = kk * q.iv;
+                axis[0] = __builtin_fmaf(-kp, p[0], ks * un[0]); axis[1] = __builtin_fmaf(-kp, p[1], ks * un[1]); axis[2] = __builtin_fmaf(-kp, p[2], ks * un[2]);
+            }
             if (__builtin_amdgcn_ballot_w64(inexact && act) != 0) {
                 float dd[3] = {d[0], d[1], d[2]}, dn[3], ax[3];
                 asm volatile("" : "+v"(dd[0]), "+v"(dd[1]), "+v"(dd[2]));  // or the normalisation (a square root and a reciprocal) is hoisted in front of the loop and paid by every step
@@ -437,7 +453,7 @@ __device__ __forceinline__ IkPair ik_pair_of(const float (&u)[3], const float lu
 }
 // from_to(u, inv(gpre) d) with the reference's eps terms and special cases (the alignment of the tile kernel's walk, same formulas);
 // `inexact`: the result does not take the rest direction exactly onto d (snapped to the identity, or the anti-parallel branch)
-__device__ __forceinline__ void ik_align(const float (&gpre)[4], const float (&d)[3], const float (&ta)[4], const float (&tb)[4], float (&r)[4], bool &inexact) {
+__device__ __forceinline__ void ik_align(const float (&gpre)[4], const float (&d)[3], const float (&ta)[4], const float (&tb)[4], float (&r)[4], bool &inexact, const bool want_axis, float (&axis)[3]) {
     const float u[3] = {ta[0], ta[1], ta[2]};
     const float iu = ta[3], lu = tb[3];
     float p[3];
@@ -462,13 +478,20 @@ __device__ __forceinline__ void ik_align(const float (&gpre)[4], const float (&d
         r[0] = 0.0f; r[1] = ax2[0]; r[2] = ax2[1]; r[3] = ax2[2];
     }
     inexact = snap || anti;
+    // the roll axis of further children, to first order in e (see the tile kernel's walk): un + e (dt N / |cr|^2) ((dt / N) un - p / |p|)
+    axis[0] = tb[0]; axis[1] = tb[1]; axis[2] = tb[2];
+    if (want_axis) {  // wave-uniform
+        const float kk = dte * q.N * frcp(q.cr2);
+        const float cs = 0.5f * (q.npd - q.nmd) * frcp(q.N), ks = 1.0f + kk * cs, kp = kk * q.iv;
+        axis[0] = __builtin_fmaf(-kp, p[0], ks * tb[0]); axis[1] = __builtin_fmaf(-kp, p[1], ks * tb[1]); axis[2] = __builtin_fmaf(-kp, p[2], ks * tb[2]);
+    }
 }
 // from_to_axis(offsets[gc], inv(g) dg, axis) (quat.py:579-650) as the tile kernel's walk evaluates it; tg = {u_gc, 1 / |u_gc|}, lug = |u_gc|
 __device__ __forceinline__ void ik_roll(const float (&g)[4], const float (&dg)[3], const float (&d)[3], const float (&un)[3], const bool inexact,
                                         const float (&tg)[4], const float lug, float (&roll)[4]) {
     float v[3];
     ik_unrotate(g, dg, v);
-    float axis[3] = {un[0], un[1], un[2]};
+    float axis[3] = {un[0], un[1], un[2]};  // (un: the axis ik_align derived, first order in e)
     if (__builtin_amdgcn_ballot_w64(inexact) != 0) {
         float dd[3] = {d[0], d[1], d[2]}, dn[3], ax[3];
         asm volatile("" : "+v"(dd[0]), "+v"(dd[1]), "+v"(dd[2]));
@@ -608,9 +631,9 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_deep_kernel(const
                 const float d[3] = {pj[0] - pp[0], pj[1] - pp[1], pj[2] - pp[2]};
                 float r[4];
                 bool inexact;
-                ik_align(gpre, d, ta, tb, r, inexact);
+                float un[3];  // the roll axis of further children
+                ik_align(gpre, d, ta, tb, r, inexact, nroll > 0, un);
                 qmul(gpre, r, g);
-                const float un[3] = {tb[0], tb[1], tb[2]};
                 for (int rr = 0; rr < nroll; ++rr) {  // further children: wave-uniform here (every lane walks the same skeleton)
                     const int gc = __builtin_amdgcn_readfirstlane(a.far_joint[fi]);
                     ++fi;

@@ -146,10 +146,11 @@ def test_fused_ortho6d_at_centimetre_scale():
     p_o, r_o = _oracle(q_o, root, off, parents)
     for want_q in (True, False):
         out = sk.fk_from_ortho6d(x, root, off, parents, return_quat=want_q)
-        # the fused chain starts from an fp32 Gram-Schmidt: rotation error ~1e-6 on ill-conditioned inputs, times the bones
-        well = np.abs(out[1] - r_o).max(axis=(1, 2, 3)) < 5e-6
-        assert well.mean() > 0.95
-        assert np.abs(out[0][well] - p_o[well]).max() <= 16 * _ulp_of(p_o)
+        # big tiles run Gram-Schmidt in float64 like the reference's chain (fk.hip: local_from_o6d): fk's own bar, on ALL frames
+        assert np.abs(out[0] - p_o).max() <= max(1e-5, 2 * _ulp_of(p_o)), (np.abs(out[0] - p_o).max() / _ulp_of(p_o), "ulp")
+        assert np.abs(out[1] - r_o).max() <= 1e-6, np.abs(out[1] - r_o).max()
+        if want_q:
+            assert np.minimum(np.abs(out[2] - q_o).max(-1), np.abs(out[2] + q_o).max(-1)).max() <= 1e-5
 
 
 def test_threshold_edges_take_a_consistent_path():

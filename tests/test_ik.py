@@ -145,10 +145,11 @@ def test_gpu_from_root_positions_long_bushy_skeletons_on_four_chains(J, F, four)
     assert four is None or name.endswith(", 4>(pm::IkArgs, int)") == four, name  # (None: whichever the schedules of this tree favour)
     ref = co.from_root_positions(pos.astype(np.float64), par, off.astype(np.float64))
     err = np.minimum(np.abs(got - ref).max(-1), np.abs(got + ref).max(-1))
-    # (2e-5 on 99.9 % of the records; the rest -- alignments within a hair of a half turn, whose twist every joint below inherits,
-    # see _reference_sensitivity -- within 1e-4: measured worst 4e-5 at 700 x 72)
+    # the tile kernel's bar, per record: 2e-5, plus -- where an alignment sits within a hair of a half turn, whose twist every joint
+    # below inherits -- a small multiple of how far one ulp of the inputs moves the reference's own answer (_reference_sensitivity)
+    sens = _reference_sensitivity(pos, par, off, ref)
+    assert (err <= 2e-5 + 8.0 * sens).all(), (float(err.max()), float(((err - 2e-5) / np.maximum(sens, 1e-12)).max()))
     assert np.quantile(err, 0.999) <= 2e-5, float(np.quantile(err, 0.999))
-    assert err.max() <= 1e-4, float(err.max())
     p2, _ = sk.fk(got, np.zeros_like(root), off, par)
     p_ref, _ = co.fk(ref, np.zeros((F, 3)), off.astype(np.float64), par)
     assert np.abs(p2 - p_ref).max() <= 2e-5
@@ -207,11 +208,15 @@ def test_gpu_from_root_positions_lane_per_frame_on_depth_first_skeletons(J, kind
         assert ("from_root_positions_deep_kernel" in _lib.last_kernel_name()) == deep, _lib.last_kernel_name()
         ref = co.from_root_positions(pos.astype(np.float64), par, off.astype(np.float64))
         err = np.minimum(np.abs(got - ref).max(-1), np.abs(got + ref).max(-1))
-        # (2e-5 on 99 % of the records of these small batches; an alignment within a hair of a half turn is decided by the last bit
-        # of its input -- see _reference_sensitivity -- and every joint below inherits the twist: the POSE is the firm check)
-        if J <= 128:  # (longer chains: a twist anywhere is inherited by hundreds of joints below it, in the reference as here)
-            assert np.quantile(err, 0.99) <= 2e-5, (F, float(np.quantile(err, 0.99)))
-        assert np.median(err) <= (1e-6 if J <= 128 else 1e-5) and (J > 128 or err.max() <= 5e-3), (F, float(np.median(err)), float(err.max()))
+        # the tile kernel's bar, per record: 2e-5 + 8 x how far one ulp of the inputs moves the reference's own answer (an alignment
+        # within a hair of a half turn is decided by the last bit of its input, and every joint below inherits the twist)
+        # (beyond 128 joints a twist anywhere is inherited -- and amplified, by tan(turn / 2) per joint -- by hundreds of joints below it,
+        # in the reference as here: the kernel's fp32 steps weigh like a few ulps of input each, hence the wider multiple there;
+        # measured 35x at 63 x 512)
+        sens = _reference_sensitivity(pos, par, off, ref)
+        k = 8.0 if J <= 128 else 64.0
+        assert (err <= 2e-5 + k * sens).all(), (F, float(err.max()), float(((err - 2e-5) / np.maximum(sens, 1e-12)).max()))
+        assert np.median(err) <= (1e-6 if J <= 128 else 1e-5), (F, float(np.median(err)))
         leaves = np.setdiff1d(np.arange(J), par[1:])
         assert (got[:, leaves] == np.array([1, 0, 0, 0], np.float32)).all()   # joints without children keep the exact identity
         p2, _ = sk.fk(got, np.zeros_like(root), off, par)
