@@ -216,6 +216,11 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
             else q[u] = v4f{gsrc[4 * ec], gsrc[4 * ec + 1], gsrc[4 * ec + 2], gsrc[4 * ec + 3]};
         }
     };
+    // The precise step bounds its fixed-point translations by max |root| + the bone lengths down the chain -- true for UNIT rotations only,
+    // and this op does not normalise its inputs (skeleton.py:207-244: "inputs are not normalised"): with |q| = 1.05 a rotated offset has
+    // grown 2.2x after eight ancestors, past the 2x headroom of the word.  A tile with a quaternion off unit length
+    // therefore keeps the fp32 step, whose floats scale with the data like the reference's.
+    bool offunit = false;
     auto park_batch = [&](const int e0, const v4f (&q)[4]) {
         if (e0 >= n) return;
 #pragma unroll
@@ -223,6 +228,8 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
             const int e = e0 + u * PM_WAVE + lane;
             const int f = (int)(((float)e + 0.5f) * invJ);  // e / J, exact for e < 2^22
             const int j = e - f * J;
+            const float n2 = __builtin_fmaf(q[u].w, q[u].w, __builtin_fmaf(q[u].z, q[u].z, __builtin_fmaf(q[u].y, q[u].y, q[u].x * q[u].x)));
+            offunit = offunit || (fabsf(n2 - 1.0f) >= 1e-3f && n2 < 3e38f);  // (NaN / Inf: the float64 chain propagates them; records past the tile's end repeat its last one)
             if (e < n) *reinterpret_cast<v4f *>(sDq + f * FS + j * 8) = q[u];
         }
     };
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
     FxScale fx = {1.0f, 1.0f};
     // (a NaN / Inf QUATERNION needs no special case: it makes the float64 chain of its joint and of every descendant NaN in all
     // four components, and the dual part 0.5 (0,t) (x) q with them, whatever the fixed-point words hold -- the reference's pattern)
-    if (__builtin_amdgcn_ballot_w64(tbig || !(fabsf(rp) < kBigRoot)) != 0) {
+    if (__builtin_amdgcn_ballot_w64(tbig || !(fabsf(rp) < kBigRoot)) != 0 && __builtin_amdgcn_ballot_w64(offunit) == 0) {
         const float bsum = wave_sum(tsum), bmax = (float)a.depth * wave_max(tmx);  // (NaN sticks in both)
         precise = fx_scale((bmax < bsum) ? bmax : bsum, fabsf(rp), fx);            // false for a non-finite bound: fp32 step
     }
@@ -474,6 +481,7 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_sched_kernel(const SchedAr
             else q[u] = v4f{gsrc[4 * ec], gsrc[4 * ec + 1], gsrc[4 * ec + 2], gsrc[4 * ec + 3]};
         }
     };
+    bool offunit = false;  // a quaternion of the tile off unit length: the precise step's fixed-point bound does not hold, see to_root_dq_kernel
     auto park_batch = [&](const int e0, const v4f (&q)[4]) {
         if (e0 >= n) return;
 #pragma unroll
@@ -481,6 +489,8 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_sched_kernel(const SchedAr
             const int e = e0 + u * PM_WAVE + lane;
             const int f = (int)(((float)e + 0.5f) * invJ);  // e / J, exact for e < 2^22
             const int j = e - f * J;
+            const float n2 = __builtin_fmaf(q[u].w, q[u].w, __builtin_fmaf(q[u].z, q[u].z, __builtin_fmaf(q[u].y, q[u].y, q[u].x * q[u].x)));
+            offunit = offunit || (fabsf(n2 - 1.0f) >= 1e-3f && n2 < 3e38f);
             if (e < n) *reinterpret_cast<v4f *>(sDq + f * FS + j * 8) = q[u];
         }
     };
@@ -517,7 +527,7 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_sched_kernel(const SchedAr
     // which arithmetic this tile gets (wave-uniform; "Big-magnitude tiles" above)
     bool precise = false;
     FxScale fx = {1.0f, 1.0f};
-    if (tbig || __builtin_amdgcn_ballot_w64(!(fabsf(rp) < kBigRoot)) != 0)
+    if ((tbig || __builtin_amdgcn_ballot_w64(!(fabsf(rp) < kBigRoot)) != 0) && __builtin_amdgcn_ballot_w64(offunit) == 0)
         precise = fx_scale(table_bound(), (k == 0) ? fabsf(rp) : 0.0f, fx);  // false for a non-finite bound: fp32 step
     fx.S = uniform_f32(fx.S);
     fx.invS = uniform_f32(fx.invS);

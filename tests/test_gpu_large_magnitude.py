@@ -137,10 +137,10 @@ def test_fused_ortho6d_at_centimetre_scale():
     import pymotion_amd.ops.skeleton as sk
 
     parents = syn.PARENTS_52
-    F = 3001
+    F = 8191
     rng = np.random.default_rng(77)
     x = rng.standard_normal((F, 52, 3, 2)).astype(np.float32)
-    _, root, off = _cm_workload(F, parents, seed=78)
+    _, root, off = _cm_workload(F, parents, seed=52)  # the skeleton and roots of test_fk_centimetre_scale_within_two_ulp_both_doors[52]: the same bar means the same thing
     with np.errstate(all="ignore"):
         q_o = co.o6d_to_quat(x.astype(np.float64))
     p_o, r_o = _oracle(q_o, root, off, parents)
@@ -280,3 +280,34 @@ def test_root_dual_quaternions_mixed_tiles_far_roots_and_non_finite_inputs():
                 if far[t0:t0 + fpw].any():
                     near_only[t0:t0 + fpw] = False
         assert err[(near_only & ~skip)[frame_of]].max() <= 1e-6
+
+
+@pytest.mark.parametrize("J,kind", [(22, "body"), (31, "random"), (52, "body"), (12, "chain")])
+def test_root_dual_quaternions_of_non_unit_rotations_at_centimetre_scale(J, kind):
+    """to_root_dual_quat does NOT normalise its inputs (skeleton.py:207-244), and with |q| != 1 a rotated offset grows by |Q_parent|^2
+    down the chain: the precise step's fixed-point bound (unit rotations) does not hold, so tiles holding an off-unit quaternion keep the
+    fp32 step (round-3 ADVICE: norm 1.05 is 2.2x after eight ancestors, past the word's headroom -- garbage, not rounding).  Bar: the
+    fp32 step's, 8 ulp of the largest component (round 2's bar for this op), on norms 0.8 ... 1.2; and unit tiles NEXT to them still
+    take the precise step (2 ulp)."""
+    import pymotion_amd.ops.skeleton as sk
+
+    parents = {"body": syn.PARENTS_22 if J == 22 else syn.PARENTS_52, "chain": _chain(J)}.get(kind)
+    if parents is None:
+        parents = syn.random_parents(J, np.random.default_rng(J))
+    rng = np.random.default_rng(300 + J)
+    F = 4096
+    rot = rng.standard_normal((F, J, 4))
+    rot = rot / np.linalg.norm(rot, axis=-1, keepdims=True)
+    scaled = np.zeros(F, bool)
+    scaled[: F // 2] = True                                   # first half: every quaternion off unit length
+    rot[scaled] *= rng.uniform(0.8, 1.2, (int(scaled.sum()), J, 1))
+    rot = rot.astype(np.float32)
+    root = rng.uniform(-200, 200, (F, 3)).astype(np.float32)
+    off = rng.uniform(-30, 30, (J, 3)).astype(np.float32)
+    off[0] = 0
+    d = sk.to_root_dual_quat(rot, root, parents, off)
+    d_o = co.to_root_dual_quat(rot.astype(np.float64), root.astype(np.float64), parents, off.astype(np.float64))
+    assert np.isfinite(d).all()
+    for sel, ulps in ((scaled, 8.0), (~scaled, 2.0)):
+        err = np.abs(d[sel] - d_o[sel]).max()
+        assert err <= ulps * _ulp_of(d_o[sel]), (err / _ulp_of(d_o[sel]), "ulp", "scaled" if ulps == 8.0 else "unit")
