@@ -5,11 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the fk hot path over one device-resident batch of synthetic frames
-(config 2 of BASELINE.json: 2^20 frames x 22 joints per GPU, fp32, quaternions not
-pre-normalised, metre-scale offsets).  Frames shard across ranks with no data-path collective
-(weak scaling: per-GPU batch fixed).  `python bench.py --gpus N` with N > 1 launches itself under
-torch.distributed.run.  Multi-GPU runs also report, after the timed region and never inside `value`, the reassembly
+A "step" is one pass of the fk hot path over one device-resident batch of synthetic frames, fp32, quaternions not
+pre-normalised, metre-scale offsets.  N = 1: BASELINE.json configs[1], 2^20 frames x 22 joints.  N > 1: BASELINE.json
+configs[4], 16 777 216 frames x 22 joints sharded over the N GPUs (16 777 216 // N frames per GPU: the TOTAL is fixed,
+"scaling": "strong"; --frames-per-gpu overrides it and makes the run a weak-scaling one).  Frames shard across ranks
+with no data-path collective.  `python bench.py --gpus N` with N > 1 launches itself under torch.distributed.run.  Multi-GPU runs also report, after the timed region and never inside `value`, the reassembly
 all-gather (ms, xGMI GB/s per GPU vs the link roofline, both implementations) and compute + gather combined.
 Rank 0 prints ONE JSON line.  Extra objects in that line:
 
@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--prewarm-ms", type=float, default=400.0,
                     help="untimed back-to-back launches before the W warmup steps so that the GPU's clocks/power state "
                          "settle (the first ~20 ms after idle run ~15%% slower); 0 disables")
-    ap.add_argument("--frames-per-gpu", type=int, default=1 << 20)
+    ap.add_argument("--frames-per-gpu", type=int, default=0,
+                    help="0 (default): 2^20 at N = 1 (BASELINE configs[1]); 16 777 216 // N at N > 1 (BASELINE configs[4], strong scaling)")
     ap.add_argument("--joints", type=int, default=22, choices=[22, 52])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=1 << 20)
@@ -413,7 +414,17 @@ def main():
 
     J = a.joints
     parents = syn.PARENTS_22 if J == 22 else syn.PARENTS_52
-    F = a.frames_per_gpu
+    CONFIG5_FRAMES = 1 << 24
+    explicit_frames = a.frames_per_gpu > 0
+    F = a.frames_per_gpu if explicit_frames else ((1 << 20) if world == 1 else CONFIG5_FRAMES // world)
+    if (F, J, world) == (1 << 20, 22, 1):
+        workload, scaling = "BASELINE.json configs[1]", "weak"
+    elif J == 22 and F * world == CONFIG5_FRAMES and F == CONFIG5_FRAMES // world:
+        workload = ("all 16 777 216 frames of BASELINE.json configs[4] on one GPU" if world == 1 else
+                    "BASELINE.json configs[4]: 16 777 216 frames sharded over %d GPUs" % world)
+        scaling = "weak" if (explicit_frames and world == 1) else "strong"
+    else:
+        workload, scaling = "non-default size", "weak"
     # synthetic workload born on the device from (seed, rank): no host->device copy is ever timed
     gen = torch.Generator(device=dev)
     gen.manual_seed(a.seed * 1000 + rank)
@@ -528,15 +539,13 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": wall / a.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "prewarm_ms": a.prewarm_ms,
-            "config": {"workload": "fk: %d frames x %d joints per GPU, fp32 (%s)" % (
-                F, J, "BASELINE.json configs[1]" if (F, J) == (1 << 20, 22) else
-                ("all 16 777 216 frames of BASELINE.json configs[4] on one GPU" if (F, J, world) == (1 << 24, 22, 1) else "non-default size")),
-                       "frames_per_gpu": F, "joints": J, "sharding": "frames, no data-path collective"},
+            "config": {"workload": "fk: %d frames x %d joints per GPU, fp32 (%s)" % (F, J, workload),
+                       "frames_per_gpu": F, "frames_total": F * world, "joints": J, "sharding": "frames, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes": bytes_per_frame * F,

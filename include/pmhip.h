@@ -209,6 +209,14 @@ int pm_dq_normalize_f32(const float *dq, int64_t N, int orthogonalize, float ato
                         pm_stream_t stream);
 int pm_dq_unit_flags_f32(const float *dq, int64_t N, float atol, int32_t *flags, pm_stream_t stream);
 
+/* io/bvh.py:352-359 BVH.get_data: rots = quat.normalize(quat.unroll(quat.from_euler(np.radians(rotations), order), axis = 0)) in ONE
+ * launch: euler_deg [T, J, 3] (DEVICE, the file's angles in degrees, fp32), order [J, 3] (HOST, axis codes 0 / 1 / 2 = x / y / z
+ * per joint: the reference tiles this table over the frames), out [T, J, 4] unit, sign-unrolled quaternions.  12 B read + 16 B
+ * written per joint and frame (the three launches it replaces: 28 + 32 + 32).  J <= 64 (PM_EUNSUPPORTED beyond: run the three
+ * ops); workspace as for pm_quat_unroll_f32 (pm_quat_unroll_workspace_bytes(T, J)). */
+int pm_bvh_rotations_f32(const float *euler_deg, const uint8_t *order, int64_t T, int32_t J, float *out, void *workspace,
+                         pm_stream_t stream);
+
 /* ---- resampling along the time axis ------------------------------------------------------------------ */
 
 /* ops/time.py:4-66 interpolate_positions (method "linear"), torch twin ops/time_torch.py.

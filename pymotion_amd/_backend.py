@@ -293,8 +293,12 @@ def _prefault(arr):
     a0 = (arr.ctypes.data + page - 1) & ~(page - 1)
     n = (arr.ctypes.data + arr.nbytes - a0) & ~(page - 1)
     step = max(64 << 20, ((n // 8) + page - 1) & ~(page - 1))
+    def populate(keep, addr, nbytes):  # `keep` pins the buffer: a task that runs after the caller dropped the result must not
+        _libc.madvise(C.c_void_p(addr), C.c_size_t(nbytes), 23)  # MADV_POPULATE_WRITE      # populate someone else's mapping
+        del keep
+
     for off in range(0, n, step):
-        _prefault_pool.submit(_libc.madvise, C.c_void_p(a0 + off), C.c_size_t(min(step, n - off)), 23)  # MADV_POPULATE_WRITE
+        _prefault_pool.submit(populate, arr, a0 + off, min(step, n - off))
 
 
 def pipelined_frames(F, ins, outs, launch):
@@ -536,6 +540,10 @@ class NumpyBackend:
     def moveaxis(x, src, dst):
         return np.moveaxis(np.asarray(x), src, dst)
 
+    @staticmethod
+    def radians(x):
+        return np.radians(np.asarray(x))
+
     def flags_alloc(self, n=3):
         """Zeroed device int32[n] for kernels that report batch-wide predicates."""
         buf = _DevBuf(4 * n, self._dev)
@@ -658,6 +666,12 @@ class TorchBackend:
     @staticmethod
     def moveaxis(x, src, dst):
         return x.movedim(src, dst)
+
+    @staticmethod
+    def radians(x):
+        import torch
+
+        return torch.deg2rad(x)
 
     def flags_alloc(self, n=3):
         t = self.torch.zeros(n, dtype=self.torch.int32, device=self.dev)

@@ -86,6 +86,7 @@ SIGNATURES = {
     "pm_quat_unroll_batched_workspace_bytes": [_i64, _i64, _i32],
     "pm_quat_unroll_batched_f32": [_f, _i64, _i64, _i32, _f, C.c_void_p, _strm],
     "pm_dq_unroll_batched_f32": [_f, _i64, _i64, _i32, _f, C.c_void_p, _strm],
+    "pm_bvh_rotations_f32": [_f, C.c_void_p, _i64, _i32, _f, C.c_void_p, _strm],
     "pm_dq_normalize_f32": [_f, _i64, _int, _flt, _f, C.c_void_p, _strm],
     "pm_dq_unit_flags_f32": [_f, _i64, _flt, C.c_void_p, _strm],
     "pm_interpolate_linear_f32": [_f, C.c_void_p, _f, _i64, _i64, _i64, _i64, _f, _strm],

@@ -274,6 +274,34 @@ def _unroll(be, x, axis, width, fname):
     return be.moveaxis(res, 0, ax)
 
 
+def bvh_rotations(be, euler_deg, order_table):
+    """io/bvh.py:352-359 (BVH.get_data): quat.normalize(quat.unroll(quat.from_euler(np.radians(euler_deg), order), axis=0)) for
+    euler_deg [T, J, 3] in DEGREES and one Euler order per joint (a [J, 3] table of 'x' | 'y' | 'z' or axis codes).  Up to 64 joints
+    this is ONE kernel (pm_bvh_rotations_f32: 12 B in, 16 B out per joint and frame, one trip over the bus through the NumPy
+    door); beyond, the three ops on the device."""
+    shp = be.shape(euler_deg)
+    if len(shp) != 3 or shp[-1] != 3:
+        raise ValueError(f"expected [frames, joints, 3] Euler angles, got {shp}")
+    T, J = shp[0], shp[1]
+    codes, _ = _order_codes(np.asarray(order_table), np.asarray(order_table).shape[:-1])
+    table = np.ascontiguousarray(np.broadcast_to(codes.reshape(-1, 3), (J, 3)), dtype=np.uint8)
+    if J > 64:
+        q = quat_from_euler(be, be.radians(euler_deg), order_table, per_joint_table=True)
+        return quat_normalize(be, quat_unroll(be, q, 0))
+    dt = be.result_dtype(euler_deg)
+    be.begin(euler_deg)
+    try:
+        xp = be.dev_in(euler_deg)
+        op, oh = be.dev_out((T, J, 4))
+        if T > 0 and J > 0:
+            ws = be.scratch(_lib.lib().pm_quat_unroll_workspace_bytes(T, J))
+            _lib.call("pm_bvh_rotations_f32", xp, table.ctypes.data_as(C.c_void_p), T, J, op, ws, be.stream())
+        res = be.result(oh, dt)
+    finally:
+        be.end()
+    return res
+
+
 def quat_unroll(be, q, axis):
     return _unroll(be, q, axis, 4, "pm_quat_unroll_f32")
 

@@ -284,8 +284,8 @@ __device__ __forceinline__ void o6d_redo_ill(const bool ill, const float (&xx)[6
     o6d_chain_f64(xx, eps, Ld, Qd);
     if (ill) {
         put_local<TRANSPOSED>(slot, Ld);
-        // qslot: the record's LDS slot (fk_tile) or its place in HBM (fk_pipe_kernel: a second store of this lane to the address
-        // it has already written -- same-address stores of one wave land in program order)
+        // qslot: the record's LDS slot (fk_tile) or its place in HBM (fk_pipe_kernel: the only store of that record, the plain
+        // conversion skips the records it flags)
         if (QOUT) { qslot[0] = Qd[0]; qslot[1] = Qd[1]; qslot[2] = Qd[2]; qslot[3] = Qd[3]; }
     }
 }
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? ((PFO && E
                     ill[u] = local_from_o6d<QOUT, M>(xx, a.eps, L[u], Q);
                     if constexpr (QOUT) {
                         const int e = u * PM_WAVE + lane;
-                        if (e < n) {
+                        if (e < n && !ill[u]) {  // (an ill record's quaternion is stored once, by its float64 redo: no second store to an address)
                             if (VEC) __builtin_nontemporal_store(v4f{Q[0], Q[1], Q[2], Q[3]}, reinterpret_cast<v4f *>(gq) + e);
                             else { gq[4 * e] = Q[0]; gq[4 * e + 1] = Q[1]; gq[4 * e + 2] = Q[2]; gq[4 * e + 3] = Q[3]; }
                         }

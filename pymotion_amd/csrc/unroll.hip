@@ -23,6 +23,7 @@
 // Layout: q [T, S, 4] (unroll axis first; the front-end moves it there), out same.
 // Algorithmic HBM bytes: 32 B per quaternion (one pass); the three-pass form moves 16 (pass 1) + 16 + 16 (pass 3) = 48 B.
 #include "common.hpp"
+#include "trig.hpp"
 
 namespace pm {
 
@@ -285,6 +286,7 @@ struct OnePassArgs {
     int32_t ngroups;   // ceil(S / 31)
     int32_t static_order;  // PM_TUNING build only: tiles by blockIdx (what the ticket costs)
     int32_t single;        // every clip is ONE tile: nobody waits for anybody, tiles by blockIdx and no ticket
+    uint32_t order_pk[64]; // EULER source (pm_bvh_rotations_f32): per series the three axis codes of its Euler order, o0 | o1 << 8 | o2 << 16
 };
 
 // ---- look-back ----
@@ -378,8 +380,14 @@ __global__ __launch_bounds__(256) void unroll_reset_kernel(unsigned long long *w
     if (i < n) w[i] = 0ull;
 }
 
-template <int W, int R, int NT>
+// EULER (W = 4): the fused BVH ingest of io/bvh.py:352-359 -- quat.normalize(quat.unroll(quat.from_euler(radians(rotations), order), axis = 0)) in
+// ONE pass: `q` holds Euler angles in DEGREES, [T][S][3] (12 B per record: consecutive lanes on consecutive records, dwordx3), the
+// load stage turns each record into its unit quaternion (trig.hpp: euler2q with the series' order from a table in LDS, then
+// q / (|q| + 1e-8), quat.py:423 -- a positive scale commutes with the sign decision) and everything downstream is the scan as
+// it stands: 12 B read + 16 B written per joint and frame where the three launches move 28 + 32 + 32.
+template <int W, int R, int NT, bool EULER = false>
 __global__ __launch_bounds__(NT, PM_OP_MINW) void unroll_onepass_kernel(const OnePassArgs a) {
+    static_assert(!EULER || W == 4, "the Euler source produces quaternions");
     constexpr int V = W / 4, TILE = NT * R;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ unsigned s_tile;
@@ -388,6 +396,8 @@ __global__ __launch_bounds__(NT, PM_OP_MINW) void unroll_onepass_kernel(const On
     const int S = a.S, words = a.words;
     unsigned *flip = reinterpret_cast<unsigned *>(smem);  // [S][words]  flip bits, then prefix parities
     unsigned *rst = flip + S * words;                      // [S][words]  reset bits, then "a reset at or before"
+    unsigned *sOrd = rst + S * words;                      // [S]  EULER: the series' axis codes
+    if (EULER && tid < S) sOrd[tid] = a.order_pk[tid];
     if (tid == 0) s_tile = (a.single || PM_ABLATED_FLAG(a.static_order & 1)) ? blockIdx.x : __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int i = tid; i < 2 * S * words; i += NT) flip[i] = 0u;
     __syncthreads();
@@ -423,11 +433,42 @@ __global__ __launch_bounds__(NT, PM_OP_MINW) void unroll_onepass_kernel(const On
         dt = (int)(((float)rl + 0.5f) * invS);  // rl / S, exact below 2^22
         s_ = rl - dt * S;
     };
+    // dwordx4 `li` of the wave's range as the scan sees it: the stored quaternion, or (EULER) the unit quaternion of the record's angles
+    // (s_: the record's series -- the record one frame earlier, which may lie ahead of the tile, has the same)
+    auto raw3 = [&](const int li) { return __builtin_nontemporal_load(reinterpret_cast<const v3f_a4 *>(a.q + (clip * a.nv + wbase + li) * 3)); };  // (sizeof(v3f_a4) is 16: index in floats)
+    auto convert = [&](const v3f_a4 d, const int s_) -> v4f {
+        const unsigned pk = sOrd[s_];
+        const int o[3] = {(int)(pk & 0xffu), (int)((pk >> 8) & 0xffu), (int)((pk >> 16) & 0xffu)};
+        // np.radians in float64 like the reference's (bvh.py:353), rounded once
+        const float e[3] = {(float)((double)d.x * 0.017453292519943295), (float)((double)d.y * 0.017453292519943295), (float)((double)d.z * 0.017453292519943295)};
+        float q[4], qn[4];
+        euler2q<false>(e, o, q);  // (no libm detour beyond 1e8 rad = 5.7e9 degrees: nobody's channel value; NaN / Inf still give NaN)
+        qnormalize(q, 1e-8f, qn);
+        return v4f{qn[0], qn[1], qn[2], qn[3]};
+    };
     v4f val[R];
+    if constexpr (!EULER) {
 #pragma unroll
-    for (int u = 0; u < R; ++u) {
-        const int li = u * 64 + lane;
-        val[u] = __builtin_nontemporal_load(wsrc + (li < left ? li : lastoff));
+        for (int u = 0; u < R; ++u) {
+            const int li = u * 64 + lane;
+            val[u] = __builtin_nontemporal_load(wsrc + (li < left ? li : lastoff));
+        }
+    } else {
+        // every load of the wave's range first (one memory latency), then the conversions, two at a time
+        v3f_a4 raw[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int li = u * 64 + lane;
+            raw[u] = raw3(li < left ? li : lastoff);
+        }
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int li = u * 64 + lane;
+            int dt0, s0_;
+            locate(li < left ? li : lastoff, dt0, s0_);
+            val[u] = convert(raw[u], s0_);
+            if ((u & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
     }
     // (the lane id through an opaque copy per phase: left to itself the compiler keeps the sixteen record indices of the load
     // phase -- and their clamps -- alive to the last store, ~30 registers of the 164)
@@ -443,7 +484,10 @@ __global__ __launch_bounds__(NT, PM_OP_MINW) void unroll_onepass_kernel(const On
         const bool ok = (li < left) && (tb + dt > 0) && (V == 1 || (li & 1) == 0);  // the real part decides (dual_quat.py:139-167)
         const bool outside = !shuffled || (u == 0 && lane < D);  // the row before lies ahead of this wave's range
         v4f prv = val[u];
-        if (outside && ok && !PM_ABLATED_FLAG(a.static_order & 2)) prv = wsrc[li - D];  // (L1 / L2: fetched 16 S bytes earlier by a neighbour)
+        if (outside && ok && !PM_ABLATED_FLAG(a.static_order & 2)) {  // (L1 / L2: fetched 16 S bytes earlier by a neighbour)
+            if constexpr (EULER) prv = convert(raw3(li - D), s_);
+            else prv = wsrc[li - D];
+        }
         if (shuffled) {
             const v4f mine = val[u], before = val[u > 0 ? u - 1 : 0];
             v4f got;
@@ -552,15 +596,20 @@ extern "C" int64_t pm_quat_unroll_batched_workspace_bytes(int64_t B, int64_t T, 
 }
 extern "C" int64_t pm_quat_unroll_workspace_bytes(int64_t T, int32_t S) { return pm_quat_unroll_batched_workspace_bytes(1, T, S); }
 
-template <int W>
-static int unroll_launch(const float *q, int64_t B, int64_t T, int32_t S, float *out, void *workspace, pm_stream_t stream) {
+template <int W, bool EULER = false>
+static int unroll_launch(const float *q, int64_t B, int64_t T, int32_t S, float *out, void *workspace, pm_stream_t stream, const uint8_t *order = nullptr) {
     PM_CHECK_ARGS(B >= 0 && T >= 0 && S >= 0, "quat_unroll: negative size");
     if (B == 0 || T == 0 || S == 0) return PM_OK;
     PM_CHECK_ARGS(q && out && workspace, "quat_unroll: null pointer");
-    PM_CHECK_ARGS(aligned16(q) && aligned16(out), "quat_unroll: q and out must be 16-byte aligned");
+    PM_CHECK_ARGS((EULER || aligned16(q)) && aligned16(out), "quat_unroll: q and out must be 16-byte aligned");
     PM_CHECK_ARGS((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, "quat_unroll: the workspace must be 8-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (S <= 64 && tune_env("PM_UNROLL_ONEPASS", 1)) {
+    if constexpr (EULER) {
+        PM_CHECK_ARGS(order, "bvh_rotations: null order table");
+        if (S > 64) { set_error("bvh_rotations: the one-pass kernel takes at most 64 joints (J = %d): run from_euler, unroll and normalize", S); return PM_EUNSUPPORTED; }
+        for (int i = 0; i < 3 * S; ++i) PM_CHECK_ARGS(order[i] <= 2, "bvh_rotations: axis codes are 0, 1, 2 (x, y, z)");
+    }
+    if (S <= 64 && (EULER || tune_env("PM_UNROLL_ONEPASS", 1))) {
         const int64_t nv = T * (int64_t)S * (W / 4);
         // tile: 4096 dwordx4 (64 KiB; 16 per thread) from 64 such tiles on, 1024 below.  Measured, S = 22, T = 2^10 / 2^12 / 2^14 /
         // 2^16 / 2^18 / 2^20 frames: three passes 17 / 20 / 34 / 79 / 60 / 195 us; one pass with 1024-dwordx4 tiles 9 / 8 / 13 / 32 /
@@ -574,6 +623,13 @@ static int unroll_launch(const float *q, int64_t B, int64_t T, int32_t S, float 
         else if (nv > 4096 && nv <= 8192 && B >= 64) Rauto = 32;  // still one tile per clip (4096 clips of 256 frames x 22: 146 -> 131 us)
         else if (nv > 4096 && B * ((nv + 4095) / 4096) < 64) Rauto = 4;
         else if (nv >= (int64_t)4 << 20) Rauto = 32;  // very long chains: fewer, bigger tiles (2^18 / 2^20 frames x 22: 51 / 159 -> 46 / 153 us; 2^16: 19.6 -> 21.3)
+        if constexpr (EULER) {
+            // the conversion (three sincos + the Euler product + normalize: ~170 VALU instructions per record) sits between a tile's loads
+            // and its map: smaller tiles spread it over more waves.  Measured (S = 22, T = 2^10 ... 2^20 frames, us; R = 4 / 8 / 16 / 32):
+            // 9.6 / 12.2 / 18.1 / 31.3,  10.6 / 12.6 / 18.4 / 32,  16.2 / 15.4 / 20.2 / 32.8,  37 / 27.3 / 27.4 / 35,  102 / 79 / 70.6 / 83,
+            // 304 / 209 / 208 / 242 (without the long-chain LDS reservation below: the kernel is bound by its arithmetic, it wants the waves)
+            Rauto = nv < ((int64_t)1 << 18) ? 4 : (nv < ((int64_t)1 << 20) ? 8 : 16);
+        }
         const int R = tune_env("PM_UNROLL_R", Rauto);
         if (R != 32 && R != 16 && R != 8 && R != 4) { set_error("PM_UNROLL_R must be 4, 8, 16 or 32"); return PM_EINVAL; }
         const int64_t tile = NT * (int64_t)R, tpc = (nv + tile - 1) / tile, bpc = (tpc + 63) / 64, ntiles = B * tpc;
@@ -586,23 +642,25 @@ static int unroll_launch(const float *q, int64_t B, int64_t T, int32_t S, float 
         a.st1 = a.st + ntiles * a.ngroups;  // B * bpc blocks
         a.static_order = tune_env("PM_UNROLL_STATIC", 0);
         a.single = tpc == 1;
+        if constexpr (EULER)
+            for (int i = 0; i < S; ++i) a.order_pk[i] = (uint32_t)order[3 * i] | ((uint32_t)order[3 * i + 1] << 8) | ((uint32_t)order[3 * i + 2] << 16);
         const int64_t rows = (tile / (W / 4) + S - 1) / S + 1;  // frames a tile can touch
         a.words = (int)((rows + 31) / 32);
-        size_t lds = 2 * (size_t)S * a.words * sizeof(unsigned);
+        size_t lds = (2 * (size_t)S * a.words + (EULER ? S : 0)) * sizeof(unsigned);
         // Long chains run best with THREE workgroups per CU: every tile in flight ahead of a tile is a word its look-back has to fold, so
         // more resident tiles lengthen every walk (2^18 x 22 with 5 / 4 / 3 / 2 workgroups per CU: 60.5 / 56.2 / 51.0 / 53.6 us; batches of
         // short clips want them all: 4096 clips of 256 frames 145 / 145 / 153 / 187 us).  The kernel needs 95 VGPRs (five workgroups per
         // CU), so long chains reserve a third of the CU's LDS each.
-        if (tpc > 64 && lds < 52 * 1024) lds = 52 * 1024;
+        if (!EULER && tpc > 64 && lds < 52 * 1024 && tune_env("PM_UNROLL_RESERVE", 1)) lds = 52 * 1024;
         lds += (size_t)tune_env("PM_UNROLL_LDS_PAD", 0);  // PM_TUNING build only: more unused LDS
         const int64_t nwords = 8 + (ntiles + B * bpc) * a.ngroups;  // the ticket's 64-byte line, then the words
         if (!a.single)  // (single-tile clips read neither the ticket nor a status word)
             hipLaunchKernelGGL(unroll_reset_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, s, static_cast<unsigned long long *>(workspace), nwords);
         PM_SET_LDS(lds);
-        if (R == 32) hipLaunchKernelGGL((unroll_onepass_kernel<W, 32, NT>), dim3((unsigned)ntiles), dim3(NT), lds, s, a);
-        else if (R == 16) hipLaunchKernelGGL((unroll_onepass_kernel<W, 16, NT>), dim3((unsigned)ntiles), dim3(NT), lds, s, a);
-        else if (R == 8) hipLaunchKernelGGL((unroll_onepass_kernel<W, 8, NT>), dim3((unsigned)ntiles), dim3(NT), lds, s, a);
-        else hipLaunchKernelGGL((unroll_onepass_kernel<W, 4, NT>), dim3((unsigned)ntiles), dim3(NT), lds, s, a);
+        if (R == 32) hipLaunchKernelGGL((unroll_onepass_kernel<W, 32, NT, EULER>), dim3((unsigned)ntiles), dim3(NT), lds, s, a);
+        else if (R == 16) hipLaunchKernelGGL((unroll_onepass_kernel<W, 16, NT, EULER>), dim3((unsigned)ntiles), dim3(NT), lds, s, a);
+        else if (R == 8) hipLaunchKernelGGL((unroll_onepass_kernel<W, 8, NT, EULER>), dim3((unsigned)ntiles), dim3(NT), lds, s, a);
+        else hipLaunchKernelGGL((unroll_onepass_kernel<W, 4, NT, EULER>), dim3((unsigned)ntiles), dim3(NT), lds, s, a);
         return PM_AFTER_LAUNCH("quat_unroll");
     }
     const int64_t nchunks = (T + UR_CHUNK - 1) / UR_CHUNK;
@@ -642,4 +700,9 @@ extern "C" int pm_quat_unroll_batched_f32(const float *q, int64_t B, int64_t T, 
 }
 extern "C" int pm_dq_unroll_batched_f32(const float *dq, int64_t B, int64_t T, int32_t S, float *out, void *workspace, pm_stream_t stream) {
     return unroll_launch<8>(dq, B, T, S, out, workspace, stream);
+}
+
+// io/bvh.py:352-359 get_data: quat.normalize(quat.unroll(quat.from_euler(np.radians(rotations), order), axis = 0)) as ONE launch.
+extern "C" int pm_bvh_rotations_f32(const float *euler_deg, const uint8_t *order, int64_t T, int32_t J, float *out, void *workspace, pm_stream_t stream) {
+    return unroll_launch<4, true>(euler_deg, 1, T, J, out, workspace, stream, order);
 }

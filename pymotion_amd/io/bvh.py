@@ -135,11 +135,12 @@ class BVH:
     def get_data(self):
         """-> (rots [F,J,4] unrolled unit quaternions, pos [F,J,3], parents, offsets, end_sites,
         end_sites_parents) -- reference bvh.py:332-365; the rotations go through from_euler -> unroll
-        (frame axis) -> normalize on the GPU."""
+        (frame axis) -> normalize on the GPU, fused into one kernel up to 64 joints."""
         d = self.data
-        # the reference tiles the per-joint order over the frames (bvh.py:352); the kernel takes the [J, 3] table itself
-        rots = quat.unroll(_ops.quat_from_euler(_be(), np.radians(d["rotations"]), d["rot_order"], per_joint_table=True), axis=0)
-        rots = quat.normalize(rots)
+        # the reference tiles the per-joint order over the frames (bvh.py:352); the kernel takes the [J, 3] table itself, and the
+        # angles in degrees as the file holds them: from_euler, the sign scan along the frames and normalize are ONE launch
+        # (pm_bvh_rotations_f32; three launches -- and three trips over the bus through this NumPy door -- before round 4)
+        rots = _ops.bvh_rotations(_be(), d["rotations"], d["rot_order"])
         return rots, d["positions"], d["parents"], d["offsets"], d["end_sites"], d["end_sites_parents"]
 
     def set_data(self, rots, pos):

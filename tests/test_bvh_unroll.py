@@ -111,6 +111,58 @@ def test_gpu_bvh_get_data_and_fk_match_reference():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T,J", [(1, 1), (2, 5), (63, 22), (1025, 22), (5000, 31), (70_000, 22), (3000, 64), (1500, 65), (40, 130)])
+def test_gpu_fused_bvh_rotations_vs_oracle_chain(T, J):
+    """pm_bvh_rotations_f32 = normalize(unroll(from_euler(radians(deg), order), axis=0)) (io/bvh.py:352-359) in one launch up to 64
+    joints (one tile, several tiles with look-back, the 64-series limit), the three ops on the device beyond; both doors."""
+    import torch
+
+    from pymotion_amd import _backend, _ops
+
+    rng = np.random.default_rng(T * 1000 + J)
+    deg = np.cumsum(rng.normal(0, 6, (T, J, 3)), axis=0) + rng.uniform(-180, 180, (1, J, 3))  # drifting angles: many cover crossings
+    orders = np.array([list(o) for o in ("zxy", "xyz", "yzx", "zyx", "xzy", "yxz", "zxz")])[rng.integers(0, 7, J)]
+    want = co.quat_from_euler(np.radians(deg.astype(np.float32).astype(np.float64)), np.tile(orders, (T, 1, 1)))
+    want = co.quat_unroll(want, 0)
+    want = want / (np.linalg.norm(want, axis=-1, keepdims=True) + 1e-8)
+    got = _ops.bvh_rotations(_backend.numpy_backend(), deg, orders)
+    assert got.shape == (T, J, 4) and got.dtype == np.float64
+    # (angles of thousands of degrees at fp32: a rounding of the ANGLE is 1e-4 degrees = 2e-6 rad there)
+    tol = 2e-6 + 1e-7 * np.abs(deg).max() * np.pi / 180
+    assert_close(got, want, tol, "fused get_data rotations")
+    if T > 1:
+        assert (np.sum(got[1:] * got[:-1], axis=-1) >= 0).all()
+    got_t = _ops.bvh_rotations(_backend.torch_backend(), torch.from_numpy(deg.astype(np.float32)).cuda(), orders)
+    assert got_t.dtype == torch.float32
+    assert_close(got_t.cpu().numpy(), want, tol, "fused get_data rotations, torch door")
+
+
+@pytest.mark.gpu
+def test_gpu_fused_bvh_rotations_raw_abi():
+    import ctypes as C
+
+    import torch
+
+    from pymotion_amd import _lib
+
+    T, J = 100, 4
+    deg = (torch.rand((T, J, 3), device="cuda") * 360 - 180).contiguous()
+    out = torch.empty((T, J, 4), device="cuda")
+    ws = torch.empty(int(_lib.lib().pm_quat_unroll_workspace_bytes(T, 70)) + 8, dtype=torch.uint8, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    order = np.tile(np.array([2, 0, 1], np.uint8), (70, 1))
+    h = _lib.lib()
+    assert h.pm_bvh_rotations_f32(p(deg), order.ctypes.data_as(C.c_void_p), T, J, p(out), p(ws), None) == _lib.PM_OK
+    torch.cuda.synchronize()
+    assert float((out.norm(dim=-1) - 1).abs().max()) < 1e-6
+    assert h.pm_bvh_rotations_f32(p(deg), order.ctypes.data_as(C.c_void_p), T, 65, p(out), p(ws), None) == _lib.PM_EUNSUPPORTED
+    bad = order.copy()
+    bad[2, 1] = 3
+    assert h.pm_bvh_rotations_f32(p(deg), bad.ctypes.data_as(C.c_void_p), T, J, p(out), p(ws), None) == _lib.PM_EINVAL
+    assert h.pm_bvh_rotations_f32(p(deg), None, T, J, p(out), p(ws), None) == _lib.PM_EINVAL
+
+
+@pytest.mark.gpu
 def test_config1_bvh_1000_frames_gpu_vs_numpy_cpu_reference(tmp_path):
     """BASELINE.json configs[0]: NumPy fk on a 22-joint BVH, 1000 frames (CPU) -- the same arrays through the
     GPU path must agree to 1e-5.  The file is generated on the fly (seeded), read by the build's own loader."""

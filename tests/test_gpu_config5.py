@@ -132,6 +132,35 @@ def test_bench_plain_invocation_with_two_ranks_launches_itself():
     assert "fk_kernel" in line["roofline"]["kernel"]
 
 
+def test_bench_eight_ranks_rehearsal_of_the_drivers_command():
+    """the exact command the driver will issue on an 8-GPU node -- `torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8
+    --steps K --warmup W` -- rehearsed end to end on this one-GPU box: eight ranks share cuda:0 over gloo (--dry-run-shared-gpu),
+    32 768 frames per rank.  Without --frames-per-gpu the same command runs BASELINE configs[4] (16 777 216 // 8 frames per GPU)."""
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port())]
+    line = _bench(["--gpus", "8", "--steps", "3", "--warmup", "1", "--prewarm-ms", "0", "--frames-per-gpu", "32768",
+                   "--oracle-slice-frames", "2048", "--dry-run-shared-gpu"], launcher=launcher)
+    assert line["n_gpus"] == 8 and line["steps"] == 3 and line["scaling"] == "weak"  # (an explicit per-GPU size: weak scaling)
+    assert line["config"]["frames_total"] == 8 * 32768
+    assert line["max_abs_err_vs_oracle_slice"]["value"] <= ATOL
+    g = line["gather"]
+    assert set(g["methods"]) == {"all_gather_into_tensor", "mesh_send_recv"}
+    for m in g["methods"].values():
+        assert m.get("own_block_intact") is True, m
+    assert g["received_GB_per_gpu"] == pytest.approx(7 * 32768 * 22 * 48 / 1e9)
+
+
+def test_bench_defaults_to_config5_when_more_than_one_gpu_is_asked_for():
+    """`--gpus N` with N > 1 and no --frames-per-gpu is BASELINE configs[4]: 16 777 216 // N frames per GPU, labelled strong
+    scaling (two ranks sharing this one GPU: 2^23 frames each, 17.7 GB of outputs in all -- the gather is skipped)."""
+    line = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm-ms", "0", "--oracle-slice-frames", "2048",
+                   "--dry-run-shared-gpu", "--no-gather"])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    assert line["config"]["frames_per_gpu"] == (1 << 24) // 2 and line["config"]["frames_total"] == 1 << 24
+    assert "configs[4]" in line["config"]["workload"]
+    assert line["max_abs_err_vs_oracle_slice"]["value"] <= ATOL
+
+
 def test_bench_under_torchrun_one_rank_rccl():
     """the driver's launch line with --nproc-per-node 1: process group "nccl" on the device, oracle slice of 2^16"""
     launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",

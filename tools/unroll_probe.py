@@ -33,3 +33,25 @@ for B, T in ((16384, 64), (4096, 256), (64, 16384)):
     ms2, _ = pp.timeit(lambda: quat_t.unroll(q, 1))
     print(f"[{tag}] batch B={B} T={T} S={S}: {ms * 1e3:8.1f} us  {B * T * S * 32 / ms / 1e6 / 80:5.1f}% of 8 TB/s on 32 B/quaternion;"
           f" quat_torch.unroll(q, 1) end to end {ms2 * 1e3:8.1f} us", flush=True)
+# BVH ingest (io/bvh.py:352-359): the fused kernel (12 B in + 16 B out per joint and frame) against the three launches it replaces
+# (from_euler 12 -> 16, unroll 16 -> 16, normalize 16 -> 16: 92 B), device-resident, raw ABI
+import numpy as np
+
+order_h = np.tile(np.array([2, 0, 1], np.uint8), (S, 1))
+order_d = torch.from_numpy(order_h).cuda()
+for lg in (10, 12, 14, 16, 18, 20):
+    T = 1 << lg
+    deg = (torch.randn((T, S, 3), device="cuda").cumsum(0) * 5.0).contiguous()
+    rad = torch.deg2rad(deg)
+    q1, q2, out = (torch.empty((T, S, 4), device="cuda") for _ in range(3))
+    ws = torch.empty(int(_lib.lib().pm_quat_unroll_workspace_bytes(T, S)) + 16, dtype=torch.uint8, device="cuda")
+
+    def three():
+        _lib.call("pm_quat_from_euler_f32", P(rad), P(order_d), S, T * S, P(q1), None)
+        _lib.call("pm_quat_unroll_f32", P(q1), T, S, P(q2), P(ws), None)
+        _lib.call("pm_quat_normalize_f32", P(q2), T * S, C.c_float(1e-8), P(out), None)
+
+    ms3, _ = pp.timeit(three)
+    ms1, _ = pp.timeit(lambda: _lib.call("pm_bvh_rotations_f32", P(deg), order_h.ctypes.data_as(C.c_void_p), T, S, P(out), P(ws), None))
+    print(f"[{tag}] get_data fused T=2^{lg} S={S}: {ms1 * 1e3:8.1f} us ({T * S * 28 / ms1 / 1e6 / 80:5.1f}% of 8 TB/s on 28 B per joint-frame)"
+          f"  three launches {ms3 * 1e3:8.1f} us  -> {ms3 / ms1:4.2f}x", flush=True)
