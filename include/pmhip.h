@@ -93,6 +93,15 @@ int pm_fk_from_ortho6d_f32(const float *o6d, const float *root_pos, const float 
 int pm_to_root_dq_f32(const float *rot, const float *root_pos, const int32_t *parents /*host*/,
                       const float *offsets, int64_t F, int32_t J, float *dq, pm_stream_t stream);
 
+/* The same with a HOST-side hint: offsets_abs_max = max |offsets[j][k]| when the caller has the table on the host (the NumPy door
+ * always has; the torch door remembers it per tensor), < 0 or NaN when unknown (= pm_to_root_dq_f32).  The library never reads
+ * device memory to choose a kernel, so without the hint skeletons below 40 joints decide per TILE (bones >= 1 unit or a root >= 16
+ * units: float64 quaternion chain + fixed-point translations); with it, big-bone skeletons (centimetre-scale BVH data) of 20 joints
+ * or more take the lane-per-frame kernel, whose float64 state costs the same at every magnitude.  Results are within the same
+ * bar either way. */
+int pm_to_root_dq_hint_f32(const float *rot, const float *root_pos, const int32_t *parents, const float *offsets, int64_t F,
+                           int32_t J, float *dq, float offsets_abs_max, pm_stream_t stream);
+
 /* ops/skeleton.py:173-204 / skeleton_torch.py:183-214  from_root_dual_quat(dq, parents)
  * -> (translations [F,J,3], rotations [F,J,4]) in that order (:204). */
 int pm_from_root_dq_f32(const float *dq, const int32_t *parents /*host*/, int64_t F, int32_t J,

@@ -51,6 +51,7 @@ SIGNATURES = {
     "pm_fk_f32": [_f, _f, _f, _int, C.c_void_p, _i64, _i32, _f, _f, _strm],
     "pm_fk_from_ortho6d_f32": [_f, _f, _f, _int, C.c_void_p, _i64, _i32, _flt, _f, _f, _f, _strm],
     "pm_to_root_dq_f32": [_f, _f, C.c_void_p, _f, _i64, _i32, _f, _strm],
+    "pm_to_root_dq_hint_f32": [_f, _f, C.c_void_p, _f, _i64, _i32, _f, _flt, _strm],
     "pm_from_root_dq_f32": [_f, C.c_void_p, _i64, _i32, _f, _f, _strm],
     "pm_from_global_rotations_f32": [_f, C.c_void_p, _i64, _i32, _f, _strm],
     "pm_from_root_positions_f32": [_f, C.c_void_p, _f, _i64, _i32, _f, _strm],

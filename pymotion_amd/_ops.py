@@ -539,6 +539,23 @@ def _assert_root_offset_is_zero(be, offsets):
     be._memo_put(_ROOT_OFFSET_CHECKED, "offsets", offsets, True)
 
 
+_OFFSETS_SCALE = {}
+
+
+def _offsets_abs_max(be, offsets):
+    """max |offsets| as a host float: the scale hint of pm_to_root_dq_hint_f32.  The NumPy door has the table on the host; on a HIP
+    tensor the reduction is a device->host synchronisation, remembered per tensor object and in-place version like the root-offset
+    check above (which already synchronises once per tensor)."""
+    if be.name != "torch" or not getattr(offsets, "is_cuda", False):
+        a = np.asarray(offsets.detach().cpu() if be.name == "torch" else offsets, dtype=np.float64)
+        return float(np.abs(a).max()) if a.size else 0.0
+    v = be._memo_get(_OFFSETS_SCALE, "offsets_scale", offsets)
+    if v is None:
+        v = float(offsets.detach().abs().max())
+        be._memo_put(_OFFSETS_SCALE, "offsets_scale", offsets, v)
+    return v
+
+
 def to_root_dual_quat(be, rotations, global_pos, parents, offsets):
     shp = be.shape(rotations)
     if len(shp) < 2 or shp[-1] != 4:
@@ -548,6 +565,7 @@ def to_root_dual_quat(be, rotations, global_pos, parents, offsets):
     if be.shape(offsets) != (J, 3):
         raise ValueError(f"offsets must be [{J}, 3], got {be.shape(offsets)}")
     _assert_root_offset_is_zero(be, offsets)  # skeleton.py:227
+    hint = C.c_float(_offsets_abs_max(be, offsets))
     out_dt = be.always64 if be.name == "numpy" else rotations.dtype
     if be.wants_pipeline(_prod(lead), 4 * (J * 12 + 3)):
         from ._backend import pipelined_frames
@@ -556,7 +574,7 @@ def to_root_dual_quat(be, rotations, global_pos, parents, offsets):
         (dq,) = pipelined_frames(
             _prod(lead), [(_pipe_np(rotations, lead, (J, 4)), True), (_pipe_np(global_pos, lead, (3,)), True), (off_np, False)],
             [((J, 8), np.dtype(out_dt))],
-            lambda ip, op, n, st: _lib.call("pm_to_root_dq_f32", ip[0], ip[1], p.ctypes.data_as(C.c_void_p), ip[2], n, J, op[0], st))
+            lambda ip, op, n, st: _lib.call("pm_to_root_dq_hint_f32", ip[0], ip[1], p.ctypes.data_as(C.c_void_p), ip[2], n, J, op[0], hint, st))
         return dq.reshape(lead + (J, 8))
     be.begin(rotations, global_pos, offsets)
     try:
@@ -566,7 +584,7 @@ def to_root_dual_quat(be, rotations, global_pos, parents, offsets):
         op = be.dev_in(offsets)
         dq_p, dq_h = be.dev_out(lead + (J, 8))
         if F > 0:
-            _lib.call("pm_to_root_dq_f32", rp, gp, p.ctypes.data_as(C.c_void_p), op, F, J, dq_p, be.stream())
+            _lib.call("pm_to_root_dq_hint_f32", rp, gp, p.ctypes.data_as(C.c_void_p), op, F, J, dq_p, hint, be.stream())
         res = be.result(dq_h, out_dt)
     finally:
         be.end()

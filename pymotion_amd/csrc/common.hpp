@@ -529,7 +529,7 @@ __device__ __forceinline__ bool fx_scale(const float tbound, const float rmax, F
 }
 
 // ---- fk's local rotation matrix from a quaternion; PREC_* levels: see fk.hip -----------------------------------
-enum { PREC_FAST = 0, PREC_RESID = 1, PREC_F64 = 2, PREC_FX = 4, PREC_DYN = 16 };
+enum { PREC_FAST = 0, PREC_RESID = 1, PREC_F64 = 2, PREC_FX = 4, PREC_DYN = 16, PREC_BIG_RESID = 32 };  // BIG_RESID: see fk.hip
 
 template <int PREC>
 __device__ __forceinline__ void local_from_quat(const float (&qi)[4], float (&L)[9]) {

@@ -389,6 +389,7 @@ static int launch_to_root(const ToRootArgs &a, bool vec, hipStream_t s) {
 // Everything else (image = output tile + identity slot, phase A / C, copy-out, the 12-instruction DPP step) is the
 // kernel above.
 // ---------------------------------------------------------------------------------------------------
+constexpr int kDeepDqHintMinJ = 20;  // ... and from here on when the caller says the bones are big (pm_to_root_dq_hint_f32)
 constexpr int kDeepDqMinJ = 40;  // from here on the lane-per-frame kernels of deep.hip where the topology allows (2^19 frames, chain-like skeleton, deep / scheduled walk: J = 32 159 / 152 us, 40 202 / 206, 48 246 / 256, 56 284 / 309, 64 315 / 383; the 52-joint SMPL-H tree at 2^18: 149 / 146 us on metre data, 148 / 196 us on centimetre data -- the float64 state does not know the difference)
 // (kSchedMax, kSchedMaxJoints: common.hpp -- mirror.hip schedules its walk the same way)
 
@@ -835,8 +836,9 @@ static int launch_gather(const GatherArgs &a, bool vec, hipStream_t s) {
 
 }  // namespace pm
 
-extern "C" int pm_to_root_dq_f32(const float *rot, const float *root_pos, const int32_t *parents,
-                                 const float *offsets, int64_t F, int32_t J, float *dq, pm_stream_t stream) {
+// offsets_abs_max: max |offsets[j][k]| if the caller knows it on the host (< 0 or NaN: unknown), see pm_to_root_dq_hint_f32
+static int to_root_dq_impl(const float *rot, const float *root_pos, const int32_t *parents, const float *offsets, int64_t F, int32_t J,
+                           float *dq, const float offsets_abs_max, pm_stream_t stream) {
     using namespace pm;
     PM_CHECK_ARGS(F >= 0 && J >= 1 && J <= PM_MAX_JOINTS, "to_root_dq: need F >= 0 and 1 <= J <= PM_MAX_JOINTS");
     if (F == 0) return PM_OK;
@@ -857,7 +859,12 @@ extern "C" int pm_to_root_dq_f32(const float *rot, const float *root_pos, const 
     hipStream_t s = static_cast<hipStream_t>(stream);
     // Long skeletons: one lane per frame, the joints streamed through LDS in chunks (deep.hip) -- if the topology's open
     // branch points fit its register slots.  PM_DQ_DEEP (PM_TUNING build only): 0 never, 1 whenever eligible.
-    if (const int deep = tune_env("PM_DQ_DEEP", -1); vec && deep != 0 && (deep == 1 || J >= kDeepDqMinJ)) {
+    // A caller that knows the bones are big (a centimetre-scale BVH skeleton: any |offset| >= kBigOffset makes EVERY tile of the tile
+    // kernels take the precise step) gets the lane-per-frame kernel from kDeepDqHintMinJ joints on: its float64 state costs the same
+    // at every magnitude (2^20 x 22: 235 us against 259 us for the precise step -- and 205 us for the fp32 step on metre data, which
+    // is why the raw ABI, which cannot see the scale without reading device memory, keeps the per-tile test below 40 joints).
+    const bool big_bones = offsets_abs_max >= kBigOffset && offsets_abs_max < 3e38f;
+    if (const int deep = tune_env("PM_DQ_DEEP", -1); vec && deep != 0 && (deep == 1 || J >= kDeepDqMinJ || (big_bones && J >= kDeepDqHintMinJ))) {
         DeepTopo topo;
         if (deep_plan(a.parents, J, true, topo) >= 0) return launch_to_root_deep(rot, root_pos, offsets, dq, F, J, topo, s);
     }
@@ -904,6 +911,15 @@ extern "C" int pm_to_root_dq_f32(const float *rot, const float *root_pos, const 
     }
     set_error("to_root_dq: J=%d does not fit the LDS tile", J);
     return PM_EUNSUPPORTED;
+}
+
+extern "C" int pm_to_root_dq_f32(const float *rot, const float *root_pos, const int32_t *parents,
+                                 const float *offsets, int64_t F, int32_t J, float *dq, pm_stream_t stream) {
+    return to_root_dq_impl(rot, root_pos, parents, offsets, F, J, dq, -1.0f, stream);
+}
+extern "C" int pm_to_root_dq_hint_f32(const float *rot, const float *root_pos, const int32_t *parents, const float *offsets, int64_t F,
+                                      int32_t J, float *dq, float offsets_abs_max, pm_stream_t stream) {
+    return to_root_dq_impl(rot, root_pos, parents, offsets, F, J, dq, offsets_abs_max, stream);
 }
 
 extern "C" int pm_from_root_dq_f32(const float *dq, const int32_t *parents, int64_t F, int32_t J, float *trans,

@@ -81,6 +81,11 @@ constexpr int fk_lds_floats() { return 12 + (PFO ? 3 : 0) + (QOUT ? 4 : 0); }
 //   PREC_DYN     what the production library runs: every tile decides for itself (fk_tile_is_big) -- PREC_RESID for
 //                human-scale data in metres, PREC_F64 | PREC_FX when bones or root positions are big enough for fp32
 //                roundings of |p| to matter (centimetre mocap, far-away roots).
+//   PREC_BIG_RESID (with PREC_DYN; shallow skeletons on the three-lane kernels, chosen in dispatch_fk): big tiles keep the
+//                residual-scaled fp32 rotations and take only the fixed-point chain.  What the float64 rotations buy is their error
+//                times the bone lengths summed down the chain; at depth <= 7 the fixed-point chain alone holds the 2-ulp bar
+//                (measured on centimetre data, J = 22: RESID + FX 1.43 ulp against 0.96 with float64 rotations, 267 us against 283;
+//                the 52-joint tree, depth 10, reads 2.7 ulp that way and keeps both).
 // Measured at 2^20 x 22 / 2^18 x 52 (sustained, us) and, on offsets +-30 / root +-200, max |pos error| in ulps of the
 // largest coordinate: FAST 267 / 175, 4.3 / 6.3 ulp; RESID 266 / 172, 2.2 / 2.9; F64 273 / 179, 2.0 / 3.0; a float64
 // chain with its residuals in LDS 310-320 / 252, 0.9 / 1.4 -- but 3/4 of that cost is the LDS (occupancy), not the math.
@@ -557,7 +562,7 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
         if (QOUT) tile_store<VEC>(a.quat_out + f0 * J * 4, sQo, n * 4, lane);
     };
     if constexpr (DYN) {
-        if (big) rest(IntC<PREC_F64 | PREC_FX>{});
+        if (big) rest(IntC<((PREC & PREC_BIG_RESID) ? PREC_RESID : PREC_F64) | PREC_FX>{});
         else rest(IntC<PREC & (PREC_RESID | PREC_F64)>{});
     } else {
         if ((PREC & PREC_FX) && !big) rest(IntC<PREC & ~PREC_FX>{});  // static FX (tuning): non-finite bound -> float walk
@@ -816,6 +821,7 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? ((PFO && E
 #ifndef PM_FK_PREC_DEFAULT
 #define PM_FK_PREC_DEFAULT (PREC_DYN | PREC_RESID)
 #endif
+constexpr int kBigResidMaxDepth = 7;
 
 template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT, bool PAD, int PREC>
 static int launch_fk_pp(const FkArgs &a, hipStream_t s) {
@@ -840,12 +846,20 @@ static int launch_fk_p(const FkArgs &a, hipStream_t s) {
         switch (tune_env("PM_FK_PREC", PM_FK_PREC_DEFAULT)) {
             case 0: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 0>(a, s);
             case 1: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 1>(a, s);
+            case 2: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 2>(a, s);
+            case 5: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 5>(a, s);
             case 6: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 6>(a, s);
-            case 17: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 17>(a, s);
-            default: set_error("PM_FK_PREC must be 0, 1, 6 or 17"); return PM_EINVAL;
+            case 17: break;  // production's own choice, below
+            case 49: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 49>(a, s);
+            case 117: return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, 17>(a, s);  // 17 without the shallow-skeleton shortcut
+            default: set_error("PM_FK_PREC must be 0, 1, 2, 5, 6, 17, 49 or 117"); return PM_EINVAL;
         }
     }
 #endif
+    // shallow skeletons (the 22-joint body: depth 7): big-magnitude tiles keep the fp32 rotations, see PREC_BIG_RESID
+    if constexpr (SRC == SRC_QUAT && !PFO && FPW > 5) {
+        if (a.depth <= kBigResidMaxDepth) return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, PM_FK_PREC_DEFAULT | PREC_BIG_RESID>(a, s);
+    }
     return launch_fk_pp<FPW, VEC, PFO, SRC, QOUT, PAD, PM_FK_PREC_DEFAULT>(a, s);
 }
 
@@ -878,9 +892,11 @@ static int launch_fk_pipe_p(const FkArgs &a, const int nt, hipStream_t s) {
         switch (tune_env("PM_FK_PREC", PM_FK_PREC_DEFAULT)) {
             case 0: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 0>(a, nt, s);
             case 1: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 1>(a, nt, s);
+            case 2: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 2>(a, nt, s);
+            case 5: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 5>(a, nt, s);
             case 6: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 6>(a, nt, s);
-            case 17: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 17>(a, nt, s);
-            default: set_error("PM_FK_PREC must be 0, 1, 6 or 17"); return PM_EINVAL;
+            case 17: case 49: case 117: return launch_fk_pipe_pp<FPW, EPL, VEC, SRC, QOUT, PAD, PFO, 17>(a, nt, s);  // (the shallow-skeleton shortcut is the three-lane kernels')
+            default: set_error("PM_FK_PREC must be 0, 1, 2, 5, 6, 17, 49 or 117"); return PM_EINVAL;
         }
     }
 #endif

@@ -170,7 +170,7 @@ def test_bench_under_torchrun_one_rank_rccl():
     assert line["n_gpus"] == 1
     assert line["max_abs_err_vs_oracle_slice"]["frames_per_rank"] == 1 << 16
     assert line["max_abs_err_vs_oracle_slice"]["value"] <= ATOL
-    assert line["roofline"]["kernel"].startswith("void pm::fk_kernel<16, true, false, 0, false, false, 17>")
+    assert line["roofline"]["kernel"].startswith("void pm::fk_kernel<16, true, false, 0, false, false, 49>")  # (49 = DYN | RESID | BIG_RESID: the 22-joint body is shallow)
 
 
 def test_bench_line_survives_a_reassembly_that_never_finishes():

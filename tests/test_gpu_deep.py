@@ -104,13 +104,17 @@ def test_to_root_dual_quat_lane_per_frame_against_the_oracle(J, kind, expect):
         rot, root, off = _batch(F, J, 1000 * J + F, osc, rsc)
         d = sk.to_root_dual_quat(rot, root, parents, off)
         name = _lib.last_kernel_name()
+        lane_per_frame = expect != "fallback"
         if expect == "fallback":
-            assert "deep_kernel" not in name and "ring_kernel" not in name, name
+            # (below 40 joints the front door's scale hint -- max |offsets| >= 1 -- still routes big-bone skeletons to the lane-per-frame
+            # kernel where the topology allows; metre-scale data and topologies with too many open branches keep the tile kernels)
+            lane_per_frame = osc >= 1.0 and 20 <= J < 40 and not kind.startswith("nested7")
+            assert ("deep_kernel" in name or "ring_kernel" in name) == lane_per_frame, (name, osc)
         else:
             assert ("to_root_dq_%s_kernel" % expect) in name, (name, expect)
         d_o = co.to_root_dual_quat(rot.astype(np.float64), root.astype(np.float64), parents, off.astype(np.float64))
         err = np.abs(d - d_o).max()
-        if expect != "fallback":
+        if lane_per_frame:
             # float64 state: the output is the oracle's value rounded once (0.5 ulp of each component, bounded here by 1 ulp of the largest)
             assert err <= _ulp_of(d_o), (F, err / _ulp_of(d_o), "ulp")
             assert np.abs(d[..., :4] - d_o[..., :4]).max() <= 6.1e-8

@@ -311,3 +311,43 @@ def test_root_dual_quaternions_of_non_unit_rotations_at_centimetre_scale(J, kind
     for sel, ulps in ((scaled, 8.0), (~scaled, 2.0)):
         err = np.abs(d[sel] - d_o[sel]).max()
         assert err <= ulps * _ulp_of(d_o[sel]), (err / _ulp_of(d_o[sel]), "ulp", "scaled" if ulps == 8.0 else "unit")
+
+
+@pytest.mark.parametrize("J,kind", [(22, "body"), (31, "random"), (20, "random"), (36, "random")])
+def test_root_dual_quaternions_raw_abi_with_and_without_the_scale_hint(J, kind):
+    """The front doors pass max |offsets| as a host-side hint (pm_to_root_dq_hint_f32): big-bone skeletons of 20 joints or more then
+    take the lane-per-frame kernel (float64 state, scale-blind).  The raw ABI without the hint cannot see the scale and keeps the
+    per-tile precise step.  Same bar for both: max(1e-6, 2 ulp of the largest component)."""
+    import ctypes as C
+
+    import torch
+
+    from pymotion_amd import _lib
+
+    parents = syn.PARENTS_22 if kind == "body" else syn.random_parents(J, np.random.default_rng(J))
+    rng = np.random.default_rng(500 + J)
+    F = 5003
+    rot = rng.standard_normal((F, J, 4))
+    rot = (rot / np.linalg.norm(rot, axis=-1, keepdims=True)).astype(np.float32)
+    root = rng.uniform(-200, 200, (F, 3)).astype(np.float32)
+    off = rng.uniform(-30, 30, (J, 3)).astype(np.float32)
+    off[0] = 0
+    d_o = co.to_root_dual_quat(rot.astype(np.float64), root.astype(np.float64), parents, off.astype(np.float64))
+    bar = max(1e-6, 2 * _ulp_of(d_o))
+    rt, gt, ot = (torch.from_numpy(x).cuda() for x in (rot, root, off))
+    out = torch.empty((F, J, 8), device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    pp = np.asarray(parents, dtype=np.int32).ctypes.data_as(C.c_void_p)
+    names = []
+    for hint in (None, float(np.abs(off).max()), -1.0, float("nan")):
+        out.zero_()
+        if hint is None:
+            _lib.call("pm_to_root_dq_f32", p(rt), p(gt), pp, p(ot), F, J, p(out), None)
+        else:
+            _lib.call("pm_to_root_dq_hint_f32", p(rt), p(gt), pp, p(ot), F, J, p(out), C.c_float(hint), None)
+        names.append(_lib.last_kernel_name())
+        err = np.abs(out.cpu().numpy() - d_o).max()
+        assert err <= bar, (hint, err / _ulp_of(d_o), "ulp", names[-1])
+    if kind == "body":  # (random trees may hold more open branch points than the lane-per-frame kernel's register slots: they stay on the tile kernels)
+        assert "ring_kernel" in names[1] or "deep_kernel" in names[1], names  # the hint routes big bones to the lane-per-frame kernel
+    assert names[0] == names[2] == names[3] and "ring_kernel" not in names[0] and "deep_kernel" not in names[0], names

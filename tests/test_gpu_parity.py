@@ -981,7 +981,7 @@ def test_every_skeleton_kernel_on_views_that_are_only_4_byte_aligned(J, osc):
                     d = np.minimum(np.abs(t.cpu().numpy() - w).max(-1), np.abs(t.cpu().numpy() + w).max(-1))
                     assert np.median(d) <= 1e-6 and (d > 5e-4).mean() <= 2e-3, (k, np.median(d), d.max())
                     continue
-                if 7 <= k <= 9 and J >= 40:
+                if 7 <= k <= 9 and (J >= 40 or (osc > 1 and J >= 20)):  # (below 40 joints: big bones, by the front door's scale hint)
                     # to_root_dual_quat: the aligned call walks one lane per frame in float64 (deep.hip), the 4-byte-aligned view stays on
                     # the tile kernel -- both within 2 ulp of the largest component of the float64 oracle, not bit-identical
                     # (8, 9: the decode of either result)

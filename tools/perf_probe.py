@@ -129,6 +129,9 @@ def main():
             root_cm = root * 100.0
             ms, mn = timeit(lambda: _lib.call("pm_to_root_dq_f32", p(rotn), p(root_cm), pp, p(off_cm), Fj, J, p(dq), None))
             report(f"to_root_dq, centimetre-scale J={J}", ms, mn, Fj * (48 * J + 12))
+            hint = C.c_float(float(off_cm.abs().max()))
+            ms, mn = timeit(lambda: _lib.call("pm_to_root_dq_hint_f32", p(rotn), p(root_cm), pp, p(off_cm), Fj, J, p(dq), hint, None))
+            report(f"to_root_dq, cm-scale, scale hint (front doors) J={J}", ms, mn, Fj * (48 * J + 12))
             del off_cm, root_cm
         if want("mirror"):
             ms, mn = timeit(lambda: _lib.call("pm_mirror_rotations_f32", p(rotn), pp, None, 0, Fj, J, p(qo), None))
