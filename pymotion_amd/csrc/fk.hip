@@ -816,12 +816,360 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? ((PFO && E
 }
 
 
+// ---- long skeletons (beyond 92 joints): the three-lane row walk over a STREAMED image -------------------------------------
+// The tile kernels keep a whole frame's 48 J B of output in LDS while its tree is walked: beyond ~90 joints that is 4-12 KB per frame, a CU
+// holds a few dozen frames and the twelve-lanes-per-frame walk they have to use costs 3 walk instructions per joint and frame against 0.7
+// for the three-lane walk (J = 128: 46 % of the HBM spec, 129: 35 %, 250: 24 %; the reference's loop, skeleton.py:51-58, has no such
+// cliff).  Here a wave owns FPW frames for ALL their joints but only a CHUNK of kFsCH = 32 joints of them is in LDS at a time:
+//   * 32 records of a frame are 512 B of quaternions in, 1152 B of rotation matrices and 384 B of positions out -- whole 128-byte
+//     lines of every array when J is a multiple of 32, and 9- / 3-line pieces with at most two partial lines otherwise (round 3's
+//     lane-per-frame attempt left 96- and 288-byte pieces, which the chip writes at 1.7-2.7 TB/s);
+//   * the walk is tree_walk's: lane (f, r) carries row r of the previous joint's [R | p] in registers and reads the joint's local
+//     rotation from the chunk image.  A parent that is not the previous joint comes from the image if it lies in the same chunk, else
+//     from one of kFsSlots register sets the host coloured the cross-chunk branch points onto (fk_stream_plan; four floats a set);
+//   * the next chunk's quaternions are requested before this chunk's walk (registers), converted and parked after its copy-out; full
+//     chunks leave with a FIXED number of unconditional stores so that the wait for those quaternions is a counted one (see copy_out
+//     of fk_pipe_kernel);
+//   * big-magnitude tiles (PREC_DYN) take float64 local rotations and the fixed-point translation chain like every fk kernel; the
+//     words stay in the image and the slots, and are converted on their way out.  A NaN / Inf that turns up in a later chunk (the tile
+//     kernels look at the whole tile before they choose) poisons the word: INT_MIN travels down the chain and leaves as NaN.
+constexpr int kFsCH = 32, kFsSlots = 8;
+enum : int { FS_CHAIN = 0xff, FS_ROOT = 0xfd, FS_LDS = 0x80, FS_NONE = 0xff };
+struct FkStreamArgs {
+    const float *rot, *root_pos, *offsets;
+    float *pos, *rotmats;
+    int64_t F;
+    int32_t J, depth, ablate;
+    int32_t chs;  // joints per chunk (kFsCH; the tuning build can shrink it)
+    int32_t code[PM_MAX_JOINTS];  // joint j: load | save << 8; load = slot, FS_LDS | index inside the chunk, FS_CHAIN, FS_ROOT; save = slot or FS_NONE
+};
+
+// Host plan: which joints' rows must survive in registers (a child in a LATER chunk that does not follow directly), coloured onto
+// kFsSlots sets by live range.  Returns false if the skeleton needs more.
+static bool fk_stream_plan(const Parents &par, const int J, const int chs, int32_t *code) {
+    int last_use[PM_MAX_JOINTS], slot_of[PM_MAX_JOINTS], busy_until[kFsSlots];
+    for (int j = 0; j < J; ++j) { last_use[j] = -1; slot_of[j] = -1; }
+    for (int j = 1; j < J; ++j) {
+        const int p = par.p[j];
+        if (p == j - 1 || p / chs == j / chs) continue;
+        if (last_use[p] < j) last_use[p] = j;
+    }
+    for (int k = 0; k < kFsSlots; ++k) busy_until[k] = -1;
+    for (int j = 0; j < J; ++j) {
+        const int p = (j == 0) ? -1 : par.p[j];
+        int load, save = FS_NONE;
+        if (j == 0) load = FS_ROOT;
+        else if (p == j - 1) load = FS_CHAIN;
+        else if (p / chs == j / chs) load = FS_LDS | (p % chs);
+        else load = slot_of[p];
+        if (last_use[j] >= 0) {
+            int k = 0;
+            while (k < kFsSlots && busy_until[k] > j) ++k;
+            if (k == kFsSlots) return false;
+            busy_until[k] = last_use[j];
+            slot_of[j] = k;
+            save = k;
+        }
+        code[j] = load | (save << 8);
+    }
+    return true;
+}
+
+struct FsSaves { float g[kFsSlots][4]; };
+template <int K>
+__device__ __forceinline__ void fs_slot_load(const int ld, const FsSaves &sv, float &p0, float &p1, float &p2, float &pt) {
+    if constexpr (K < kFsSlots) {
+        int code = ld;
+        asm volatile("" : "+s"(code));  // an opaque copy per test (an indexed array would live in scratch memory)
+        if (code == K) { p0 = sv.g[K][0]; p1 = sv.g[K][1]; p2 = sv.g[K][2]; pt = sv.g[K][3]; }
+        fs_slot_load<K + 1>(ld, sv, p0, p1, p2, pt);
+    }
+}
+template <int K>
+__device__ __forceinline__ void fs_slot_save(const int st, FsSaves &sv, const float g0, const float g1, const float g2, const float gt) {
+    if constexpr (K < kFsSlots) {
+        int code = st;
+        asm volatile("" : "+s"(code));
+        if (code == K) { sv.g[K][0] = g0; sv.g[K][1] = g1; sv.g[K][2] = g2; sv.g[K][3] = gt; }
+        fs_slot_save<K + 1>(st, sv, g0, g1, g2, gt);
+    }
+}
+
+// Alignment for ANY joint count: a frame's segment of chunk c starts at float (f J + 32 c) 9 of `rotmats` and (f J + 32 c) 3 of `pos`,
+// i.e. at f J mod 4 resp. 3 f J mod 4 floats past a 16-byte boundary.  The frame's image is SHIFTED by just that in LDS, so that a
+// 16-byte vector of the image is a 16-byte vector of HBM: the copy-out is dwordx4 throughout, and only the first / last vector of a
+// segment (which it shares with the neighbouring segment) is written float by float (measured before the shift, with dwordx2 / dword
+// stores for J % 4 != 0: J = 130 43 %, 129 36 % against 54 % at 128).
+template <int FPW>
+__global__ __launch_bounds__(PM_WAVE) void fk_stream_kernel(const FkStreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int CH = kFsCH;
+    constexpr int RS = CH * 9 + 4, PS = CH * 3 + 4;  // floats between frames in the chunk images: never a multiple of 8 (see the note on LDS bank conflicts above)
+    constexpr int EPL = (FPW * CH + PM_WAVE - 1) / PM_WAVE;
+    const int lane = threadIdx.x, J = a.J;
+    const int64_t ntiles = (a.F + FPW - 1) / FPW;
+    const int64_t tile = xcd_tile(ntiles);
+    if (tile < 0) return;
+    const int64_t f0 = tile * FPW;
+    const int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
+    float *sRot = smem;               // [FPW][RS]
+    float *sPos = sRot + FPW * RS;    // [FPW][PS]
+    float *sConst = sPos + FPW * PS;  // [J + 2] {-, t0, t1, t2}
+    const int CHS = a.chs;  // joints per chunk (<= CH, a multiple of 4)
+    const int NC = (J + CHS - 1) / CHS;
+    const int f0l = (int)(f0 & 3), Jl = J & 3;  // (only the low bits matter)
+    auto shift_r = [&](const int fe) __attribute__((always_inline)) { return ((f0l + fe) * Jl) & 3; };        // floats the rotation segment of frame fe sits past 16 B
+    auto shift_p = [&](const int fe) __attribute__((always_inline)) { return (3 * ((f0l + fe) * Jl)) & 3; };  // ... the position segment
+
+    // the joint table, and what it says about the arithmetic this tile needs (PREC_DYN, see fk_tile)
+    bool tbig_l = false;
+    float tsum_l = 0.0f, tmx_l = 0.0f;
+    for (int j = lane; j <= J + 1; j += PM_WAVE) {
+        const int jc = j < J ? j : J - 1;
+        const bool none = j == 0;  // offsets[0] is ignored (skeleton.py:49)
+        const v4f cj = v4f{0.0f, none ? 0.0f : a.offsets[3 * jc], none ? 0.0f : a.offsets[3 * jc + 1], none ? 0.0f : a.offsets[3 * jc + 2]};
+        reinterpret_cast<v4f *>(sConst)[j] = cj;
+        if (j < J) { const float l1 = const_l1(cj); tbig_l = tbig_l || const_is_big(cj); tsum_l += l1; tmx_l = (l1 > tmx_l || l1 != l1) ? l1 : tmx_l; }
+    }
+    const int wl = lane % (3 * FPW);
+    const int f = wl / 3, r = wl - 3 * f;
+    const int64_t fg = f0 + (f < nf ? f : nf - 1);  // frames past a partial tile repeat its last one (their stores are predicated)
+    const float gp = a.root_pos[fg * 3 + r];
+    bool big = false;
+    FxScale fx = {1.0f, 1.0f};
+    {
+        const bool tbig = __builtin_amdgcn_ballot_w64(tbig_l) != 0;
+        const float bsum = wave_sum(tsum_l), bmax = (float)a.depth * wave_max(tmx_l);  // (NaN sticks in both)
+        big = tbig || __builtin_amdgcn_ballot_w64(!(fabsf(gp) < kBigRoot)) != 0;
+        if (big) big = fx_scale((bmax < bsum) ? bmax : bsum, fabsf(gp), fx);  // false for a non-finite bound: the float walk propagates NaN / Inf
+    }
+
+    v4f in4[EPL];
+    int cv_next = 0;  // the chunk's per-joint codes across the lanes (lane i: joint 32 c + i): one v_readlane per step -- an s_load inside the
+                      // walk shares lgkmcnt with its LDS traffic and drains it on every joint (measured: 10.7 us per chunk with the s_load)
+    auto issue = [&](const int c) __attribute__((always_inline)) {  // chunk c's quaternions -> registers; record e = (frame e / nj, joint e % nj of the chunk)
+        const int nj = (J - c * CHS) < CHS ? (J - c * CHS) : CHS;
+        const float inv = 1.0f / (float)nj;
+        {
+            const int jc = c * CHS + (lane & (CH - 1));
+            cv_next = a.code[jc < J ? jc : J - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < EPL; ++u) {
+            const int e = u * PM_WAVE + lane;
+            int fe = (int)(((float)e + 0.5f) * inv);
+            const int jl = e - fe * nj;
+            fe = fe < nf ? fe : nf - 1;
+            in4[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(a.rot) + ((f0 + fe) * J + c * CHS + jl));
+        }
+    };
+    auto park = [&](const int c, auto mode) __attribute__((always_inline)) {  // phase A for chunk c: quaternion -> local rotation -> its slot of the image
+        constexpr int M = decltype(mode)::value;
+        const int nj = (J - c * CHS) < CHS ? (J - c * CHS) : CHS;
+        const float inv = 1.0f / (float)nj;
+#pragma unroll
+        for (int u = 0; u < EPL; ++u) {
+            const int e = u * PM_WAVE + lane;
+            const int fe = (int)(((float)e + 0.5f) * inv), jl = e - fe * nj;
+            const float qi[4] = {in4[u].x, in4[u].y, in4[u].z, in4[u].w};
+            float L[9];
+            local_from_quat<M>(qi, L);
+            if (fe < FPW) lds_put<9>(sRot + fe * RS + shift_r(fe) + jl * 9, 0, L);
+            if ((u & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // two conversions in flight, not EPL
+        }
+    };
+
+    // ---- the walk over one chunk (tree_walk's step; FX: positions as fixed-point words) ----
+    float *fL = sRot + f * RS + shift_r(f), *fRot = fL + r * 3, *fPos = sPos + f * PS + shift_p(f) + r;
+    float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, gt = 0.0f;
+    FsSaves sv;
+#pragma unroll
+    for (int k = 0; k < kFsSlots; ++k) { sv.g[k][0] = 0.0f; sv.g[k][1] = 0.0f; sv.g[k][2] = 0.0f; sv.g[k][3] = 0.0f; }
+    auto walk = [&](const int c, const int cv, auto fxmode) __attribute__((always_inline)) {
+        constexpr bool FX = decltype(fxmode)::value != 0;
+        const int nj = (J - c * CHS) < CHS ? (J - c * CHS) : CHS;
+        const v4f *cst = reinterpret_cast<const v4f *>(sConst) + c * CHS;
+        auto joint = [&](const int jl, const float (&L)[9], const v4f cj) __attribute__((always_inline)) {
+            const int code = __builtin_amdgcn_readlane(cv, jl);  // wave-uniform
+            const int ld = code & 0xff, st = (code >> 8) & 0xff;
+            float p0 = g0, p1 = g1, p2 = g2, pt = gt;
+            if (ld == FS_ROOT) {  // e_r . L = row r of L (exact), translation = the root position (offsets[0] ignored)
+                p0 = (r == 0) ? 1.0f : 0.0f; p1 = (r == 1) ? 1.0f : 0.0f; p2 = (r == 2) ? 1.0f : 0.0f;
+                pt = FX ? __int_as_float((int)__builtin_rintf(gp * fx.S)) : gp;
+            } else if (ld != FS_CHAIN) {
+                if (ld & FS_LDS) {
+                    const int pl = ld & 0x7f;
+                    p0 = fRot[pl * 9]; p1 = fRot[pl * 9 + 1]; p2 = fRot[pl * 9 + 2];
+                    pt = fPos[pl * 3];
+                } else {
+                    fs_slot_load<0>(ld, sv, p0, p1, p2, pt);
+                }
+            }
+            g0 = __builtin_fmaf(p2, L[6], __builtin_fmaf(p1, L[3], p0 * L[0]));
+            g1 = __builtin_fmaf(p2, L[7], __builtin_fmaf(p1, L[4], p0 * L[1]));
+            g2 = __builtin_fmaf(p2, L[8], __builtin_fmaf(p1, L[5], p0 * L[2]));
+            const float dt = __builtin_fmaf(p2, cj.w, __builtin_fmaf(p1, cj.z, p0 * cj.y));
+            if (FX) {
+                const int pw = __float_as_int(pt);
+                const bool poison = pw == (int)0x80000000 || !(fabsf(dt) < 3e38f);  // a NaN / Inf met on the way: it leaves as NaN, and so does everything below
+                gt = __int_as_float(poison ? (int)0x80000000 : pw + (int)__builtin_rintf(dt * fx.S));
+            } else {
+                gt = dt + pt;
+            }
+            fRot[jl * 9] = g0; fRot[jl * 9 + 1] = g1; fRot[jl * 9 + 2] = g2;
+            fPos[jl * 3] = gt;
+            if (st != FS_NONE) fs_slot_save<0>(st, sv, g0, g1, g2, gt);
+        };
+        float La[9], Lb[9];
+        v4f ca, cb;
+        lds_get<9>(fL, 0, La);
+        ca = cst[0];
+        for (int jl = PM_ABLATED(a, 2) ? nj : 0; jl < nj; jl += 2) {
+            lds_get<9>(fL, jl + 1, Lb);  // (slot jl + 1 still holds L; one slot of slack past the chunk lies inside the frame's padding + the next frame)
+            cb = cst[jl + 1];
+            joint(jl, La, ca);
+            if (jl + 1 >= nj) break;
+            lds_get<9>(fL, jl + 2, La);
+            ca = cst[jl + 2];
+            joint(jl + 1, Lb, cb);
+        }
+    };
+
+    // ---- copy-out of chunk c: per frame nj * 9 floats of rotation matrices and nj * 3 of positions, contiguous in HBM ----
+    // One 16-byte vector of a frame's (shifted) image: `lo` .. `hi` = the floats of it that belong to this segment.
+    auto out_vec = [&](float *g, const float *l, const int lo, const int hi, const bool fx_words, const int root_q0, const int64_t frame) __attribute__((always_inline)) {
+        // fixed-point words are converted here (the image keeps them for the walk); root_q0: where in this vector the frame's root position
+        // starts (chunk 0 of `pos` only, else out of reach): the root is the caller's value, bit for bit (skeleton.py:49)
+        const v4f raw = *reinterpret_cast<const v4f *>(l);
+        float v[4] = {raw.x, raw.y, raw.z, raw.w};
+        if (fx_words) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int w = __float_as_int(v[q]);
+                v[q] = (w == (int)0x80000000) ? __builtin_nanf("") : (float)w * fx.invS;
+                const int ri = q - root_q0;
+                if (ri >= 0 && ri < 3) v[q] = a.root_pos[frame * 3 + ri];
+            }
+        }
+        if (lo == 0 && hi == 4) {
+            *reinterpret_cast<v4f *>(g) = v4f{v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q >= lo && q < hi) g[q] = v[q];
+        }
+    };
+    // segment geometry of frame fe: sh = its shift, len = floats of the segment -> vectors 0 .. nv - 1 of the image row; vector k holds the
+    // segment's floats [max(sh, 4 k), min(sh + len, 4 k + 4)) - 4 k; full vectors are k in [kf, kf + nfull)
+    auto copy_region = [&](float *gbase, const float *lbase, const int stride, auto per_joint_c, const int c, const int nj, const bool fx_words, const bool full_chunk, auto shift_of)
+        __attribute__((always_inline)) {
+        constexpr int per_joint = decltype(per_joint_c)::value;
+        const int len = nj * per_joint;
+        // (1) the partial first / last vector of every frame's segment, float by float (they share their 16 bytes with the neighbouring segment)
+        if (lane < 2 * nf) {
+            const int fe = lane >> 1, last = lane & 1;
+            const int sh = shift_of(fe), end = sh + len;
+            const int k = last ? (end >> 2) : 0;
+            const int lo = last ? 0 : sh, hi = last ? (end & 3) : 4;
+            const bool partial = last ? ((end & 3) != 0 && (end >> 2) != 0) : (sh != 0 || end < 4);
+            if (partial) {
+                float *g = gbase + ((f0 + fe) * J + c * CHS) * per_joint - sh + 4 * k;
+                out_vec(g, lbase + fe * stride + 4 * k, lo, (!last && end < 4) ? end : hi, fx_words, (per_joint == 3 && c == 0) ? sh - 4 * k : 100, f0 + fe);
+            }
+        }
+        // (2) the full vectors: unconditional dwordx4, for a full chunk a FIXED number of them (slots past a frame's full vectors, or past the
+        // tile's end, repeat a vector that is stored anyway) so that the wait for the next chunk's quaternions stays a counted one
+        constexpr int PV = (CH * per_joint) / 4;  // full vectors of an unshifted full segment: an upper bound per frame
+        if (full_chunk) {
+            constexpr int NS = (FPW * PV + PM_WAVE - 1) / PM_WAVE;
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const float ipv = 1.0f / (float)PV;
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                const int i = u * PM_WAVE + ln;
+                int fe = (int)(((float)i + 0.5f) * ipv);
+                int kk = i - fe * PV;
+                if (fe >= nf) { fe = nf - 1; kk = 0; }
+                const int sh = shift_of(fe), kf = sh ? 1 : 0, nfull = ((sh + len) >> 2) - kf;
+                const int k = kf + (kk < nfull ? kk : nfull - 1);
+                out_vec(gbase + ((f0 + fe) * J + c * CHS) * per_joint - sh + 4 * k, lbase + fe * stride + 4 * k, 0, 4, fx_words, (per_joint == 3 && c == 0) ? sh - 4 * k : 100, f0 + fe);
+            }
+        } else {
+            const float ipv = 1.0f / (float)PV;
+            for (int i = lane; i < nf * PV; i += PM_WAVE) {
+                const int fe = (int)(((float)i + 0.5f) * ipv), kk = i - fe * PV;
+                const int sh = shift_of(fe), kf = sh ? 1 : 0, nfull = ((sh + len) >> 2) - kf;
+                if (kk < nfull) out_vec(gbase + ((f0 + fe) * J + c * CHS) * per_joint - sh + 4 * (kf + kk), lbase + fe * stride + 4 * (kf + kk), 0, 4, fx_words, (per_joint == 3 && c == 0) ? sh - 4 * (kf + kk) : 100, f0 + fe);
+            }
+        }
+    };
+    auto copy_out = [&](const int c, const bool fixed_words) __attribute__((always_inline)) {
+        const int nj = (J - c * CHS) < CHS ? (J - c * CHS) : CHS;
+        copy_region(a.rotmats, sRot, RS, IntC<9>{}, c, nj, false, nj == CHS, shift_r);
+        copy_region(a.pos, sPos, PS, IntC<3>{}, c, nj, fixed_words, nj == CHS, shift_p);
+    };
+
+    auto run = [&](auto mode) __attribute__((always_inline)) {
+        constexpr int M = decltype(mode)::value;
+        constexpr bool FX = (M & PREC_FX) != 0;
+        issue(0);
+        wave_sync();  // the joint table
+        park(0, mode);
+        for (int c = 0; c < NC; ++c) {
+            const int cv = cv_next;
+            asm volatile("" ::"v"(cv));  // settle the code load here, not inside the walk
+            if (c + 1 < NC) issue(c + 1);  // in flight during the walk below
+            wave_sync();
+            walk(c, cv, IntC<FX ? 1 : 0>{});
+            wave_sync();
+            copy_out(c, FX);
+            if (c + 1 < NC) park(c + 1, mode);  // (in-order DS: after the copy-out's reads)
+        }
+    };
+    if (big) run(IntC<PREC_F64 | PREC_FX>{});
+    else run(IntC<PREC_RESID>{});
+}
+
+template <int FPW>
+static int launch_fk_stream(const FkStreamArgs &a, hipStream_t s) {
+    constexpr int RS = kFsCH * 9 + 4, PS = kFsCH * 3 + 4;
+    const size_t lds = ((size_t)FPW * (RS + PS) + 4 * ((size_t)a.J + 2) + 16) * sizeof(float);
+    const int64_t ntiles = (a.F + FPW - 1) / FPW;
+    const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
+    if (grid > 0x7fffffffLL) { set_error("fk: grid too large"); return PM_EUNSUPPORTED; }
+    auto k = fk_stream_kernel<FPW>;
+    if (int e = allow_lds(k, lds)) return e;
+    set_kernel_name("void pm::fk_stream_kernel<%d>(pm::FkStreamArgs)", FPW);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
+    return PM_AFTER_LAUNCH("fk launch");
+}
+
+// quaternion source, shared offsets, 16-byte aligned arrays; false: not eligible (the caller falls back to the tile kernels)
+static bool try_fk_stream(const FkArgs &fa, hipStream_t s, int &rc) {
+    FkStreamArgs a;
+    {
+        // (chunks of equal work -- ceil(J / chunks) rounded up to a multiple of 4: J = 132 as 28 28 28 28 20 instead of 32 32 32 32 4 -- were
+        // measured and are SLOWER: J = 100 42.5 % against 53.1 %, 132 41.7 / 47.8, 144 47.1 / 50.4, 161 39.7 / 47.9; the knob stays)
+        a.chs = tune_env("PM_FKS_CHS", kFsCH);  // PM_TUNING build only: a multiple of 4, <= kFsCH
+        if (a.chs < 4 || a.chs > kFsCH || a.chs % 4) a.chs = kFsCH;
+    }
+    if (!fk_stream_plan(fa.parents, fa.J, a.chs, a.code)) return false;
+    a.rot = fa.src; a.root_pos = fa.root_pos; a.offsets = fa.offsets; a.pos = fa.pos; a.rotmats = fa.rotmats;
+    a.F = fa.F; a.J = fa.J; a.depth = fa.depth; a.ablate = fa.ablate;
+    const int fpw = tune_env("PM_FKS_FPW", fa.J > 384 ? 20 : 16);  // frames per wave (PM_TUNING build only: 20 or 16): 16 leave six waves per CU, 20 five (measured: J = 128 54 / 50 %, 256 55.5 / 51 %, 512 48 / 53 %)
+    rc = fpw == 16 ? launch_fk_stream<16>(a, s) : launch_fk_stream<20>(a, s);
+    return true;
+}
+
 // Arithmetic of the production library (see local_from_quat); the PM_TUNING build can override it per call (PM_FK_PREC)
 // on the main variants to measure what each step costs.
 #ifndef PM_FK_PREC_DEFAULT
 #define PM_FK_PREC_DEFAULT (PREC_DYN | PREC_RESID)
 #endif
 constexpr int kBigResidMaxDepth = 7;
+constexpr int kFkStreamMinJ = 96;  // fk_stream_kernel: every skeleton beyond 128 joints, and from here on those whose joint count is a multiple of 4 (chain-like, 2^19 frames,
+                                   // stream / pipelined tile kernel: J = 96 61 / 56 %, 100 53 / 52, 104 54.5 / 52.7, 112 49.5 / 46, 128 54 / 46.5; 93 42.5 / 54.6, 97 48.5 / 56, 127 42 / 47)
 
 template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT, bool PAD, int PREC>
 static int launch_fk_pp(const FkArgs &a, hipStream_t s) {
@@ -1004,6 +1352,15 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
     if ((size_t)pick * frame_bytes(pad3) + fixed > kMaxLds) pick = 4;
     a.pad = (pick == 4) ? pad12 : pad3;
     const size_t per_frame = frame_bytes(a.pad);
+    if constexpr (SRC == SRC_QUAT) {
+        // long skeletons: the streamed three-lane walk (fk_stream_kernel) where the topology's cross-chunk branch points fit its register
+        // slots; PM_FK_STREAM (PM_TUNING build only): 0 never, 1 from any joint count
+        const int st = tune_env("PM_FK_STREAM", -1);
+        if (!pfo && vec && a.quat_out == nullptr && st != 0 && (st == 1 || a.J > 128 || (a.J >= kFkStreamMinJ && a.J % 4 == 0))) {
+            int rc = PM_OK;
+            if (try_fk_stream(a, s, rc)) return rc;
+        }
+    }
     if (pick == 4 && a.J <= 128) {
         // mid-size skeletons: registers-first phase A and tiles pipelined inside a workgroup (fk_pipe_kernel; 4 records
         // per lane up to 64 joints, 8 up to 128).  Measured at 2^18 x 52: fused ortho6d 224 us (fk_kernel) -> 188 / 183 /

@@ -623,6 +623,9 @@ static int unroll_launch(const float *q, int64_t B, int64_t T, int32_t S, float 
         else if (nv > 4096 && nv <= 8192 && B >= 64) Rauto = 32;  // still one tile per clip (4096 clips of 256 frames x 22: 146 -> 131 us)
         else if (nv > 4096 && B * ((nv + 4095) / 4096) < 64) Rauto = 4;
         else if (nv >= (int64_t)4 << 20) Rauto = 32;  // very long chains: fewer, bigger tiles (2^18 / 2^20 frames x 22: 51 / 159 -> 46 / 153 us; 2^16: 19.6 -> 21.3)
+        else if (B == 1 && nv < ((int64_t)1 << 19)) Rauto = 8;  // a clip of a few hundred thousand records: more, smaller tiles (2^14 x 22: 13.2 -> 11.5 us; 2^16 x 22: 19.3 with 16, 22.7 with 8)
+        // (round 4, asked for by the review: 128-thread workgroups -- more look-back chains in flight per CU -- are slower at every length,
+        // 2^14 / 2^16 / 2^18 / 2^20 x 22 with R = 16: 13.6 / 24.5 / 69.9 / 214 us against 13.2 / 19.3 / 51.0 / 158.5 us; tools/unroll_nt_sweep.py)
         if constexpr (EULER) {
             // the conversion (three sincos + the Euler product + normalize: ~170 VALU instructions per record) sits between a tile's loads
             // and its map: smaller tiles spread it over more waves.  Measured (S = 22, T = 2^10 ... 2^20 frames, us; R = 4 / 8 / 16 / 32):
@@ -632,7 +635,8 @@ static int unroll_launch(const float *q, int64_t B, int64_t T, int32_t S, float 
         }
         const int R = tune_env("PM_UNROLL_R", Rauto);
         if (R != 32 && R != 16 && R != 8 && R != 4) { set_error("PM_UNROLL_R must be 4, 8, 16 or 32"); return PM_EINVAL; }
-        const int64_t tile = NT * (int64_t)R, tpc = (nv + tile - 1) / tile, bpc = (tpc + 63) / 64, ntiles = B * tpc;
+        const int NTsel = (!EULER && W == 4) ? tune_env("PM_UNROLL_NT", NT) : NT;  // PM_TUNING build only: 128-thread workgroups
+        const int64_t tile = NTsel * (int64_t)R, tpc = (nv + tile - 1) / tile, bpc = (tpc + 63) / 64, ntiles = B * tpc;
         if (ntiles > 0x7fffffffLL) { set_error("quat_unroll: problem too large"); return PM_EUNSUPPORTED; }
         OnePassArgs a;
         a.q = q; a.out = out; a.nv = nv; a.S = S; a.nclips = B; a.tpc = tpc; a.bpc = bpc;
@@ -657,6 +661,15 @@ static int unroll_launch(const float *q, int64_t B, int64_t T, int32_t S, float 
         if (!a.single)  // (single-tile clips read neither the ticket nor a status word)
             hipLaunchKernelGGL(unroll_reset_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, s, static_cast<unsigned long long *>(workspace), nwords);
         PM_SET_LDS(lds);
+        if (NTsel == 128) {
+            if constexpr (!EULER && W == 4) {
+                if (R == 32) hipLaunchKernelGGL((unroll_onepass_kernel<W, 32, 128, EULER>), dim3((unsigned)ntiles), dim3(128), lds, s, a);
+                else if (R == 16) hipLaunchKernelGGL((unroll_onepass_kernel<W, 16, 128, EULER>), dim3((unsigned)ntiles), dim3(128), lds, s, a);
+                else if (R == 8) hipLaunchKernelGGL((unroll_onepass_kernel<W, 8, 128, EULER>), dim3((unsigned)ntiles), dim3(128), lds, s, a);
+                else hipLaunchKernelGGL((unroll_onepass_kernel<W, 4, 128, EULER>), dim3((unsigned)ntiles), dim3(128), lds, s, a);
+                return PM_AFTER_LAUNCH("quat_unroll");
+            }
+        }
         if (R == 32) hipLaunchKernelGGL((unroll_onepass_kernel<W, 32, NT, EULER>), dim3((unsigned)ntiles), dim3(NT), lds, s, a);
         else if (R == 16) hipLaunchKernelGGL((unroll_onepass_kernel<W, 16, NT, EULER>), dim3((unsigned)ntiles), dim3(NT), lds, s, a);
         else if (R == 8) hipLaunchKernelGGL((unroll_onepass_kernel<W, 8, NT, EULER>), dim3((unsigned)ntiles), dim3(NT), lds, s, a);

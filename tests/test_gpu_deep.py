@@ -172,3 +172,60 @@ def test_to_root_dual_quat_lane_per_frame_through_the_torch_door_and_an_unaligne
     assert "deep" not in _lib.last_kernel_name() and "ring" not in _lib.last_kernel_name()
     assert np.abs(d2.cpu().numpy() - d_o).max() <= 1e-5
 
+
+
+# ---- fk on long skeletons: the streamed three-lane walk (fk.hip: fk_stream_kernel) ----------------------------------------------
+
+FK_STREAM_CASES = [
+    (96, "chain_like", True), (100, "humanoid", True), (128, "chain_like", True), (129, "chain_like", True), (130, "humanoid", True),
+    (131, "chain_like", True), (160, "humanoid", True), (250, "humanoid", True), (300, "chain_like", True), (512, "chain_like", True),
+    (97, "chain_like", False), (127, "humanoid", False), (92, "chain_like", False),   # below 129 only multiples of four from 96 on
+    (200, "random", False),                                                            # more cross-chunk branch points than register slots
+]
+
+
+@pytest.mark.parametrize("J,kind,stream", FK_STREAM_CASES)
+def test_fk_streamed_walk_on_long_skeletons(J, kind, stream):
+    """beyond 128 joints (and for multiples of four from 96 on) fk walks three lanes per frame over an image that holds 32 joints at a time:
+    which kernel ran, parity with the float64 oracle on metre and centimetre data (float64 rotations + fixed-point chain on big tiles),
+    single frames, partial tiles of 16 frames, every alignment of a frame's rows (J mod 4), the root position bit for bit"""
+    import pymotion_amd.ops.skeleton as sk
+    from pymotion_amd import synthetic as syn
+
+    parents = syn.random_parents(J, np.random.default_rng(J)) if kind == "random" else _parents(kind, J)
+    depth = int(syn.depth_of(parents).max())
+    for F, osc, rsc in ((1, 0.1, 2.0), (15, 0.1, 2.0), (16, 10.0, 200.0), (17, 0.1, 2.0), (333, 10.0, 200.0), (1000, 0.1, 2.0)):
+        rot, root, off = _batch(F, J, 7000 * J + F, osc, rsc)
+        rot = (rot * np.random.default_rng(F).uniform(0.5, 2.0, (F, J, 1))).astype(np.float32)  # fk normalises (skeleton.py:45)
+        pos, rm = sk.fk(rot, root, off, parents)
+        name = _lib.last_kernel_name()
+        assert ("fk_stream_kernel" in name) == stream, (name, J, kind)
+        p_o, r_o = co.fk(rot.astype(np.float64), root.astype(np.float64), off.astype(np.float64), parents)
+        # rotations: an fp32 chain of `depth` 3 x 3 products; positions: those errors times the bones, or 2 ulp of the largest coordinate
+        assert np.abs(rm - r_o).max() <= max(2e-6, 2.5e-7 * depth), (F, np.abs(rm - r_o).max())
+        bar = max(1e-5, 3 * _ulp_of(p_o)) if osc < 1 else max(1e-5, 2 * _ulp_of(p_o), 4e-7 * depth * osc * 3)
+        assert np.abs(pos - p_o).max() <= bar, (F, osc, np.abs(pos - p_o).max() / _ulp_of(p_o), "ulp")
+        np.testing.assert_array_equal(pos[:, 0].astype(np.float32), root)  # the root is the caller's value (skeleton.py:49)
+
+
+def test_fk_streamed_walk_keeps_nan_and_inf_where_the_reference_has_them():
+    """a NaN quaternion poisons its joint and everything below it, a NaN root coordinate its row of every position of the frame --
+    on the fp32 walk and on the fixed-point chain of big tiles (where the words carry a poison value) alike"""
+    import pymotion_amd.ops.skeleton as sk
+
+    J = 160
+    parents = chain_like(J)
+    for osc, rsc in ((0.1, 2.0), (10.0, 200.0)):
+        F = 100
+        rot, root, off = _batch(F, J, 99, osc, rsc)
+        rot[7, 100, 1] = np.nan      # deep in the fourth chunk
+        rot[40, 3, 0] = np.nan       # near the root: most of the skeleton
+        root[60, 2] = np.nan
+        with np.errstate(all="ignore"):
+            p_o, r_o = co.fk(rot.astype(np.float64), root.astype(np.float64), off.astype(np.float64), parents)
+        pos, rm = sk.fk(rot, root, off, parents)
+        assert "fk_stream_kernel" in _lib.last_kernel_name()
+        assert (np.isnan(rm) == np.isnan(r_o)).all()
+        assert (np.isnan(pos) == np.isnan(p_o)).all()
+        fin = np.isfinite(p_o)
+        assert np.abs(pos[fin] - p_o[fin]).max() <= max(1e-5, 3 * _ulp_of(p_o[fin]))
