@@ -630,7 +630,7 @@ static int unroll_launch(const float *q, int64_t B, int64_t T, int32_t S, float 
             // the conversion (three sincos + the Euler product + normalize: ~170 VALU instructions per record) sits between a tile's loads
             // and its map: smaller tiles spread it over more waves.  Measured (S = 22, T = 2^10 ... 2^20 frames, us; R = 4 / 8 / 16 / 32):
             // 9.6 / 12.2 / 18.1 / 31.3,  10.6 / 12.6 / 18.4 / 32,  16.2 / 15.4 / 20.2 / 32.8,  37 / 27.3 / 27.4 / 35,  102 / 79 / 70.6 / 83,
-            // 304 / 209 / 208 / 242 (without the long-chain LDS reservation below: the kernel is bound by its arithmetic, it wants the waves)
+            // 340 / 243 / 210 / 242 (with the long-chain LDS reservation below)
             Rauto = nv < ((int64_t)1 << 18) ? 4 : (nv < ((int64_t)1 << 20) ? 8 : 16);
         }
         const int R = tune_env("PM_UNROLL_R", Rauto);
@@ -655,7 +655,9 @@ static int unroll_launch(const float *q, int64_t B, int64_t T, int32_t S, float 
         // more resident tiles lengthen every walk (2^18 x 22 with 5 / 4 / 3 / 2 workgroups per CU: 60.5 / 56.2 / 51.0 / 53.6 us; batches of
         // short clips want them all: 4096 clips of 256 frames 145 / 145 / 153 / 187 us).  The kernel needs 95 VGPRs (five workgroups per
         // CU), so long chains reserve a third of the CU's LDS each.
-        if (!EULER && tpc > 64 && lds < 52 * 1024 && tune_env("PM_UNROLL_RESERVE", 1)) lds = 52 * 1024;
+        // (the Euler source too: without the reservation its 2^20-frame time is bimodal, 218 / 366 / 453 us run to run -- five workgroups per CU
+        // make the look-back chains as long as they can get)
+        if (tpc > 64 && lds < 52 * 1024 && tune_env("PM_UNROLL_RESERVE", 1)) lds = 52 * 1024;
         lds += (size_t)tune_env("PM_UNROLL_LDS_PAD", 0);  // PM_TUNING build only: more unused LDS
         const int64_t nwords = 8 + (ntiles + B * bpc) * a.ngroups;  // the ticket's 64-byte line, then the words
         if (!a.single)  // (single-tile clips read neither the ticket nor a status word)

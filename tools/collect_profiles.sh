@@ -10,7 +10,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/bench.log 2>&1
 tail -1 $OUT/bench.log > $OUT/r${RN}_bench_1gpu.json
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- python $R/bench.py --no-cpu-baseline > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- python $R/bench.py --no-cpu-baseline --no-secondary > $OUT/trace.log 2>&1
 cp $(find $OUT/trace -name '*kernel_stats.csv' | head -1) $OUT/r${RN}_bench_kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f --output-format csv -- python $R/tools/perf_probe.py --only fk,ceiling,dq,o6d --sustained 20 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o w --output-format csv -- python $R/tools/perf_probe.py --only fk,ceiling,dq,o6d --sustained 20 > $OUT/pmc_write.log 2>&1
@@ -26,5 +26,9 @@ python $R/tools/ik_probe.py 4,22,28,52,96,128 > $OUT/r${RN}_from_root_positions_
 python $R/tools/unroll_probe.py > $OUT/r${RN}_unroll_sweep.txt 2>&1
 python $R/tools/prec_probe.py > $OUT/r${RN}_fk_precision_levels.txt 2>&1
 python $R/tools/numpy_door_probe.py > $OUT/r${RN}_numpy_door.txt 2>&1
+python $R/tools/store_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/r${RN}_store_patterns.txt
+python $R/tools/fk_shape_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/r${RN}_fk_tile_shapes.txt
+python $R/tools/fk_long_sweep.py 2>&1 | grep -v amdgpu.ids > $OUT/r${RN}_fk_long_sweep.txt
+python $R/bench.py --frames-per-gpu 16777216 --steps 20 --warmup 3 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 > $OUT/r${RN}_bench_16m_frames_1gpu.json
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
 ls -la $OUT
