@@ -233,9 +233,10 @@ def secondary_configs(torch, _lib, syn, dev, rot, root, off, parents, sptr):
 def stream_ceilings(torch, _lib, dev, rot, rm, F, J, sptr):
     """What this chip moves with NO arithmetic, measured in the same process right after the timed region (never inside it):
     a copy with fk's traffic shape through fk's own tiling (`pm_stream_ceiling_f32`: 16 J B read, 48 J B written per frame;
-    the 12 B root position is left out), and LDS-free grid-stride streams for a pure read, a pure write and the 1:1 / 1:3
-    read:write mixes.  fk_kernel_ms / copy_ceiling_ms says how far the kernel is from what the memory system gives this
-    access pattern; the pure rows say which direction caps it."""
+    the 12 B root position is left out), LDS-free grid-stride streams for a pure read and the 1:1 / 1:2 / 1:3 read:write mixes, and
+    the store probe's chunk-per-wave streams (round 4: the grid-stride pure write of round 3 measured its own pattern, 4.5 TB/s,
+    where a chunk per wave writes 6.5 TB/s).  fk_kernel_ms / copy_ceiling_ms says how far the kernel is from a plain copy through
+    its tiling; DESIGN.md section 6 says why neither is the chip's limit for a 1:3 mix."""
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
     ev = [C.c_void_p(), C.c_void_p()]
     for e in ev:
@@ -263,7 +264,23 @@ def stream_ceilings(torch, _lib, dev, rot, rm, F, J, sptr):
     t = timed(lambda: _lib.call("pm_stream_plain_f32", p(big), p(dst), n4 * 3, 0, 8192, sptr))
     rates["pure_read"] = {"bytes": n4 * 48, "ms": t, "GBps": n4 * 48 / (t * 1e-3) / 1e9}
     t = timed(lambda: _lib.call("pm_stream_plain_f32", p(src), p(big), n4 * 3, -1, 8192, sptr))
-    rates["pure_write"] = {"bytes": n4 * 48, "ms": t, "GBps": n4 * 48 / (t * 1e-3) / 1e9}
+    rates["pure_write_grid_stride"] = {"bytes": n4 * 48, "ms": t, "GBps": n4 * 48 / (t * 1e-3) / 1e9,
+                                       "note": "round 3's pure-write figure: 8192 persistent 256-thread workgroups, each store instruction of a wave 1 KiB away from "
+                                               "its last -- the PATTERN's rate, not the chip's (profiles/r04_store_patterns.txt)"}
+
+    # round 4: what the store path does when every wave writes ONE contiguous chunk (pm_store_probe_f32: burst KiB per wave, reads in front,
+    # nt stores, one contiguous range of chunks per XCD) -- pure writes, and the 1 : 3 mix at fk's chunk size and waves per CU
+    def probe(burst, rd4, lds):
+        cfg = (C.c_int32 * 12)(burst, rd4, 1, 1, 1, 64, 0, 0, 0, 0, 0, lds)
+        nw = n4 * 3  # dwordx4 written = fk's outputs
+        tt = timed(lambda: _lib.call("pm_store_probe_f32", p(src) if rd4 else None, p(big), nw, cfg, sptr))
+        chunks = nw // (burst * 64)
+        nbytes = chunks * (burst + rd4) * 1024
+        return {"bytes": nbytes, "ms": tt, "GBps": nbytes / (tt * 1e-3) / 1e9}
+
+    rates["pure_write"] = dict(probe(4, 0, 0), note="4 KiB contiguous per wave, one chunk per wave")
+    rates["read_write_1_3_chunks_4k_12k_9_waves_per_cu"] = dict(probe(12, 4, 17 * 1024), note="fk's mix, chunk size and residency, no arithmetic, no LDS traffic")
+    rates["read_write_1_4_chunks_2k_8k"] = dict(probe(8, 2, 0), note="the best mixed stream found")
     t = timed(lambda: _lib.call("pm_stream_plain_f32", p(src), p(big), n4, 1, 8192, sptr))
     rates["read_write_1_1"] = {"bytes": n4 * 32, "ms": t, "GBps": n4 * 32 / (t * 1e-3) / 1e9}
     t = timed(lambda: _lib.call("pm_stream_plain_f32", p(src), p(big), n4, 2, 8192, sptr))
