@@ -160,6 +160,10 @@ def main():
             ms, mn = timeit(lambda: _lib.call("pm_fk_from_ortho6d_f32", p(x), p(root), p(off), 0, pp, Fj, J, C.c_float(0.0),
                                               p(pos), p(rm), p(qo), None))
             report(f"fk_from_ortho6d + quaternions out J={J}", ms, mn, Fj * (88 * J + 12))
+            off_cm, root_cm = off * 100.0, root * 100.0
+            ms, mn = timeit(lambda: _lib.call("pm_fk_from_ortho6d_f32", p(x), p(root_cm), p(off_cm), 0, pp, Fj, J, C.c_float(0.0),
+                                              p(pos), p(rm), None, None))
+            report(f"fk_from_ortho6d, centimetre-scale J={J}", ms, mn, Fj * (72 * J + 12))
         if want("ew") and J == 22:
             N = Fj * J
             q = rotn.view(N, 4)
