@@ -154,6 +154,64 @@ __device__ __forceinline__ void tree_walk(float *sRot, float *sPos, const float 
     }
 }
 
+// ---- phase B, sixteen frames: the row walk with L shared across a quad (round 4) --------------------------------------------
+// tree_walk's three lanes of a frame each read all nine entries of L_j (six LDS instructions per joint and wave), and the walks of the nine
+// waves of a CU keep its LDS pipe about a third busy: prefetching the parent's row as well (three more reads per joint, every wait a counted
+// one) made the kernel 8 % SLOWER (273 against 254 us) -- the walk is bound by LDS instructions, not by their latency.  With 16 frames per
+// wave a frame can own a QUAD (lane 4 f + r, lane 3 idle): lane r reads only ROW r of L_j -- one third of the LDS traffic -- and the other
+// two rows reach it through the DPP operand of the multiply-adds: g_c = sum_k p_k L[k][c] with L[k][c] a quad broadcast from lane k.  The
+// operand that crosses lanes was loaded from LDS, not computed, so there is no VALU -> DPP wait state, and the dependency chain runs through
+// the lane's own accumulators.
+template <bool FX>
+__device__ __forceinline__ void tree_walk_q4(float *sRot, float *sPos, const float *sConst, const int J, const int pad, const int f, const int r,
+                                             const float gp, const bool skip, const float S) {
+    float *fL = sRot + f * (J * 9 + pad);
+    float *fRot = fL + r * 3;  // this lane's row inside a slot: L[r][0..2] before the step, G[r][0..2] after
+    float *fPos = sPos + f * (J * 3 + pad) + r;
+    float g0 = (r == 0) ? 1.0f : 0.0f, g1 = (r == 1) ? 1.0f : 0.0f, g2 = (r == 2) ? 1.0f : 0.0f;
+    float gt = FX ? __int_as_float((int)__builtin_rintf(gp * S)) : gp;
+    // out = p0 * bcast_0(l) + p1 * bcast_1(l) + p2 * bcast_2(l), l = this lane's element c of its row of L (lane k of the quad: L[k][c])
+    auto dot_bcast = [](const float l, const float p0, const float p1, const float p2) __attribute__((always_inline)) {
+        float acc;
+        asm("v_mul_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %1, %3 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %1, %4 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf"
+            : "=&v"(acc)
+            : "v"(l), "v"(p0), "v"(p1), "v"(p2));
+        return acc;
+    };
+    auto joint = [&](const int j, const float (&Lr)[3], const v4f c) __attribute__((always_inline)) {
+        const int par = __builtin_amdgcn_readfirstlane(__float_as_int(c.x));
+        float p0 = g0, p1 = g1, p2 = g2, pt = gt;
+        if (par != j - 1) {  // wave-uniform: not the previous joint -> its row is in the image
+            p0 = fRot[par * 9]; p1 = fRot[par * 9 + 1]; p2 = fRot[par * 9 + 2];
+            pt = fPos[par * 3];
+        }
+        g0 = dot_bcast(Lr[0], p0, p1, p2);
+        g1 = dot_bcast(Lr[1], p0, p1, p2);
+        g2 = dot_bcast(Lr[2], p0, p1, p2);
+        const float dt = __builtin_fmaf(p2, c.w, __builtin_fmaf(p1, c.z, p0 * c.y));
+        if (FX) gt = __int_as_float(__float_as_int(pt) + (int)__builtin_rintf(dt * S));
+        else gt = dt + pt;
+        fRot[j * 9] = g0; fRot[j * 9 + 1] = g1; fRot[j * 9 + 2] = g2;
+        fPos[j * 3] = gt;
+    };
+    const v4f *cst = reinterpret_cast<const v4f *>(sConst);
+    float La[3], Lb[3];
+    v4f ca, cb;
+    La[0] = fRot[0]; La[1] = fRot[1]; La[2] = fRot[2];
+    ca = cst[0];
+    for (int j = skip ? J : 0; j < J; j += 2) {
+        Lb[0] = fRot[(j + 1) * 9]; Lb[1] = fRot[(j + 1) * 9 + 1]; Lb[2] = fRot[(j + 1) * 9 + 2];
+        cb = cst[j + 1];
+        joint(j, La, ca);
+        if (j + 1 >= J) break;
+        La[0] = fRot[(j + 2) * 9]; La[1] = fRot[(j + 2) * 9 + 1]; La[2] = fRot[(j + 2) * 9 + 2];
+        ca = cst[j + 2 <= J ? j + 2 : J];
+        joint(j + 1, Lb, cb);
+    }
+}
+
 // ---- phase B, wide form: TWELVE lanes per frame (row r x column c of [R | p]) -------------------------
 // For big skeletons the LDS image (48 J B per frame) leaves room for few frames per CU, and with three
 // lanes per frame a wave needs 8-20 frames to be worth its instructions.  Here a QUAD (4 consecutive
@@ -382,6 +440,8 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
     const int FJ = FPW * J;
     const int n = nf * J;  // (frame, joint) elements in this tile
     constexpr bool QUAD = FPW <= 5;  // few frames per wave (big J): 12 lanes per frame, see tree_walk_quad
+    constexpr bool Q4 = FPW == 16 && !PFO;  // sixteen frames: a quad per frame, the joint's L shared through DPP (tree_walk_q4)
+    const bool q4 = Q4 && !PM_ABLATED(a, 8);  // PM_FK_ABLATE & 8 (tuning build): the three-lane walk
     constexpr bool DYN = (PREC & PREC_DYN) != 0;
 
     const int pad = PAD ? a.pad : 0;                   // floats between frames in the per-frame regions (see FkArgs::pad)
@@ -396,9 +456,9 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
     // latency: root position (used first by phase B), skeleton constants, then the rotations.
     // Lanes >= 3*FPW shadow lanes 0.. (same frame, same row, same values, same addresses) and frames
     // past the end of a partial tile walk uninitialised slots of their own: phase B needs no masking.
-    const int wl = lane % ((QUAD ? 12 : 3) * FPW);
-    const int f = QUAD ? wl / 12 : wl / 3;
-    const int r = QUAD ? (wl - 12 * f) / 4 : wl - 3 * f;
+    const int wl = q4 ? lane : lane % ((QUAD ? 12 : 3) * FPW);
+    const int f = q4 ? (lane >> 2) : (QUAD ? wl / 12 : wl / 3);
+    const int r = q4 ? ((lane & 3) < 3 ? (lane & 3) : 2) : (QUAD ? (wl - 12 * f) / 4 : wl - 3 * f);  // (q4: lane 3 of a quad shadows lane 2's loads and sits the walk out)
     const int c = wl & 3;  // QUAD only: column of [R | p]
     const float gp = (f < nf) ? a.root_pos[f0 * 3 + f * 3 + r] : 0.0f;
 
@@ -546,6 +606,11 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
             if (!PM_ABLATED(a, 2)) {
                 if (FX && fixed) tree_walk_quad<PFO, FX>(sRot, sPos, sOff, sConst, J, pad, f, r, c, seed, lane, fx.S);
                 else tree_walk_quad<PFO, false>(sRot, sPos, sOff, sConst, J, pad, f, r, c, seed, lane, 1.0f);
+            }
+        } else if (Q4 && q4) {
+            if ((lane & 3) < 3) {  // (the DPP operands come from lanes 0..2 of the quad only)
+                if (FX && fixed) tree_walk_q4<FX>(sRot, sPos, sConst, J, pad, f, r, gp, PM_ABLATED(a, 2), fx.S);
+                else tree_walk_q4<false>(sRot, sPos, sConst, J, pad, f, r, gp, PM_ABLATED(a, 2), 1.0f);
             }
         } else {
             if (FX && fixed) tree_walk<PFO, FX>(sRot, sPos, sOff, sConst, J, pad, f, r, gp, PM_ABLATED(a, 2), fx.S);
