@@ -996,8 +996,9 @@ __global__ __launch_bounds__(PM_WAVE) void fk_stream_kernel(const FkStreamArgs a
         reinterpret_cast<v4f *>(sConst)[j] = cj;
         if (j < J) { const float l1 = const_l1(cj); tbig_l = tbig_l || const_is_big(cj); tsum_l += l1; tmx_l = (l1 > tmx_l || l1 != l1) ? l1 : tmx_l; }
     }
+    constexpr bool Q4 = FPW == 16;  // a quad per frame, L shared through DPP (see tree_walk_q4): a third of the walk's LDS reads
     const int wl = lane % (3 * FPW);
-    const int f = wl / 3, r = wl - 3 * f;
+    const int f = Q4 ? (lane >> 2) : wl / 3, r = Q4 ? ((lane & 3) < 3 ? (lane & 3) : 2) : wl - 3 * f;  // (Q4: lane 3 of a quad shadows lane 2 and sits the walk out)
     const int64_t fg = f0 + (f < nf ? f : nf - 1);  // frames past a partial tile repeat its last one (their stores are predicated)
     const float gp = a.root_pos[fg * 3 + r];
     bool big = false;
@@ -1054,7 +1055,21 @@ __global__ __launch_bounds__(PM_WAVE) void fk_stream_kernel(const FkStreamArgs a
         constexpr bool FX = decltype(fxmode)::value != 0;
         const int nj = (J - c * CHS) < CHS ? (J - c * CHS) : CHS;
         const v4f *cst = reinterpret_cast<const v4f *>(sConst) + c * CHS;
-        auto joint = [&](const int jl, const float (&L)[9], const v4f cj) __attribute__((always_inline)) {
+        auto dot_bcast = [](const float l, const float p0, const float p1, const float p2) __attribute__((always_inline)) {  // p0 L[0][c] + p1 L[1][c] + p2 L[2][c], L[k][c] from lane k of the quad
+            float acc;
+            asm("v_mul_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                "v_fmac_f32_dpp %0, %1, %3 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                "v_fmac_f32_dpp %0, %1, %4 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf"
+                : "=&v"(acc)
+                : "v"(l), "v"(p0), "v"(p1), "v"(p2));
+            return acc;
+        };
+        constexpr int NL = Q4 ? 3 : 9;  // floats of L_j a lane reads: its own row (Q4) or all of it
+        auto getL = [&](const int jl, float (&L)[NL]) __attribute__((always_inline)) {
+            if constexpr (Q4) { L[0] = fRot[jl * 9]; L[1] = fRot[jl * 9 + 1]; L[2] = fRot[jl * 9 + 2]; }
+            else lds_get<9>(fL, jl, L);
+        };
+        auto joint = [&](const int jl, const float (&L)[NL], const v4f cj) __attribute__((always_inline)) {
             const int code = __builtin_amdgcn_readlane(cv, jl);  // wave-uniform
             const int ld = code & 0xff, st = (code >> 8) & 0xff;
             float p0 = g0, p1 = g1, p2 = g2, pt = gt;
@@ -1070,9 +1085,13 @@ __global__ __launch_bounds__(PM_WAVE) void fk_stream_kernel(const FkStreamArgs a
                     fs_slot_load<0>(ld, sv, p0, p1, p2, pt);
                 }
             }
-            g0 = __builtin_fmaf(p2, L[6], __builtin_fmaf(p1, L[3], p0 * L[0]));
-            g1 = __builtin_fmaf(p2, L[7], __builtin_fmaf(p1, L[4], p0 * L[1]));
-            g2 = __builtin_fmaf(p2, L[8], __builtin_fmaf(p1, L[5], p0 * L[2]));
+            if constexpr (Q4) {
+                g0 = dot_bcast(L[0], p0, p1, p2); g1 = dot_bcast(L[1], p0, p1, p2); g2 = dot_bcast(L[2], p0, p1, p2);
+            } else {
+                g0 = __builtin_fmaf(p2, L[6], __builtin_fmaf(p1, L[3], p0 * L[0]));
+                g1 = __builtin_fmaf(p2, L[7], __builtin_fmaf(p1, L[4], p0 * L[1]));
+                g2 = __builtin_fmaf(p2, L[8], __builtin_fmaf(p1, L[5], p0 * L[2]));
+            }
             const float dt = __builtin_fmaf(p2, cj.w, __builtin_fmaf(p1, cj.z, p0 * cj.y));
             if (FX) {
                 const int pw = __float_as_int(pt);
@@ -1085,16 +1104,17 @@ __global__ __launch_bounds__(PM_WAVE) void fk_stream_kernel(const FkStreamArgs a
             fPos[jl * 3] = gt;
             if (st != FS_NONE) fs_slot_save<0>(st, sv, g0, g1, g2, gt);
         };
-        float La[9], Lb[9];
+        if (Q4 && (lane & 3) == 3) return;  // (the DPP operands come from lanes 0..2 of a quad)
+        float La[NL], Lb[NL];
         v4f ca, cb;
-        lds_get<9>(fL, 0, La);
+        getL(0, La);
         ca = cst[0];
         for (int jl = PM_ABLATED(a, 2) ? nj : 0; jl < nj; jl += 2) {
-            lds_get<9>(fL, jl + 1, Lb);  // (slot jl + 1 still holds L; one slot of slack past the chunk lies inside the frame's padding + the next frame)
+            getL(jl + 1, Lb);  // (slot jl + 1 still holds L; one slot of slack past the chunk lies inside the frame's padding + the next frame)
             cb = cst[jl + 1];
             joint(jl, La, ca);
             if (jl + 1 >= nj) break;
-            lds_get<9>(fL, jl + 2, La);
+            getL(jl + 2, La);
             ca = cst[jl + 2];
             joint(jl + 1, Lb, cb);
         }
@@ -1112,8 +1132,10 @@ __global__ __launch_bounds__(PM_WAVE) void fk_stream_kernel(const FkStreamArgs a
             for (int q = 0; q < 4; ++q) {
                 const int w = __float_as_int(v[q]);
                 v[q] = (w == (int)0x80000000) ? __builtin_nanf("") : (float)w * fx.invS;
-                const int ri = q - root_q0;
-                if (ri >= 0 && ri < 3) v[q] = a.root_pos[frame * 3 + ri];
+                if (root_q0 < 100) {  // (chunk 0 of `pos` only: wave-uniform, so that no other vector carries a load -- and the wait for it -- in its store loop)
+                    const int ri = q - root_q0;
+                    if (ri >= 0 && ri < 3) v[q] = a.root_pos[frame * 3 + ri];
+                }
             }
         }
         if (lo == 0 && hi == 4) {
@@ -1126,9 +1148,10 @@ __global__ __launch_bounds__(PM_WAVE) void fk_stream_kernel(const FkStreamArgs a
     };
     // segment geometry of frame fe: sh = its shift, len = floats of the segment -> vectors 0 .. nv - 1 of the image row; vector k holds the
     // segment's floats [max(sh, 4 k), min(sh + len, 4 k + 4)) - 4 k; full vectors are k in [kf, kf + nfull)
-    auto copy_region = [&](float *gbase, const float *lbase, const int stride, auto per_joint_c, const int c, const int nj, const bool fx_words, const bool full_chunk, auto shift_of)
+    auto copy_region = [&](float *gbase, const float *lbase, const int stride, auto per_joint_c, auto rootc_c, const int c, const int nj, const bool fx_words, const bool full_chunk, auto shift_of)
         __attribute__((always_inline)) {
         constexpr int per_joint = decltype(per_joint_c)::value;
+        constexpr bool rootc = decltype(rootc_c)::value != 0;  // chunk 0 of `pos` on a fixed-point tile: the root leaves as the caller's bits
         const int len = nj * per_joint;
         // (1) the partial first / last vector of every frame's segment, float by float (they share their 16 bytes with the neighbouring segment)
         if (lane < 2 * nf) {
@@ -1139,7 +1162,7 @@ __global__ __launch_bounds__(PM_WAVE) void fk_stream_kernel(const FkStreamArgs a
             const bool partial = last ? ((end & 3) != 0 && (end >> 2) != 0) : (sh != 0 || end < 4);
             if (partial) {
                 float *g = gbase + ((f0 + fe) * J + c * CHS) * per_joint - sh + 4 * k;
-                out_vec(g, lbase + fe * stride + 4 * k, lo, (!last && end < 4) ? end : hi, fx_words, (per_joint == 3 && c == 0) ? sh - 4 * k : 100, f0 + fe);
+                out_vec(g, lbase + fe * stride + 4 * k, lo, (!last && end < 4) ? end : hi, fx_words, rootc ? sh - 4 * k : 100, f0 + fe);
             }
         }
         // (2) the full vectors: unconditional dwordx4, for a full chunk a FIXED number of them (slots past a frame's full vectors, or past the
@@ -1158,21 +1181,22 @@ __global__ __launch_bounds__(PM_WAVE) void fk_stream_kernel(const FkStreamArgs a
                 if (fe >= nf) { fe = nf - 1; kk = 0; }
                 const int sh = shift_of(fe), kf = sh ? 1 : 0, nfull = ((sh + len) >> 2) - kf;
                 const int k = kf + (kk < nfull ? kk : nfull - 1);
-                out_vec(gbase + ((f0 + fe) * J + c * CHS) * per_joint - sh + 4 * k, lbase + fe * stride + 4 * k, 0, 4, fx_words, (per_joint == 3 && c == 0) ? sh - 4 * k : 100, f0 + fe);
+                out_vec(gbase + ((f0 + fe) * J + c * CHS) * per_joint - sh + 4 * k, lbase + fe * stride + 4 * k, 0, 4, fx_words, rootc ? sh - 4 * k : 100, f0 + fe);
             }
         } else {
             const float ipv = 1.0f / (float)PV;
             for (int i = lane; i < nf * PV; i += PM_WAVE) {
                 const int fe = (int)(((float)i + 0.5f) * ipv), kk = i - fe * PV;
                 const int sh = shift_of(fe), kf = sh ? 1 : 0, nfull = ((sh + len) >> 2) - kf;
-                if (kk < nfull) out_vec(gbase + ((f0 + fe) * J + c * CHS) * per_joint - sh + 4 * (kf + kk), lbase + fe * stride + 4 * (kf + kk), 0, 4, fx_words, (per_joint == 3 && c == 0) ? sh - 4 * (kf + kk) : 100, f0 + fe);
+                if (kk < nfull) out_vec(gbase + ((f0 + fe) * J + c * CHS) * per_joint - sh + 4 * (kf + kk), lbase + fe * stride + 4 * (kf + kk), 0, 4, fx_words, rootc ? sh - 4 * (kf + kk) : 100, f0 + fe);
             }
         }
     };
     auto copy_out = [&](const int c, const bool fixed_words) __attribute__((always_inline)) {
         const int nj = (J - c * CHS) < CHS ? (J - c * CHS) : CHS;
-        copy_region(a.rotmats, sRot, RS, IntC<9>{}, c, nj, false, nj == CHS, shift_r);
-        copy_region(a.pos, sPos, PS, IntC<3>{}, c, nj, fixed_words, nj == CHS, shift_p);
+        copy_region(a.rotmats, sRot, RS, IntC<9>{}, IntC<0>{}, c, nj, false, nj == CHS, shift_r);
+        if (fixed_words && c == 0) copy_region(a.pos, sPos, PS, IntC<3>{}, IntC<1>{}, c, nj, true, nj == CHS, shift_p);
+        else copy_region(a.pos, sPos, PS, IntC<3>{}, IntC<0>{}, c, nj, fixed_words, nj == CHS, shift_p);
     };
 
     auto run = [&](auto mode) __attribute__((always_inline)) {

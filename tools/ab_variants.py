@@ -6,8 +6,12 @@ import numpy as np, torch
 from pymotion_amd import _lib, synthetic as syn
 from tools.store_probe import sustained, p
 from oracle import c_oracle as co
-for J, F in ((22, 1 << 20), (8, 1 << 21), (16, 1 << 20), (29, 1 << 19), (33, 1 << 19)):
-    par = syn.PARENTS_22 if J == 22 else syn.random_parents(J, np.random.default_rng(J))
+def chain_like(J):
+    q = np.maximum(np.arange(J) - 1, 0).astype(np.int32); q[J // 2] = 0; q[3 * J // 4] = J // 4
+    return q
+LONG = os.environ.get("AB_LONG") == "1"
+for J, F in (((96, 1 << 18), (128, 1 << 18), (130, 1 << 18), (192, 1 << 17), (256, 1 << 17)) if LONG else ((22, 1 << 20), (8, 1 << 21), (16, 1 << 20), (29, 1 << 19), (33, 1 << 19))):
+    par = chain_like(J) if LONG else (syn.PARENTS_22 if J == 22 else syn.random_parents(J, np.random.default_rng(J)))
     for scale in (1.0, 100.0):
         rot, root, off, par = syn.fk_workload(F, parents=par, seed=0)
         off = off * scale; root = root * scale
