@@ -885,7 +885,7 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? ((PFO && E
 // The tile kernels keep a whole frame's 48 J B of output in LDS while its tree is walked: beyond ~90 joints that is 4-12 KB per frame, a CU
 // holds a few dozen frames and the twelve-lanes-per-frame walk they have to use costs 3 walk instructions per joint and frame against 0.7
 // for the three-lane walk (J = 128: 46 % of the HBM spec, 129: 35 %, 250: 24 %; the reference's loop, skeleton.py:51-58, has no such
-// cliff).  Here a wave owns FPW frames for ALL their joints but only a CHUNK of kFsCH = 32 joints of them is in LDS at a time:
+// cliff).  Here a wave owns FPW frames for ALL their joints but only a CHUNK of 32 (24: see CARRY below) joints of them is in LDS at a time:
 //   * 32 records of a frame are 512 B of quaternions in, 1152 B of rotation matrices and 384 B of positions out -- whole 128-byte
 //     lines of every array when J is a multiple of 32, and 9- / 3-line pieces with at most two partial lines otherwise (round 3's
 //     lane-per-frame attempt left 96- and 288-byte pieces, which the chip writes at 1.7-2.7 TB/s);
@@ -894,7 +894,10 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? ((PFO && E
 //     from one of kFsSlots register sets the host coloured the cross-chunk branch points onto (fk_stream_plan; four floats a set);
 //   * the next chunk's quaternions are requested before this chunk's walk (registers), converted and parked after its copy-out; full
 //     chunks leave with a FIXED number of unconditional stores so that the wait for those quaternions is a counted one (see copy_out
-//     of fk_pipe_kernel);
+//     of fk_pipe_kernel, and `run` below: no path to that wait may hold a load or a store loop of unknown length);
+//   * addresses are a wave-uniform 64-bit base (scalar unit) plus 24-bit products per lane: the 64-bit multiply per vector that
+//     (f0 + fe) * J * 9 costs on the vector unit was 5 points at J = 128 (54.8 -> 59.9 % on one box);
+//   * the joint table is in LDS one chunk at a time (the whole table cost a wave per CU from ~130 joints on);
 //   * big-magnitude tiles (PREC_DYN) take float64 local rotations and the fixed-point translation chain like every fk kernel; the
 //     words stay in the image and the slots, and are converted on their way out.  A NaN / Inf that turns up in a later chunk (the tile
 //     kernels look at the whole tile before they choose) poisons the word: INT_MIN travels down the chain and leaves as NaN.
@@ -905,7 +908,8 @@ struct FkStreamArgs {
     float *pos, *rotmats;
     int64_t F;
     int32_t J, depth, ablate;
-    int32_t chs;  // joints per chunk (kFsCH; the tuning build can shrink it)
+    int32_t chs;  // joints per chunk: 32 without carry, 24 with
+    int32_t rs, ps;  // carry variant: floats between frames in the rotation / position image
     int32_t code[PM_MAX_JOINTS];  // joint j: load | save << 8; load = slot, FS_LDS | index inside the chunk, FS_CHAIN, FS_ROOT; save = slot or FS_NONE
 };
 
@@ -960,16 +964,22 @@ __device__ __forceinline__ void fs_slot_save(const int st, FsSaves &sv, const fl
     }
 }
 
-// Alignment for ANY joint count: a frame's segment of chunk c starts at float (f J + 32 c) 9 of `rotmats` and (f J + 32 c) 3 of `pos`,
-// i.e. at f J mod 4 resp. 3 f J mod 4 floats past a 16-byte boundary.  The frame's image is SHIFTED by just that in LDS, so that a
-// 16-byte vector of the image is a 16-byte vector of HBM: the copy-out is dwordx4 throughout, and only the first / last vector of a
-// segment (which it shares with the neighbouring segment) is written float by float (measured before the shift, with dwordx2 / dword
-// stores for J % 4 != 0: J = 130 43 %, 129 36 % against 54 % at 128).
-template <int FPW>
+// Whole 128-byte lines for ANY joint count (CARRY): a frame's segment of chunk c starts at float (f J + CHS c) 9 of `rotmats` and (f J + CHS c) 3
+// of `pos` -- on a line only when J is a multiple of 32.  Written as it stands, every segment ends in two partial lines that the next chunk
+// completes ~10 us later, by which time the line has left the L2 (measured with whole lines faked by padding the output rows to 32 joints:
+// J = 250 40.8 -> 51.4 %, 252 42.7 -> 53.8 %).  So the image row of a frame is laid out from the LINE its segment starts in: [0, cr) holds the cr < 32
+// floats the chunk before left behind, [cr, cr + len) this chunk's segment; out go the 16-byte vectors up to the last line boundary inside the row,
+// the floats past it move to the row's front (two ds_read_b128 / ds_write_b128 a lane) and leave with chunk c + 1.  Only a frame's very first and
+// last vector (chunk 0 / the last chunk; 16 bytes shared with the neighbouring frame) are written float by float.  Rows are CH * {9, 3} + 32 floats
+// (+ what fs_pick_stride adds against bank conflicts); with 24-joint chunks that is six waves a CU, which the walk needs (it is one dependent
+// chain per frame: at J = 128, 6 / 5 / 4 waves a CU measured 61.3 / 54.0 / 44.9 %, the walk switched off 64-65 % throughout).
+template <int FPW, bool CARRY, int CH>
 __global__ __launch_bounds__(PM_WAVE) void fk_stream_kernel(const FkStreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int CH = kFsCH;
-    constexpr int RS = CH * 9 + 4, PS = CH * 3 + 4;  // floats between frames in the chunk images: never a multiple of 8 (see the note on LDS bank conflicts above)
+    constexpr int XR = CARRY ? 32 : 0;  // room in front of a frame's segment for the floats carried over from the chunk before (see above)
+    // floats between frames in the chunk images: never a multiple of 8 (see the note on LDS bank conflicts above); with a carry the host picks them
+    // per joint count (fs_pick_stride: the frames' segments start a.rs + 9 J floats apart modulo the banks)
+    const int RS = CARRY ? a.rs : CH * 9 + 4, PS = CARRY ? a.ps : CH * 3 + 4;
     constexpr int EPL = (FPW * CH + PM_WAVE - 1) / PM_WAVE;
     const int lane = threadIdx.x, J = a.J;
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
@@ -979,21 +989,24 @@ __global__ __launch_bounds__(PM_WAVE) void fk_stream_kernel(const FkStreamArgs a
     const int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
     float *sRot = smem;               // [FPW][RS]
     float *sPos = sRot + FPW * RS;    // [FPW][PS]
-    float *sConst = sPos + FPW * PS;  // [J + 2] {-, t0, t1, t2}
+    float *sRoot = sPos + FPW * PS;   // [FPW][3] the frames' root positions, bit for bit (chunk 0's copy-out of a fixed-point tile)
+    float *sConst = sRoot + 4 * FPW;  // [CH + 2] {-, t0, t1, t2} of the chunk being walked (the whole table would cost a wave per CU from ~130 joints on)
     const int CHS = a.chs;  // joints per chunk (<= CH, a multiple of 4)
     const int NC = (J + CHS - 1) / CHS;
-    const int f0l = (int)(f0 & 3), Jl = J & 3;  // (only the low bits matter)
-    auto shift_r = [&](const int fe) __attribute__((always_inline)) { return ((f0l + fe) * Jl) & 3; };        // floats the rotation segment of frame fe sits past 16 B
-    auto shift_p = [&](const int fe) __attribute__((always_inline)) { return (3 * ((f0l + fe) * Jl)) & 3; };  // ... the position segment
+    const int Jo = PM_ABLATED(a, 64) ? ((J + 31) & ~31) : J, Ji = PM_ABLATED(a, 128) ? ((J + 31) & ~31) : J;  // PM_FK_ABLATE & 64 / & 128 (tuning build, wrong results): output / input frames 32 joints apart
+    // floats the segment of (chunk c, frame fe) sits past a 128-byte line of `rotmats` / `pos` (only the low bits matter)
+    const int f0l = (int)(f0 & 31), jr = (Jo * 9) & 31, jp = (Jo * 3) & 31;
+    const int br = (int)((reinterpret_cast<uintptr_t>(a.rotmats) >> 2) & 31), bp = (int)((reinterpret_cast<uintptr_t>(a.pos) >> 2) & 31);
+    auto carry_r = [&](const int c, const int fe) __attribute__((always_inline)) { return CARRY ? ((br + __mul24(f0l + fe, jr) + c * CHS * 9) & 31) : 0; };
+    auto carry_p = [&](const int c, const int fe) __attribute__((always_inline)) { return CARRY ? ((bp + __mul24(f0l + fe, jp) + c * CHS * 3) & 31) : 0; };
 
-    // the joint table, and what it says about the arithmetic this tile needs (PREC_DYN, see fk_tile)
+    // what the joint table says about the arithmetic this tile needs (PREC_DYN, see fk_tile)
     bool tbig_l = false;
     float tsum_l = 0.0f, tmx_l = 0.0f;
-    for (int j = lane; j <= J + 1; j += PM_WAVE) {
+    for (int j = lane; j < J; j += PM_WAVE) {
         const int jc = j < J ? j : J - 1;
         const bool none = j == 0;  // offsets[0] is ignored (skeleton.py:49)
         const v4f cj = v4f{0.0f, none ? 0.0f : a.offsets[3 * jc], none ? 0.0f : a.offsets[3 * jc + 1], none ? 0.0f : a.offsets[3 * jc + 2]};
-        reinterpret_cast<v4f *>(sConst)[j] = cj;
         if (j < J) { const float l1 = const_l1(cj); tbig_l = tbig_l || const_is_big(cj); tsum_l += l1; tmx_l = (l1 > tmx_l || l1 != l1) ? l1 : tmx_l; }
     }
     constexpr bool Q4 = FPW == 16;  // a quad per frame, L shared through DPP (see tree_walk_q4): a third of the walk's LDS reads
@@ -1001,6 +1014,7 @@ __global__ __launch_bounds__(PM_WAVE) void fk_stream_kernel(const FkStreamArgs a
     const int f = Q4 ? (lane >> 2) : wl / 3, r = Q4 ? ((lane & 3) < 3 ? (lane & 3) : 2) : wl - 3 * f;  // (Q4: lane 3 of a quad shadows lane 2 and sits the walk out)
     const int64_t fg = f0 + (f < nf ? f : nf - 1);  // frames past a partial tile repeat its last one (their stores are predicated)
     const float gp = a.root_pos[fg * 3 + r];
+    if (lane < 3 * FPW || Q4) sRoot[f * 3 + r] = gp;
     bool big = false;
     FxScale fx = {1.0f, 1.0f};
     {
@@ -1011,14 +1025,20 @@ __global__ __launch_bounds__(PM_WAVE) void fk_stream_kernel(const FkStreamArgs a
     }
 
     v4f in4[EPL];
+    v4f cn_next = v4f{0.0f, 0.0f, 0.0f, 0.0f};
     int cv_next = 0;  // the chunk's per-joint codes across the lanes (lane i: joint 32 c + i): one v_readlane per step -- an s_load inside the
                       // walk shares lgkmcnt with its LDS traffic and drains it on every joint (measured: 10.7 us per chunk with the s_load)
     auto issue = [&](const int c) __attribute__((always_inline)) {  // chunk c's quaternions -> registers; record e = (frame e / nj, joint e % nj of the chunk)
         const int nj = (J - c * CHS) < CHS ? (J - c * CHS) : CHS;
         const float inv = 1.0f / (float)nj;
+        const v4f *src = reinterpret_cast<const v4f *>(a.rot) + (f0 * Ji + c * CHS);  // (wave-uniform: the 64-bit product stays on the scalar unit)
         {
-            const int jc = c * CHS + (lane & (CH - 1));
+            const int jc = c * CHS + (lane & 31);
             cv_next = a.code[jc < J ? jc : J - 1];
+            const int jt = c * CHS + lane, jo = jt < J ? jt : J - 1;  // the chunk's rows of the joint table (lanes 0 .. CH + 1; one slot of slack for the walk's look-ahead)
+            const bool none = jt == 0;  // offsets[0] is ignored (skeleton.py:49)
+            const float o0 = a.offsets[3 * jo], o1 = a.offsets[3 * jo + 1], o2 = a.offsets[3 * jo + 2];  // (unconditional: a load under a branch would end the counted waits)
+            cn_next = v4f{0.0f, none ? 0.0f : o0, none ? 0.0f : o1, none ? 0.0f : o2};
         }
 #pragma unroll
         for (int u = 0; u < EPL; ++u) {
@@ -1026,13 +1046,14 @@ __global__ __launch_bounds__(PM_WAVE) void fk_stream_kernel(const FkStreamArgs a
             int fe = (int)(((float)e + 0.5f) * inv);
             const int jl = e - fe * nj;
             fe = fe < nf ? fe : nf - 1;
-            in4[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(a.rot) + ((f0 + fe) * J + c * CHS + jl));
+            in4[u] = __builtin_nontemporal_load(src + (__mul24(fe, Ji) + jl));
         }
     };
     auto park = [&](const int c, auto mode) __attribute__((always_inline)) {  // phase A for chunk c: quaternion -> local rotation -> its slot of the image
         constexpr int M = decltype(mode)::value;
         const int nj = (J - c * CHS) < CHS ? (J - c * CHS) : CHS;
         const float inv = 1.0f / (float)nj;
+        if (lane < CH + 2) reinterpret_cast<v4f *>(sConst)[lane] = cn_next;
 #pragma unroll
         for (int u = 0; u < EPL; ++u) {
             const int e = u * PM_WAVE + lane;
@@ -1040,13 +1061,12 @@ __global__ __launch_bounds__(PM_WAVE) void fk_stream_kernel(const FkStreamArgs a
             const float qi[4] = {in4[u].x, in4[u].y, in4[u].z, in4[u].w};
             float L[9];
             local_from_quat<M>(qi, L);
-            if (fe < FPW) lds_put<9>(sRot + fe * RS + shift_r(fe) + jl * 9, 0, L);
+            if (fe < FPW && !PM_ABLATED(a, 32)) lds_put<9>(sRot + __mul24(fe, RS) + carry_r(c, fe) + jl * 9, 0, L);  // (& 32: without phase A's LDS writes)
             if ((u & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // two conversions in flight, not EPL
         }
     };
 
     // ---- the walk over one chunk (tree_walk's step; FX: positions as fixed-point words) ----
-    float *fL = sRot + f * RS + shift_r(f), *fRot = fL + r * 3, *fPos = sPos + f * PS + shift_p(f) + r;
     float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, gt = 0.0f;
     FsSaves sv;
 #pragma unroll
@@ -1054,7 +1074,8 @@ __global__ __launch_bounds__(PM_WAVE) void fk_stream_kernel(const FkStreamArgs a
     auto walk = [&](const int c, const int cv, auto fxmode) __attribute__((always_inline)) {
         constexpr bool FX = decltype(fxmode)::value != 0;
         const int nj = (J - c * CHS) < CHS ? (J - c * CHS) : CHS;
-        const v4f *cst = reinterpret_cast<const v4f *>(sConst) + c * CHS;
+        float *fL = sRot + __mul24(f, RS) + carry_r(c, f), *fRot = fL + r * 3, *fPos = sPos + __mul24(f, PS) + carry_p(c, f) + r;
+        const v4f *cst = reinterpret_cast<const v4f *>(sConst);
         auto dot_bcast = [](const float l, const float p0, const float p1, const float p2) __attribute__((always_inline)) {  // p0 L[0][c] + p1 L[1][c] + p2 L[2][c], L[k][c] from lane k of the quad
             float acc;
             asm("v_mul_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
@@ -1122,7 +1143,7 @@ __global__ __launch_bounds__(PM_WAVE) void fk_stream_kernel(const FkStreamArgs a
 
     // ---- copy-out of chunk c: per frame nj * 9 floats of rotation matrices and nj * 3 of positions, contiguous in HBM ----
     // One 16-byte vector of a frame's (shifted) image: `lo` .. `hi` = the floats of it that belong to this segment.
-    auto out_vec = [&](float *g, const float *l, const int lo, const int hi, const bool fx_words, const int root_q0, const int64_t frame) __attribute__((always_inline)) {
+    auto out_vec = [&](float *g, const float *l, const int lo, const int hi, const bool fx_words, const int root_q0, const int fe) __attribute__((always_inline)) {
         // fixed-point words are converted here (the image keeps them for the walk); root_q0: where in this vector the frame's root position
         // starts (chunk 0 of `pos` only, else out of reach): the root is the caller's value, bit for bit (skeleton.py:49)
         const v4f raw = *reinterpret_cast<const v4f *>(l);
@@ -1132,9 +1153,9 @@ __global__ __launch_bounds__(PM_WAVE) void fk_stream_kernel(const FkStreamArgs a
             for (int q = 0; q < 4; ++q) {
                 const int w = __float_as_int(v[q]);
                 v[q] = (w == (int)0x80000000) ? __builtin_nanf("") : (float)w * fx.invS;
-                if (root_q0 < 100) {  // (chunk 0 of `pos` only: wave-uniform, so that no other vector carries a load -- and the wait for it -- in its store loop)
+                if (root_q0 < 100) {  // (chunk 0 of `pos` only; from LDS: a global load here would change the count of the waits behind it)
                     const int ri = q - root_q0;
-                    if (ri >= 0 && ri < 3) v[q] = a.root_pos[frame * 3 + ri];
+                    if (ri >= 0 && ri < 3) v[q] = sRoot[fe * 3 + ri];
                 }
             }
         }
@@ -1146,29 +1167,33 @@ __global__ __launch_bounds__(PM_WAVE) void fk_stream_kernel(const FkStreamArgs a
                 if (q >= lo && q < hi) g[q] = v[q];
         }
     };
-    // segment geometry of frame fe: sh = its shift, len = floats of the segment -> vectors 0 .. nv - 1 of the image row; vector k holds the
-    // segment's floats [max(sh, 4 k), min(sh + len, 4 k + 4)) - 4 k; full vectors are k in [kf, kf + nfull)
-    auto copy_region = [&](float *gbase, const float *lbase, const int stride, auto per_joint_c, auto rootc_c, const int c, const int nj, const bool fx_words, const bool full_chunk, auto shift_of)
+    // segment geometry of (chunk c, frame fe): cr = its carry, len = floats of the segment.  Float i of the image row is float i of the 128-byte
+    // line the segment starts in; the row holds [0, cr) = what chunk c - 1 left behind, [cr, cr + len) = this chunk.  Out go the full vectors
+    // kf .. ke - 1: from the frame's first float (chunk 0) or the line boundary on, up to the last line boundary inside the row (or the
+    // frame's end, last chunk); the floats past it move to the row's front for chunk c + 1.
+    auto copy_region = [&](float *gbase, float *lbase, const int stride, auto per_joint_c, auto rootc_c, const int c, const int nj, const bool fx_words, auto full_c, auto carry_of)
         __attribute__((always_inline)) {
         constexpr int per_joint = decltype(per_joint_c)::value;
+        constexpr bool full_chunk = decltype(full_c)::value != 0;  // every chunk but the last is one
         constexpr bool rootc = decltype(rootc_c)::value != 0;  // chunk 0 of `pos` on a fixed-point tile: the root leaves as the caller's bits
         const int len = nj * per_joint;
-        // (1) the partial first / last vector of every frame's segment, float by float (they share their 16 bytes with the neighbouring segment)
-        if (lane < 2 * nf) {
+        const bool firstc = c == 0, lastc = c == NC - 1;
+        float *gtile = gbase + (f0 * Jo + c * CHS) * per_joint;  // (wave-uniform) frame fe's segment starts fe * gstep floats further on
+        const int gstep = Jo * per_joint;
+        auto first_vec = [&](const int cr) __attribute__((always_inline)) { return firstc ? ((cr + 3) >> 2) : 0; };
+        auto end_vec = [&](const int cr) __attribute__((always_inline)) { return (lastc || !CARRY) ? ((cr + len) >> 2) : (((cr + len) >> 5) << 3); };
+        // (1) the partial first vector of a frame (chunk 0) and its partial last one (last chunk), float by float: they share their 16 bytes with the neighbouring frame
+        if (CARRY && (firstc || lastc) && lane < 2 * nf && !PM_ABLATED(a, 16)) {  // PM_FK_ABLATE & 16 (tuning build): without the partial vectors
             const int fe = lane >> 1, last = lane & 1;
-            const int sh = shift_of(fe), end = sh + len;
-            const int k = last ? (end >> 2) : 0;
-            const int lo = last ? 0 : sh, hi = last ? (end & 3) : 4;
-            const bool partial = last ? ((end & 3) != 0 && (end >> 2) != 0) : (sh != 0 || end < 4);
-            if (partial) {
-                float *g = gbase + ((f0 + fe) * J + c * CHS) * per_joint - sh + 4 * k;
-                out_vec(g, lbase + fe * stride + 4 * k, lo, (!last && end < 4) ? end : hi, fx_words, rootc ? sh - 4 * k : 100, f0 + fe);
-            }
+            const int cr = carry_of(c, fe), end = cr + len;
+            float *g = gtile + (__mul24(fe, gstep) - cr);
+            if (!last && firstc && (cr & 3) != 0) { const int k = cr >> 2; out_vec(g + 4 * k, lbase + __mul24(fe, stride) + 4 * k, cr & 3, 4, fx_words, rootc ? cr - 4 * k : 100, fe); }
+            if (last && lastc && (end & 3) != 0) { const int k = end >> 2; out_vec(g + 4 * k, lbase + __mul24(fe, stride) + 4 * k, 0, end & 3, fx_words, 100, fe); }
         }
         // (2) the full vectors: unconditional dwordx4, for a full chunk a FIXED number of them (slots past a frame's full vectors, or past the
         // tile's end, repeat a vector that is stored anyway) so that the wait for the next chunk's quaternions stays a counted one
-        constexpr int PV = (CH * per_joint) / 4;  // full vectors of an unshifted full segment: an upper bound per frame
-        if (full_chunk) {
+        constexpr int PV = (CH * per_joint + XR) / 4;  // vectors of a full segment and its carry: an upper bound per frame
+        if constexpr (full_chunk) {
             constexpr int NS = (FPW * PV + PM_WAVE - 1) / PM_WAVE;
             int ln = lane;
             asm volatile("" : "+v"(ln));
@@ -1179,57 +1204,109 @@ __global__ __launch_bounds__(PM_WAVE) void fk_stream_kernel(const FkStreamArgs a
                 int fe = (int)(((float)i + 0.5f) * ipv);
                 int kk = i - fe * PV;
                 if (fe >= nf) { fe = nf - 1; kk = 0; }
-                const int sh = shift_of(fe), kf = sh ? 1 : 0, nfull = ((sh + len) >> 2) - kf;
+                const int cr = carry_of(c, fe), kf = first_vec(cr), nfull = end_vec(cr) - kf;
                 const int k = kf + (kk < nfull ? kk : nfull - 1);
-                out_vec(gbase + ((f0 + fe) * J + c * CHS) * per_joint - sh + 4 * k, lbase + fe * stride + 4 * k, 0, 4, fx_words, rootc ? sh - 4 * k : 100, f0 + fe);
+                out_vec(gtile + (__mul24(fe, gstep) - cr + 4 * k), lbase + (__mul24(fe, stride) + 4 * k), 0, 4, fx_words, rootc ? cr - 4 * k : 100, fe);
             }
         } else {
-            const float ipv = 1.0f / (float)PV;
-            for (int i = lane; i < nf * PV; i += PM_WAVE) {
-                const int fe = (int)(((float)i + 0.5f) * ipv), kk = i - fe * PV;
-                const int sh = shift_of(fe), kf = sh ? 1 : 0, nfull = ((sh + len) >> 2) - kf;
-                if (kk < nfull) out_vec(gbase + ((f0 + fe) * J + c * CHS) * per_joint - sh + 4 * (kf + kk), lbase + fe * stride + 4 * (kf + kk), 0, 4, fx_words, rootc ? sh - 4 * (kf + kk) : 100, f0 + fe);
+            const int pv = (len + XR + 3) >> 2;  // (a short last chunk: as many slots per frame as it can have vectors)
+            const float ipv = 1.0f / (float)pv;
+            for (int i = lane; i < nf * pv; i += PM_WAVE) {
+                const int fe = (int)(((float)i + 0.5f) * ipv), kk = i - fe * pv;
+                const int cr = carry_of(c, fe), kf = first_vec(cr), nfull = end_vec(cr) - kf;
+                if (kk < nfull) out_vec(gtile + (__mul24(fe, gstep) - cr + 4 * (kf + kk)), lbase + (__mul24(fe, stride) + 4 * (kf + kk)), 0, 4, fx_words, rootc ? cr - 4 * (kf + kk) : 100, fe);
+            }
+        }
+        // (3) what lies past the last line boundary (less than 32 floats a frame) moves to the front of the row: chunk c + 1 lands behind it
+        if (CARRY && !lastc) {
+            for (int i = lane; i < FPW * 8; i += PM_WAVE) {
+                const int fe = i >> 3, q = i & 7;
+                const int we = ((carry_of(c, fe) + len) >> 5) << 5;
+                float *row = lbase + __mul24(fe, stride);
+                const v4f v = *reinterpret_cast<const v4f *>(row + we + 4 * q);
+                *reinterpret_cast<v4f *>(row + 4 * q) = v;
             }
         }
     };
-    auto copy_out = [&](const int c, const bool fixed_words) __attribute__((always_inline)) {
+    auto copy_out = [&](const int c, const bool fixed_words, auto full_c) __attribute__((always_inline)) {
         const int nj = (J - c * CHS) < CHS ? (J - c * CHS) : CHS;
-        copy_region(a.rotmats, sRot, RS, IntC<9>{}, IntC<0>{}, c, nj, false, nj == CHS, shift_r);
-        if (fixed_words && c == 0) copy_region(a.pos, sPos, PS, IntC<3>{}, IntC<1>{}, c, nj, true, nj == CHS, shift_p);
-        else copy_region(a.pos, sPos, PS, IntC<3>{}, IntC<0>{}, c, nj, fixed_words, nj == CHS, shift_p);
+        copy_region(a.rotmats, sRot, RS, IntC<9>{}, IntC<0>{}, c, nj, false, full_c, carry_r);
+        if (fixed_words && c == 0) copy_region(a.pos, sPos, PS, IntC<3>{}, IntC<1>{}, c, nj, true, full_c, carry_p);
+        else copy_region(a.pos, sPos, PS, IntC<3>{}, IntC<0>{}, c, nj, fixed_words, full_c, carry_p);
     };
 
+    // Chunks with a successor are full ones, and their copy-out is straight-line code with a fixed number of stores: the wait for chunk c + 1's
+    // quaternions (issued before the walk of chunk c) is then a counted one and the stores drain under the next walk.  A store loop of unknown length
+    // on ANY path to that wait turns it into vmcnt(7 - u) -- all stores acknowledged -- which is why the last chunk has its own copy of the code.
     auto run = [&](auto mode) __attribute__((always_inline)) {
         constexpr int M = decltype(mode)::value;
         constexpr bool FX = (M & PREC_FX) != 0;
         issue(0);
-        wave_sync();  // the joint table
         park(0, mode);
-        for (int c = 0; c < NC; ++c) {
+        int c = 0;
+        for (; c + 1 < NC; ++c) {
             const int cv = cv_next;
             asm volatile("" ::"v"(cv));  // settle the code load here, not inside the walk
-            if (c + 1 < NC) issue(c + 1);  // in flight during the walk below
+            issue(c + 1);  // in flight during the walk below
             wave_sync();
             walk(c, cv, IntC<FX ? 1 : 0>{});
             wave_sync();
-            copy_out(c, FX);
-            if (c + 1 < NC) park(c + 1, mode);  // (in-order DS: after the copy-out's reads)
+            copy_out(c, FX, IntC<1>{});
+            park(c + 1, mode);  // (in-order DS: after the copy-out's reads)
         }
+        const int cv = cv_next;
+        wave_sync();
+        walk(c, cv, IntC<FX ? 1 : 0>{});
+        wave_sync();
+        if (J - c * CHS == CHS) copy_out(c, FX, IntC<1>{});
+        else copy_out(c, FX, IntC<0>{});
     };
     if (big) run(IntC<PREC_F64 | PREC_FX>{});
     else run(IntC<PREC_RESID>{});
 }
 
+// Carry variant: the segment of frame f starts f (stride + step) + const floats into the banks, step = floats per frame in HBM.  Of the strides that
+// keep rows 16-byte aligned, the first one under which the walk's accesses (lane -> frame f, row r; word f (stride + step) + mul r) collide least in
+// a 32-lane group of ds_read_b32 / ds_write_b32 (32 banks): measured before, with one stride for all, J = 252 (eight frames on one bank) 37.5 %.
 template <int FPW>
-static int launch_fk_stream(const FkStreamArgs &a, hipStream_t s) {
-    constexpr int RS = kFsCH * 9 + 4, PS = kFsCH * 3 + 4;
-    const size_t lds = ((size_t)FPW * (RS + PS) + 4 * ((size_t)a.J + 2) + 16) * sizeof(float);
+static int fs_pick_stride(const int min_floats, const int step, const int mul) {
+    int best = min_floats, best_cost = 1 << 30;
+    for (int extra = 0; extra < 32; extra += 4) {
+        const int sb = (min_floats + extra + step) & 31;
+        int cost = 0;
+        for (int g = 0; g < 2; ++g) {
+            int cnt[32] = {0}, seen_n = 0, seen[32];
+            for (int lane = 32 * g; lane < 32 * g + 32; ++lane) {
+                const int wl = lane % (3 * FPW);
+                const int f = FPW == 16 ? (lane >> 2) : wl / 3, r = FPW == 16 ? ((lane & 3) < 3 ? (lane & 3) : 2) : wl - 3 * f;
+                const int word = f * 4096 + mul * r;  // (distinct addresses: lanes on one address are one access)
+                bool dup = false;
+                for (int k = 0; k < seen_n; ++k) dup = dup || seen[k] == word;
+                if (dup) continue;
+                seen[seen_n++] = word;
+                const int b = (f * sb + mul * r) & 31;
+                if (++cnt[b] > cost) cost = cnt[b];
+            }
+        }
+        if (cost < best_cost) { best_cost = cost; best = min_floats + extra; }
+    }
+    return best;
+}
+
+template <int FPW, bool CARRY, int CH>
+static int launch_fk_stream(FkStreamArgs &a, hipStream_t s) {
+    int RS = CH * 9 + 4, PS = CH * 3 + 4;
+    if (CARRY) {
+        a.rs = RS = tune_env("PM_FKS_RS", fs_pick_stride<FPW>(CH * 9 + 32, a.J * 9, 3));  // PM_TUNING build only
+        a.ps = PS = tune_env("PM_FKS_PS", fs_pick_stride<FPW>(CH * 3 + 32, a.J * 3, 1));
+    }
+    const size_t lds = ((size_t)FPW * (RS + PS + 4) + 4 * ((size_t)CH + 2) + 16) * sizeof(float) + (size_t)tune_env("PM_FKS_LDSX", 0);  // (PM_TUNING build only: bytes of LDS on top, fewer waves a CU)
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
     const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
     if (grid > 0x7fffffffLL) { set_error("fk: grid too large"); return PM_EUNSUPPORTED; }
-    auto k = fk_stream_kernel<FPW>;
+    auto k = fk_stream_kernel<FPW, CARRY, CH>;
     if (int e = allow_lds(k, lds)) return e;
-    set_kernel_name("void pm::fk_stream_kernel<%d>(pm::FkStreamArgs)", FPW);
+    set_kernel_name("void pm::fk_stream_kernel<%d, %s, %d>(pm::FkStreamArgs)", FPW, CARRY ? "true" : "false", CH);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
     return PM_AFTER_LAUNCH("fk launch");
 }
@@ -1237,17 +1314,22 @@ static int launch_fk_stream(const FkStreamArgs &a, hipStream_t s) {
 // quaternion source, shared offsets, 16-byte aligned arrays; false: not eligible (the caller falls back to the tile kernels)
 static bool try_fk_stream(const FkArgs &fa, hipStream_t s, int &rc) {
     FkStreamArgs a;
-    {
-        // (chunks of equal work -- ceil(J / chunks) rounded up to a multiple of 4: J = 132 as 28 28 28 28 20 instead of 32 32 32 32 4 -- were
-        // measured and are SLOWER: J = 100 42.5 % against 53.1 %, 132 41.7 / 47.8, 144 47.1 / 50.4, 161 39.7 / 47.9; the knob stays)
-        a.chs = tune_env("PM_FKS_CHS", kFsCH);  // PM_TUNING build only: a multiple of 4, <= kFsCH
-        if (a.chs < 4 || a.chs > kFsCH || a.chs % 4) a.chs = kFsCH;
-    }
+    // segments that start and end on 128-byte lines of both outputs (32-joint chunks of a skeleton whose joint count is a multiple of 32) need no carry
+    const bool lines = fa.J % 32 == 0 && ((reinterpret_cast<uintptr_t>(fa.pos) | reinterpret_cast<uintptr_t>(fa.rotmats)) & 127) == 0;
+    // chunks of 24 joints leave the carry variant six waves a CU (32: five); measured on one box, 24 / 32: J = 100 56.2 / 50.5 %, 120 58.4 / 51.4,
+    // 144 58.7 / 52.0, 200 58.9 / 53.7, 250 50.3 / 51.2, 300 56.8 / 55.1, 400 61.6 / 57.1, 511 59.4 / 57.3 (28: between the two, ahead only where 28 divides J)
+    const int chs_auto = lines ? 32 : 24;
+    a.chs = tune_env("PM_FKS_CHS", chs_auto);  // PM_TUNING build only: 24 or 32
+    if (a.chs != 24 && a.chs != 32) a.chs = chs_auto;
     if (!fk_stream_plan(fa.parents, fa.J, a.chs, a.code)) return false;
     a.rot = fa.src; a.root_pos = fa.root_pos; a.offsets = fa.offsets; a.pos = fa.pos; a.rotmats = fa.rotmats;
     a.F = fa.F; a.J = fa.J; a.depth = fa.depth; a.ablate = fa.ablate;
-    const int fpw = tune_env("PM_FKS_FPW", fa.J > 384 ? 20 : 16);  // frames per wave (PM_TUNING build only: 20 or 16): 16 leave six waves per CU, 20 five (measured: J = 128 54 / 50 %, 256 55.5 / 51 %, 512 48 / 53 %)
-    rc = fpw == 16 ? launch_fk_stream<16>(a, s) : launch_fk_stream<20>(a, s);
+    // (twenty frames a wave -- five waves a CU -- were ahead beyond 384 joints while the whole joint table sat in LDS; with the chunk's rows only,
+    // sixteen are: J = 512 62.1 / 57.4 %, 400 54.0 / 52.1; the kernel is instantiated for sixteen)
+    const bool carry = tune_env("PM_FKS_CARRY", 0) != 0 || !lines || a.chs != 32;
+    if (!carry) rc = launch_fk_stream<16, false, 32>(a, s);
+    else if (a.chs == 24) rc = launch_fk_stream<16, true, 24>(a, s);
+    else rc = launch_fk_stream<16, true, 32>(a, s);
     return true;
 }
 
@@ -1257,8 +1339,11 @@ static bool try_fk_stream(const FkArgs &fa, hipStream_t s, int &rc) {
 #define PM_FK_PREC_DEFAULT (PREC_DYN | PREC_RESID)
 #endif
 constexpr int kBigResidMaxDepth = 7;
-constexpr int kFkStreamMinJ = 96;  // fk_stream_kernel: every skeleton beyond 128 joints, and from here on those whose joint count is a multiple of 4 (chain-like, 2^19 frames,
-                                   // stream / pipelined tile kernel: J = 96 61 / 56 %, 100 53 / 52, 104 54.5 / 52.7, 112 49.5 / 46, 128 54 / 46.5; 93 42.5 / 54.6, 97 48.5 / 56, 127 42 / 47)
+// fk_stream_kernel: every skeleton beyond 128 joints; below, multiples of 32 from 64 on (whole lines, no carry) and multiples of 4 from 96 on (chain-like,
+// 2^19 frames, stream / pipelined tile kernel on one box: J = 64 64.6 / 59.6 %, 96 68.0 / 55.9, 100 56.2 / 52.1, 104 57.2 / 53.1, 112 58.7 / 46.4,
+// 120 58.4 / 48.1, 128 69.2 / 47.3; 80 54.1 / 57.9, 97 53.9 / 56.4, 127 50.2 / 47.4)
+constexpr int kFkStreamMinJ = 96, kFkStreamMinLinesJ = 64;
+static bool fk_stream_wanted(const int J) { return J > 128 || (J >= kFkStreamMinJ && J % 4 == 0) || (J >= kFkStreamMinLinesJ && J % 32 == 0); }
 
 template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT, bool PAD, int PREC>
 static int launch_fk_pp(const FkArgs &a, hipStream_t s) {
@@ -1445,7 +1530,7 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
         // long skeletons: the streamed three-lane walk (fk_stream_kernel) where the topology's cross-chunk branch points fit its register
         // slots; PM_FK_STREAM (PM_TUNING build only): 0 never, 1 from any joint count
         const int st = tune_env("PM_FK_STREAM", -1);
-        if (!pfo && vec && a.quat_out == nullptr && st != 0 && (st == 1 || a.J > 128 || (a.J >= kFkStreamMinJ && a.J % 4 == 0))) {
+        if (!pfo && vec && a.quat_out == nullptr && st != 0 && (st == 1 || fk_stream_wanted(a.J))) {
             int rc = PM_OK;
             if (try_fk_stream(a, s, rc)) return rc;
         }

@@ -177,6 +177,7 @@ def test_to_root_dual_quat_lane_per_frame_through_the_torch_door_and_an_unaligne
 # ---- fk on long skeletons: the streamed three-lane walk (fk.hip: fk_stream_kernel) ----------------------------------------------
 
 FK_STREAM_CASES = [
+    (64, "chain_like", True), (64, "humanoid", True), (80, "chain_like", False),         # multiples of 32 from 64 on
     (96, "chain_like", True), (100, "humanoid", True), (128, "chain_like", True), (129, "chain_like", True), (130, "humanoid", True),
     (131, "chain_like", True), (160, "humanoid", True), (250, "humanoid", True), (300, "chain_like", True), (512, "chain_like", True),
     (97, "chain_like", False), (127, "humanoid", False), (92, "chain_like", False),   # below 129 only multiples of four from 96 on
@@ -206,6 +207,40 @@ def test_fk_streamed_walk_on_long_skeletons(J, kind, stream):
         bar = max(1e-5, 3 * _ulp_of(p_o)) if osc < 1 else max(1e-5, 2 * _ulp_of(p_o), 4e-7 * depth * osc * 3)
         assert np.abs(pos - p_o).max() <= bar, (F, osc, np.abs(pos - p_o).max() / _ulp_of(p_o), "ulp")
         np.testing.assert_array_equal(pos[:, 0].astype(np.float32), root)  # the root is the caller's value (skeleton.py:49)
+
+
+@pytest.mark.parametrize("J,shift_pos,shift_rot", [(96, 4, 0), (128, 0, 12), (130, 20, 8), (161, 28, 28)])
+def test_fk_streamed_walk_with_outputs_off_the_cache_line(J, shift_pos, shift_rot):
+    """raw ABI: `pos` / `rotmats` 16-byte aligned but not on a 128-byte line (a view into a bigger buffer): the carry of every segment counts
+    from the line, not from the array -- same bits as the call with line-aligned outputs, nothing written outside the arrays"""
+    import ctypes as C
+
+    import torch
+
+    F = 77
+    parents = chain_like(J)
+    rot, root, off = _batch(F, J, 31 * J, 10.0, 200.0)
+    dev = torch.device("cuda:0")
+    rot_d, root_d, off_d = (torch.from_numpy(x).to(dev) for x in (rot, root, off))
+    pp = parents.astype(np.int32).ctypes.data_as(C.c_void_p)
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    pos0 = torch.empty(F * J * 3, device=dev)
+    rm0 = torch.empty(F * J * 9, device=dev)
+    _lib.call("pm_fk_f32", P(rot_d), P(root_d), P(off_d), 0, pp, F, J, P(pos0), P(rm0), None)
+    assert "fk_stream_kernel" in _lib.last_kernel_name()
+    pad = 64
+    pos_b = torch.full((F * J * 3 + 2 * pad,), -7.0, device=dev)
+    rm_b = torch.full((F * J * 9 + 2 * pad,), -7.0, device=dev)
+    pos1 = pos_b[pad + shift_pos: pad + shift_pos + F * J * 3]
+    rm1 = rm_b[pad + shift_rot: pad + shift_rot + F * J * 9]
+    assert pos1.data_ptr() % 16 == 0 and rm1.data_ptr() % 16 == 0 and (pos1.data_ptr() % 128 != 0 or rm1.data_ptr() % 128 != 0)
+    _lib.call("pm_fk_f32", P(rot_d), P(root_d), P(off_d), 0, pp, F, J, P(pos1), P(rm1), None)
+    assert "fk_stream_kernel" in _lib.last_kernel_name()
+    torch.cuda.synchronize()
+    assert torch.equal(pos1.view(torch.int32), pos0.view(torch.int32))
+    assert torch.equal(rm1.view(torch.int32), rm0.view(torch.int32))
+    for buf, lo, n in ((pos_b, pad + shift_pos, F * J * 3), (rm_b, pad + shift_rot, F * J * 9)):
+        assert bool((buf[:lo] == -7.0).all()) and bool((buf[lo + n:] == -7.0).all())
 
 
 def test_fk_streamed_walk_keeps_nan_and_inf_where_the_reference_has_them():

@@ -1,0 +1,26 @@
+import ctypes as C, os, sys
+sys.path.insert(0, "/root/repo")
+os.environ["PMHIP_VARIANT"] = "tuning"
+import numpy as np, torch
+import tools.perf_probe as pp
+from pymotion_amd import _lib
+pp.SUSTAINED = 30
+P = lambda t: C.c_void_p(t.data_ptr())
+def chain_like(J):
+    p = np.maximum(np.arange(J) - 1, 0).astype(np.int32); p[J // 2] = 0; p[3 * J // 4] = J // 4
+    return p
+os.environ["PM_FK_STREAM"] = "1"
+Js = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "96,97,100,112,128,129,130,132,161,250,252,256,300,511,512").split(",")]
+for J in Js:
+    par = chain_like(J); F = (1 << 19) if J <= 128 else (1 << 18)
+    rot = torch.randn((F, J, 4), device="cuda"); root = torch.rand((F, 3), device="cuda") * 4 - 2
+    off = torch.randn((J, 3), device="cuda") * 0.1; off[0] = 0
+    pos = torch.empty((F, J, 3), device="cuda"); rm = torch.empty((F, J, 3, 3), device="cuda")
+    pp_ = par.ctypes.data_as(C.c_void_p)
+    row = []
+    for v, abl in (("tuning", 0), ("ab", 0), ("tuning", 2), ("ab", 2), ("tuning", 0), ("ab", 0)):
+        os.environ["PM_FK_ABLATE"] = str(abl)
+        with _lib.variant(v):
+            ms, _ = pp.timeit(lambda: _lib.call("pm_fk_f32", P(rot), P(root), P(off), 0, pp_, F, J, P(pos), P(rm), None))
+        row.append(f"{'new' if v == 'tuning' else 'old'}{'-walk' if abl else ''}: {ms * 1e3:7.1f} us {F * (64 * J + 12) / ms / 1e6 / 80:5.1f}%")
+    print(f"J={J:3d}: " + " | ".join(row), flush=True)
