@@ -759,6 +759,284 @@ static int launch_ik_deep(const IkDeepArgs &a, hipStream_t s) {
     return PM_AFTER_LAUNCH("from_root_positions (lane per frame) launch");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// ONE LANE PER FRAME for tables in ANY parents-first order (the level-order tables of the SMPL family: the first child of a joint
+// is NOT the next joint) -- the kernel above with the walk driven by a host-made list of OPERATIONS instead of "joint j finishes
+// joint j - 1".  Same ring of sixteen 16-byte slots per frame, same loads, parks and stores; what changes:
+//   * joint p is finished by ONE operation that reads P_p and the positions of its children out of the ring (they are still
+//     there: see the window below) or, for children stored too far down the row, out of the queue of per-lane fetches made when
+//     the tile starts (the five finger roots of each SMPL-H hand), aligns, rolls once per further child and writes the LOCAL
+//     rotation of p over P_p; a joint without children is an operation that writes the identity;
+//   * the window: while step c of the tile loop runs, the ring holds groups c - 1 and c of every lane, i.e. the joints
+//     [8 c - 8, 8 c + D] whatever the lane's line shift sf = (frame J) & 7 is, D = gcd(J, 8) - 1 (J = 52: D = 3; J % 8 == 0: 7;
+//     odd J: 0).  ik_order_plan puts joint p into step (p >> 3) + 1 -- the last one before its line leaves -- takes the children
+//     at index <= 8 step + D from the ring and the others from the queue, orders a step's operations by joint index (parents
+//     first) and colours the world quaternions that a later operation needs onto the kDeepSlots register sets;
+//   * the operands of the next operation (two positions, the table row of the first child) are requested while the current one
+//     computes, as above.
+// SMPL-H as stored (52 joints, level order): 8 queue entries, 4 register sets.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int kIkOrderMinJ = 24;
+constexpr int kIkOrderSteps = PM_MAX_JOINTS / 8 + 4;
+enum : int { IKO_CHAIN = 6, IKO_ROOT = 7, IKO_NONE = 7 };
+
+struct IkOrderArgs {
+    const float *pos;      // [F,J,3]
+    const float *offsets;  // [J,3]
+    float *out;            // [F,J,4]
+    int64_t F;
+    int32_t J;
+    int32_t nfar;
+    int32_t far_joint[kIkFar];         // joints fetched per lane at the start of a tile, in the order the operations consume them
+    int32_t wst[kIkOrderSteps];        // step c runs operations [wst[c], wst[c + 1])
+    int32_t rsrc[PM_MAX_JOINTS / 2];   // further children, 16 bits each: joint | far << 15, in the order the operations consume them
+    int32_t ops[PM_MAX_JOINTS];        // p | c1 << 9 | c1far << 18 | ld << 19 | st << 22 | nroll << 25 | leaf << 29
+};
+static_assert(sizeof(IkOrderArgs) <= 4096, "kernel arguments are limited to 4 KB");
+
+template <int G>
+__global__ __launch_bounds__(PM_WAVE) void from_root_positions_order_kernel(const IkOrderArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int RS = ik_deep_row(G), FPI = PM_WAVE / G, LG = 3, SM = 2 * G - 1;
+    static_assert(G == 8, "groups of eight records");
+    const int lane = threadIdx.x;
+    const int J = a.J;
+    const int64_t tile = xcd_tile((a.F + PM_WAVE - 1) / PM_WAVE);
+    if (tile < 0) return;
+    float *sImg = smem;                 // [64][RS]
+    float *sOff = smem + PM_WAVE * RS;  // [J][4]  {u, 1 / |u|} of every joint's rest offset ...
+    float *sLen = sOff + 4 * J;         // [J]     ... and |u|
+    for (int j = lane; j < J; j += PM_WAVE) {
+        const float o[3] = {a.offsets[3 * j], a.offsets[3 * j + 1], a.offsets[3 * j + 2]};
+        const float u2 = __builtin_fmaf(o[0], o[0], __builtin_fmaf(o[1], o[1], o[2] * o[2]));
+        const float iu = (u2 > 0.0f) ? __builtin_amdgcn_rsqf(u2) : 0.0f;
+        float *t = sOff + 4 * j;
+        if (PM_LDS_OK(t, 16u)) *reinterpret_cast<v4f *>(t) = v4f{o[0], o[1], o[2], iu};
+        if (PM_LDS_OK(sLen + j, 4u)) sLen[j] = fsqrt(u2);
+    }
+    const int64_t f0 = tile * PM_WAVE;
+    const int nf = (int)((a.F - f0) < PM_WAVE ? (a.F - f0) : PM_WAVE);
+    const int ngroups = ((J + G - 2) >> LG) + 1;
+    const float *gpos = a.pos + f0 * J * 3;
+    float *gout = a.out + f0 * J * 4;
+    const int fl = lane < nf ? lane : nf - 1;
+
+    v3f_a4 farq[kIkFar];
+#pragma unroll
+    for (int k = 0; k < kIkFar; ++k) {
+        farq[k] = v3f_a4{0.0f, 0.0f, 0.0f};
+        if (k < a.nfar) farq[k] = *reinterpret_cast<const v3f_a4 *>(gpos + ((int64_t)fl * J + a.far_joint[k]) * 3);
+    }
+
+    const int l_frl = lane >> LG, l_d = (lane & (G - 1)) - ((l_frl * J) & (G - 1));
+    v3f_a4 pre[G], pre1[G];
+    auto issue = [&](const int c, v3f_a4 (&pre)[G]) {
+        int j = G * c + l_d;
+        j = j < 0 ? 0 : (j > J - 1 ? J - 1 : j);
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const int fr = FPI * u + l_frl, fc = fr < nf ? fr : nf - 1;
+            pre[u] = *reinterpret_cast<const v3f_a4 *>(gpos + ((int64_t)fc * J + j) * 3);
+        }
+    };
+    issue(0, pre);
+    if (ngroups > 1) issue(1, pre1);
+    auto park = [&](const int c, const v3f_a4 (&pre)[G]) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            float *p = sImg + (FPI * u + l_frl) * RS + ((c & 1) * G + (lane & (G - 1))) * 4;
+            if (PM_LDS_OK(p, 16u)) { p[0] = pre[u].x; p[1] = pre[u].y; p[2] = pre[u].z; }
+        }
+    };
+    float *row = sImg + lane * RS;
+    const int sf = (lane * J) & (G - 1);
+    float g[4] = {1.0f, 0.0f, 0.0f, 0.0f};   // world quaternion of the joint finished last
+    IkSaves sv = {};
+    int ri = 0;                              // next entry of the further-children list (wave-uniform)
+    wave_sync();
+    auto walk = [&](const int c) {
+        const int ob = __builtin_amdgcn_readfirstlane(a.wst[c]), oe = __builtin_amdgcn_readfirstlane(a.wst[c + 1]);
+        if (ob >= oe) return;
+        int code = __builtin_amdgcn_readfirstlane(a.ops[ob]);
+        float ppn[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pcn[4] = {0.0f, 0.0f, 0.0f, 0.0f}, tan[4] = {0.0f, 0.0f, 0.0f, 0.0f}, lenn = 0.0f;
+        auto fetch = [&](const int cd) {
+            if (!(cd & (1 << 29))) {
+                const int p = cd & 511, c1 = (cd >> 9) & 511;
+                lds_get<4>(row + ((p + sf) & SM) * 4, 0, ppn);
+                if (!(cd & (1 << 18))) lds_get<4>(row + ((c1 + sf) & SM) * 4, 0, pcn);
+                lds_get<4>(sOff, c1, tan);
+                lenn = sLen[c1];
+            }
+        };
+        fetch(code);
+#pragma unroll 1
+        for (int o = ob; o < oe; ++o) {
+            const int cur = code;
+            float pp[3] = {ppn[0], ppn[1], ppn[2]}, pc[3] = {pcn[0], pcn[1], pcn[2]}, ta[4] = {tan[0], tan[1], tan[2], tan[3]}, tb[4];
+            tb[0] = ta[0] * ta[3]; tb[1] = ta[1] * ta[3]; tb[2] = ta[2] * ta[3]; tb[3] = lenn;
+            const int p = cur & 511;
+            if (o + 1 < oe) {  // the next operation's operands: positions parked before this step began, never this operation's slot
+                code = __builtin_amdgcn_readfirstlane(a.ops[o + 1]);
+                fetch(code);
+            }
+            if (cur & (1 << 29)) {  // a joint without children keeps the identity (skeleton.py:126-130)
+                const float id[4] = {1.0f, 0.0f, 0.0f, 0.0f};
+                lds_put<4>(row + ((p + sf) & SM) * 4, 0, id);
+                continue;
+            }
+            const int ld = (cur >> 19) & 7, st = (cur >> 22) & 7, nroll = (cur >> 25) & 15;
+            if (cur & (1 << 18)) {  // the first child lies beyond the window
+                pc[0] = farq[0].x; pc[1] = farq[0].y; pc[2] = farq[0].z;
+#pragma unroll
+                for (int k = 0; k + 1 < kIkFar; ++k) farq[k] = farq[k + 1];
+            }
+            float gpre[4] = {g[0], g[1], g[2], g[3]};
+            ik_slot_load<0>(ld, sv, gpre);
+            if (ld == IKO_ROOT) { gpre[0] = 1.0f; gpre[1] = 0.0f; gpre[2] = 0.0f; gpre[3] = 0.0f; }
+            const float d[3] = {pc[0] - pp[0], pc[1] - pp[1], pc[2] - pp[2]};
+            float r[4];
+            bool inexact;
+            float un[3];
+            ik_align(gpre, d, ta, tb, r, inexact, nroll > 0, un);
+            qmul(gpre, r, g);
+            for (int rr = 0; rr < nroll; ++rr) {  // further children (wave-uniform)
+                const int w = __builtin_amdgcn_readfirstlane(a.rsrc[ri >> 1]);
+                const int e = (ri & 1) ? (w >> 16) & 0xffff : w & 0xffff;
+                ++ri;
+                const int gc = e & 511;
+                float tg[4], pg[4];
+                lds_get<4>(sOff, gc, tg);
+                const float lug = sLen[gc];
+                if (e & 0x8000) {
+                    pg[0] = farq[0].x; pg[1] = farq[0].y; pg[2] = farq[0].z;
+#pragma unroll
+                    for (int k = 0; k + 1 < kIkFar; ++k) farq[k] = farq[k + 1];
+                    } else {
+                    lds_get<4>(row + ((gc + sf) & SM) * 4, 0, pg);
+                }
+                const float dg[3] = {pg[0] - pp[0], pg[1] - pp[1], pg[2] - pp[2]};
+                float roll[4], g2[4], r2[4];
+                ik_roll(g, dg, d, un, inexact, tg, lug, roll);
+                qmul(g, roll, g2);
+                qmul(r, roll, r2);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { g[k] = g2[k]; r[k] = r2[k]; }
+            }
+            ik_slot_save<0>(st, sv, g);
+            lds_put<4>(row + ((p + sf) & SM) * 4, 0, r);  // the local rotation of p, through the slot its position came in by
+        }
+    };
+    const int s_d = l_d;
+    v4f outr[G];
+    auto read_group = [&](const int k) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const float *p = sImg + (FPI * u + l_frl) * RS + ((k & 1) * G + (lane & (G - 1))) * 4;
+            outr[u] = PM_LDS_OK(p, 16u) ? *reinterpret_cast<const v4f *>(p) : v4f{0, 0, 0, 0};
+        }
+    };
+    auto store_group = [&](const int k) {
+        const int j = G * k + s_d;
+        const bool jok = j >= 0 && j < J;
+        float *g0 = gout + (l_frl * J + (jok ? j : 0)) * 4;
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+            if (jok && FPI * u + l_frl < nf) __builtin_nontemporal_store(outr[u], reinterpret_cast<v4f *>(g0 + FPI * u * J * 4));
+    };
+    park(0, pre);
+    if (ngroups > 1) park(1, pre1);
+#pragma unroll
+    for (int k = 0; k < kIkFar; ++k) asm volatile("" : "+v"(farq[k]));
+    if (ngroups > 2) issue(2, pre);
+    for (int c = 0; c <= ngroups; ++c) {
+        wave_sync();
+        walk(c);
+        wave_sync();
+        if (c >= 1) {
+            read_group(c - 1);
+            wave_sync();
+            if (c + 1 < ngroups) park(c + 1, pre);
+            if (c + 2 < ngroups) issue(c + 2, pre);
+            store_group(c - 1);
+        }
+    }
+}
+
+// Host plan of the kernel above (see its header).  Returns false when the table does not fit: a child inside the window rule but
+// more than kIkFar children beyond it, more than 15 further children of one joint, more than kDeepSlots world quaternions alive.
+static bool ik_order_plan(const Topo16 &t, const int J, IkOrderArgs &a) {
+    int g8 = 8;
+    while (J % g8) g8 >>= 1;
+    const int D = g8 - 1;
+    const int ngroups = ((J + 6) >> 3) + 1;
+    if (ngroups + 2 > kIkOrderSteps) return false;
+    // operations in execution order: step (p >> 3) + 1, joint index inside a step -- i.e. plain index order, cut into steps
+    int nfar = 0, nr = 0;
+    uint16_t rs[PM_MAX_JOINTS];
+    for (int c = 0; c <= ngroups + 1; ++c) a.wst[c] = 0;
+    for (int p = 0; p < J; ++p) a.wst[(p >> 3) + 2]++;          // count of step (p >> 3) + 1, shifted by one for the prefix sum
+    for (int c = 1; c <= ngroups + 1; ++c) a.wst[c] += a.wst[c - 1];
+    for (int c = ngroups + 2; c < kIkOrderSteps; ++c) a.wst[c] = a.wst[ngroups + 1];
+    // world quaternion of p: needed by the operations of its children that have children; `chain` if that operation is the next
+    // one that aligns anything (operations of childless joints do not touch the registers)
+    int next_align[PM_MAX_JOINTS + 1];
+    next_align[J] = -1;
+    for (int p = J - 1; p >= 0; --p) next_align[p] = (t.cstart[p + 1] > t.cstart[p]) ? p : next_align[p + 1];
+    int last_use[PM_MAX_JOINTS], slot_of[PM_MAX_JOINTS], busy_until[kDeepSlots];
+    for (int p = 0; p < J; ++p) { last_use[p] = -1; slot_of[p] = -1; }
+    for (int j = 1; j < J; ++j) {
+        const int pa = t.parent[j];
+        if (t.cstart[j + 1] > t.cstart[j] && next_align[pa + 1] != j && last_use[pa] < j) last_use[pa] = j;
+    }
+    for (int k = 0; k < kDeepSlots; ++k) busy_until[k] = -1;
+    for (int p = 0; p < J; ++p) {
+        const int cs = t.cstart[p], ce = t.cstart[p + 1];
+        if (ce == cs) { a.ops[p] = p | (1 << 29); continue; }
+        const int hi = 8 * ((p >> 3) + 1) + D;                  // children up to here are read from the ring
+        const int c1 = t.clist[cs], c1far = c1 > hi;
+        if (c1far) { if (nfar == kIkFar) return false; a.far_joint[nfar++] = c1; }
+        const int nroll = ce - cs - 1;
+        if (nroll > 15) return false;
+        for (int k = cs + 1; k < ce; ++k) {
+            const int gc = t.clist[k], far = gc > hi;
+            if (far) { if (nfar == kIkFar) return false; a.far_joint[nfar++] = gc; }
+            rs[nr++] = (uint16_t)(gc | (far ? 0x8000 : 0));
+        }
+        int ld;
+        if (p == 0) ld = IKO_ROOT;
+        else if (next_align[t.parent[p] + 1] == p) ld = IKO_CHAIN;
+        else { ld = slot_of[t.parent[p]]; if (ld < 0) return false; }
+        int st = IKO_NONE;
+        if (last_use[p] >= 0) {
+            int k = 0;
+            while (k < kDeepSlots && busy_until[k] > p) ++k;   // (a set is free again for the operation that follows its last reader)
+            if (k == kDeepSlots) return false;
+            busy_until[k] = last_use[p];
+            slot_of[p] = k;
+            st = k;
+        }
+        a.ops[p] = p | (c1 << 9) | (c1far << 18) | (ld << 19) | (st << 22) | (nroll << 25);
+    }
+    for (int k = nfar; k < kIkFar; ++k) a.far_joint[k] = 0;
+    a.nfar = nfar;
+    for (int k = 0; k < PM_MAX_JOINTS / 2; ++k) a.rsrc[k] = 0;
+    for (int k = 0; k < nr; ++k) a.rsrc[k >> 1] |= (int32_t)((uint32_t)rs[k] << (16 * (k & 1)));
+    return true;
+}
+
+static int launch_ik_order(const IkOrderArgs &a, hipStream_t s) {
+    constexpr int G = 8;
+    const size_t lds = ((size_t)PM_WAVE * ik_deep_row(G) + 5 * (size_t)a.J) * sizeof(float);
+    const int64_t ntiles = (a.F + PM_WAVE - 1) / PM_WAVE;
+    const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
+    if (grid > 0x7fffffffLL) { set_error("from_root_positions: grid too large"); return PM_EUNSUPPORTED; }
+    set_kernel_name("void pm::from_root_positions_order_kernel<%d>(pm::IkOrderArgs)", G);
+    if (int e = allow_lds(from_root_positions_order_kernel<G>, lds)) return e;
+    hipLaunchKernelGGL(from_root_positions_order_kernel<G>, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
+    return PM_AFTER_LAUNCH("from_root_positions (lane per frame, any order) launch");
+}
+
+
 // Joints with children onto two chains, one item per chain and step.  A joint is ready two steps after its parent, or
 // right after it on the parent's own chain (its quaternion is still in that lane's registers; the look-ahead fetch of the
 // next step is issued before the current one stores).  Longest remaining path first, a further child counting like an
@@ -856,6 +1134,15 @@ extern "C" int pm_from_root_positions_f32(const float *positions, const int32_t 
         if (ik_deep_plan(a.topo, J, da)) {
             da.pos = positions; da.offsets = offsets; da.out = rotations; da.F = F; da.J = J;
             return launch_ik_deep<8>(da, s);
+        }
+    }
+    // any other parents-first order (level-order tables): the same lane-per-frame walk driven by a list of operations, if the
+    // table fits its window / queue / register sets.  PM_IK_ORDER (PM_TUNING build only): 0 = never, 1 = whenever eligible
+    if (const int ord = tune_env("PM_IK_ORDER", -1); aligned16(rotations) && J >= 2 && ord != 0 && tune_env("PM_IK_DEEP", -1) != 0 && (ord == 1 || J >= kIkOrderMinJ)) {
+        IkOrderArgs oa;
+        if (ik_order_plan(a.topo, J, oa)) {
+            oa.pos = positions; oa.offsets = offsets; oa.out = rotations; oa.F = F; oa.J = J;
+            return launch_ik_order(oa, s);
         }
     }
     const size_t per_frame = (size_t)ik_frame_stride(J) * sizeof(float), fixed = (size_t)ik_tables_floats(J) * sizeof(float) + (size_t)(J + 2) * 32 + 256;

@@ -224,6 +224,89 @@ def test_gpu_from_root_positions_lane_per_frame_on_depth_first_skeletons(J, kind
         assert np.abs(p2 - p_ref).max() <= (2e-5 if J <= 128 else 1e-4), float(np.abs(p2 - p_ref).max())
 
 
+def _level_order(par):
+    """the same tree stored breadth first (the order of the SMPL family's tables): children of a joint in their old order"""
+    J = len(par)
+    kids = [[] for _ in range(J)]
+    for j in range(1, J):
+        kids[par[j]].append(j)
+    order, q = [], [0]
+    while q:
+        j = q.pop(0)
+        order.append(j)
+        q.extend(kids[j])
+    new = {o: i for i, o in enumerate(order)}
+    p2 = np.zeros(J, np.int32)
+    for o in range(1, J):
+        p2[new[o]] = new[par[o]]
+    return p2
+
+
+def _windowed_tree(J, w, rng):
+    """parents first, every parent at most `w` joints before its child: neither depth first nor breadth first"""
+    p = np.zeros(J, np.int32)
+    for j in range(1, J):
+        p[j] = rng.integers(max(0, j - w), j)
+    return p
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,order", [("smplh", True), ("smpl24", True), ("smplx55", None), ("bfs_body4_47", None), ("bfs_body5_53", None), ("win3_40", None),
+                                        ("win4_64", None), ("win2_128", None), ("win6_96", None), ("win3_33", None), ("bfs_chain_64", None), ("win2_511", None)])
+def test_gpu_from_root_positions_lane_per_frame_on_tables_in_any_order(kind, order):
+    """tables that are parents-first but NOT depth first (SMPL-H's level-order 52 joints) take from_root_positions_order_kernel when their
+    children sit inside the ring's window or the per-lane queue (ik_order_plan), the tile kernels otherwise: same bars either way, full and
+    partial tiles of 64 frames"""
+    import pymotion_amd.ops.skeleton as sk
+    from pymotion_amd import _lib
+    from pymotion_amd import synthetic as syn
+
+    rng = np.random.default_rng(len(kind))
+    if kind == "smplh":
+        par = syn.PARENTS_52
+    elif kind == "smpl24":
+        par = np.concatenate([syn.PARENTS_52[:22], [20, 21]]).astype(np.int32)
+    elif kind == "smplx55":  # body, jaw and eyes under the head, two hands: level order
+        hand = lambda w, b: [w if k % 3 == 0 else b + k - 1 for k in range(15)]  # noqa: E731
+        par = np.asarray(list(syn.PARENTS_52[:22]) + [15, 15, 15] + hand(20, 25) + hand(21, 40), np.int32)
+    elif kind.startswith("bfs_body"):
+        par = _level_order(_dfs_humanoid(int(kind.split("_")[2]), int(kind[8])))
+    elif kind.startswith("bfs_chain"):
+        par = _level_order(_chain_like(int(kind.split("_")[2])))
+    else:
+        par = _windowed_tree(int(kind.split("_")[1]), int(kind[3]), rng)
+    J = len(par)
+    assert (par[1:] < np.arange(1, J)).all()
+    dep = np.zeros(J, int)
+    for j in range(1, J):
+        dep[j] = dep[par[j]] + 1
+    depth = int(dep.max())
+    took = set()
+    for F in (1, 63, 64, 65, 400):
+        rot, root, off, par = syn.fk_workload(F, parents=par, seed=J + F, normalized=True, offset_scale=0.1)
+        pos, _ = co.fk(rot.astype(np.float64), np.zeros((F, 3)), off.astype(np.float64), par)
+        pos = pos.astype(np.float32)
+        got = sk.from_root_positions(pos, par, off)
+        name = _lib.last_kernel_name()
+        took.add("order" if "from_root_positions_order_kernel" in name else ("deep" if "deep_kernel" in name else "tile"))
+        assert order is None or ("from_root_positions_order_kernel" in name) == order, name
+        ref = co.from_root_positions(pos.astype(np.float64), par, off.astype(np.float64))
+        err = np.minimum(np.abs(got - ref).max(-1), np.abs(got + ref).max(-1))
+        # (these deep, narrow trees have many nearly straight bones: the sensitivity is the max over twelve one-ulp draws -- with three the
+        # worst record of win6_96 read 13.8 x, with twelve 1.5 x, on this kernel and on the tile kernel alike)
+        sens = _reference_sensitivity(pos, par, off, ref, draws=12 if J <= 128 else 3)
+        k = 8.0 if J <= 128 else 64.0
+        assert (err <= 2e-5 + k * sens).all(), (F, name, float(err.max()), float(((err - 2e-5) / np.maximum(sens, 1e-12)).max()))
+        assert np.median(err) <= (1e-6 if J <= 128 else 1e-5), (F, float(np.median(err)))
+        leaves = np.setdiff1d(np.arange(J), par[1:])
+        assert (got[:, leaves] == np.array([1, 0, 0, 0], np.float32)).all()
+        p2, _ = sk.fk(got, np.zeros_like(root), off, par)
+        p_ref, _ = co.fk(ref, np.zeros((F, 3)), off.astype(np.float64), par)
+        # (positions through fk: the rotations' errors add up along a chain -- beyond ~64 joints deep the bar of the long skeletons above)
+        assert np.abs(p2 - p_ref).max() <= (2e-5 if depth <= 64 else 1e-4), float(np.abs(p2 - p_ref).max())
+    print(kind, J, depth, sorted(took))
+
+
 @pytest.mark.gpu
 def test_gpu_mirror_positions_vs_reference_golden():
     import pymotion_amd.ops.skeleton as sk

@@ -62,6 +62,10 @@ def trees(J):
     yield n
     for _ in range(3):
         yield syn.random_parents(J, rng)
+    for w in (2, 3, 6):                                              # parents a few joints back: ik_order_plan's window, queue and register sets
+        yield np.concatenate([[0], [rng.integers(max(0, j - w), j) for j in range(1, J)]]).astype(np.int32)
+    if J == 52:
+        yield syn.PARENTS_52                                         # SMPL-H's level-order table
 for J in (1, 2, 3, 22, 27, 28, 52, 64, 65, 128, 250, 251, 254, 255, 512):
     for par in trees(J):
         pp = par.ctypes.data_as(C.c_void_p)
