@@ -19,6 +19,7 @@ VARIANT_PATHS = {
     "debug": os.path.join(_HERE, "libpmhip_debug.so"),
     "asan": os.path.join(_HERE, "libpmhip_asan.so"),  # host code under ASan + UBSan (tests/test_sanitizers.py)
     "ab": os.path.join(_HERE, "libpmhip_ab.so"),      # scratch build for same-box A/B timing (tools/ab_build.sh); never shipped
+    "ab2": os.path.join(_HERE, "libpmhip_ab2.so"),    # a second one (tools/ab_file.sh)
 }
 
 PM_OK, PM_EINVAL, PM_ETOPOLOGY, PM_EHIP, PM_EUNSUPPORTED = 0, -1, -2, -3, -4

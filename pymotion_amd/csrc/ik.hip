@@ -538,7 +538,8 @@ __device__ __forceinline__ void ik_slot_save(const int st, IkSaves &sv, const fl
 // half the ring, sixteen waves per CU -- moves HALF lines and is slower for it (240 us; J = 128 at 2^19: 615 against 444 us): not instantiated.
 __host__ __device__ constexpr int ik_deep_row(const int G) { return 2 * G * 4 + 4; }  // 2 G 16-byte slots + 16 bytes: (row / 4) odd
 
-template <int G>
+// NF: entries of the queue of further children (4 / 8 / 12: every consumption shifts the whole queue, 3 (NF - 1) moves)
+template <int G, int NF>
 __global__ __launch_bounds__(PM_WAVE) void from_root_positions_deep_kernel(const IkDeepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int RS = ik_deep_row(G), FPI = PM_WAVE / G, LG = (G == 8) ? 3 : 2, SM = 2 * G - 1;  // frames per load / store instruction, log2 G, slot mask
@@ -566,9 +567,9 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_deep_kernel(const
     const int fl = lane < nf ? lane : nf - 1;
 
     // the further children's positions of this lane's frame, in the order they are consumed
-    v3f_a4 farq[kIkFar];
+    v3f_a4 farq[NF];
 #pragma unroll
-    for (int k = 0; k < kIkFar; ++k) {
+    for (int k = 0; k < NF; ++k) {
         farq[k] = v3f_a4{0.0f, 0.0f, 0.0f};
         if (k < a.nfar) farq[k] = *reinterpret_cast<const v3f_a4 *>(gpos + ((int64_t)fl * J + a.far_joint[k]) * 3);
     }
@@ -642,7 +643,7 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_deep_kernel(const
                     const float lug = sLen[gc];
                     const float dg[3] = {farq[0].x - pp[0], farq[0].y - pp[1], farq[0].z - pp[2]};
 #pragma unroll
-                    for (int k = 0; k + 1 < kIkFar; ++k) farq[k] = farq[k + 1];
+                    for (int k = 0; k + 1 < NF; ++k) farq[k] = farq[k + 1];
                     float roll[4], g2[4], r2[4];
                     ik_roll(g, dg, d, un, inexact, tg, lug, roll);
                     qmul(g, roll, g2);
@@ -687,7 +688,7 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_deep_kernel(const
     park(0, pre);
     if (ngroups > 1) park(1, pre1);
 #pragma unroll
-    for (int k = 0; k < kIkFar; ++k) asm volatile("" : "+v"(farq[k]));  // settled HERE (everything requested so far has arrived): their first use is inside the walk
+    for (int k = 0; k < NF; ++k) asm volatile("" : "+v"(farq[k]));  // settled HERE (everything requested so far has arrived): their first use is inside the walk
     if (ngroups > 2) issue(2, pre);
     for (int c = 0; c <= ngroups; ++c) {
         wave_sync();
@@ -753,9 +754,15 @@ static int launch_ik_deep(const IkDeepArgs &a, hipStream_t s) {
     const int64_t ntiles = (a.F + PM_WAVE - 1) / PM_WAVE;
     const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
     if (grid > 0x7fffffffLL) { set_error("from_root_positions: grid too large"); return PM_EUNSUPPORTED; }
-    set_kernel_name("void pm::from_root_positions_deep_kernel<%d>(pm::IkDeepArgs)", G);
-    if (int e = allow_lds(from_root_positions_deep_kernel<G>, lds)) return e;
-    hipLaunchKernelGGL(from_root_positions_deep_kernel<G>, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
+    const int nf = a.nfar <= 4 ? 4 : (a.nfar <= 8 ? 8 : 12);
+    set_kernel_name("void pm::from_root_positions_deep_kernel<%d, %d>(pm::IkDeepArgs)", G, nf);
+#define PM_IKD_LAUNCH(N)                                                                                       \
+    {                                                                                                          \
+        if (int e = allow_lds(from_root_positions_deep_kernel<G, N>, lds)) return e;                          \
+        hipLaunchKernelGGL((from_root_positions_deep_kernel<G, N>), dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a); \
+    }
+    if (nf == 4) PM_IKD_LAUNCH(4) else if (nf == 8) PM_IKD_LAUNCH(8) else PM_IKD_LAUNCH(12)
+#undef PM_IKD_LAUNCH
     return PM_AFTER_LAUNCH("from_root_positions (lane per frame) launch");
 }
 
@@ -777,6 +784,7 @@ static int launch_ik_deep(const IkDeepArgs &a, hipStream_t s) {
 // SMPL-H as stored (52 joints, level order): 8 queue entries, 4 register sets.
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int kIkOrderMinJ = 24;
+constexpr int kIkOrderFar = 16;  // queue entries (the kernel is instantiated for 4 / 8 / 12 / 16: every consumption shifts the whole queue)
 constexpr int kIkOrderSteps = PM_MAX_JOINTS / 8 + 4;
 enum : int { IKO_CHAIN = 6, IKO_ROOT = 7, IKO_NONE = 7 };
 
@@ -787,14 +795,14 @@ struct IkOrderArgs {
     int64_t F;
     int32_t J;
     int32_t nfar;
-    int32_t far_joint[kIkFar];         // joints fetched per lane at the start of a tile, in the order the operations consume them
+    int32_t far_joint[kIkOrderFar];    // joints fetched per lane at the start of a tile, in the order the operations consume them
     int32_t wst[kIkOrderSteps];        // step c runs operations [wst[c], wst[c + 1])
     int32_t rsrc[PM_MAX_JOINTS / 2];   // further children, 16 bits each: joint | far << 15, in the order the operations consume them
     int32_t ops[PM_MAX_JOINTS];        // p | c1 << 9 | c1far << 18 | ld << 19 | st << 22 | nroll << 25 | leaf << 29
 };
 static_assert(sizeof(IkOrderArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
-template <int G>
+template <int G, int NF>
 __global__ __launch_bounds__(PM_WAVE) void from_root_positions_order_kernel(const IkOrderArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int RS = ik_deep_row(G), FPI = PM_WAVE / G, LG = 3, SM = 2 * G - 1;
@@ -821,9 +829,9 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_order_kernel(cons
     float *gout = a.out + f0 * J * 4;
     const int fl = lane < nf ? lane : nf - 1;
 
-    v3f_a4 farq[kIkFar];
+    v3f_a4 farq[NF];
 #pragma unroll
-    for (int k = 0; k < kIkFar; ++k) {
+    for (int k = 0; k < NF; ++k) {
         farq[k] = v3f_a4{0.0f, 0.0f, 0.0f};
         if (k < a.nfar) farq[k] = *reinterpret_cast<const v3f_a4 *>(gpos + ((int64_t)fl * J + a.far_joint[k]) * 3);
     }
@@ -888,7 +896,7 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_order_kernel(cons
             if (cur & (1 << 18)) {  // the first child lies beyond the window
                 pc[0] = farq[0].x; pc[1] = farq[0].y; pc[2] = farq[0].z;
 #pragma unroll
-                for (int k = 0; k + 1 < kIkFar; ++k) farq[k] = farq[k + 1];
+                for (int k = 0; k + 1 < NF; ++k) farq[k] = farq[k + 1];
             }
             float gpre[4] = {g[0], g[1], g[2], g[3]};
             ik_slot_load<0>(ld, sv, gpre);
@@ -910,7 +918,7 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_order_kernel(cons
                 if (e & 0x8000) {
                     pg[0] = farq[0].x; pg[1] = farq[0].y; pg[2] = farq[0].z;
 #pragma unroll
-                    for (int k = 0; k + 1 < kIkFar; ++k) farq[k] = farq[k + 1];
+                    for (int k = 0; k + 1 < NF; ++k) farq[k] = farq[k + 1];
                     } else {
                     lds_get<4>(row + ((gc + sf) & SM) * 4, 0, pg);
                 }
@@ -946,7 +954,7 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_order_kernel(cons
     park(0, pre);
     if (ngroups > 1) park(1, pre1);
 #pragma unroll
-    for (int k = 0; k < kIkFar; ++k) asm volatile("" : "+v"(farq[k]));
+    for (int k = 0; k < NF; ++k) asm volatile("" : "+v"(farq[k]));
     if (ngroups > 2) issue(2, pre);
     for (int c = 0; c <= ngroups; ++c) {
         wave_sync();
@@ -963,7 +971,7 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_order_kernel(cons
 }
 
 // Host plan of the kernel above (see its header).  Returns false when the table does not fit: a child inside the window rule but
-// more than kIkFar children beyond it, more than 15 further children of one joint, more than kDeepSlots world quaternions alive.
+// more than kIkOrderFar children beyond it, more than 15 further children of one joint, more than kDeepSlots world quaternions alive.
 static bool ik_order_plan(const Topo16 &t, const int J, IkOrderArgs &a) {
     int g8 = 8;
     while (J % g8) g8 >>= 1;
@@ -994,12 +1002,12 @@ static bool ik_order_plan(const Topo16 &t, const int J, IkOrderArgs &a) {
         if (ce == cs) { a.ops[p] = p | (1 << 29); continue; }
         const int hi = 8 * ((p >> 3) + 1) + D;                  // children up to here are read from the ring
         const int c1 = t.clist[cs], c1far = c1 > hi;
-        if (c1far) { if (nfar == kIkFar) return false; a.far_joint[nfar++] = c1; }
+        if (c1far) { if (nfar == kIkOrderFar) return false; a.far_joint[nfar++] = c1; }
         const int nroll = ce - cs - 1;
         if (nroll > 15) return false;
         for (int k = cs + 1; k < ce; ++k) {
             const int gc = t.clist[k], far = gc > hi;
-            if (far) { if (nfar == kIkFar) return false; a.far_joint[nfar++] = gc; }
+            if (far) { if (nfar == kIkOrderFar) return false; a.far_joint[nfar++] = gc; }
             rs[nr++] = (uint16_t)(gc | (far ? 0x8000 : 0));
         }
         int ld;
@@ -1017,7 +1025,7 @@ static bool ik_order_plan(const Topo16 &t, const int J, IkOrderArgs &a) {
         }
         a.ops[p] = p | (c1 << 9) | (c1far << 18) | (ld << 19) | (st << 22) | (nroll << 25);
     }
-    for (int k = nfar; k < kIkFar; ++k) a.far_joint[k] = 0;
+    for (int k = nfar; k < kIkOrderFar; ++k) a.far_joint[k] = 0;
     a.nfar = nfar;
     for (int k = 0; k < PM_MAX_JOINTS / 2; ++k) a.rsrc[k] = 0;
     for (int k = 0; k < nr; ++k) a.rsrc[k >> 1] |= (int32_t)((uint32_t)rs[k] << (16 * (k & 1)));
@@ -1030,17 +1038,18 @@ static int launch_ik_order(const IkOrderArgs &a, hipStream_t s) {
     const int64_t ntiles = (a.F + PM_WAVE - 1) / PM_WAVE;
     const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
     if (grid > 0x7fffffffLL) { set_error("from_root_positions: grid too large"); return PM_EUNSUPPORTED; }
-    set_kernel_name("void pm::from_root_positions_order_kernel<%d>(pm::IkOrderArgs)", G);
-    if (int e = allow_lds(from_root_positions_order_kernel<G>, lds)) return e;
-    hipLaunchKernelGGL(from_root_positions_order_kernel<G>, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
+    const int nf = a.nfar <= 4 ? 4 : (a.nfar <= 8 ? 8 : (a.nfar <= 12 ? 12 : 16));
+    set_kernel_name("void pm::from_root_positions_order_kernel<%d, %d>(pm::IkOrderArgs)", G, nf);
+#define PM_IKO_LAUNCH(N)                                                                                        \
+    {                                                                                                           \
+        if (int e = allow_lds(from_root_positions_order_kernel<G, N>, lds)) return e;                          \
+        hipLaunchKernelGGL((from_root_positions_order_kernel<G, N>), dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a); \
+    }
+    if (nf == 4) PM_IKO_LAUNCH(4) else if (nf == 8) PM_IKO_LAUNCH(8) else if (nf == 12) PM_IKO_LAUNCH(12) else PM_IKO_LAUNCH(16)
+#undef PM_IKO_LAUNCH
     return PM_AFTER_LAUNCH("from_root_positions (lane per frame, any order) launch");
 }
 
-
-// Joints with children onto two chains, one item per chain and step.  A joint is ready two steps after its parent, or
-// right after it on the parent's own chain (its quaternion is still in that lane's registers; the look-ahead fetch of the
-// next step is issued before the current one stores).  Longest remaining path first, a further child counting like an
-// alignment.  Returns the number of steps; 0 if it does not fit or the tree is too narrow to pay.
 static int ik_schedule(const Topo16 &t, const int J, uint8_t *sched, const int C = 2) {
     int height[PM_MAX_JOINTS], done_step[PM_MAX_JOINTS], done_chain[PM_MAX_JOINTS], items = 0;
     for (int j = 0; j < J; ++j) { height[j] = 0; done_step[j] = -1; done_chain[j] = -1; }

@@ -252,7 +252,7 @@ def _windowed_tree(J, w, rng):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,order", [("smplh", True), ("smpl24", True), ("smplx55", None), ("bfs_body4_47", None), ("bfs_body5_53", None), ("win3_40", None),
-                                        ("win4_64", None), ("win2_128", None), ("win6_96", None), ("win3_33", None), ("bfs_chain_64", None), ("win2_511", None)])
+                                        ("win4_64", None), ("win2_128", None), ("win6_96", None), ("win3_33", None), ("bfs_chain_64", None), ("bfs_chain_128", None)])
 def test_gpu_from_root_positions_lane_per_frame_on_tables_in_any_order(kind, order):
     """tables that are parents-first but NOT depth first (SMPL-H's level-order 52 joints) take from_root_positions_order_kernel when their
     children sit inside the ring's window or the per-lane queue (ik_order_plan), the tile kernels otherwise: same bars either way, full and
