@@ -802,8 +802,11 @@ struct IkOrderArgs {
 };
 static_assert(sizeof(IkOrderArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
-template <int G, int NF>
+template <int G, int NF, bool TWO>
 __global__ __launch_bounds__(PM_WAVE) void from_root_positions_order_kernel(const IkOrderArgs a) {
+    // TWO: the ring leaves room for eight waves on a CU, which the dispatcher spreads evenly only if no SIMD can take a third: a register
+    // count beyond 512 / 3 makes sure (the kernel needs ~160; without this 2^18 x 52 reads 109 us against 104 us)
+    if constexpr (TWO) asm volatile("; two waves per SIMD" ::: "v183");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int RS = ik_deep_row(G), FPI = PM_WAVE / G, LG = 3, SM = 2 * G - 1;
     static_assert(G == 8, "groups of eight records");
@@ -829,12 +832,13 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_order_kernel(cons
     float *gout = a.out + f0 * J * 4;
     const int fl = lane < nf ? lane : nf - 1;
 
-    v3f_a4 farq[NF];
+    v3f_a4 farl[NF];
 #pragma unroll
     for (int k = 0; k < NF; ++k) {
-        farq[k] = v3f_a4{0.0f, 0.0f, 0.0f};
-        if (k < a.nfar) farq[k] = *reinterpret_cast<const v3f_a4 *>(gpos + ((int64_t)fl * J + a.far_joint[k]) * 3);
+        farl[k] = v3f_a4{0.0f, 0.0f, 0.0f};
+        if (k < a.nfar) farl[k] = *reinterpret_cast<const v3f_a4 *>(gpos + ((int64_t)fl * J + a.far_joint[k]) * 3);
     }
+    float fq[NF][3];  // the queue itself: consumed from entry 0, shifted IN PLACE (far_pop)
 
     const int l_frl = lane >> LG, l_d = (lane & (G - 1)) - ((l_frl * J) & (G - 1));
     v3f_a4 pre[G], pre1[G];
@@ -862,76 +866,94 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_order_kernel(cons
     IkSaves sv = {};
     int ri = 0;                              // next entry of the further-children list (wave-uniform)
     wave_sync();
+    // entry 0 out, the rest one place down -- as moves the compiler cannot re-home: written as plain assignments it gives the queue other
+    // registers on the path that shifts, and the path that does NOT then copies the whole queue (18 v_mov in every operation)
+    auto far_pop = [&](auto &dst) {
+        dst[0] = fq[0][0]; dst[1] = fq[0][1]; dst[2] = fq[0][2];
+#pragma unroll
+        for (int k = 0; k + 1 < NF; ++k)
+            asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5"
+                         : "+v"(fq[k][0]), "+v"(fq[k][1]), "+v"(fq[k][2]) : "v"(fq[k + 1][0]), "v"(fq[k + 1][1]), "v"(fq[k + 1][2]));
+    };
+    // An operation's operands (P_p, P_c1, the first child's table row) are requested while the operation before it computes; two sets used in
+    // turn (a single look-ahead set is copied with ~20 v_mov per operation)
+    struct Opn { float pp[4], pc[4], ta[4], len; };
+    auto fetch = [&](const int cd, Opn &q) {
+        if (!(cd & (1 << 29))) {
+            const int p = cd & 511, c1 = (cd >> 9) & 511;
+            lds_get<4>(row + ((p + sf) & SM) * 4, 0, q.pp);
+            if (!(cd & (1 << 18))) lds_get<4>(row + ((c1 + sf) & SM) * 4, 0, q.pc);
+            lds_get<4>(sOff, c1, q.ta);
+            q.len = sLen[c1];
+        }
+    };
+    auto op = [&](const int cur, const Opn &q, const bool more, const int nxt, Opn &qn) {
+        asm volatile("" ::"v"(q.pp[3]), "v"(q.pc[3]));  // (the unused fourth floats: left free, their registers are re-used for addresses right behind the read -- a wait per read)
+        const float pp[3] = {q.pp[0], q.pp[1], q.pp[2]}, ta[4] = {q.ta[0], q.ta[1], q.ta[2], q.ta[3]};
+        float pc[3] = {q.pc[0], q.pc[1], q.pc[2]}, tb[4];
+        tb[0] = ta[0] * ta[3]; tb[1] = ta[1] * ta[3]; tb[2] = ta[2] * ta[3]; tb[3] = q.len;
+        const int p = cur & 511;
+        if (more) fetch(nxt, qn);  // positions parked before this step began, never this operation's own slot
+        if (cur & (1 << 29)) {  // a joint without children keeps the identity (skeleton.py:126-130)
+            const float id[4] = {1.0f, 0.0f, 0.0f, 0.0f};
+            lds_put<4>(row + ((p + sf) & SM) * 4, 0, id);
+            return;
+        }
+        const int ld = (cur >> 19) & 7, st = (cur >> 22) & 7, nroll = (cur >> 25) & 15;
+        if (cur & (1 << 18)) {  // the first child lies beyond the window
+            far_pop(pc);
+        }
+        float gpre[4] = {g[0], g[1], g[2], g[3]};
+        ik_slot_load<0>(ld, sv, gpre);
+        if (ld == IKO_ROOT) { gpre[0] = 1.0f; gpre[1] = 0.0f; gpre[2] = 0.0f; gpre[3] = 0.0f; }
+        const float d[3] = {pc[0] - pp[0], pc[1] - pp[1], pc[2] - pp[2]};
+        float r[4];
+        bool inexact;
+        float un[3];
+        ik_align(gpre, d, ta, tb, r, inexact, nroll > 0, un);
+        qmul(gpre, r, g);
+        for (int rr = 0; rr < nroll; ++rr) {  // further children (wave-uniform)
+            const int w = __builtin_amdgcn_readfirstlane(a.rsrc[ri >> 1]);
+            const int e = (ri & 1) ? (w >> 16) & 0xffff : w & 0xffff;
+            ++ri;
+            const int gc = e & 511;
+            float tg[4], pg[4];
+            lds_get<4>(sOff, gc, tg);
+            const float lug = sLen[gc];
+            if (e & 0x8000) {
+                far_pop(pg);
+            } else {
+                lds_get<4>(row + ((gc + sf) & SM) * 4, 0, pg);
+            }
+            const float dg[3] = {pg[0] - pp[0], pg[1] - pp[1], pg[2] - pp[2]};
+            float roll[4], g2[4], r2[4];
+            ik_roll(g, dg, d, un, inexact, tg, lug, roll);
+            qmul(g, roll, g2);
+            qmul(r, roll, r2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { g[k] = g2[k]; r[k] = r2[k]; }
+        }
+        ik_slot_save<0>(st, sv, g);
+        lds_put<4>(row + ((p + sf) & SM) * 4, 0, r);  // the local rotation of p, through the slot its position came in by
+    };
     auto walk = [&](const int c) {
         const int ob = __builtin_amdgcn_readfirstlane(a.wst[c]), oe = __builtin_amdgcn_readfirstlane(a.wst[c + 1]);
         if (ob >= oe) return;
-        int code = __builtin_amdgcn_readfirstlane(a.ops[ob]);
-        float ppn[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pcn[4] = {0.0f, 0.0f, 0.0f, 0.0f}, tan[4] = {0.0f, 0.0f, 0.0f, 0.0f}, lenn = 0.0f;
-        auto fetch = [&](const int cd) {
-            if (!(cd & (1 << 29))) {
-                const int p = cd & 511, c1 = (cd >> 9) & 511;
-                lds_get<4>(row + ((p + sf) & SM) * 4, 0, ppn);
-                if (!(cd & (1 << 18))) lds_get<4>(row + ((c1 + sf) & SM) * 4, 0, pcn);
-                lds_get<4>(sOff, c1, tan);
-                lenn = sLen[c1];
-            }
-        };
-        fetch(code);
+        Opn qa = {}, qb = {};
+        int code = __builtin_amdgcn_readfirstlane(a.ops[ob]), o = ob;
+        fetch(code, qa);
 #pragma unroll 1
-        for (int o = ob; o < oe; ++o) {
-            const int cur = code;
-            float pp[3] = {ppn[0], ppn[1], ppn[2]}, pc[3] = {pcn[0], pcn[1], pcn[2]}, ta[4] = {tan[0], tan[1], tan[2], tan[3]}, tb[4];
-            tb[0] = ta[0] * ta[3]; tb[1] = ta[1] * ta[3]; tb[2] = ta[2] * ta[3]; tb[3] = lenn;
-            const int p = cur & 511;
-            if (o + 1 < oe) {  // the next operation's operands: positions parked before this step began, never this operation's slot
-                code = __builtin_amdgcn_readfirstlane(a.ops[o + 1]);
-                fetch(code);
-            }
-            if (cur & (1 << 29)) {  // a joint without children keeps the identity (skeleton.py:126-130)
-                const float id[4] = {1.0f, 0.0f, 0.0f, 0.0f};
-                lds_put<4>(row + ((p + sf) & SM) * 4, 0, id);
-                continue;
-            }
-            const int ld = (cur >> 19) & 7, st = (cur >> 22) & 7, nroll = (cur >> 25) & 15;
-            if (cur & (1 << 18)) {  // the first child lies beyond the window
-                pc[0] = farq[0].x; pc[1] = farq[0].y; pc[2] = farq[0].z;
-#pragma unroll
-                for (int k = 0; k + 1 < NF; ++k) farq[k] = farq[k + 1];
-            }
-            float gpre[4] = {g[0], g[1], g[2], g[3]};
-            ik_slot_load<0>(ld, sv, gpre);
-            if (ld == IKO_ROOT) { gpre[0] = 1.0f; gpre[1] = 0.0f; gpre[2] = 0.0f; gpre[3] = 0.0f; }
-            const float d[3] = {pc[0] - pp[0], pc[1] - pp[1], pc[2] - pp[2]};
-            float r[4];
-            bool inexact;
-            float un[3];
-            ik_align(gpre, d, ta, tb, r, inexact, nroll > 0, un);
-            qmul(gpre, r, g);
-            for (int rr = 0; rr < nroll; ++rr) {  // further children (wave-uniform)
-                const int w = __builtin_amdgcn_readfirstlane(a.rsrc[ri >> 1]);
-                const int e = (ri & 1) ? (w >> 16) & 0xffff : w & 0xffff;
-                ++ri;
-                const int gc = e & 511;
-                float tg[4], pg[4];
-                lds_get<4>(sOff, gc, tg);
-                const float lug = sLen[gc];
-                if (e & 0x8000) {
-                    pg[0] = farq[0].x; pg[1] = farq[0].y; pg[2] = farq[0].z;
-#pragma unroll
-                    for (int k = 0; k + 1 < NF; ++k) farq[k] = farq[k + 1];
-                    } else {
-                    lds_get<4>(row + ((gc + sf) & SM) * 4, 0, pg);
-                }
-                const float dg[3] = {pg[0] - pp[0], pg[1] - pp[1], pg[2] - pp[2]};
-                float roll[4], g2[4], r2[4];
-                ik_roll(g, dg, d, un, inexact, tg, lug, roll);
-                qmul(g, roll, g2);
-                qmul(r, roll, r2);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { g[k] = g2[k]; r[k] = r2[k]; }
-            }
-            ik_slot_save<0>(st, sv, g);
-            lds_put<4>(row + ((p + sf) & SM) * 4, 0, r);  // the local rotation of p, through the slot its position came in by
+        for (;;) {
+            bool more = o + 1 < oe;
+            int nxt = more ? __builtin_amdgcn_readfirstlane(a.ops[o + 1]) : 0;
+            op(code, qa, more, nxt, qb);
+            if (!more) break;
+            ++o; code = nxt;
+            more = o + 1 < oe;
+            nxt = more ? __builtin_amdgcn_readfirstlane(a.ops[o + 1]) : 0;
+            op(code, qb, more, nxt, qa);
+            if (!more) break;
+            ++o; code = nxt;
         }
     };
     const int s_d = l_d;
@@ -954,7 +976,10 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_order_kernel(cons
     park(0, pre);
     if (ngroups > 1) park(1, pre1);
 #pragma unroll
-    for (int k = 0; k < NF; ++k) asm volatile("" : "+v"(farq[k]));
+    for (int k = 0; k < NF; ++k) {  // settled HERE (everything requested so far has arrived): their first use is inside the walk
+        fq[k][0] = farl[k].x; fq[k][1] = farl[k].y; fq[k][2] = farl[k].z;
+        asm volatile("" : "+v"(fq[k][0]), "+v"(fq[k][1]), "+v"(fq[k][2]));
+    }
     if (ngroups > 2) issue(2, pre);
     for (int c = 0; c <= ngroups; ++c) {
         wave_sync();
@@ -1039,13 +1064,15 @@ static int launch_ik_order(const IkOrderArgs &a, hipStream_t s) {
     const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
     if (grid > 0x7fffffffLL) { set_error("from_root_positions: grid too large"); return PM_EUNSUPPORTED; }
     const int nf = a.nfar <= 4 ? 4 : (a.nfar <= 8 ? 8 : (a.nfar <= 12 ? 12 : 16));
-    set_kernel_name("void pm::from_root_positions_order_kernel<%d, %d>(pm::IkOrderArgs)", G, nf);
-#define PM_IKO_LAUNCH(N)                                                                                        \
-    {                                                                                                           \
-        if (int e = allow_lds(from_root_positions_order_kernel<G, N>, lds)) return e;                          \
-        hipLaunchKernelGGL((from_root_positions_order_kernel<G, N>), dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a); \
+    const bool two = 9 * ((lds + 511) & ~(size_t)511) > kMaxLds;  // fewer than nine waves fit a CU (LDS is granted in 512-byte units)
+    set_kernel_name("void pm::from_root_positions_order_kernel<%d, %d, %s>(pm::IkOrderArgs)", G, nf, tf(two));
+#define PM_IKO_LAUNCH(N, T)                                                                                        \
+    {                                                                                                              \
+        if (int e = allow_lds(from_root_positions_order_kernel<G, N, T>, lds)) return e;                          \
+        hipLaunchKernelGGL((from_root_positions_order_kernel<G, N, T>), dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a); \
     }
-    if (nf == 4) PM_IKO_LAUNCH(4) else if (nf == 8) PM_IKO_LAUNCH(8) else if (nf == 12) PM_IKO_LAUNCH(12) else PM_IKO_LAUNCH(16)
+    if (two) { if (nf == 4) PM_IKO_LAUNCH(4, true) else if (nf == 8) PM_IKO_LAUNCH(8, true) else if (nf == 12) PM_IKO_LAUNCH(12, true) else PM_IKO_LAUNCH(16, true) }
+    else { if (nf == 4) PM_IKO_LAUNCH(4, false) else if (nf == 8) PM_IKO_LAUNCH(8, false) else if (nf == 12) PM_IKO_LAUNCH(12, false) else PM_IKO_LAUNCH(16, false) }
 #undef PM_IKO_LAUNCH
     return PM_AFTER_LAUNCH("from_root_positions (lane per frame, any order) launch");
 }

@@ -35,3 +35,14 @@ for name, par in (("SMPL-H level order (as stored)", syn.PARENTS_52), ("SMPL-H r
         ms, _ = pp.timeit(lambda: _lib.call("pm_from_root_positions_f32", P(pos), pp_, P(off), F, J, P(out), None))
         print(f"{name:36s} 2^{lf} x {J:3d} {ms * 1e3:7.1f} us {F * 28 * J / ms / 1e6 / 80:5.1f}%  {_lib.last_kernel_name().replace('void pm::from_root_positions_', '')}", flush=True)
         del pos, out
+
+def chain_like(J):
+    p = np.maximum(np.arange(J) - 1, 0).astype(np.int32); p[J // 2] = 0; p[3 * J // 4] = J // 4
+    return p
+
+for J in (24, 32, 40, 52, 64, 96, 128):
+    par = chain_like(J); F = 1 << 19
+    pos = torch.randn((F, J, 3), device="cuda"); off = torch.randn((J, 3), device="cuda"); out = torch.empty((F, J, 4), device="cuda")
+    ms, _ = pp.timeit(lambda: _lib.call("pm_from_root_positions_f32", P(pos), par.ctypes.data_as(C.c_void_p), P(off), F, J, P(out), None))
+    print(f"{'chain-like (depth first)':36s} 2^19 x {J:3d} {ms * 1e3:7.1f} us {F * 28 * J / ms / 1e6 / 80:5.1f}%  {_lib.last_kernel_name().replace('void pm::from_root_positions_', '')}", flush=True)
+    del pos, out
