@@ -533,6 +533,19 @@ __device__ __forceinline__ void ik_slot_save(const int st, IkSaves &sv, const fl
     }
 }
 
+// The same two behind one test that skips the chain when no set is named (a halving test in front of two half chains was tried: the compiler
+// merges the halves into an indexed array, which lives in scratch memory)
+__device__ __forceinline__ void ik_set_load(const int code, const IkSaves &sv, float (&g)[4]) {
+    int c0 = code;
+    asm volatile("" : "+s"(c0));
+    if (c0 < kDeepSlots) ik_slot_load<0>(code, sv, g);
+}
+__device__ __forceinline__ void ik_set_save(const int code, IkSaves &sv, const float (&g)[4]) {
+    int c0 = code;
+    asm volatile("" : "+s"(c0));
+    if (c0 < kDeepSlots) ik_slot_save<0>(code, sv, g);
+}
+
 // G = records per group.  8: whole 128-byte lines of output, 96 bytes of input, 17 KB of LDS per wave (eight waves per CU).  The kernel
 // is a latency chain per lane and lives on occupancy (2^20 x 22 with 8 / 7 / 5 / 4 waves per CU: 158 / 174 / 193 / 267 us), but G = 4 --
 // half the ring, sixteen waves per CU -- moves HALF lines and is slower for it (240 us; J = 128 at 2^19: 615 against 444 us): not instantiated.
@@ -904,7 +917,7 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_order_kernel(cons
             far_pop(pc);
         }
         float gpre[4] = {g[0], g[1], g[2], g[3]};
-        ik_slot_load<0>(ld, sv, gpre);
+        ik_set_load(ld, sv, gpre);
         if (ld == IKO_ROOT) { gpre[0] = 1.0f; gpre[1] = 0.0f; gpre[2] = 0.0f; gpre[3] = 0.0f; }
         const float d[3] = {pc[0] - pp[0], pc[1] - pp[1], pc[2] - pp[2]};
         float r[4];
@@ -933,7 +946,7 @@ __global__ __launch_bounds__(PM_WAVE) void from_root_positions_order_kernel(cons
 #pragma unroll
             for (int k = 0; k < 4; ++k) { g[k] = g2[k]; r[k] = r2[k]; }
         }
-        ik_slot_save<0>(st, sv, g);
+        ik_set_save(st, sv, g);
         lds_put<4>(row + ((p + sf) & SM) * 4, 0, r);  // the local rotation of p, through the slot its position came in by
     };
     auto walk = [&](const int c) {
