@@ -256,6 +256,10 @@ __device__ __forceinline__ void mirror_slot_save(const int st, MirrorSaves &sv, 
 constexpr int kMirrorDeepRow = 16 * 4 + 4;  // sixteen 16-byte slots + 16 bytes: (row / 4) odd
 
 __global__ __launch_bounds__(PM_WAVE) void mirror_deep_kernel(const MirrorDeepArgs a) {
+    // the ring leaves room for eight waves on a CU (this kernel runs from 66 joints on: the tables take the ninth's share), which the dispatcher
+    // spreads evenly only if no SIMD can take a third: a register count beyond 512 / 3 makes sure (146 used; chain-like 2^19 x 72 / 96 / 128:
+    // 254 / 341 / 441 us without, 249 / 334 / 427 us with -- see from_root_positions_order_kernel)
+    asm volatile("; two waves per SIMD" ::: "v183");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int G = 8, RS = kMirrorDeepRow;
     const int lane = threadIdx.x;

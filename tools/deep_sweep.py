@@ -37,5 +37,10 @@ for J in [int(x) for x in sys.argv[1].split(",")]:
         ms, _ = pp.timeit(lambda: _lib.call("pm_fk_f32", P(rot), P(root), P(off), 0, pp_, F, J, P(pos), P(rm), None))
         line += f" | fk {ms * 1e3:7.1f} us {F * (64 * J + 12) / ms / 1e6 / 80:5.1f}%  {_lib.last_kernel_name().split('(')[0].split('::')[-1]}"
         del pos, rm
+    if "mirror" in which:
+        mi = torch.empty((F, J, 4), device="cuda")
+        ms, _ = pp.timeit(lambda: _lib.call("pm_mirror_rotations_f32", P(rot), pp_, None, 0, F, J, P(mi), None))
+        line += f" | mirror(all) {ms * 1e3:7.1f} us {F * 32 * J / ms / 1e6 / 80:5.1f}%  {_lib.last_kernel_name().split('(')[0].split('::')[-1]}"
+        del mi
     print(line, flush=True)
     del rot
