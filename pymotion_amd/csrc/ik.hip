@@ -1178,7 +1178,7 @@ extern "C" int pm_from_root_positions_f32(const float *positions, const int32_t 
     hipStream_t s = static_cast<hipStream_t>(stream);
     // depth-first skeletons from 24 joints on: one lane per frame, joints streamed (see from_root_positions_deep_kernel).
     // PM_IK_DEEP (PM_TUNING build only): 0 = never, 1 = whenever eligible
-    if (const int deep = tune_env("PM_IK_DEEP", -1); aligned16(rotations) && J >= 2 && deep != 0 && (deep == 1 || J >= kIkDeepMinJ)) {
+    if (const int deep = tune_env("PM_IK_DEEP", -1); aligned16(rotations) && J >= 2 && deep != 0 && tune_env("PM_IK_ORDER", -1) != 2 && (deep == 1 || J >= kIkDeepMinJ)) {
         IkDeepArgs da;
         if (ik_deep_plan(a.topo, J, da)) {
             da.pos = positions; da.offsets = offsets; da.out = rotations; da.F = F; da.J = J;
@@ -1186,8 +1186,9 @@ extern "C" int pm_from_root_positions_f32(const float *positions, const int32_t 
         }
     }
     // any other parents-first order (level-order tables): the same lane-per-frame walk driven by a list of operations, if the
-    // table fits its window / queue / register sets.  PM_IK_ORDER (PM_TUNING build only): 0 = never, 1 = whenever eligible
-    if (const int ord = tune_env("PM_IK_ORDER", -1); aligned16(rotations) && J >= 2 && ord != 0 && tune_env("PM_IK_DEEP", -1) != 0 && (ord == 1 || J >= kIkOrderMinJ)) {
+    // table fits its window / queue / register sets.  PM_IK_ORDER (PM_TUNING build only): 0 = never, 1 = whenever eligible, 2 = also in
+    // place of the depth-first kernel
+    if (const int ord = tune_env("PM_IK_ORDER", -1); aligned16(rotations) && J >= 2 && ord != 0 && tune_env("PM_IK_DEEP", -1) != 0 && (ord >= 1 || J >= kIkOrderMinJ)) {
         IkOrderArgs oa;
         if (ik_order_plan(a.topo, J, oa)) {
             oa.pos = positions; oa.offsets = offsets; oa.out = rotations; oa.F = F; oa.J = J;
