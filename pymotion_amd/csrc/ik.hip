@@ -394,38 +394,35 @@ __global__ __launch_bounds__(PM_WAVE, (NL > 0 && NL <= 12) ? PM_IK_MINW : ((NL >
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// ONE LANE PER FRAME, the joints streamed through LDS (the shape of deep.hip) -- for skeletons stored depth first, which is how
-// every BVH hierarchy and every SMPL-style table comes: the FIRST child of a joint is the next joint.
+// ONE LANE PER FRAME, the joints streamed through LDS (the shape of deep.hip) -- for any table, parents first, whose children sit close
+// enough behind their parent: depth-first storage (every BVH hierarchy), the level-order tables of the SMPL family, anything between.
 // The kernel above keeps a frame's 16 J bytes in LDS for the whole walk, which is what bounds it: 32 frames x 2 chains per wave
 // at 11 waves per CU (J = 22), half the lane-steps of its two-chain schedule idle, a final lane-per-record pass to turn world
 // quaternions back into local ones; five 31 KB images per CU at J = 52.  Here
-//   * a lane walks ITS frame's joints in index order -- 64 frames per wave, no idle chains, no schedule;
-//   * joint p is finished when its first child p + 1 arrives: d = P_(p+1) - P_p with P_p still in registers, the parent's world
-//     quaternion the lane's own registers (parent = previous joint) or one of six saved register sets (ik_deep_plan colours the
-//     open branch points like deep_plan);
-//   * the positions of FURTHER children, which the reference consumes at the same moment (skeleton.py:147-168) and which lie
-//     further down the stream, are fetched per lane when the tile starts (<= kIkFar of them: 4 on the 22-joint body, 12 on
-//     SMPL-H) and wait in registers as a queue;
-//   * the LOCAL rotation is what the alignment and the rolls produce (r (x) roll (x) ...): no world -> local pass;
+//   * a lane walks ITS frame's joints in memory order -- 64 frames per wave, no idle chains;
 //   * LDS is a ring of sixteen 16-byte slots per frame -- a joint's position comes in (cut at the output's 128-byte lines:
-//     groups of eight records g = f J + j, as in to_root_dq_ring_kernel), is read once, and the joint's rotation goes out
-//     through the same slot: 17 KB per wave, nine waves = 576 frames in flight per CU.
+//     groups of eight records g = f J + j, as in to_root_dq_ring_kernel), and the joint's LOCAL rotation -- what the alignment and
+//     the rolls produce (r (x) roll (x) ...): no world -> local pass -- goes out through the same slot: 17 KB per wave, eight or nine
+//     waves = 512-576 frames in flight per CU;
+//   * the walk is a host-made list of OPERATIONS, one per joint (ik_order_plan).  Joint p is finished by ONE operation that reads P_p
+//     and the positions of its children out of the ring (they are still there: see the window below) or, for children stored too far
+//     down the row (the further children of a depth-first table, the finger roots of a level-order hand), out of a queue of per-lane
+//     fetches made when the tile starts, aligns, rolls once per further child (the reference consumes them at the same moment,
+//     skeleton.py:147-168) and writes the rotation over P_p; a joint without children is an operation that writes the identity;
+//   * the window: while step c of the tile loop runs, the ring holds groups c - 1 and c of every lane, i.e. the joints
+//     [8 c - 8, 8 c + D] whatever the lane's line shift sf = (frame J) & 7 is, D = gcd(J, 8) - 1 (J = 52: D = 3; J % 8 == 0: 7;
+//     odd J: 0).  The plan puts joint p into step (p >> 3) + 1 -- the last one before its line leaves -- takes the children at index
+//     <= 8 step + D from the ring and the others from the queue, and runs a step's operations in joint order (parents first: every
+//     parent is final before any of its children is touched);
+//   * the parent's world quaternion: the lane's own registers if the parent's operation was the last one that aligned anything, else
+//     one of six saved register sets (the plan colours their live ranges over the operation sequence, like deep_plan);
+//   * the operands of the next operation (two positions, the table row of the first child) are requested while the current one
+//     computes, into two operand sets used in turn.
+// SMPL-H as stored (52 joints, level order): 8 queue entries, 4 register sets; the 22-joint BVH body: 4 and 1.
+// Round 3's depth-first-only form of this kernel ("joint j finishes joint j - 1", every further child through the queue) is gone: the
+// operation list covers every table it took, with fewer queue entries, and measured faster on all of them (chain-like 2^19 x 24 / 32 /
+// 64 / 128: 82 / 105 / 232 / 406 us against 88 / 118 / 244 / 452 us; a depth-first SMPL-H 95 against 111 us at 2^18 frames).
 // ---------------------------------------------------------------------------------------------------------------------------
-constexpr int kIkFar = 12;
-constexpr int kIkDeepMinJ = 24;  // (chain-like skeletons at 2^19 frames, lane per frame / tile kernel: J = 16 58.5 / 56.7 us, 22 80.5 / 80.3, 24 85 / 91, 32 109 / 132,
-                                 // 40 138 / 186, 64 232 / 365, 96 327 / 1026, 128 450 / 1400)
-
-struct IkDeepArgs {
-    const float *pos;      // [F,J,3]
-    const float *offsets;  // [J,3]
-    float *out;            // [F,J,4]
-    int64_t F;
-    int32_t J;
-    int32_t nfar;
-    int32_t far_joint[kIkFar];     // the further children, in the order the walk consumes them (dwords: s_load, not a vector-memory byte load)
-    int32_t code[PM_MAX_JOINTS];   // step j: load_p | save_p << 8 | nroll_p << 16 | fin << 24 | leaf << 25   (p = j - 1, the joint finished at step j)
-};
-
 __device__ __forceinline__ void ik_unrotate(const float (&g)[4], const float (&v)[3], float (&o)[3]) {  // v turned by the inverse of unit g
     const float c0 = __builtin_fmaf(g[3], v[1], -(g[2] * v[2]));
     const float c1 = __builtin_fmaf(g[1], v[2], -(g[3] * v[0]));
@@ -546,257 +543,16 @@ __device__ __forceinline__ void ik_set_save(const int code, IkSaves &sv, const f
     if (c0 < kDeepSlots) ik_slot_save<0>(code, sv, g);
 }
 
-// G = records per group.  8: whole 128-byte lines of output, 96 bytes of input, 17 KB of LDS per wave (eight waves per CU).  The kernel
-// is a latency chain per lane and lives on occupancy (2^20 x 22 with 8 / 7 / 5 / 4 waves per CU: 158 / 174 / 193 / 267 us), but G = 4 --
-// half the ring, sixteen waves per CU -- moves HALF lines and is slower for it (240 us; J = 128 at 2^19: 615 against 444 us): not instantiated.
+// Records per group: 8 -- whole 128-byte lines of output, 96 bytes of input, 17 KB of LDS per wave.  The kernel is a latency chain per lane
+// and lives on occupancy (round 3, 2^20 x 22 with 8 / 7 / 5 / 4 waves per CU: 158 / 174 / 193 / 267 us), but groups of four -- half the ring,
+// sixteen waves per CU -- move HALF lines and were slower for it (240 us; J = 128 at 2^19: 615 against 444 us): not instantiated.
 __host__ __device__ constexpr int ik_deep_row(const int G) { return 2 * G * 4 + 4; }  // 2 G 16-byte slots + 16 bytes: (row / 4) odd
 
-// NF: entries of the queue of further children (4 / 8 / 12: every consumption shifts the whole queue, 3 (NF - 1) moves)
-template <int G, int NF>
-__global__ __launch_bounds__(PM_WAVE) void from_root_positions_deep_kernel(const IkDeepArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int RS = ik_deep_row(G), FPI = PM_WAVE / G, LG = (G == 8) ? 3 : 2, SM = 2 * G - 1;  // frames per load / store instruction, log2 G, slot mask
-    static_assert(G == 8 || G == 4, "groups of eight or four records");
-    const int lane = threadIdx.x;
-    const int J = a.J;
-    const int64_t tile = xcd_tile((a.F + PM_WAVE - 1) / PM_WAVE);
-    if (tile < 0) return;
-    float *sImg = smem;                 // [64][RS]
-    float *sOff = smem + PM_WAVE * RS;  // [J][4]  {u, 1 / |u|} of every joint's rest offset ...
-    float *sLen = sOff + 4 * J;         // [J]     ... and |u|
-    for (int j = lane; j < J; j += PM_WAVE) {
-        const float o[3] = {a.offsets[3 * j], a.offsets[3 * j + 1], a.offsets[3 * j + 2]};
-        const float u2 = __builtin_fmaf(o[0], o[0], __builtin_fmaf(o[1], o[1], o[2] * o[2]));
-        const float iu = (u2 > 0.0f) ? __builtin_amdgcn_rsqf(u2) : 0.0f;
-        float *t = sOff + 4 * j;
-        if (PM_LDS_OK(t, 16u)) *reinterpret_cast<v4f *>(t) = v4f{o[0], o[1], o[2], iu};
-        if (PM_LDS_OK(sLen + j, 4u)) sLen[j] = fsqrt(u2);
-    }
-    const int64_t f0 = tile * PM_WAVE;  // a multiple of 64: (f0 + fr) J & (G - 1) == fr J & (G - 1)
-    const int nf = (int)((a.F - f0) < PM_WAVE ? (a.F - f0) : PM_WAVE);
-    const int ngroups = ((J + G - 2) >> LG) + 1;
-    const float *gpos = a.pos + f0 * J * 3;
-    float *gout = a.out + f0 * J * 4;
-    const int fl = lane < nf ? lane : nf - 1;
-
-    // the further children's positions of this lane's frame, in the order they are consumed
-    v3f_a4 farq[NF];
-#pragma unroll
-    for (int k = 0; k < NF; ++k) {
-        farq[k] = v3f_a4{0.0f, 0.0f, 0.0f};
-        if (k < a.nfar) farq[k] = *reinterpret_cast<const v3f_a4 *>(gpos + ((int64_t)fl * J + a.far_joint[k]) * 3);
-    }
-
-    // loads: lane = (frl, jj) = (lane / G, lane % G); load u covers frame FPI u + frl, whose shift is that of frl (FPI J = 0 mod G)
-    const int l_frl = lane >> LG, l_d = (lane & (G - 1)) - ((l_frl * J) & (G - 1));  // joint of this lane's place in group c: G c + l_d
-    v3f_a4 pre[G], pre1[G];
-    auto issue = [&](const int c, v3f_a4 (&pre)[G]) {
-        int j = G * c + l_d;
-        j = j < 0 ? 0 : (j > J - 1 ? J - 1 : j);  // outside the frame: a valid record again, parked where nobody reads
-#pragma unroll
-        for (int u = 0; u < G; ++u) {
-            const int fr = FPI * u + l_frl, fc = fr < nf ? fr : nf - 1;
-            pre[u] = *reinterpret_cast<const v3f_a4 *>(gpos + ((int64_t)fc * J + j) * 3);  // (not nontemporal: the rest of the line is the next group's)
-        }
-    };
-    issue(0, pre);
-    if (ngroups > 1) issue(1, pre1);  // the far positions and the first TWO groups are in flight together: one exposed latency per tile
-    auto park = [&](const int c, const v3f_a4 (&pre)[G]) {
-#pragma unroll
-        for (int u = 0; u < G; ++u) {
-            float *p = sImg + (FPI * u + l_frl) * RS + ((c & 1) * G + (lane & (G - 1))) * 4;
-            if (PM_LDS_OK(p, 16u)) { p[0] = pre[u].x; p[1] = pre[u].y; p[2] = pre[u].z; }
-        }
-    };
-    float *row = sImg + lane * RS;
-    const int sf = (lane * J) & (G - 1);
-    float g[4] = {1.0f, 0.0f, 0.0f, 0.0f};   // world quaternion of the joint finished last
-    float pp[3] = {0.0f, 0.0f, 0.0f};        // position of the previous joint (finished when its first child arrives)
-    IkSaves sv = {};
-    int fi = 0;                              // next entry of the far list (wave-uniform)
-    wave_sync();
-    auto walk = [&](const int c) {
-        const int jlo = G * c - (G - 1) < 0 ? 0 : G * c - (G - 1), jhi = G * c > J - 1 ? J - 1 : G * c;
-        // a joint's operands (its position, the table rows of its rest offset) are requested while the joint before it computes
-        float pjn[4], tan[4], tbn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (jlo <= jhi) {
-            lds_get<4>(row + ((jlo + sf) & SM) * 4, 0, pjn);
-            lds_get<4>(sOff, jlo, tan);
-            tbn[3] = sLen[jlo];
-        }
-#pragma unroll 1
-        for (int j = jlo; j <= jhi; ++j) {
-            const int code = __builtin_amdgcn_readfirstlane(a.code[j]);  // wave-uniform (kernarg)
-            float *slot = row + ((j + sf) & SM) * 4;
-            float pj[4], ta[4], tb[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { pj[k] = pjn[k]; ta[k] = tan[k]; }
-            tb[0] = ta[0] * ta[3]; tb[1] = ta[1] * ta[3]; tb[2] = ta[2] * ta[3]; tb[3] = tbn[3];  // u / |u|, |u|
-            if (j < jhi) {  // (the step's last joint: the next one's slot may not be parked yet)
-                lds_get<4>(row + ((j + 1 + sf) & SM) * 4, 0, pjn);
-                lds_get<4>(sOff, j + 1, tan);
-                tbn[3] = sLen[j + 1];
-            }
-            if (code & (1 << 24)) {  // joint j is the first child of p = j - 1: p is finished now
-                const int p = j - 1, ld = code & 0xff, st = (code >> 8) & 0xff, nroll = (code >> 16) & 0xff;
-                float gpre[4] = {g[0], g[1], g[2], g[3]};
-                ik_slot_load<0>(ld, sv, gpre);
-                if (ld == DEEP_ROOT) { gpre[0] = 1.0f; gpre[1] = 0.0f; gpre[2] = 0.0f; gpre[3] = 0.0f; }
-                const float d[3] = {pj[0] - pp[0], pj[1] - pp[1], pj[2] - pp[2]};
-                float r[4];
-                bool inexact;
-                float un[3];  // the roll axis of further children
-                ik_align(gpre, d, ta, tb, r, inexact, nroll > 0, un);
-                qmul(gpre, r, g);
-                for (int rr = 0; rr < nroll; ++rr) {  // further children: wave-uniform here (every lane walks the same skeleton)
-                    const int gc = __builtin_amdgcn_readfirstlane(a.far_joint[fi]);
-                    ++fi;
-                    float tg[4];
-                    lds_get<4>(sOff, gc, tg);
-                    const float lug = sLen[gc];
-                    const float dg[3] = {farq[0].x - pp[0], farq[0].y - pp[1], farq[0].z - pp[2]};
-#pragma unroll
-                    for (int k = 0; k + 1 < NF; ++k) farq[k] = farq[k + 1];
-                    float roll[4], g2[4], r2[4];
-                    ik_roll(g, dg, d, un, inexact, tg, lug, roll);
-                    qmul(g, roll, g2);
-                    qmul(r, roll, r2);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { g[k] = g2[k]; r[k] = r2[k]; }
-                }
-                ik_slot_save<0>(st, sv, g);
-                lds_put<4>(row + ((p + sf) & SM) * 4, 0, r);  // the local rotation of p, through the slot its position came in by
-            }
-            if (code & (1 << 25)) {  // a joint without children keeps the identity (skeleton.py:126-130)
-                const float id[4] = {1.0f, 0.0f, 0.0f, 0.0f};
-                lds_put<4>(slot, 0, id);
-            }
-            pp[0] = pj[0]; pp[1] = pj[1]; pp[2] = pj[2];
-        }
-    };
-    // group k leaves: lane (frl, place) of store u writes the 16-byte record of frame 8 u + frl.  Its slots are READ into registers,
-    // then the next group's positions are parked over them, then the stores go out: no store sits between the request for a
-    // group's positions and the wait for them, so that wait is never a wait for stores (half of a 22-joint frame's groups are
-    // partial ones whose stores are predicated and cannot be counted past -- see deep.hip).
-    const int s_d = l_d;
-    v4f outr[G];
-    auto read_group = [&](const int k) {
-#pragma unroll
-        for (int u = 0; u < G; ++u) {
-            const float *p = sImg + (FPI * u + l_frl) * RS + ((k & 1) * G + (lane & (G - 1))) * 4;
-            outr[u] = PM_LDS_OK(p, 16u) ? *reinterpret_cast<const v4f *>(p) : v4f{0, 0, 0, 0};
-        }
-    };
-    auto store_group = [&](const int k) {
-        const int j = G * k + s_d;
-        const bool jok = j >= 0 && j < J;
-        float *g0 = gout + (l_frl * J + (jok ? j : 0)) * 4;
-#pragma unroll
-        for (int u = 0; u < G; ++u)
-            if (jok && FPI * u + l_frl < nf) {
-                if (G == 8) __builtin_nontemporal_store(outr[u], reinterpret_cast<v4f *>(g0 + FPI * u * J * 4));
-                else *reinterpret_cast<v4f *>(g0 + FPI * u * J * 4) = outr[u];  // half lines: the other half is the next step's, merged in L2
-            }
-    };
-    park(0, pre);
-    if (ngroups > 1) park(1, pre1);
-#pragma unroll
-    for (int k = 0; k < NF; ++k) asm volatile("" : "+v"(farq[k]));  // settled HERE (everything requested so far has arrived): their first use is inside the walk
-    if (ngroups > 2) issue(2, pre);
-    for (int c = 0; c <= ngroups; ++c) {
-        wave_sync();
-        walk(c);
-        wave_sync();
-        if (c >= 1) {
-            read_group(c - 1);
-            wave_sync();
-            if (c + 1 < ngroups) park(c + 1, pre);          // over the slots just read; requested a whole step ago
-            if (c + 2 < ngroups) issue(c + 2, pre);         // in flight during the next step
-            store_group(c - 1);
-        }
-    }
-}
-
-// Host plan of the lane-per-frame kernel.  Eligible: every joint with children has joint + 1 as its first child (depth-first
-// storage), at most kIkFar further children in all, at most kDeepSlots branch points open at once.  Returns false otherwise.
-static bool ik_deep_plan(const Topo16 &t, const int J, IkDeepArgs &a) {
-    int nfar = 0, last_use[PM_MAX_JOINTS], slot_of[PM_MAX_JOINTS], busy_until[kDeepSlots];
-    for (int j = 0; j < J; ++j) {
-        const int cs = t.cstart[j], ce = t.cstart[j + 1];
-        if (ce > cs && t.clist[cs] != j + 1) return false;
-        for (int k = cs + 1; k < ce; ++k) {
-            if (nfar == kIkFar) return false;
-            a.far_joint[nfar++] = t.clist[k];
-        }
-        last_use[j] = -1; slot_of[j] = -1;
-    }
-    for (int k = nfar; k < kIkFar; ++k) a.far_joint[k] = 0;
-    a.nfar = nfar;
-    // a joint WITH children whose parent is not the previous joint reads the parent's world quaternion from a slot
-    for (int j = 1; j < J; ++j)
-        if (t.cstart[j + 1] > t.cstart[j] && t.parent[j] != j - 1 && last_use[t.parent[j]] < j) last_use[t.parent[j]] = j;
-    for (int k = 0; k < kDeepSlots; ++k) busy_until[k] = -1;
-    int load_of[PM_MAX_JOINTS], save_of[PM_MAX_JOINTS];
-    for (int j = 0; j < J; ++j) {
-        load_of[j] = (j == 0) ? DEEP_ROOT : ((t.parent[j] == j - 1) ? DEEP_CHAIN : slot_of[t.parent[j]]);
-        save_of[j] = DEEP_NONE;
-        if (t.cstart[j + 1] > t.cstart[j] && load_of[j] < 0) return false;  // (cannot happen: parents come first)
-        if (last_use[j] >= 0) {
-            int k = 0;
-            while (k < kDeepSlots && busy_until[k] > j) ++k;
-            if (k == kDeepSlots) return false;
-            busy_until[k] = last_use[j];
-            slot_of[j] = k;
-            save_of[j] = k;
-        }
-    }
-    for (int j = 0; j < J; ++j) {
-        const bool leaf = t.cstart[j + 1] == t.cstart[j];
-        const int p = j - 1;
-        const bool fin = j >= 1 && t.cstart[p + 1] > t.cstart[p];  // p has children, so j = p + 1 is its first
-        int code = (leaf ? 1 << 25 : 0);
-        if (fin) code |= (load_of[p] & 0xff) | ((save_of[p] & 0xff) << 8) | ((t.cstart[p + 1] - t.cstart[p] - 1) << 16) | (1 << 24);
-        a.code[j] = code;
-    }
-    return true;
-}
-
-template <int G>
-static int launch_ik_deep(const IkDeepArgs &a, hipStream_t s) {
-    const size_t lds = ((size_t)PM_WAVE * ik_deep_row(G) + 5 * (size_t)a.J) * sizeof(float);
-    const int64_t ntiles = (a.F + PM_WAVE - 1) / PM_WAVE;
-    const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
-    if (grid > 0x7fffffffLL) { set_error("from_root_positions: grid too large"); return PM_EUNSUPPORTED; }
-    const int nf = a.nfar <= 4 ? 4 : (a.nfar <= 8 ? 8 : 12);
-    set_kernel_name("void pm::from_root_positions_deep_kernel<%d, %d>(pm::IkDeepArgs)", G, nf);
-#define PM_IKD_LAUNCH(N)                                                                                       \
-    {                                                                                                          \
-        if (int e = allow_lds(from_root_positions_deep_kernel<G, N>, lds)) return e;                          \
-        hipLaunchKernelGGL((from_root_positions_deep_kernel<G, N>), dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a); \
-    }
-    if (nf == 4) PM_IKD_LAUNCH(4) else if (nf == 8) PM_IKD_LAUNCH(8) else PM_IKD_LAUNCH(12)
-#undef PM_IKD_LAUNCH
-    return PM_AFTER_LAUNCH("from_root_positions (lane per frame) launch");
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// ONE LANE PER FRAME for tables in ANY parents-first order (the level-order tables of the SMPL family: the first child of a joint
-// is NOT the next joint) -- the kernel above with the walk driven by a host-made list of OPERATIONS instead of "joint j finishes
-// joint j - 1".  Same ring of sixteen 16-byte slots per frame, same loads, parks and stores; what changes:
-//   * joint p is finished by ONE operation that reads P_p and the positions of its children out of the ring (they are still
-//     there: see the window below) or, for children stored too far down the row, out of the queue of per-lane fetches made when
-//     the tile starts (the five finger roots of each SMPL-H hand), aligns, rolls once per further child and writes the LOCAL
-//     rotation of p over P_p; a joint without children is an operation that writes the identity;
-//   * the window: while step c of the tile loop runs, the ring holds groups c - 1 and c of every lane, i.e. the joints
-//     [8 c - 8, 8 c + D] whatever the lane's line shift sf = (frame J) & 7 is, D = gcd(J, 8) - 1 (J = 52: D = 3; J % 8 == 0: 7;
-//     odd J: 0).  ik_order_plan puts joint p into step (p >> 3) + 1 -- the last one before its line leaves -- takes the children
-//     at index <= 8 step + D from the ring and the others from the queue, orders a step's operations by joint index (parents
-//     first) and colours the world quaternions that a later operation needs onto the kDeepSlots register sets;
-//   * the operands of the next operation (two positions, the table row of the first child) are requested while the current one
-//     computes, as above.
-// SMPL-H as stored (52 joints, level order): 8 queue entries, 4 register sets.
-// ---------------------------------------------------------------------------------------------------------------------------
-constexpr int kIkOrderMinJ = 24;
+// Which tables take it (ik_order_wanted): measured against the tile kernels on chain-like skeletons at 2^20 frames, tile / this kernel --
+// J = 8 52 / 56 us, 12 85 / 79, 16 108 / 98, 20 139 / 125, 24 174 / 154, 32 247 / 222 (J % 4 == 0: few distinct line shifts, D >= 3);
+// J = 14 95 / 118, 18 128 / 138, 22 159 / 170, 26 193 / 200, 30 231 / 227, 34 279 / 258; odd J = 13 92 / 131, 19 134 / 165, 25 191 / 211,
+// 29 231 / 233, 31 233 / 224, 35 284 / 258, 41 371 / 306, 47 468 / 337.  The 22-joint BVH body: 155-165 / 144-164 us, a draw.
+static bool ik_order_wanted(const int J) { return (J >= 12 && J % 4 == 0) || J >= 30; }
 constexpr int kIkOrderFar = 16;  // queue entries (the kernel is instantiated for 4 / 8 / 12 / 16: every consumption shifts the whole queue)
 constexpr int kIkOrderSteps = PM_MAX_JOINTS / 8 + 4;
 enum : int { IKO_CHAIN = 6, IKO_ROOT = 7, IKO_NONE = 7 };
@@ -1176,19 +932,9 @@ extern "C" int pm_from_root_positions_f32(const float *positions, const int32_t 
     for (int32_t j = 1; j < J; ++j) a.topo.clist[fill[p.p[j]]++] = (int16_t)j;
     const bool vec = aligned16(positions) && aligned16(rotations);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // depth-first skeletons from 24 joints on: one lane per frame, joints streamed (see from_root_positions_deep_kernel).
-    // PM_IK_DEEP (PM_TUNING build only): 0 = never, 1 = whenever eligible
-    if (const int deep = tune_env("PM_IK_DEEP", -1); aligned16(rotations) && J >= 2 && deep != 0 && tune_env("PM_IK_ORDER", -1) != 2 && (deep == 1 || J >= kIkDeepMinJ)) {
-        IkDeepArgs da;
-        if (ik_deep_plan(a.topo, J, da)) {
-            da.pos = positions; da.offsets = offsets; da.out = rotations; da.F = F; da.J = J;
-            return launch_ik_deep<8>(da, s);
-        }
-    }
-    // any other parents-first order (level-order tables): the same lane-per-frame walk driven by a list of operations, if the
-    // table fits its window / queue / register sets.  PM_IK_ORDER (PM_TUNING build only): 0 = never, 1 = whenever eligible, 2 = also in
-    // place of the depth-first kernel
-    if (const int ord = tune_env("PM_IK_ORDER", -1); aligned16(rotations) && J >= 2 && ord != 0 && tune_env("PM_IK_DEEP", -1) != 0 && (ord >= 1 || J >= kIkOrderMinJ)) {
+    // one lane per frame, joints streamed through a ring of LDS slots (from_root_positions_order_kernel) where that pays and the table fits
+    // its window / queue / register sets.  PM_IK_ORDER (PM_TUNING build only): 0 = never, 1 = whenever the table fits
+    if (const int ord = tune_env("PM_IK_ORDER", -1); aligned16(rotations) && J >= 2 && ord != 0 && (ord == 1 || ik_order_wanted(J))) {
         IkOrderArgs oa;
         if (ik_order_plan(a.topo, J, oa)) {
             oa.pos = positions; oa.offsets = offsets; oa.out = rotations; oa.F = F; oa.J = J;

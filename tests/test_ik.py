@@ -188,13 +188,13 @@ def _chain_like(J):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("J,kind,deep", [(24, "chain", True), (31, "chain", True), (23, "chain", False), (53, "body5", True), (47, "body4", True), (64, "chain", True),
-                                         (65, "body5", True), (128, "chain", True), (250, "body5", True), (512, "chain", True), (59, "body6", False),
-                                         (52, "smplh", False)])
-def test_gpu_from_root_positions_lane_per_frame_on_depth_first_skeletons(J, kind, deep):
-    """skeletons stored depth first (every BVH hierarchy) take from_root_positions_deep_kernel from 24 joints on: one lane per frame,
-    joints streamed through a ring of LDS slots, further children prefetched (at most 12: six fingers a hand are one too many),
-    full and partial tiles of 64 frames; a breadth-first table like SMPL-H's stays on the tile kernel"""
+@pytest.mark.parametrize("J,kind,lane", [(24, "chain", True), (31, "chain", True), (23, "chain", False), (53, "body5", True), (47, "body4", True), (64, "chain", True),
+                                         (65, "body5", True), (128, "chain", True), (250, "body5", True), (512, "chain", True), (59, "body6", None),
+                                         (52, "smplh", True), (16, "chain", True), (12, "body4", True), (22, "body4", False), (29, "chain", False)])
+def test_gpu_from_root_positions_lane_per_frame_on_depth_first_skeletons(J, kind, lane):
+    """skeletons stored depth first (every BVH hierarchy) take from_root_positions_order_kernel from 30 joints on and at multiples of four from
+    12: one lane per frame, joints streamed through a ring of LDS slots, the further children of a joint read from the ring's window or
+    prefetched per lane (at most 16), full and partial tiles of 64 frames; the others stay on the tile kernels"""
     import pymotion_amd.ops.skeleton as sk
     from pymotion_amd import _lib
     from pymotion_amd import synthetic as syn
@@ -205,7 +205,7 @@ def test_gpu_from_root_positions_lane_per_frame_on_depth_first_skeletons(J, kind
         pos, _ = co.fk(rot.astype(np.float64), np.zeros((F, 3)), off.astype(np.float64), par)
         pos = pos.astype(np.float32)
         got = sk.from_root_positions(pos, par, off)
-        assert ("from_root_positions_deep_kernel" in _lib.last_kernel_name()) == deep, _lib.last_kernel_name()
+        assert lane is None or ("from_root_positions_order_kernel" in _lib.last_kernel_name()) == lane, _lib.last_kernel_name()
         ref = co.from_root_positions(pos.astype(np.float64), par, off.astype(np.float64))
         err = np.minimum(np.abs(got - ref).max(-1), np.abs(got + ref).max(-1))
         # the tile kernel's bar, per record: 2e-5 + 8 x how far one ulp of the inputs moves the reference's own answer (an alignment
@@ -288,7 +288,7 @@ def test_gpu_from_root_positions_lane_per_frame_on_tables_in_any_order(kind, ord
         pos = pos.astype(np.float32)
         got = sk.from_root_positions(pos, par, off)
         name = _lib.last_kernel_name()
-        took.add("order" if "from_root_positions_order_kernel" in name else ("deep" if "deep_kernel" in name else "tile"))
+        took.add("order" if "from_root_positions_order_kernel" in name else "tile")
         assert order is None or ("from_root_positions_order_kernel" in name) == order, name
         ref = co.from_root_positions(pos.astype(np.float64), par, off.astype(np.float64))
         err = np.minimum(np.abs(got - ref).max(-1), np.abs(got + ref).max(-1))

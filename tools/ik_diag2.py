@@ -20,8 +20,8 @@ def run(par, F, seed, scale, label):
     pos = pos.astype(np.float32)
     ref = co.from_root_positions(pos.astype(np.float64), par, off.astype(np.float64))
     sens = _reference_sensitivity(pos, par, off, ref, draws=4)
-    for env in ({"PM_IK_CHAINS": "1", "PM_IK_DEEP": "0"}, {"PM_IK_CHAINS": "2", "PM_IK_DEEP": "0"}, {"PM_IK_CHAINS": "4", "PM_IK_DEEP": "0"}, {"PM_IK_DEEP": "1"}):
-        for k in ("PM_IK_CHAINS", "PM_IK_DEEP"):
+    for env in ({"PM_IK_CHAINS": "1", "PM_IK_ORDER": "0"}, {"PM_IK_CHAINS": "2", "PM_IK_ORDER": "0"}, {"PM_IK_CHAINS": "4", "PM_IK_ORDER": "0"}, {"PM_IK_ORDER": "1"}):
+        for k in ("PM_IK_CHAINS", "PM_IK_ORDER"):
             os.environ.pop(k, None)
         os.environ.update(env)
         got = sk.from_root_positions(pos, par, off)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """from_root_positions on tables that are parents-first but not depth first: SMPL-H as stored (52 joints, level order), the SMPL body (24), a 55-joint
-SMPL-X-like table, against the same trees relabelled depth first (from_root_positions_deep_kernel) and the 22-joint BVH body."""
+SMPL-X-like table, the same trees relabelled depth first, the 22-joint BVH body and chain-like depth-first skeletons (PMHIP_VARIANT=tuning PM_IK_ORDER=0: the tile kernels)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -28,7 +28,7 @@ for name, par in (("SMPL-H level order", syn.PARENTS_52), ("SMPL-H relabelled de
     Fj = F if J > 24 else F * 4
     pos = torch.randn((Fj, J, 3), device="cuda"); off = torch.randn((J, 3), device="cuda"); out = torch.empty((Fj, J, 4), device="cuda")
     pp_ = np.asarray(par, np.int32).ctypes.data_as(C.c_void_p)
-    for env in ({}, {"PM_IK_CHAINS": "1"}, {"PM_IK_CHAINS": "2"}, {"PM_IK_CHAINS": "4"}, {"PM_IK_FPW": "64"}, {"PM_IK_FPW": "32"}, {"PM_IK_FPW": "16"}, {"PM_IK_DEEP": "1"},
+    for env in ({}, {"PM_IK_CHAINS": "1"}, {"PM_IK_CHAINS": "2"}, {"PM_IK_CHAINS": "4"}, {"PM_IK_FPW": "64"}, {"PM_IK_FPW": "32"}, {"PM_IK_FPW": "16"}, {"PM_IK_ORDER": "1"}, {"PM_IK_ORDER": "0"},
                 {"PM_IK_CHAINS": "2", "PM_IK_NT": "1"}, {"PM_IK_CHAINS": "2", "PM_IK_NT": "2"}, {"PM_IK_CHAINS": "4", "PM_IK_NT": "2"}):
         for k in list(os.environ):
             if k.startswith("PM_IK"): del os.environ[k]
