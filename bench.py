@@ -203,7 +203,14 @@ def secondary_configs(torch, _lib, syn, dev, rot, root, off, parents, sptr):
     t52 = timed(lambda: _lib.call("pm_fk_f32", p(q4), p(root4), p(off4), 0, pp4, F4, 52, p(pos4), p(rm4), sptr))
     out["fk_J52"] = {"frames": F4, "ms": t52, "frames_per_s": F4 / (t52 * 1e-3),
                      "hbm_frac": F4 * (64 * 52 + 12) / (t52 * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-    del x, root4, off4, pos4, rm4, q4
+    # from_root_positions (positions -> local rotations) on the fk output just made: SMPL-H's 52-joint table AS STORED
+    # (level order -- round 3: 30.5 % on the two-chain tile kernel) on the operation-driven lane-per-frame kernel, 28 J B per frame
+    ik4 = torch.empty((F4, 52, 4), device=dev)
+    pos4 -= pos4[:, :1].clone()
+    t_ik = timed(lambda: _lib.call("pm_from_root_positions_f32", p(pos4), pp4, p(off4), F4, 52, p(ik4), sptr))
+    out["from_root_positions_J52_level_order"] = {"frames": F4, "ms": t_ik, "frames_per_s": F4 / (t_ik * 1e-3),
+                                                   "hbm_frac": F4 * 28 * 52 / (t_ik * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel": _lib.last_kernel_name()}
+    del x, root4, off4, pos4, rm4, q4, ik4
     # a LONG, chain-like skeleton (128 joints: one chain, a second one off the root, a third off joint 32; 2^18 frames): what the
     # tile kernels are worst at (round 2: to_root_dual_quat 31 %, fk 46 %).  to_root_dual_quat: the lane-per-frame kernel of deep.hip.
     F5, J5 = 1 << 18, 128
