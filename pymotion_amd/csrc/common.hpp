@@ -656,6 +656,22 @@ int schedule_chains(const Parents &par, int J, int C, uint8_t *sched, bool root_
 
 // ---- deep.hip: lane-per-frame walks for long skeletons -------------------------------------------------------------
 constexpr int kDeepM = 8;      // joints per chunk
+// The lane-per-frame kernels (deep.hip, mirror_deep_kernel, from_root_positions_order_kernel) put 64 frames in a wave and walk a frame's J
+// joints one after the other: a tile takes the same time however few tiles there are (SMPL-H's 52 joints: to_root_dual_quat 33 us,
+// mirror 27 us, from_root_positions 38 us from 2^10 to 2^15 frames), where the tile kernels put 8-32 frames in a wave and two or four
+// chains on a frame (9-13 / 8-10 / 21-24 us).  Clips of real length -- 2^10...2^15 frames -- are on that floor, so the long-skeleton
+// kernels only take a call that has enough joint-frames to fill the chip; the crossovers measured on SMPL-H and chain-like skeletons of
+// 24-128 joints (round 4, tools/scratch/*smallF_sweep.py) sit at F J = 2.1-2.6 M (to_root_dual_quat), 5.2-8.4 M (mirror), 2.2-3.7 M
+// (from_root_positions).  The bounds-checked build keeps every kernel reachable at test sizes.
+#ifdef PM_DEBUG
+inline bool lane_per_frame_pays(const int64_t, const int, const int64_t) { return true; }
+#else
+inline bool lane_per_frame_pays(const int64_t F, const int J, const int64_t min_joint_frames) {
+    const int over = tune_env("PM_LPF_MIN_JOINT_FRAMES", -1);  // PM_TUNING build only: the parity tests run these kernels at test sizes with 0
+    return F * (int64_t)J >= (over >= 0 ? (int64_t)over : min_joint_frames);
+}
+#endif
+constexpr int64_t kDeepDqMinJointFrames = 2400000, kMirrorDeepMinJointFrames = 6000000, kIkOrderMinJointFrames = 3000000, kFkStreamMinJointFrames = 1000000;
 constexpr int kDeepSlots = 6;  // parent states kept in registers for children that do not follow their parent directly (the kernels are LDS-bound at two waves per SIMD: the registers are there)
 enum : uint8_t { DEEP_CHAIN = 0xff, DEEP_LOCAL = 0xfe, DEEP_ROOT = 0xfd, DEEP_NONE = 0xff };
 struct DeepTopo {                    // by value in the kernarg segment: one s_load_dword per joint (a byte table would be read with

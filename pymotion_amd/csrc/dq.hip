@@ -858,13 +858,14 @@ static int to_root_dq_impl(const float *rot, const float *root_pos, const int32_
     const bool vec = aligned16(rot) && aligned16(dq);
     hipStream_t s = static_cast<hipStream_t>(stream);
     // Long skeletons: one lane per frame, the joints streamed through LDS in chunks (deep.hip) -- if the topology's open
-    // branch points fit its register slots.  PM_DQ_DEEP (PM_TUNING build only): 0 never, 1 whenever eligible.
+    // branch points fit its register slots and the call has the joint-frames to fill the chip (lane_per_frame_pays, common.hpp).
+    // PM_DQ_DEEP (PM_TUNING build only): 0 never, 1 whenever the topology fits.
     // A caller that knows the bones are big (a centimetre-scale BVH skeleton: any |offset| >= kBigOffset makes EVERY tile of the tile
     // kernels take the precise step) gets the lane-per-frame kernel from kDeepDqHintMinJ joints on: its float64 state costs the same
     // at every magnitude (2^20 x 22: 235 us against 259 us for the precise step -- and 205 us for the fp32 step on metre data, which
     // is why the raw ABI, which cannot see the scale without reading device memory, keeps the per-tile test below 40 joints).
     const bool big_bones = offsets_abs_max >= kBigOffset && offsets_abs_max < 3e38f;
-    if (const int deep = tune_env("PM_DQ_DEEP", -1); vec && deep != 0 && (deep == 1 || J >= kDeepDqMinJ || (big_bones && J >= kDeepDqHintMinJ))) {
+    if (const int deep = tune_env("PM_DQ_DEEP", -1); vec && deep != 0 && (deep == 1 || ((J >= kDeepDqMinJ || (big_bones && J >= kDeepDqHintMinJ)) && lane_per_frame_pays(F, J, kDeepDqMinJointFrames)))) {
         DeepTopo topo;
         if (deep_plan(a.parents, J, true, topo) >= 0) return launch_to_root_deep(rot, root_pos, offsets, dq, F, J, topo, s);
     }

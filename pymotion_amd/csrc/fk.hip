@@ -1530,7 +1530,9 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
         // long skeletons: the streamed three-lane walk (fk_stream_kernel) where the topology's cross-chunk branch points fit its register
         // slots; PM_FK_STREAM (PM_TUNING build only): 0 never, 1 from any joint count
         const int st = tune_env("PM_FK_STREAM", -1);
-        if (!pfo && vec && a.quat_out == nullptr && st != 0 && (st == 1 || fk_stream_wanted(a.J))) {
+        // (and only with the joint-frames to fill the chip: sixteen frames to a wave that walks all J joints -- chain-like J = 64 / 128 / 256 at
+        // 2^10 frames: 16 / 28 / 54 us against 9 / 15 / 26 us for the four-frame tiles; the crossovers sit at F J = 0.7-1.0 M)
+        if (!pfo && vec && a.quat_out == nullptr && st != 0 && (st == 1 || (fk_stream_wanted(a.J) && lane_per_frame_pays(a.F, a.J, kFkStreamMinJointFrames)))) {
             int rc = PM_OK;
             if (try_fk_stream(a, s, rc)) return rc;
         }

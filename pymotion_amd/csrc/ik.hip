@@ -934,7 +934,7 @@ extern "C" int pm_from_root_positions_f32(const float *positions, const int32_t 
     hipStream_t s = static_cast<hipStream_t>(stream);
     // one lane per frame, joints streamed through a ring of LDS slots (from_root_positions_order_kernel) where that pays and the table fits
     // its window / queue / register sets.  PM_IK_ORDER (PM_TUNING build only): 0 = never, 1 = whenever the table fits
-    if (const int ord = tune_env("PM_IK_ORDER", -1); aligned16(rotations) && J >= 2 && ord != 0 && (ord == 1 || ik_order_wanted(J))) {
+    if (const int ord = tune_env("PM_IK_ORDER", -1); aligned16(rotations) && J >= 2 && ord != 0 && (ord == 1 || (ik_order_wanted(J) && lane_per_frame_pays(F, J, kIkOrderMinJointFrames)))) {
         IkOrderArgs oa;
         if (ik_order_plan(a.topo, J, oa)) {
             oa.pos = positions; oa.offsets = offsets; oa.out = rotations; oa.F = F; oa.J = J;

@@ -412,9 +412,11 @@ extern "C" int pm_mirror_rotations_f32(const float *rot, const int32_t *parents,
     }
     const bool vec = aligned16(rot) && aligned16(out);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // mode 'all' on long skeletons: one lane per frame, joints streamed (mirror_deep_kernel).  PM_MIRROR_DEEP (PM_TUNING build only):
-    // 0 = never, 1 = whenever eligible
-    if (const int deep = tune_env("PM_MIRROR_DEEP", -1); vec && mapping == nullptr && deep != 0 && (deep == 1 || J >= kMirrorDeepMinJ)) {
+    // mode 'all' on long skeletons: one lane per frame, joints streamed (mirror_deep_kernel), where the call has the joint-frames to fill the
+    // chip (common.hpp).  From 66 joints on, and from 52 when the row is a whole number of 64-byte pieces (round 4, with the kernel's eight
+    // waves two to a SIMD: SMPL-H as stored and a chain-like 52 at 2^18 / 2^20 frames 81 / 324 us against 89-95 / 339 us for the scheduled
+    // walk; J = 40 a draw, J = 50 -- 8-byte row ends -- 9 % slower).  PM_MIRROR_DEEP (PM_TUNING build only): 0 = never, 1 = whenever eligible
+    if (const int deep = tune_env("PM_MIRROR_DEEP", -1); vec && mapping == nullptr && deep != 0 && (deep == 1 || ((J >= kMirrorDeepMinJ || (J >= 52 && J % 4 == 0)) && lane_per_frame_pays(F, J, kMirrorDeepMinJointFrames)))) {
         MirrorDeepArgs da;
         if (deep_plan(a.parents, J, false, da.topo) >= 0) {
             da.rot = rot; da.out = out; da.F = F; da.J = J; da.c0 = a.c0; da.c1 = a.c1;

@@ -68,3 +68,16 @@ def assert_close(a, b, atol, what=""):
     if a.size:
         err = np.abs(np.where(nan_a, 0, a) - np.where(nan_b, 0, b)).max()
         assert err <= atol, f"{what}: max abs err {err:.3e} > {atol:.1e}"
+
+
+@pytest.fixture
+def lane_per_frame_at_test_sizes(monkeypatch):
+    """The long-skeleton kernels (one lane per frame: deep.hip, mirror_deep_kernel, from_root_positions_order_kernel, and fk's streamed walk)
+    only take calls with enough joint-frames to fill the chip (common.hpp: lane_per_frame_pays -- a clip of real length is faster on the tile
+    kernels).  Parity tests that want THOSE kernels at sizes the oracle finishes in seconds run on the tuning build with the threshold at 0:
+    same kernels, same dispatch otherwise.  The production library's choice on either side of the threshold: tests/test_gpu_dispatch.py."""
+    from pymotion_amd import _lib
+
+    monkeypatch.setenv("PM_LPF_MIN_JOINT_FRAMES", "0")
+    with _lib.variant("tuning"):
+        yield

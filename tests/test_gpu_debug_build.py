@@ -47,11 +47,24 @@ def _p(t):
 
 
 def _both(fn):
-    """run fn(lib-variant-is-active) under production and debug; return both result lists"""
+    """run fn(lib-variant-is-active) under a release build and the debug build; return both result lists.  The debug build keeps every
+    kernel reachable at these sizes (common.hpp: lane_per_frame_pays is `true` there), so its partner is the tuning build with that
+    threshold at 0 -- the production kernels under the same dispatch; below the long-skeleton kernels' joint counts that IS the
+    production dispatch."""
+    import os
+
     out = []
-    for name in ("prod", "debug"):
-        with _lib.variant(name):
-            out.append(fn())
+    old = os.environ.get("PM_LPF_MIN_JOINT_FRAMES")
+    os.environ["PM_LPF_MIN_JOINT_FRAMES"] = "0"
+    try:
+        for name in ("tuning", "debug"):
+            with _lib.variant(name):
+                out.append(fn())
+    finally:
+        if old is None:
+            del os.environ["PM_LPF_MIN_JOINT_FRAMES"]
+        else:
+            os.environ["PM_LPF_MIN_JOINT_FRAMES"] = old
     return out
 
 

@@ -11,7 +11,7 @@ import pytest
 from oracle import c_oracle as co
 from pymotion_amd import _lib
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("lane_per_frame_at_test_sizes")]
 
 
 def _ulp_of(x):

@@ -313,6 +313,7 @@ def test_root_dual_quaternions_of_non_unit_rotations_at_centimetre_scale(J, kind
         assert err <= ulps * _ulp_of(d_o[sel]), (err / _ulp_of(d_o[sel]), "ulp", "scaled" if ulps == 8.0 else "unit")
 
 
+@pytest.mark.usefixtures("lane_per_frame_at_test_sizes")
 @pytest.mark.parametrize("J,kind", [(22, "body"), (31, "random"), (20, "random"), (36, "random")])
 def test_root_dual_quaternions_raw_abi_with_and_without_the_scale_hint(J, kind):
     """The front doors pass max |offsets| as a host-side hint (pm_to_root_dq_hint_f32): big-bone skeletons of 20 joints or more then

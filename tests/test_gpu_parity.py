@@ -693,6 +693,7 @@ def test_mirror_argument_errors():
         sk.mirror(*args, axis="W")
 
 
+@pytest.mark.usefixtures("lane_per_frame_at_test_sizes")
 @pytest.mark.parametrize("J,kind", [(52, "body"), (31, "random"), (130, "random"), (40, "random"), (41, "chain"), (64, "chain"), (65, "random"),
                                     (96, "random"), (96, "chain"), (250, "random"), (251, "random"), (300, "chain"), (66, "chain"), (71, "chain"), (128, "chain"), (512, "chain")])
 def test_mirror_big_skeletons_vs_oracle_composition(J, kind):
@@ -714,7 +715,8 @@ def test_mirror_big_skeletons_vs_oracle_composition(J, kind):
     off = syn.make_offsets(J, rng, 0.1)
     got, gt, o2, _ = sk.mirror(rot, root, parents, off, None, None, "all", "Y")
     from pymotion_amd import _lib
-    assert ("mirror_deep_kernel" in _lib.last_kernel_name()) == (kind == "chain" and J >= 66), _lib.last_kernel_name()  # mode 'all', long, few open branch points
+    # mode 'all', long (from 66 joints, from 52 when the row is whole 64-byte pieces), few open branch points
+    assert ("mirror_deep_kernel" in _lib.last_kernel_name()) == (kind in ("chain", "body") and (J >= 66 or (J >= 52 and J % 4 == 0))), _lib.last_kernel_name()
     _, rm = co.fk(rot.astype(np.float64), np.zeros((F, 3)), off.astype(np.float64), parents)
     g = co.quat_from_matrix(rm)
     g[..., 1] *= -1  # axis Y -> components (1, 3)  (skeleton.py:313-315)

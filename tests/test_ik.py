@@ -187,6 +187,7 @@ def _chain_like(J):
     return p
 
 
+@pytest.mark.usefixtures("lane_per_frame_at_test_sizes")
 @pytest.mark.gpu
 @pytest.mark.parametrize("J,kind,lane", [(24, "chain", True), (31, "chain", True), (23, "chain", False), (53, "body5", True), (47, "body4", True), (64, "chain", True),
                                          (65, "body5", True), (128, "chain", True), (250, "body5", True), (512, "chain", True), (59, "body6", None),
@@ -250,6 +251,7 @@ def _windowed_tree(J, w, rng):
     return p
 
 
+@pytest.mark.usefixtures("lane_per_frame_at_test_sizes")
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,order", [("smplh", True), ("smpl24", True), ("smplx55", None), ("bfs_body4_47", None), ("bfs_body5_53", None), ("win3_40", None),
                                         ("win4_64", None), ("win2_128", None), ("win6_96", None), ("win3_33", None), ("bfs_chain_64", None), ("bfs_chain_128", None)])
