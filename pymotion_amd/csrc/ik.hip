@@ -22,6 +22,7 @@
 namespace pm {
 
 constexpr int kIkFourChainsMinJ = 56;
+constexpr int64_t kIkClipFrames = 32768;  // a clip of real length: see the four-chain dispatch in pm_from_root_positions_f32
 
 #ifndef PM_IK_MINW
 #define PM_IK_MINW 4
@@ -954,10 +955,14 @@ extern "C" int pm_from_root_positions_f32(const float *positions, const int32_t 
     a.K = (J <= 254 && chains != 1 && chains != 4) ? ik_schedule(a.topo, J, a.sched) : 0;
     // FOUR chains (16 frames per wave) for long skeletons whose tree is wide enough to shorten the walk again: beyond ~56 joints the
     // 32-frame image leaves room for two to four waves per CU and the walk is all the kernel waits for
-    if (J <= 254 && (chains == 4 || (chains == 0 && J > kIkFourChainsMinJ))) {
+    // -- and for a clip of real length whatever the joint count: up to 2^15 frames a launch is a few waves per CU and takes as long as ONE
+    // wave's walk, which four chains shorten (the 22-joint body 10.5 -> 8.9 us, SMPL-H 20.8 -> 16.3 us at 2^10...2^14 frames; from 2^16
+    // frames on two chains -- twice the frames in a wave -- are ahead again: 14.3 against 18.8 us on the body)
+    const bool clip = F <= kIkClipFrames;
+    if (J <= 254 && (chains == 4 || (chains == 0 && (J > kIkFourChainsMinJ || clip)))) {
         uint8_t s4[512];
         const int K4 = ik_schedule(a.topo, J, s4, 4);
-        if (K4 > 0 && (chains == 4 || a.K == 0 || 10 * K4 <= 7 * a.K) && 2 * (16 * per_frame + fixed + (size_t)(J + 2) * 32) <= kMaxLds) {
+        if (K4 > 0 && (chains == 4 || a.K == 0 || 10 * K4 <= 7 * a.K || (clip && K4 < a.K)) && 2 * (16 * per_frame + fixed + (size_t)(J + 2) * 32) <= kMaxLds) {
             a.K = K4;
             memcpy(a.sched, s4, sizeof(s4));
             return launch_ik<16, 4>(a, vec, s);
