@@ -25,6 +25,7 @@ python $R/tools/dq_probe.py 22,28,40,48,52,56,64,65,96,128 > $OUT/r${RN}_to_root
 python $R/tools/ik_probe.py 4,22,28,52,96,128 2>&1 | grep -v amdgpu.ids > $OUT/r${RN}_from_root_positions_sweep.txt
 python $R/tools/ik_order_probe.py 2>&1 | grep -v amdgpu.ids >> $OUT/r${RN}_from_root_positions_sweep.txt
 python $R/tools/unroll_probe.py > $OUT/r${RN}_unroll_sweep.txt 2>&1
+python $R/tools/small_clip_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/r${RN}_small_clips.txt
 python $R/tools/prec_probe.py > $OUT/r${RN}_fk_precision_levels.txt 2>&1
 python $R/tools/numpy_door_probe.py > $OUT/r${RN}_numpy_door.txt 2>&1
 python $R/tools/store_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/r${RN}_store_patterns.txt
