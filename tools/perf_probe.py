@@ -3,6 +3,7 @@
 Prints one line per kernel: time, algorithmic GB/s, fraction of the 8 TB/s HBM spec.
 Not part of the graded bench; used while tuning and to produce profiles/ summaries."""
 import argparse
+import time
 import ctypes as C
 import os
 import sys
@@ -30,13 +31,24 @@ def timeit(fn, reps=20, warm=3):
     if SUSTAINED:  # back-to-back launches, one pair of events around all of them (what bench.py does)
         for _ in range(150):  # the clocks only settle under THIS kernel's load (~50 ms)
             fn()
-        _lib.call("pm_event_record", ev[0], None)
-        for _ in range(SUSTAINED):
-            fn()
-        _lib.call("pm_event_record", ev[1], None)
-        ms = C.c_float()
-        _lib.call("pm_event_elapsed_ms", ev[0], ev[1], C.byref(ms))
-        return ms.value / SUSTAINED, ms.value / SUSTAINED
+        # The window only measures the KERNEL while the host stays ahead of the device.  On the shared boxes the launching thread is descheduled
+        # for 15-35 ms a few times per process (round 4: a 10 us kernel read 900 us "per launch" in one window of 40 launches and 10 us in the
+        # next, whichever kernel was being timed -- tools/scratch/bvh_fused_hunt*.py); a window in which enqueueing took more than half of the
+        # device time is repeated, up to three times, and the fastest window counts.
+        best = float("inf")
+        for _attempt in range(3):
+            t0 = time.perf_counter()
+            _lib.call("pm_event_record", ev[0], None)
+            for _ in range(SUSTAINED):
+                fn()
+            _lib.call("pm_event_record", ev[1], None)
+            t_enq = (time.perf_counter() - t0) * 1e3
+            ms = C.c_float()
+            _lib.call("pm_event_elapsed_ms", ev[0], ev[1], C.byref(ms))
+            best = min(best, ms.value / SUSTAINED)
+            if t_enq < 0.5 * ms.value:
+                break
+        return best, best
     ts = []
     for _ in range(reps):
         _lib.call("pm_event_record", ev[0], None)

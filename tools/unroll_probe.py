@@ -55,6 +55,14 @@ for lg in (10, 12, 14, 16, 18, 20):
     ms1, _ = pp.timeit(fused)
     ms3, _ = pp.timeit(three)
     ms1b, _ = pp.timeit(fused)  # (again, after the three launches: the order must not matter)
-    ms1 = min(ms1, ms1b) if abs(ms1 - ms1b) < 0.1 * ms1 else max(ms1, ms1b)
+    # (a timing window is only the kernel while the host stays ahead of the device; pp.timeit repeats a window in which the launching thread was
+    # descheduled -- round 4: 15-35 ms stalls a few times per process made a 10 us kernel read 900 us in one window and 10 us in the next.  The
+    # before / after pair is kept as a second guard.)
+    note = ""
+    if max(ms1, ms1b) > 2.0 * min(ms1, ms1b):
+        ms1c, _ = pp.timeit(fused)
+        note = f"  [one timing window of three was slow: {ms1 * 1e3:.1f} / {ms1b * 1e3:.1f} / {ms1c * 1e3:.1f} us]"
+        ms1, ms1b = sorted((ms1, ms1b, ms1c))[:2]
+    ms1, ms1b = min(ms1, ms1b), max(ms1, ms1b)
     print(f"[{tag}] get_data fused T=2^{lg} S={S}: {ms1 * 1e3:8.1f} us ({T * S * 28 / ms1 / 1e6 / 80:5.1f}% of 8 TB/s on 28 B per joint-frame)"
-          f"  three launches {ms3 * 1e3:8.1f} us  -> {ms3 / ms1:4.2f}x   (fused before / after: {ms1 * 1e3:.1f} / {ms1b * 1e3:.1f})", flush=True)
+          f"  three launches {ms3 * 1e3:8.1f} us  -> {ms3 / ms1:4.2f}x   (fused before / after: {ms1 * 1e3:.1f} / {ms1b * 1e3:.1f}){note}", flush=True)
