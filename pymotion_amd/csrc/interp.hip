@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void interp_linear_kernel(const InterpArgs a) 
 // accesses, one lane in ceil(B / 4)).  Round 2 fell back to dwordx2 / single floats per lane there: 58 % / 40 % of the HBM spec
 // against 78-82 % for rows of 72 / 156 floats.
 typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef float v2f_a4 __attribute__((ext_vector_type(2), aligned(4)));
 
 __global__ __launch_bounds__(256) void interp_linear_flat_kernel(const InterpArgs a) {
     // lane-elements are dwordx4 counted PER ROW: V = ceil(B / 4) to a row, the last one of a row holding B % 4 floats
@@ -124,9 +125,18 @@ __global__ __launch_bounds__(256) void interp_linear_flat_kernel(const InterpArg
         const float w = a.w[s], u = 1.0f - w;                  // time.py:61-64
         const float *p0 = a.pos + ((aa * a.T + i0) * B) + 4 * v;
         float *o_ = a.out + (row0 + dr) * B + 4 * v;
-        if (tail == 0 || v != V - 1) {
+        // A row's last vector holds B % 4 floats.  Its LOADS are whole dwordx4 like everybody's (the floats past the row's end are the next
+        // row's first ones, read and dropped) -- per-float loads and stores there cost the whole wave six more memory instructions per vector
+        // for one lane in 17 (rows of 66 floats: 39.7 us against 31-32 us for rows of 64 / 72) -- unless that would read past the end of the
+        // array (the last vector of the last frame pair); its store is one dwordx2 (or one / three floats).
+        const bool whole = tail == 0 || v != V - 1;
+        const bool at_end = aa == a.A - 1 && (int64_t)i0 + 2 == a.T;
+        if (whole || !at_end) {
             const v4f_a4 x = *reinterpret_cast<const v4f_a4 *>(p0), y = *reinterpret_cast<const v4f_a4 *>(p0 + B);
-            *reinterpret_cast<v4f_a4 *>(o_) = v4f_a4{u * x.x + w * y.x, u * x.y + w * y.y, u * x.z + w * y.z, u * x.w + w * y.w};
+            const v4f_a4 r = v4f_a4{u * x.x + w * y.x, u * x.y + w * y.y, u * x.z + w * y.z, u * x.w + w * y.w};
+            if (whole) *reinterpret_cast<v4f_a4 *>(o_) = r;
+            else if (tail == 2) *reinterpret_cast<v2f_a4 *>(o_) = v2f_a4{r.x, r.y};
+            else { o_[0] = r.x; if (tail == 3) { o_[1] = r.y; o_[2] = r.z; } }
         } else {
             for (int j = 0; j < tail; ++j) o_[j] = u * p0[j] + w * p0[B + j];
         }
