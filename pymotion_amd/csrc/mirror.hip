@@ -214,7 +214,7 @@ __global__ __launch_bounds__(PM_WAVE) void mirror_kernel(const MirrorArgs a) {
 // Mode 'all' (no joint permutation) on skeletons whose open branch points fit deep.hip's six register slots: ONE LANE PER FRAME,
 // the joints streamed through a ring of sixteen 16-byte LDS slots per frame (a quaternion comes in, the mirrored local rotation goes
 // out through the same slot; groups of eight records cut at the 128-byte lines of both arrays, a group's slots read into registers
-// before the next group is parked over them and stored after: the structure of from_root_positions_deep_kernel, ik.hip).  A lane's
+// before the next group is parked over them and stored after: the structure of from_root_positions_order_kernel, ik.hip).  A lane's
 // state is the world quaternion of the joint before and its mirrored, sign-fixed form; a parent that is not the previous joint
 // comes from a saved register set.  Nothing grows with J, and a chain-like skeleton -- where the scheduled walk has nothing to
 // schedule -- costs what a bushy one costs.
