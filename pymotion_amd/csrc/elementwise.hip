@@ -22,8 +22,14 @@ extern "C" void pm_debug_shrink_lds(int bytes) { g_debug_shrink = bytes; }
 
 namespace pm {
 
-constexpr int EW_TILE = 128;  // elements per wave
+constexpr int EW_TILE = 128;  // elements per wave (the default; EwTileOf below)
 constexpr int EW_PER_LANE = EW_TILE / PM_WAVE;
+// Elements per wave of ew_kernel, per op.  Round 4, same box, 64 / 128 / 256 per wave (us at 23 M elements): the Euler conversions want more
+// in flight per wave (from_euler 246 / 112 / 105.5, to_euler 114 / 112.6 / 107.7; dq.to_rotation_translation 220 / 226.6 / 216 on one box and
+// 213 -> 215 on the next: left at 128),
+// the ops with two or three operand tiles fewer and more waves (from_to_axis 171 / 182.6 / 196.7, from_to 140 / 143 / 147, mul_vec 146.8 / 149.8 /
+// 151.3, ortho6d.to_quat 141.7 / 145.4 / 147); the rest is best at 128 or indifferent (specialisations next to the entry points).
+template <class Op> struct EwTileOf { static constexpr int v = EW_TILE; };
 
 struct EwArgs {
     const float *in0, *in1, *in2;
@@ -98,18 +104,19 @@ template <class Op, bool VEC>
 __global__ __launch_bounds__(PM_WAVE) void ew_kernel(const EwArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int I0 = Op::I0, I1 = Op::I1, I2 = Op::I2, O0 = Op::O0, O1 = Op::O1;
+    constexpr int TILE = EwTileOf<Op>::v, PER_LANE = TILE / PM_WAVE;
     const int lane = threadIdx.x;
-    const int64_t ntiles = (a.N + EW_TILE - 1) / EW_TILE;
+    const int64_t ntiles = (a.N + TILE - 1) / TILE;
     const int64_t tile = xcd_tile(ntiles);
     if (tile < 0) return;
-    const int64_t e0 = tile * EW_TILE;
-    const int n = (int)((a.N - e0) < EW_TILE ? (a.N - e0) : EW_TILE);
+    const int64_t e0 = tile * TILE;
+    const int n = (int)((a.N - e0) < TILE ? (a.N - e0) : TILE);
 
     float *s0 = smem;  // tiles of the staged operands only
-    float *s1 = s0 + EW_TILE * ew_lds_in(I0);
-    float *s2 = s1 + EW_TILE * ew_lds_in(I1);
-    float *t0 = s2 + EW_TILE * ew_lds_in(I2);
-    float *t1 = t0 + EW_TILE * ew_lds_out(O0);
+    float *s1 = s0 + TILE * ew_lds_in(I0);
+    float *s2 = s1 + TILE * ew_lds_in(I1);
+    float *t0 = s2 + TILE * ew_lds_in(I2);
+    float *t1 = t0 + TILE * ew_lds_out(O0);
 
     EwArgs b = a;
     b.tile_e0 = e0;
@@ -117,16 +124,16 @@ __global__ __launch_bounds__(PM_WAVE) void ew_kernel(const EwArgs a) {
     // Euler orders: three bytes per element from a side table.  Requested here, ahead of the operands -- inside the op they were a
     // second, dependent trip to memory per tile (to_euler: waves waiting 77 % of their time, 51 % of the HBM spec).
     // (to_euler needs its order first thing; from_euler only after three sincos, which hide the trip -- fetched early it was 3.5 % slower)
-    int opk[EW_PER_LANE];
+    int opk[PER_LANE];
 #pragma unroll
-    for (int m = 0; m < EW_PER_LANE; ++m) opk[m] = 0;
+    for (int m = 0; m < PER_LANE; ++m) opk[m] = 0;
     if constexpr (__is_same(Op, OpToEuler)) {
 #pragma unroll
-        for (int m = 0; m < EW_PER_LANE; ++m) {
+        for (int m = 0; m < PER_LANE; ++m) {
             const int idx = m * PM_WAVE + lane, ic = idx < n ? idx : n - 1;
             int64_t row = 0;
             if (a.flag == 1) row = e0 + ic;
-            else if (a.flag >= 2) row = (unsigned)(b.order_r0 + ic) % (unsigned)a.flag;  // < P + EW_TILE: 32-bit
+            else if (a.flag >= 2) row = (unsigned)(b.order_r0 + ic) % (unsigned)a.flag;  // < P + TILE: 32-bit
             const uint8_t *p = a.order + row * 3;
             opk[m] = (int)p[0] | ((int)p[1] << 8) | ((int)p[2] << 16);
         }
@@ -138,16 +145,16 @@ __global__ __launch_bounds__(PM_WAVE) void ew_kernel(const EwArgs a) {
     // Reads and arithmetic are unconditional (a slot past a partial tile re-reads the tile's last record), so
     // that the elements of a lane are scheduled and packed together with no exec-mask branch between them;
     // only the write-back is guarded.
-    float x0[EW_PER_LANE][I0 ? I0 : 1], x1[EW_PER_LANE][I1 ? I1 : 1], x2[EW_PER_LANE][I2 ? I2 : 1];
+    float x0[PER_LANE][I0 ? I0 : 1], x1[PER_LANE][I1 ? I1 : 1], x2[PER_LANE][I2 ? I2 : 1];
 #pragma unroll
-    for (int m = 0; m < EW_PER_LANE; ++m) {
+    for (int m = 0; m < PER_LANE; ++m) {
         const int idx = m * PM_WAVE + lane, ic = idx < n ? idx : n - 1;
         ew_get<I0, VEC>(a.in0, s0, e0, ic, x0[m]);
         ew_get<I1, VEC>(a.in1, s1, e0, ic, x1[m]);
         ew_get<I2, VEC>(a.in2, s2, e0, ic, x2[m]);
     }
 #pragma unroll
-    for (int m = 0; m < EW_PER_LANE; ++m) {
+    for (int m = 0; m < PER_LANE; ++m) {
         const int idx = m * PM_WAVE + lane, ic = idx < n ? idx : n - 1;
         float y0[O0 ? O0 : 1], y1[O1 ? O1 : 1];
         b.order_pk = opk[m];
@@ -170,8 +177,9 @@ static int launch_ew(const EwArgs &a, pm_stream_t stream, const char *name) {
         set_error("%s: null pointer", name);
         return PM_EINVAL;
     }
-    constexpr size_t lds = (size_t)EW_TILE * (ew_lds_in(Op::I0) + ew_lds_in(Op::I1) + ew_lds_in(Op::I2) + ew_lds_out(Op::O0) + ew_lds_out(Op::O1)) * sizeof(float);
-    const int64_t ntiles = (a.N + EW_TILE - 1) / EW_TILE;
+    constexpr int TILE = EwTileOf<Op>::v;
+    constexpr size_t lds = (size_t)TILE * (ew_lds_in(Op::I0) + ew_lds_in(Op::I1) + ew_lds_in(Op::I2) + ew_lds_out(Op::O0) + ew_lds_out(Op::O1)) * sizeof(float);
+    const int64_t ntiles = (a.N + TILE - 1) / TILE;
     const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
     if (grid > 0x7fffffffLL) { set_error("%s: grid too large", name); return PM_EUNSUPPORTED; }
     const bool vec = aligned16(a.in0) && aligned16(a.in1) && aligned16(a.in2) && aligned16(a.out0) && aligned16(a.out1);
@@ -528,6 +536,14 @@ __global__ __launch_bounds__(256) void plain_stream_kernel(const v4f *__restrict
         }
     }
 }
+
+// (see EwTileOf)
+template <> struct EwTileOf<OpFromEuler> { static constexpr int v = 256; };
+template <> struct EwTileOf<OpToEuler> { static constexpr int v = 256; };
+template <> struct EwTileOf<OpFromToAxis> { static constexpr int v = 64; };
+template <> struct EwTileOf<OpFromTo> { static constexpr int v = 64; };
+template <> struct EwTileOf<OpMulVec> { static constexpr int v = 64; };
+template <> struct EwTileOf<OpO6dToQuat> { static constexpr int v = 64; };
 
 }  // namespace pm
 
