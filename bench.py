@@ -145,13 +145,23 @@ def secondary_configs(torch, _lib, syn, dev, rot, root, off, parents, sptr):
     def timed(fn, n=100):
         for _ in range(150):
             fn()
-        _lib.call("pm_event_record", ev[0], sptr)
-        for _ in range(n):
-            fn()
-        _lib.call("pm_event_record", ev[1], sptr)
-        ms = C.c_float()
-        _lib.call("pm_event_elapsed_ms", ev[0], ev[1], C.byref(ms))
-        return ms.value / n
+        # (a window is the kernel's time only while the launching thread stays ahead of the device: one in which enqueueing took more than half
+        # of the device time -- the thread was descheduled, DESIGN section 6 -- is repeated, up to three times; secondary numbers only, the
+        # headline region is timed exactly once)
+        best = float("inf")
+        for _attempt in range(3):
+            t0 = time.perf_counter()
+            _lib.call("pm_event_record", ev[0], sptr)
+            for _ in range(n):
+                fn()
+            _lib.call("pm_event_record", ev[1], sptr)
+            t_enq = (time.perf_counter() - t0) * 1e3
+            ms = C.c_float()
+            _lib.call("pm_event_elapsed_ms", ev[0], ev[1], C.byref(ms))
+            best = min(best, ms.value / n)
+            if t_enq < 0.5 * ms.value:
+                break
+        return best
 
     out = {}
     rotn = rot / rot.norm(dim=-1, keepdim=True)
