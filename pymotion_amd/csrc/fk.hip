@@ -440,7 +440,9 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
     const int FJ = FPW * J;
     const int n = nf * J;  // (frame, joint) elements in this tile
     constexpr bool QUAD = FPW <= 5;  // few frames per wave (big J): 12 lanes per frame, see tree_walk_quad
-    constexpr bool Q4 = FPW == 16 && !PFO;  // sixteen frames: a quad per frame, the joint's L shared through DPP (tree_walk_q4)
+    // a quad per frame, the joint's L shared through DPP (tree_walk_q4): sixteen frames fill the wave; with twelve / eight the last quads sit
+    // the walk out (round 5: the walk is ~18 instructions per joint this way against ~42 for the three-lane one)
+    constexpr bool Q4 = (FPW == 16 || FPW == 12 || FPW == 8) && !PFO;
     const bool q4 = Q4 && !PM_ABLATED(a, 8);  // PM_FK_ABLATE & 8 (tuning build): the three-lane walk
     constexpr bool DYN = (PREC & PREC_DYN) != 0;
 
@@ -457,7 +459,7 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
     // Lanes >= 3*FPW shadow lanes 0.. (same frame, same row, same values, same addresses) and frames
     // past the end of a partial tile walk uninitialised slots of their own: phase B needs no masking.
     const int wl = q4 ? lane : lane % ((QUAD ? 12 : 3) * FPW);
-    const int f = q4 ? (lane >> 2) : (QUAD ? wl / 12 : wl / 3);
+    const int f = q4 ? ((lane >> 2) < FPW ? (lane >> 2) : FPW - 1) : (QUAD ? wl / 12 : wl / 3);  // (q4, fewer than sixteen frames: the quads past the tile shadow its last frame and sit the walk out)
     const int r = q4 ? ((lane & 3) < 3 ? (lane & 3) : 2) : (QUAD ? (wl - 12 * f) / 4 : wl - 3 * f);  // (q4: lane 3 of a quad shadows lane 2's loads and sits the walk out)
     const int c = wl & 3;  // QUAD only: column of [R | p]
     const float gp = (f < nf) ? a.root_pos[f0 * 3 + f * 3 + r] : 0.0f;
@@ -608,7 +610,7 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
                 else tree_walk_quad<PFO, false>(sRot, sPos, sOff, sConst, J, pad, f, r, c, seed, lane, 1.0f);
             }
         } else if (Q4 && q4) {
-            if ((lane & 3) < 3) {  // (the DPP operands come from lanes 0..2 of the quad only)
+            if ((lane & 3) < 3 && (lane >> 2) < FPW) {  // (the DPP operands come from lanes 0..2 of the quad only)
                 if (FX && fixed) tree_walk_q4<FX>(sRot, sPos, sConst, J, pad, f, r, gp, PM_ABLATED(a, 2), fx.S);
                 else tree_walk_q4<false>(sRot, sPos, sConst, J, pad, f, r, gp, PM_ABLATED(a, 2), 1.0f);
             }
@@ -702,9 +704,10 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? ((PFO && E
         tsum = (bmax < bsum) ? bmax : bsum;
     }
 
+    constexpr bool Q4 = (FPW == 16 || FPW == 12 || FPW == 8) && !PFO;  // a quad per frame, L shared through DPP (tree_walk_q4; see fk_tile)
     const int wl = lane % ((QUAD ? 12 : 3) * FPW);
-    const int f = QUAD ? wl / 12 : wl / 3;
-    const int r = QUAD ? (wl - 12 * f) / 4 : wl - 3 * f;
+    const int f = Q4 ? ((lane >> 2) < FPW ? (lane >> 2) : FPW - 1) : (QUAD ? wl / 12 : wl / 3);
+    const int r = Q4 ? ((lane & 3) < 3 ? (lane & 3) : 2) : (QUAD ? (wl - 12 * f) / 4 : wl - 3 * f);
     const int c = wl & 3;  // QUAD only: column of [R | p]
 
     v4f in4[EPL];       // SRC_QUAT: one quaternion per record
@@ -866,6 +869,11 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? ((PFO && E
                 if (CAN_FX && fixed) tree_walk_quad<PFO, CAN_FX>(sRot, sPos, sOff, sConst, J, pad, f, r, c, seed, lane, fx.S);
                 else tree_walk_quad<PFO, false>(sRot, sPos, sOff, sConst, J, pad, f, r, c, seed, lane, 1.0f);
             }
+        } else if constexpr (Q4) {
+            if ((lane & 3) < 3 && (lane >> 2) < FPW) {  // (the DPP operands come from lanes 0..2 of a quad)
+                if (CAN_FX && fixed) tree_walk_q4<CAN_FX>(sRot, sPos, sConst, J, pad, f, r, gp_i, PM_ABLATED(a, 2), fx.S);
+                else tree_walk_q4<false>(sRot, sPos, sConst, J, pad, f, r, gp_i, PM_ABLATED(a, 2), 1.0f);
+            }
         } else {
             if (CAN_FX && fixed) tree_walk<PFO, CAN_FX>(sRot, sPos, sOff, sConst, J, pad, f, r, gp_i, PM_ABLATED(a, 2), fx.S);
             else tree_walk<PFO, false>(sRot, sPos, sOff, sConst, J, pad, f, r, gp_i, PM_ABLATED(a, 2), 1.0f);
@@ -901,7 +909,7 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? ((PFO && E
 //   * big-magnitude tiles (PREC_DYN) take float64 local rotations and the fixed-point translation chain like every fk kernel; the
 //     words stay in the image and the slots, and are converted on their way out.  A NaN / Inf that turns up in a later chunk (the tile
 //     kernels look at the whole tile before they choose) poisons the word: INT_MIN travels down the chain and leaves as NaN.
-constexpr int kFsCH = 32, kFsSlots = 8;
+constexpr int kFsSlots = 8;
 enum : int { FS_CHAIN = 0xff, FS_ROOT = 0xfd, FS_LDS = 0x80, FS_NONE = 0xff };
 struct FkStreamArgs {
     const float *rot, *root_pos, *offsets;
@@ -1514,11 +1522,14 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
 #ifdef PM_TUNING
     if constexpr (SRC == SRC_QUAT) {  // the three-lane tile, several tiles per workgroup with the next tile's records prefetched into registers
         const int pnt = tune_env("PM_FK_PIPE3", 0);
-        if (pnt > 0 && !pfo && a.J == 22) {
+        if (pnt > 0 && !pfo) {
             a.pad = pad3;
-            if (pick == 20) return dispatch_fk_pipe<20, 7, SRC>(a, vec, pfo, pnt, s);
-            if (pick == 16) return dispatch_fk_pipe<16, 6, SRC>(a, vec, pfo, pnt, s);
-            if (pick == 12) return dispatch_fk_pipe<12, 5, SRC>(a, vec, pfo, pnt, s);
+            if (pick == 20 && a.J <= 22) return dispatch_fk_pipe<20, 7, SRC>(a, vec, pfo, pnt, s);
+            if (pick == 16 && a.J <= 24) return dispatch_fk_pipe<16, 6, SRC>(a, vec, pfo, pnt, s);
+            if (pick == 12 && a.J <= 26) return dispatch_fk_pipe<12, 5, SRC>(a, vec, pfo, pnt, s);
+            if (pick == 8 && a.J <= 40) return dispatch_fk_pipe<8, 5, SRC>(a, vec, pfo, pnt, s);
+            if (pick == 8 && a.J <= 56) return dispatch_fk_pipe<8, 7, SRC>(a, vec, pfo, pnt, s);
+            if (pick == 8 && a.J <= 64) return dispatch_fk_pipe<8, 8, SRC>(a, vec, pfo, pnt, s);
         }
     }
 #endif

@@ -168,6 +168,9 @@ extern "C" int pm_store_probe_f32(const float *src, float *dst, int64_t n4, cons
     if (pol == -1) return check_hip(hipMemsetD32Async((hipDeviceptr_t)dst, 0x3f800000, (size_t)n4 * 4, s), "hipMemsetD32Async");
     PM_CHECK_ARGS((threads == 64 || threads == 256) && rd4 >= 0 && (rd4 == 0 || src) && placement >= 0 && placement <= 2 && split >= 0 && split <= 2,
                   "store_probe: bad configuration");
+    bool burst_ok = false;
+    for (const int b : {1, 2, 3, 4, 6, 8, 12, 16, 24, 32}) burst_ok |= burst == b;
+    PM_CHECK_ARGS(burst_ok, "store_probe: burst must be 1, 2, 3, 4, 6, 8, 12, 16, 24 or 32 KiB");   // before it divides anything
     PM_CHECK_ARGS(split == 0 || burst % 4 == 0, "store_probe: split needs a burst that is a multiple of 4");
     ProbeArgs a;
     const int wpb = threads / 64;
@@ -195,6 +198,5 @@ extern "C" int pm_store_probe_f32(const float *src, float *dst, int64_t n4, cons
         case 16: return launch_probe_b<16>(a, pol, (int)grid, threads, s);
         case 32: return launch_probe_b<32>(a, pol, (int)grid, threads, s);
     }
-    set_error("store_probe: burst must be 1, 2, 3, 4, 6, 8, 12, 16, 24 or 32 KiB");
-    return PM_EINVAL;
+    return PM_EINVAL;  // (unreachable: burst_ok above)
 }

@@ -81,3 +81,46 @@ def lane_per_frame_at_test_sizes(monkeypatch):
     monkeypatch.setenv("PM_LPF_MIN_JOINT_FRAMES", "0")
     with _lib.variant("tuning"):
         yield
+
+
+class ReferenceSuite:
+    """tests/golden/reference_suite.npz (oracle/record_reference_suite.py): every call the reference's own test suite makes into the
+    hot-path modules -- module, function, arguments and the result the reference returned -- as data."""
+
+    def __init__(self):
+        import json
+
+        z = np.load(os.path.join(GOLDEN, "reference_suite.npz"))
+        self.pools = {k[5:]: z[k] for k in z.files if k.startswith("pool_")}
+        self.records = json.loads(str(z["manifest"]))
+
+    def value(self, spec, as_tensor=True, device=None):
+        """materialise a recorded value; arrays recorded from torch tensors come back as tensors (on `device`) unless as_tensor is False"""
+        k = spec["k"]
+        if k == "none":
+            return None
+        if k == "scalar":
+            return spec["v"]
+        if k in ("tuple", "list"):
+            items = [self.value(s, as_tensor, device) for s in spec["items"]]
+            return tuple(items) if k == "tuple" else items
+        n = int(np.prod(spec["shape"], dtype=np.int64))
+        a = self.pools[spec["dtype"]][spec["off"]:spec["off"] + n].reshape(spec["shape"]).copy()
+        if spec["tensor"] and as_tensor:
+            import torch
+
+            t = torch.from_numpy(a)
+            return t.to(device) if device is not None else t
+        return a
+
+    def by_function(self):
+        out = {}
+        for i, r in enumerate(self.records):
+            out.setdefault(r["module"] + "." + r["function"], []).append(i)
+        return out
+
+
+def reference_suite():
+    if "reference_suite" not in _cache:
+        _cache["reference_suite"] = ReferenceSuite()
+    return _cache["reference_suite"]

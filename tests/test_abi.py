@@ -122,3 +122,19 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "oracle" not in txt.lower() or f == "synthetic.py", f"{f} mentions the oracle"
+
+
+def test_kernel_names_listed_for_the_oracle_tie_are_the_ones_the_sources_can_report():
+    """tests/test_gpu_dispatch.py ties every kernel `pm_last_kernel_name()` can name to the oracle on the production library; its list must be
+    the `set_kernel_name` sites of the sources"""
+    import glob
+    import re
+
+    names = set()
+    for f in glob.glob(os.path.join(ROOT, "pymotion_amd", "csrc", "*.hip")):
+        src = open(f).read()
+        for call in re.finditer(r"set_kernel_name\((.*?)\);", src, re.S):
+            names.update(re.findall(r"pm::(\w+_kernel)", call.group(1)))
+    import test_gpu_dispatch as d
+
+    assert names == d.ALL_SKELETON_KERNELS, (sorted(names ^ d.ALL_SKELETON_KERNELS))

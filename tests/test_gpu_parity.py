@@ -863,9 +863,14 @@ def test_maximum_joint_count_everywhere():
     r_ik = sk.from_root_positions(pos32, parents, off)
     r_or = co.from_root_positions(f64(pos32), parents, f64(off))
     d = np.minimum(np.abs(r_ik - r_or).max(-1), np.abs(r_ik + r_or).max(-1))
-    # a handful of the 3072 random bones sit next to from_to's anti-parallel case, where fp32 vs fp64 rounding
-    # alone moves the answer by ~1e-2: judge the bulk tightly and cap the outliers
-    assert np.median(d) <= 1e-5 and (d > 1e-3).mean() < 0.005 and d.max() < 0.05, (np.median(d), (d > 1e-3).mean(), d.max())
+    # per record, tests/test_ik.py's bar beyond 128 joints: 2e-5 + what 64 ulps of the fp32 positions do to the reference's own float64
+    # answer (a handful of the 3072 random bones sit next to from_to's anti-parallel case, where one ulp of input alone moves the
+    # reference by ~1e-3; round 4 judged this call by quantiles with a 0.05 cap)
+    from test_ik import _record_bar
+
+    bar, sens = _record_bar(pos32, parents, off, r_or, k=64, draws=12)
+    assert (d <= bar).all(), (float(d.max()), float(((d - 2e-5) / np.maximum(sens, 1e-12)).max()), int((d > bar).sum()))
+    assert np.median(d) <= 1e-5, float(np.median(d))
     with pytest.raises(ValueError):
         sk.fk(np.zeros((2, 513, 4), np.float32), np.zeros((2, 3), np.float32), np.zeros((513, 3), np.float32), np.maximum(np.arange(513) - 1, 0))
 

@@ -88,17 +88,34 @@ def test_gpu_from_root_positions(case):
     assert _same_rotation_err(got_t.cpu().numpy(), want) <= 2e-5
 
 
-def _reference_sensitivity(pos, par, off, ref, draws=3):
-    """How far the REFERENCE's own (float64) answer moves when its fp32 inputs move by one ulp: from_to is ill-conditioned where a
+def _reference_sensitivity(pos, par, off, ref, draws=3, ulps=1):
+    """How far the REFERENCE's own (float64) answer moves when its fp32 inputs move by `ulps` ulps: from_to is ill-conditioned where a
     bone has to turn by nearly 180 degrees (the axis of a half turn is any direction perpendicular to the bone), and everything
-    below such a joint inherits the twist.  Max over a few random one-ulp perturbations, per (frame, joint)."""
+    below such a joint inherits the twist.  Max over a few random perturbations, per (frame, joint)."""
     s = np.zeros(ref.shape[:2])
     for k in range(draws):
         up = np.random.default_rng(k + 1).random(pos.shape) < 0.5
-        pos2 = np.nextafter(pos, np.where(up, np.inf, -np.inf).astype(np.float32))
+        pos2 = pos
+        for _ in range(ulps):
+            pos2 = np.nextafter(pos2, np.where(up, np.inf, -np.inf).astype(np.float32))
         ref2 = co.from_root_positions(pos2.astype(np.float64), par, off.astype(np.float64))
         s = np.maximum(s, np.minimum(np.abs(ref2 - ref).max(-1), np.abs(ref2 + ref).max(-1)))
     return s
+
+
+def _record_bar(pos, par, off, ref, k=8, draws=3):
+    """The bar of one (frame, joint) record: 2e-5, plus what `k` ulps of the fp32 inputs do to the reference's own float64 answer --
+    estimated linearly (k x the movement under one ulp) AND directly (the movement under k ulps).  The second catches what the first
+    cannot: the reference's answer is DISCONTINUOUS in its inputs -- np.sign(cross . axis) decides which way a roll turns
+    (quat.py:628), np.isclose(dot, +-1) picks the parallel / anti-parallel branches (:551-571, :635-645) -- and a record that sits within
+    k ulps of such a switch has no well-defined answer at fp32 input precision: either side is the reference's answer to inputs a few
+    ulps away.  (Round 4's win2_511 -- 511 joints, depth 334, mostly one-child chains -- read 0.67 on ONE record of 204 400: joint 309 of
+    frame 351 sits below an alignment of 177.8 degrees that nothing re-anchors, where the reference itself moves by 1.4e-4 per ulp, and its
+    roll's cross . axis is within that of zero: tools/ik_path_diag.py, profiles/r05_ik_deep_tables.txt.  Every other joint of that path is
+    within 2 x the reference's own movement.)"""
+    lin = _reference_sensitivity(pos, par, off, ref, draws=draws, ulps=1)
+    direct = _reference_sensitivity(pos, par, off, ref, draws=draws, ulps=k)
+    return 2e-5 + np.maximum(k * lin, direct), lin
 
 
 @pytest.mark.gpu
@@ -254,7 +271,8 @@ def _windowed_tree(J, w, rng):
 @pytest.mark.usefixtures("lane_per_frame_at_test_sizes")
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,order", [("smplh", True), ("smpl24", True), ("smplx55", None), ("bfs_body4_47", None), ("bfs_body5_53", None), ("win3_40", None),
-                                        ("win4_64", None), ("win2_128", None), ("win6_96", None), ("win3_33", None), ("bfs_chain_64", None), ("bfs_chain_128", None)])
+                                        ("win4_64", None), ("win2_128", None), ("win6_96", None), ("win3_33", None), ("bfs_chain_64", None), ("bfs_chain_128", None),
+                                        ("win2_511", None), ("win3_300", None), ("bfs_body5_253", None)])
 def test_gpu_from_root_positions_lane_per_frame_on_tables_in_any_order(kind, order):
     """tables that are parents-first but NOT depth first (SMPL-H's level-order 52 joints) take from_root_positions_order_kernel when their
     children sit inside the ring's window or the per-lane queue (ik_order_plan), the tile kernels otherwise: same bars either way, full and
@@ -294,18 +312,24 @@ def test_gpu_from_root_positions_lane_per_frame_on_tables_in_any_order(kind, ord
         assert order is None or ("from_root_positions_order_kernel" in name) == order, name
         ref = co.from_root_positions(pos.astype(np.float64), par, off.astype(np.float64))
         err = np.minimum(np.abs(got - ref).max(-1), np.abs(got + ref).max(-1))
-        # (these deep, narrow trees have many nearly straight bones: the sensitivity is the max over twelve one-ulp draws -- with three the
-        # worst record of win6_96 read 13.8 x, with twelve 1.5 x, on this kernel and on the tile kernel alike)
-        sens = _reference_sensitivity(pos, par, off, ref, draws=12 if J <= 128 else 3)
-        k = 8.0 if J <= 128 else 64.0
-        assert (err <= 2e-5 + k * sens).all(), (F, name, float(err.max()), float(((err - 2e-5) / np.maximum(sens, 1e-12)).max()))
+        # (these deep, narrow trees have many nearly straight bones: the sensitivity is the max over twelve draws -- with three the worst
+        # record of win6_96 read 13.8 x, with twelve 1.5 x, on this kernel and on the tile kernel alike.  Beyond 128 joints -- win2_511:
+        # depth 334 -- a twist is inherited by hundreds of joints below it, in the reference as here, and the kernel's fp32 steps weigh
+        # like a few ulps of input each: 64 ulps there; and the bar counts the reference's discontinuities, see _record_bar)
+        k = 8 if J <= 128 else 64
+        bar, sens = _record_bar(pos, par, off, ref, k=k, draws=12)
+        assert (err <= bar).all(), (F, name, float(err.max()), float(((err - 2e-5) / np.maximum(sens, 1e-12)).max()), int((err > bar).sum()))
+        flipped = err > 2e-5 + k * sens   # records held by the direct k-ulp measure only: a switch of the reference within k ulps
+        assert flipped.sum() <= max(1, 1e-4 * flipped.size), (F, name, int(flipped.sum()))
         assert np.median(err) <= (1e-6 if J <= 128 else 1e-5), (F, float(np.median(err)))
         leaves = np.setdiff1d(np.arange(J), par[1:])
         assert (got[:, leaves] == np.array([1, 0, 0, 0], np.float32)).all()
         p2, _ = sk.fk(got, np.zeros_like(root), off, par)
         p_ref, _ = co.fk(ref, np.zeros((F, 3)), off.astype(np.float64), par)
-        # (positions through fk: the rotations' errors add up along a chain -- beyond ~64 joints deep the bar of the long skeletons above)
-        assert np.abs(p2 - p_ref).max() <= (2e-5 if depth <= 64 else 1e-4), float(np.abs(p2 - p_ref).max())
+        # (positions through fk: the rotations' errors add up along a chain -- beyond ~64 joints deep the bar of the long skeletons above;
+        # frames with a record on the other side of one of the reference's switches are a different -- equally valid -- pose below it)
+        ok = ~flipped.any(axis=1)
+        assert not ok.any() or np.abs(p2 - p_ref)[ok].max() <= (2e-5 if depth <= 64 else (1e-4 if depth <= 128 else 1e-3)), float(np.abs(p2 - p_ref)[ok].max())
     print(kind, J, depth, sorted(took))
 
 
