@@ -61,7 +61,7 @@ def parse():
                          "gloo (RCCL refuses two ranks on one device).  Numbers from such a run mean nothing; the JSON says so")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short measurements of BASELINE configs 3 and 4 (N=1)")
     ap.add_argument("--rccl-debug-file", default="",
-                    help="write RCCL's own log (NCCL_DEBUG=INFO, subsystems INIT,COLL,P2P: topology, channels, the algorithm / protocol "
+                    help="(default at N > 1: profiles/rccl_debug_N<N>; 'none' = off) write RCCL's own log (NCCL_DEBUG=INFO, subsystems INIT,COLL,P2P: topology, channels, the algorithm / protocol "
                          "each collective ran with) to PATH.<host>.<pid> per rank -- the record of what the reassembly actually did")
     ap.add_argument("--oracle-slice-frames", type=int, default=1 << 16,
                     help="N>1: frames of its own shard every rank checks against the CPU oracle (SURVEY 8d config 5: 2^16)")
@@ -247,6 +247,96 @@ def secondary_configs(torch, _lib, syn, dev, rot, root, off, parents, sptr):
     return out
 
 
+def config1_clip(torch, _lib, syn, dev, sptr):
+    """BASELINE.json configs[0] on the GPU side: a 1000-frame 22-joint BVH clip (synthetic.write_synthetic_bvh: the reference's README
+    joint names, metre-scale offsets) -> BVH.load -> get_data (from_euler + unroll + normalize, one launch) -> fk, through the NumPy
+    door (host arrays in and out: two trips over PCIe) and through the torch door (device-resident tensors), median per call of 200
+    calls in five batches, next to the kernel's own time (HIP events around 200 back-to-back raw pm_fk_f32 launches) and to the NumPy
+    restatement of the reference on the SAME arrays on this box's host cores.  At this size the kernel is a few microseconds and the
+    front door is the cost: this is the honest answer to "how much faster is a real clip"."""
+    import tempfile
+
+    import numpy as np
+
+    import pymotion_amd.ops.skeleton as sk
+    import pymotion_amd.ops.skeleton_torch as skt
+    from oracle import numpy_ref as nr
+    from pymotion_amd.io.bvh import BVH
+
+    def per_call_us(fn, n=200, warm=20):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        per = []
+        for _ in range(5):  # median of five batches: a process sees the odd 10-40 ms host stall
+            t0 = time.perf_counter()
+            for _ in range(n // 5):
+                fn()
+            torch.cuda.synchronize()
+            per.append((time.perf_counter() - t0) / (n // 5) * 1e6)
+        return sorted(per)[2]
+
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "clip1000.bvh")
+        syn.write_synthetic_bvh(path, n_frames=1000, seed=7)
+        b = BVH()
+        t0 = time.perf_counter()
+        b.load(path)
+        t_load = time.perf_counter() - t0
+    t_get = per_call_us(b.get_data, n=50, warm=5)
+    rots, pos, parents, offsets, _, _ = b.get_data()
+    root = np.ascontiguousarray(pos[:, 0, :])
+    F, J = rots.shape[0], rots.shape[1]
+    # CPU: the cost-equivalent NumPy restatement of the reference on these arrays (float64 as get_data returns them)
+    nr.fk(rots, root, offsets, parents)
+    cpu = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        p_cpu, r_cpu = nr.fk(rots, root, offsets, parents)
+        cpu.append(time.perf_counter() - t0)
+    cpu_us = min(cpu) * 1e6
+    # NumPy door
+    t_np = per_call_us(lambda: sk.fk(rots, root, offsets, parents))
+    p_np, r_np = sk.fk(rots, root, offsets, parents)
+    # torch door, device-resident
+    tr, tg, to = (torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev) for x in (rots, root, offsets))
+    tp = torch.from_numpy(np.asarray(parents))
+    with torch.no_grad():
+        t_t = per_call_us(lambda: skt.fk(tr, tg, to, tp))
+        p_t, r_t = skt.fk(tr, tg, to, tp)
+    # the kernel alone: raw C-ABI launches back to back between two HIP events
+    pp = np.ascontiguousarray(parents, dtype=np.int32)
+    po, ro = torch.empty((F, J, 3), device=dev), torch.empty((F, J, 3, 3), device=dev)
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    raw = lambda: _lib.call("pm_fk_f32", P(tr), P(tg), P(to), 0, pp.ctypes.data_as(C.c_void_p), F, J, P(po), P(ro), sptr)  # noqa: E731
+    ev = [C.c_void_p(), C.c_void_p()]
+    for e in ev:
+        _lib.call("pm_event_create", C.byref(e))
+    for _ in range(50):
+        raw()
+    _lib.call("pm_event_record", ev[0], sptr)
+    for _ in range(200):
+        raw()
+    _lib.call("pm_event_record", ev[1], sptr)
+    torch.cuda.synchronize()
+    ms = C.c_float()
+    _lib.call("pm_event_elapsed_ms", ev[0], ev[1], C.byref(ms))
+    t_raw_host = per_call_us(raw)
+    err = max(float(np.abs(p_np - p_cpu).max()), float(np.abs(r_np - r_cpu).max()),
+              float(np.abs(p_t.cpu().numpy() - p_cpu).max()), float(np.abs(r_t.cpu().numpy() - r_cpu).max()))
+    return {
+        "clip": "%d frames x %d joints, synthetic BVH (pymotion_amd.synthetic.write_synthetic_bvh), loaded by pymotion_amd.io.bvh" % (F, J),
+        "bvh_load_ms": t_load * 1e3, "get_data_us": t_get,
+        "fk_numpy_port_on_host_us": cpu_us, "fk_numpy_port_frames_per_s": F / (cpu_us * 1e-6),
+        "fk_numpy_door_us": t_np, "fk_numpy_door_frames_per_s": F / (t_np * 1e-6),
+        "fk_torch_door_us": t_t, "fk_torch_door_frames_per_s": F / (t_t * 1e-6),
+        "fk_raw_abi_call_us": t_raw_host, "fk_kernel_us": ms.value / 200 * 1e3, "kernel": _lib.last_kernel_name(),
+        "speedup_over_numpy_port": {"numpy_door": cpu_us / t_np, "torch_door": cpu_us / t_t},
+        "max_abs_err_vs_numpy_port": err,
+        "method": "median per call of 200 calls in five batches (device synchronised per batch); kernel: HIP events around 200 launches",
+    }
+
+
 def stream_ceilings(torch, _lib, dev, rot, rm, F, J, sptr):
     """What this chip moves with NO arithmetic, measured in the same process right after the timed region (never inside it):
     a copy with fk's traffic shape through fk's own tiling (`pm_stream_ceiling_f32`: 16 J B read, 48 J B written per frame;
@@ -346,6 +436,48 @@ def cpu_baseline_extras(np, syn, threads):
     return out
 
 
+def one_gpu_same_total(torch, _lib, syn, np, dev, F, J, parents, a):
+    """all F frames of the N-GPU workload on this ONE GPU: prewarm, W warmup steps, K timed steps between two HIP events"""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(a.seed * 1000 + 999)
+    rot = torch.randn((F, J, 4), generator=gen, device=dev, dtype=torch.float32)
+    root = torch.rand((F, 3), generator=gen, device=dev, dtype=torch.float32) * 4 - 2
+    off = torch.from_numpy(syn.make_offsets(J, np.random.default_rng(a.seed), 0.3)).to(dev)
+    pos = torch.empty((F, J, 3), device=dev, dtype=torch.float32)
+    rm = torch.empty((F, J, 3, 3), device=dev, dtype=torch.float32)
+    sptr = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    pp = parents.ctypes.data_as(C.c_void_p)
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    step = lambda: _lib.call("pm_fk_f32", P(rot), P(root), P(off), 0, pp, F, J, P(pos), P(rm), sptr)  # noqa: E731
+    tp = time.perf_counter()
+    while (time.perf_counter() - tp) * 1e3 < a.prewarm_ms:
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize()
+    for _ in range(a.warmup):
+        step()
+    ev = [C.c_void_p(), C.c_void_p()]
+    for e in ev:
+        _lib.call("pm_event_create", C.byref(e))
+    steps = max(1, min(a.steps, 50))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _lib.call("pm_event_record", ev[0], sptr)
+    for _ in range(steps):
+        step()
+    _lib.call("pm_event_record", ev[1], sptr)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ms = C.c_float()
+    _lib.call("pm_event_elapsed_ms", ev[0], ev[1], C.byref(ms))
+    out = {"frames": F, "steps": steps, "ms_per_step": wall / steps * 1e3, "frames_per_s": F * steps / wall,
+           "kernel_ms": ms.value / steps, "hbm_frac": F * (64 * J + 12) / (ms.value / steps * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+           "kernel": _lib.last_kernel_name(),
+           "note": "the whole N-GPU workload on rank 0's GPU alone, measured before the sharded run: N-GPU value / this = the speed-up on the SAME problem"}
+    del rot, root, pos, rm
+    return out
+
+
 def gather_report(torch, dist, a, world, rank, F, J, pos, rm, barrier, compute_s, cdev, shared):
     """(ii) reassembling (pos, rotmats) on every GPU -- the ONE collective a caller may ask for -- timed for
     both implementations in pymotion_amd.parallel, with the achieved xGMI receive rate per GPU against the (W-1)-link
@@ -423,6 +555,21 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("PM_BENCH_FORCE_DIST") == "1"
+    if world > 1 and not a.rccl_debug_file and not shared:
+        # every N > 1 run leaves RCCL's own record of what it did (topology, channels, algorithm / protocol per collective) under profiles/:
+        # the reassembly has never run on 8 GPUs anywhere but the driver's box.  Only if the directory takes a file ("none" switches it off;
+        # a log that cannot open its file would fall back to stdout, which carries the one JSON line).
+        try:
+            pdir = os.path.join(ROOT, "profiles")
+            probe_path = os.path.join(pdir, ".rccl_probe.%d" % os.getpid())
+            with open(probe_path, "w") as fh:
+                fh.write("x")
+            os.remove(probe_path)
+            a.rccl_debug_file = os.path.join(pdir, "rccl_debug_N%d" % world)
+        except OSError:
+            a.rccl_debug_file = ""
+    if a.rccl_debug_file == "none":
+        a.rccl_debug_file = ""
     if a.rccl_debug_file:
         os.environ["NCCL_DEBUG"] = "INFO"
         os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,COLL,P2P"
@@ -456,9 +603,21 @@ def main():
     elif J == 22 and F * world == CONFIG5_FRAMES and F == CONFIG5_FRAMES // world:
         workload = ("all 16 777 216 frames of BASELINE.json configs[4] on one GPU" if world == 1 else
                     "BASELINE.json configs[4]: 16 777 216 frames sharded over %d GPUs" % world)
-        scaling = "weak" if (explicit_frames and world == 1) else "strong"
+        scaling = "weak" if explicit_frames else "strong"  # --frames-per-gpu fixes the work per GPU, the default fixes the total
     else:
         workload, scaling = "non-default size", "weak"
+    # N > 1 on the default (strong-scaling) workload: the SAME total -- all 16 777 216 frames -- on ONE GPU first (rank 0, the others wait
+    # at a barrier), same method as the timed region below, so that the N-GPU value is read against the same problem and not only against
+    # the driver's N = 1 run of configs[1] (2^20 frames).  ~24 GB of device memory for a few seconds; reported, never part of `value`.
+    one_gpu = None
+    if world > 1 and not explicit_frames and not shared and J == 22:
+        if rank == 0:
+            try:
+                one_gpu = one_gpu_same_total(torch, _lib, syn, np, dev, CONFIG5_FRAMES, J, parents, a)
+            except Exception as exc:  # noqa: BLE001
+                one_gpu = {"error": repr(exc)[:300]}
+            torch.cuda.empty_cache()
+        dist.barrier()
     # synthetic workload born on the device from (seed, rank): no host->device copy is ever timed
     gen = torch.Generator(device=dev)
     gen.manual_seed(a.seed * 1000 + rank)
@@ -549,6 +708,10 @@ def main():
         torch.cuda.synchronize()
     if world == 1 and not a.no_secondary and J == 22:
         extra["secondary"] = secondary_configs(torch, _lib, syn, dev, rot, root, off, parents, sptr)
+        try:
+            extra["secondary"]["config1_bvh_clip_1000_frames"] = config1_clip(torch, _lib, syn, dev, sptr)
+        except Exception as exc:  # noqa: BLE001  (a secondary line: never costs the run its bench line)
+            extra["secondary"]["config1_bvh_clip_1000_frames"] = {"error": repr(exc)[:300]}
 
     if rank == 0:
         bytes_per_frame = 64 * J + 12
@@ -586,6 +749,11 @@ def main():
                          "kernel": kernel_name, "kernel_ms": kern_ms,
                          "bytes_per_frame": bytes_per_frame},
         }
+        if one_gpu is not None:
+            line["one_gpu_same_total"] = one_gpu
+            if "frames_per_s" in one_gpu:
+                line["one_gpu_same_total_frames_per_s"] = one_gpu["frames_per_s"]
+                line["speedup_over_one_gpu_same_total"] = line["value"] / one_gpu["frames_per_s"]
         if ceil is not None:
             line["roofline"].update(ceil)
             line["roofline"]["kernel_over_copy_ceiling"] = kern_ms / ceil["copy_ceiling_ms"]

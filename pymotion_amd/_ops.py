@@ -291,12 +291,15 @@ def bvh_rotations(be, euler_deg, order_table):
     dt = be.result_dtype(euler_deg)
     if be.name == "numpy":
         a = np.asarray(euler_deg)
-        if a.dtype == np.float64 and a.size and np.abs(a).max() > 360.0:
+        if a.dtype == np.float64 and a.size and max(a.max(), -a.min()) > 360.0:
             # the file's float64 degrees are rounded to fp32 on their way to the device: bring channels that wound up past a turn back to
-            # [-360, 360] first, EXACTLY (fmod and the +-720 are exact in float64; a quaternion is 720-degree periodic in each Euler angle, so
-            # not even its sign changes) -- the fp32 rounding is then <= 1.5e-5 degrees whatever the channel's winding
-            r = np.fmod(a, 720.0)
-            euler_deg = np.where(r > 360.0, r - 720.0, np.where(r < -360.0, r + 720.0, r))
+            # [-360, 360] first, EXACTLY (a - 720 k with k = rint(a / 720): 720 k is an integer and within a factor of two of a, so the
+            # difference is exact in float64; a quaternion is 720-degree periodic in each Euler angle, so not even its sign changes) --
+            # the fp32 rounding is then <= 1.5e-5 degrees whatever the channel's winding.  Files whose channels stay within a
+            # turn -- nearly all -- pay the two reductions of the test only.
+            k = np.rint(a * (1.0 / 720.0))
+            k *= 720.0
+            euler_deg = a - k
     be.begin(euler_deg)
     try:
         xp = be.dev_in(euler_deg)

