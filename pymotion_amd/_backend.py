@@ -116,6 +116,12 @@ def trim():
     _pool.trim()
     _stage.trim()
     _pinned.trim()
+    table = getattr(_arenas, "table", None)  # (the calling thread's small-call arenas; other threads keep theirs: 8 MB per thread and device)
+    if table:
+        for a in table.values():
+            _lib.call("pm_free", C.c_void_p(a.dptr))
+            _lib.call("pm_host_free", C.c_void_p(a.hptr))
+        table.clear()
 
 
 # ---- host side of the NumPy door: staging buffers that are reused (no page faults on the copy path) and
@@ -449,12 +455,45 @@ def _pipelined_frames_locked(F, ins, outs, launch, dev, ctx):
     return results
 
 
+# ---- small calls (a clip of real length: config 1's 1000 frames x 22 joints is 0.35 MB in, 1.06 MB out) ---------------------------------
+# The plain path pays one hipMemcpy from PAGEABLE memory per operand and per result (each a synchronous staging inside the runtime: ~10-20 us
+# apiece, bench.py's config1 line: 150-175 us per fk call of which ~100 are those five copies and their waits).  Here every operand of the call
+# is cast straight into one PAGE-LOCKED arena, goes over the bus as ONE asynchronous copy right before the launch, the results come back as ONE
+# copy into the same arena, and the cast to the result dtype reads from there.  One arena per thread and device, allocated on first use.
+_ARENA_BYTES = 4 << 20
+
+
+class _Arena:
+    def __init__(self, dev):
+        self.dev = dev
+        d = C.c_void_p()
+        _lib.call("pm_malloc", C.byref(d), _ARENA_BYTES)
+        h = C.c_void_p()
+        _lib.call("pm_host_alloc", C.byref(h), _ARENA_BYTES)
+        self.dptr, self.hptr = d.value, h.value
+        self.host = np.ctypeslib.as_array(C.cast(h.value, C.POINTER(C.c_uint8)), shape=(_ARENA_BYTES,))
+
+
+_arenas = threading.local()
+
+
+def _arena_for(dev):
+    table = getattr(_arenas, "table", None)
+    if table is None:
+        table = _arenas.table = {}
+    a = table.get(dev)
+    if a is None:
+        a = table[dev] = _Arena(dev)
+    return a
+
+
 class NumpyBackend:
     name = "numpy"
 
     def __init__(self):
         self._live = []
         self._stages = []
+        self._ar = None
 
     # -- introspection
     @staticmethod
@@ -473,6 +512,7 @@ class NumpyBackend:
         return np.dtype(np.float64) if config.numpy_float64_outputs else np.dtype(np.float32)
 
     def stream(self):
+        self._ar_flush()  # (every launch takes be.stream() as its last argument: the staged operands go over the bus right before it)
         return None
 
     @staticmethod
@@ -485,12 +525,40 @@ class NumpyBackend:
         self._dev = _current_device()  # device blocks are pooled per device
         self._live = []
         self._stages = []
+        # the small-call arena: [0, _ar_top) is in use, [_ar_sent, _ar_in) holds staged operands not yet sent, [_ar_out0, _ar_out1) results
+        self._ar = _arena_for(self._dev) if os.environ.get("PM_NO_ARENA") != "1" else None
+        self._ar_top = self._ar_in = self._ar_sent = 0
+        self._ar_out0 = self._ar_out1 = self._ar_got = 0
+
+    # -- the arena (see _Arena)
+    def _ar_take(self, nbytes):
+        """offset of `nbytes` of arena (256-byte aligned), or -1"""
+        if self._ar is None:
+            return -1
+        off = (self._ar_top + 255) & ~255
+        if off + nbytes > _ARENA_BYTES:
+            return -1
+        self._ar_top = off + nbytes
+        return off
+
+    def _ar_flush(self):
+        if self._ar is not None and self._ar_in > self._ar_sent:
+            a = self._ar
+            _lib.call("pm_memcpy_h2d", C.c_void_p(a.dptr + self._ar_sent), C.c_void_p(a.hptr + self._ar_sent), self._ar_in - self._ar_sent, None)
+            self._ar_sent = self._ar_in
 
     # -- data movement
     def dev_in(self, x, shape=None, dtype=np.float32):
         a = np.asarray(x)
         if shape is not None and a.shape != tuple(shape):
             a = np.broadcast_to(a, shape)
+        nb = a.size * np.dtype(dtype).itemsize
+        if 0 < nb <= _ARENA_BYTES // 2 and self._ar_out1 == 0:  # (operands come before results: one range each)
+            off = self._ar_take(nb)
+            if off >= 0:
+                np.copyto(self._ar.host[off:off + nb].view(dtype).reshape(a.shape), a, casting="unsafe")  # cast + gather in one pass
+                self._ar_in = off + nb
+                return C.c_void_p(self._ar.dptr + off)
         keep = None
         if a.dtype == dtype and a.flags.c_contiguous:
             src = a                                    # straight from the caller's memory
@@ -508,11 +576,29 @@ class NumpyBackend:
         return C.c_void_p(buf.ptr)
 
     def dev_out(self, shape):
-        buf = _DevBuf(_prod(shape) * 4, self._dev)
+        nb = _prod(shape) * 4
+        if 0 < nb and self._ar_got == 0:
+            off = self._ar_take(nb)
+            if off >= 0:
+                if self._ar_out1 == 0:
+                    self._ar_out0 = off
+                self._ar_out1 = off + nb
+                return C.c_void_p(self._ar.dptr + off), (None, tuple(shape), off)
+        buf = _DevBuf(nb, self._dev)
         self._live.append((buf, None))
         return C.c_void_p(buf.ptr), (buf, tuple(shape))
 
     def result(self, handle, dtype):
+        if handle[0] is None:  # in the arena: every result of the call in ONE copy, then the cast from page-locked memory
+            _, shape, off = handle
+            if self._ar_got == 0:
+                self._ar_flush()
+                a = self._ar
+                _lib.call("pm_memcpy_d2h", C.c_void_p(a.hptr + self._ar_out0), C.c_void_p(a.dptr + self._ar_out0), self._ar_out1 - self._ar_out0, None)
+                _lib.call("pm_stream_synchronize", None)
+                self._ar_got = 1
+            n = _prod(shape)
+            return self._ar.host[off:off + 4 * n].view(np.float32).reshape(shape).astype(dtype)  # (always a copy: the arena is reused)
         buf, shape = handle
         n = _prod(shape)
         if n * 4 < _PAR_MIN_BYTES:
@@ -587,6 +673,8 @@ class NumpyBackend:
 # ---------------------------------------------------------------------------------------------
 class TorchBackend:
     name = "torch"
+    _device_seen = False
+    _raw_stream = None
 
     def __init__(self):
         import torch
@@ -613,8 +701,10 @@ class TorchBackend:
 
     def begin(self, *tensors):
         torch = self.torch
-        if not torch.cuda.is_available():
-            raise RuntimeError("pymotion_amd (torch path): no HIP device visible and there is no CPU fallback")
+        if not TorchBackend._device_seen:  # (asked once per process: the call is 2 us of a clip-sized launch's 15)
+            if not torch.cuda.is_available():
+                raise RuntimeError("pymotion_amd (torch path): no HIP device visible and there is no CPU fallback")
+            TorchBackend._device_seen = True
         for t in tensors:
             if isinstance(t, torch.Tensor) and t.requires_grad and torch.is_grad_enabled():
                 raise NotImplementedError(
@@ -637,6 +727,11 @@ class TorchBackend:
         return False  # device tensors: nothing to overlap
 
     def stream(self):
+        raw = TorchBackend._raw_stream
+        if raw is None:  # torch's own accessor of the current stream's handle (what its inductor backend calls): no Stream object per launch
+            raw = TorchBackend._raw_stream = getattr(self.torch._C, "_cuda_getCurrentRawStream", False)
+        if raw and self.dev.index is not None:
+            return C.c_void_p(raw(self.dev.index))
         return C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
 
     def dev_in(self, x, shape=None, dtype=None):

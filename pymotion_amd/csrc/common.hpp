@@ -452,10 +452,64 @@ __device__ __forceinline__ void from_to_unit(const float (&a)[3], const float (&
         o[0] = 0.0f; o[1] = ax2[0]; o[2] = ax2[1]; o[3] = ax2[2];
     }
 }
+// normalize_input = True (the default, :541-543), from the RAW vectors (round 5).  The literal form above computes 1 - dot from a rounded
+// dot: between nearly parallel directions (1 - dot ~ 1e-4) one ulp of dot is 2e-6 of sqrt((1 - dot) / 2) -- the reference's own suite
+// (test_quat.py:507-660: random vectors of one octant) read 1.3e-6 / 2.2e-6 there.  Here, as in from_root_positions' alignment (ik.hip):
+//     cr = u x v (Kahan's difference of products), dt = u . v, N = |u| |v|;   N + dt and N - dt: the one that does not cancel as it
+//     stands, the other as |cr|^2 / (that one);
+//     the reference's dot is (dt / N) k with k = |u| / (|u| + 1e-8) x |v| / (|v| + 1e-8) (vec.normalize), so N (1 -+ dot) = (N -+ dt) +- dt (1 - k);
+//     w = sqrt((1 + dot) / 2), s = sqrt((1 - dot) / 2), axis = normalize(un x vn) with ITS 1e-8; np.isclose(dot, +-1) = a test of
+//     N (1 -+ dot) against 1.001e-5 N.
+// `ok` false (a zero-length, non-finite or subnormal-length vector): the caller takes the literal form, whose NaN / zero rules are the reference's.
+struct FromToTerms { float cr[3], w, s, npr, nmr, tol, kn; bool ok; };
+__device__ __forceinline__ FromToTerms from_to_terms(const float (&u)[3], const float (&v)[3]) {
+    FromToTerms r;
+    r.cr[0] = diff_of_products(u[1], v[2], u[2], v[1]);
+    r.cr[1] = diff_of_products(u[2], v[0], u[0], v[2]);
+    r.cr[2] = diff_of_products(u[0], v[1], u[1], v[0]);
+    const float cr2 = __builtin_fmaf(r.cr[0], r.cr[0], __builtin_fmaf(r.cr[1], r.cr[1], r.cr[2] * r.cr[2]));
+    const float dt = __builtin_fmaf(u[0], v[0], __builtin_fmaf(u[1], v[1], u[2] * v[2]));
+    const float u2 = __builtin_fmaf(u[0], u[0], __builtin_fmaf(u[1], u[1], u[2] * u[2]));
+    const float v2 = __builtin_fmaf(v[0], v[0], __builtin_fmaf(v[1], v[1], v[2] * v[2]));
+    const float iu = __builtin_amdgcn_rsqf(u2), iv = __builtin_amdgcn_rsqf(v2);
+    const float N = (u2 * iu) * (v2 * iv);
+    r.ok = N > 1e-30f && N < 1e30f && u2 > 1e-30f && v2 > 1e-30f;  // (NaN fails every test)
+    const float big = N + fabsf(dt), small = cr2 * frcp(big);
+    const float npd = (dt >= 0.0f) ? big : small, nmd = (dt >= 0.0f) ? small : big;
+    const float eu = 1e-8f * iu, ev = 1e-8f * iv, kden = frcp((1.0f + eu) * (1.0f + ev));
+    const float dte = dt * (eu + ev + eu * ev) * kden;  // dt (1 - k)
+    r.npr = npd - dte; r.nmr = nmd + dte;
+    r.tol = 1.001e-5f * N;
+    const float i2n = 0.5f * frcp(N);
+    r.w = fsqrt(fmaxf(r.npr, 0.0f) * i2n); r.s = fsqrt(fmaxf(r.nmr, 0.0f) * i2n);
+    r.kn = kden * frcp(N);  // un x vn = cr kn
+    return r;
+}
 __device__ __forceinline__ void from_to(const float (&v1)[3], const float (&v2)[3], bool normalize_input, float (&o)[4]) {
     float a[3] = {v1[0], v1[1], v1[2]}, b[3] = {v2[0], v2[1], v2[2]};
-    if (normalize_input) { vnormalize(v1, 1e-8f, a); vnormalize(v2, 1e-8f, b); }
-    from_to_unit(a, b, o);
+    if (!normalize_input) { from_to_unit(a, b, o); return; }  // (wave-uniform)
+    const FromToTerms t = from_to_terms(v1, v2);
+    if (__builtin_amdgcn_ballot_w64(!t.ok) != 0) {  // rare: the literal form for the whole wave, kept by the lanes that need it
+        vnormalize(v1, 1e-8f, a); vnormalize(v2, 1e-8f, b);
+        from_to_unit(a, b, o);
+    }
+    if (t.ok) {
+        const float cn[3] = {t.cr[0] * t.kn, t.cr[1] * t.kn, t.cr[2] * t.kn};  // un x vn
+        float ax[3];
+        vnormalize(cn, 1e-8f, ax);  // quat.normalize on a 3-vector (:545)
+        o[0] = t.w; o[1] = ax[0] * t.s; o[2] = ax[1] * t.s; o[3] = ax[2] * t.s;
+        if (t.nmr <= t.tol) { o[0] = 1.0f; o[1] = 0.0f; o[2] = 0.0f; o[3] = 0.0f; }  // parallel (:551-552)
+    }
+    const bool anti = t.ok && t.npr <= t.tol;
+    if (__builtin_amdgcn_ballot_w64(anti) != 0 && anti) {  // anti-parallel (:554-571), rare
+        vnormalize(v1, 1e-8f, a);
+        const bool xlike = isclose_to(fabsf(a[0]), 1.0f);
+        const float og[3] = {xlike ? 0.0f : 1.0f, xlike ? 1.0f : 0.0f, 0.0f};
+        const float c2[3] = {a[1] * og[2] - a[2] * og[1], a[2] * og[0] - a[0] * og[2], a[0] * og[1] - a[1] * og[0]};
+        float ax2[3];
+        vnormalize(c2, 1e-8f, ax2);
+        o[0] = 0.0f; o[1] = ax2[0]; o[2] = ax2[1]; o[3] = ax2[2];
+    }
 }
 
 // rotations/quat.py:579-650 from_to_axis(v1, v2, rot_axis): same angle, rotation axis fixed (a, b as above).
@@ -473,8 +527,19 @@ __device__ __forceinline__ void from_to_axis_unit(const float (&a)[3], const flo
 __device__ __forceinline__ void from_to_axis(const float (&v1)[3], const float (&v2)[3], const float (&axis)[3],
                                              bool normalize_input, float (&o)[4]) {
     float a[3] = {v1[0], v1[1], v1[2]}, b[3] = {v2[0], v2[1], v2[2]};
-    if (normalize_input) { vnormalize(v1, 1e-8f, a); vnormalize(v2, 1e-8f, b); }
-    from_to_axis_unit(a, b, axis, o);
+    if (!normalize_input) { from_to_axis_unit(a, b, axis, o); return; }  // (wave-uniform)
+    const FromToTerms t = from_to_terms(v1, v2);  // the same (w, s) without the cancellation in 1 - dot, see from_to
+    if (__builtin_amdgcn_ballot_w64(!t.ok) != 0) {
+        vnormalize(v1, 1e-8f, a); vnormalize(v2, 1e-8f, b);
+        from_to_axis_unit(a, b, axis, o);
+    }
+    if (t.ok) {
+        const float cda = t.cr[0] * axis[0] + t.cr[1] * axis[1] + t.cr[2] * axis[2];  // (sign of (un x vn) . axis = sign of cr . axis)
+        const float s = t.s * ((cda > 0.0f) ? 1.0f : ((cda < 0.0f) ? -1.0f : cda));   // np.sign (0 -> 0, NaN -> NaN)
+        o[0] = t.w; o[1] = axis[0] * s; o[2] = axis[1] * s; o[3] = axis[2] * s;
+        if (t.nmr <= t.tol) { o[0] = 1.0f; o[1] = 0.0f; o[2] = 0.0f; o[3] = 0.0f; }
+        if (t.npr <= t.tol) { o[0] = 0.0f; o[1] = axis[0]; o[2] = axis[1]; o[3] = axis[2]; }
+    }
 }
 
 template <int V>

@@ -1199,30 +1199,64 @@ __global__ __launch_bounds__(PM_WAVE) void fk_stream_kernel(const FkStreamArgs a
             if (last && lastc && (end & 3) != 0) { const int k = end >> 2; out_vec(g + 4 * k, lbase + __mul24(fe, stride) + 4 * k, 0, end & 3, fx_words, 100, fe); }
         }
         // (2) the full vectors: unconditional dwordx4, for a full chunk a FIXED number of them (slots past a frame's full vectors, or past the
-        // tile's end, repeat a vector that is stored anyway) so that the wait for the next chunk's quaternions stays a counted one
+        // tile's end, repeat a vector that is stored anyway) so that the wait for the next chunk's quaternions stays a counted one.
+        // With a carry, FOUR LANES A FRAME (round 5): lane (fe, q) takes the frame's vectors kf + q, kf + q + 4, ... -- one row base, one clamp and
+        // two shifts per vector, where round 4's form (kept below for segments that start on lines: a wave instruction covers one frame's
+        // kilobyte) pays a division by the vectors per frame, the frame's carry and both row bases per vector.  What that buys, measured in
+        // ONE process on the same arrays (the streamed walk's timing depends on where the allocator put the arrays: boxes and runs differ by
+        // 5-8 points on it while the tile kernels repeat to a point, so separate runs say nothing -- tools/fk_long_ab.py,
+        // profiles/r05_fk_long_ab.txt): J = 100 / 112 / 144 / 200 / 400 +0.9 / +2.1 / +1.0 / +1.8 / +0.3 points, 129 / 130 / 250 / 300 / 511 the
+        // same; without a carry 0.5-1.1 points BEHIND.  The copy-out's index arithmetic was not what holds the carry variant at 48-59 %.
         constexpr int PV = (CH * per_joint + XR) / 4;  // vectors of a full segment and its carry: an upper bound per frame
-        if constexpr (full_chunk) {
-            constexpr int NS = (FPW * PV + PM_WAVE - 1) / PM_WAVE;
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
-            const float ipv = 1.0f / (float)PV;
+        if constexpr (CARRY) {
+            constexpr int LPF = PM_WAVE / FPW;             // lanes per frame in the copy-out
+            {
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                const int fe0 = ln / LPF, q = ln - fe0 * LPF;
+                const int fe = fe0 < nf ? fe0 : nf - 1;
+                const int cr = carry_of(c, fe), kf = first_vec(cr), ke = end_vec(cr);
+                const float *lrow = lbase + __mul24(fe, stride);
+                float *grow = gtile + (__mul24(fe, gstep) - cr);
+                if constexpr (full_chunk) {
+                    constexpr int NT = (PV + LPF - 1) / LPF;
 #pragma unroll
-            for (int u = 0; u < NS; ++u) {
-                const int i = u * PM_WAVE + ln;
-                int fe = (int)(((float)i + 0.5f) * ipv);
-                int kk = i - fe * PV;
-                if (fe >= nf) { fe = nf - 1; kk = 0; }
-                const int cr = carry_of(c, fe), kf = first_vec(cr), nfull = end_vec(cr) - kf;
-                const int k = kf + (kk < nfull ? kk : nfull - 1);
-                out_vec(gtile + (__mul24(fe, gstep) - cr + 4 * k), lbase + (__mul24(fe, stride) + 4 * k), 0, 4, fx_words, rootc ? cr - 4 * k : 100, fe);
+                    for (int t = 0; t < NT; ++t) {
+                        const int k0 = kf + q + LPF * t, k = k0 < ke ? k0 : ke - 1;
+                        out_vec(grow + 4 * k, lrow + 4 * k, 0, 4, fx_words, rootc ? cr - 4 * k : 100, fe);
+                    }
+                } else {
+                    const int nt = ((len + XR + 3) >> 2) + LPF - 1;  // (a short last chunk: as many trips as its longest frame can need)
+                    for (int t = 0; LPF * t < nt; ++t) {
+                        const int k = kf + q + LPF * t;
+                        if (k < ke && fe0 < nf) out_vec(grow + 4 * k, lrow + 4 * k, 0, 4, fx_words, rootc ? cr - 4 * k : 100, fe);
+                    }
+                }
             }
         } else {
-            const int pv = (len + XR + 3) >> 2;  // (a short last chunk: as many slots per frame as it can have vectors)
-            const float ipv = 1.0f / (float)pv;
-            for (int i = lane; i < nf * pv; i += PM_WAVE) {
-                const int fe = (int)(((float)i + 0.5f) * ipv), kk = i - fe * pv;
-                const int cr = carry_of(c, fe), kf = first_vec(cr), nfull = end_vec(cr) - kf;
-                if (kk < nfull) out_vec(gtile + (__mul24(fe, gstep) - cr + 4 * (kf + kk)), lbase + (__mul24(fe, stride) + 4 * (kf + kk)), 0, 4, fx_words, rootc ? cr - 4 * (kf + kk) : 100, fe);
+            if constexpr (full_chunk) {
+                constexpr int NS = (FPW * PV + PM_WAVE - 1) / PM_WAVE;
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                const float ipv = 1.0f / (float)PV;
+#pragma unroll
+                for (int u = 0; u < NS; ++u) {
+                    const int i = u * PM_WAVE + ln;
+                    int fe = (int)(((float)i + 0.5f) * ipv);
+                    int kk = i - fe * PV;
+                    if (fe >= nf) { fe = nf - 1; kk = 0; }
+                    const int cr = carry_of(c, fe), kf = first_vec(cr), nfull = end_vec(cr) - kf;
+                    const int k = kf + (kk < nfull ? kk : nfull - 1);
+                    out_vec(gtile + (__mul24(fe, gstep) - cr + 4 * k), lbase + (__mul24(fe, stride) + 4 * k), 0, 4, fx_words, rootc ? cr - 4 * k : 100, fe);
+                }
+            } else {
+                const int pv = (len + XR + 3) >> 2;  // (a short last chunk: as many slots per frame as it can have vectors)
+                const float ipv = 1.0f / (float)pv;
+                for (int i = lane; i < nf * pv; i += PM_WAVE) {
+                    const int fe = (int)(((float)i + 0.5f) * ipv), kk = i - fe * pv;
+                    const int cr = carry_of(c, fe), kf = first_vec(cr), nfull = end_vec(cr) - kf;
+                    if (kk < nfull) out_vec(gtile + (__mul24(fe, gstep) - cr + 4 * (kf + kk)), lbase + (__mul24(fe, stride) + 4 * (kf + kk)), 0, 4, fx_words, rootc ? cr - 4 * (kf + kk) : 100, fe);
+                }
             }
         }
         // (3) what lies past the last line boundary (less than 32 floats a frame) moves to the front of the row: chunk c + 1 lands behind it
@@ -1301,7 +1335,7 @@ static int fs_pick_stride(const int min_floats, const int step, const int mul) {
                 if (++cnt[b] > cost) cost = cnt[b];
             }
         }
-        if (cost < best_cost) { best_cost = cost; best = min_floats + extra; }
+        if (cost < best_cost) { best_cost = cost; best = min_floats + extra; }  // (a tie-break on the copy-out's banks -- rows half the banks apart -- measured the same to 0.1 point)
     }
     return best;
 }

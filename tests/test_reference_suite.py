@@ -25,13 +25,11 @@ SUITE = reference_suite()
 BY_FN = SUITE.by_function()
 ATOL = 1e-6   # the reference suite's own bar (TestQuat.atol, TestSkeleton.atol, ...)
 
-# Exceptions to ATOL on the GPU replay: function -> (bar, why).  Everything not listed is held to 1e-6 x max(1, |expected|).
-BARS = {
-    # the element-wise kernel evaluates the reference's sqrt((1 - dot) / 2) (quat.py:547) literally in fp32: between nearly parallel
-    # directions (the suite's random vectors all lie in the positive octant; 1 - dot ~ 1e-4) one ulp of `dot` is 2e-6 of the result.
-    # Measured on the suite's 10 from_to records: 1.3e-6 (1 of 2000 elements above 1e-6).
-    "from_to": (4e-6, "fp32 cancellation in 1 - dot at small angles"),
-}
+# Bars of the GPU replay: function -> (bar, why); everything not listed is held to 1e-6 x max(1, |expected|).
+# Exceptions to ATOL: none.  (Round 5's first replay read 1.3e-6 / 2.2e-6 on from_to -- the element-wise kernel evaluated the reference's
+# sqrt((1 - dot) / 2), quat.py:547, literally in fp32, and between the suite's nearly parallel octant vectors one ulp of `dot` is 2e-6 of
+# the result; from_to / from_to_axis now take 1 - dot from the cross product (common.hpp: from_to_terms) and read 1.2e-7.)
+BARS = {}
 
 
 def _bar(fn_name, want):
