@@ -260,6 +260,13 @@ int pm_stream_plain_f32(const float *src, float *dst, int64_t n4, int32_t ratio,
  * [11] bytes of unused LDS per workgroup (bounds the resident workgroups per CU like a kernel's LDS tile).  Bench / tuning only. */
 int pm_store_probe_f32(const float *src, float *dst, int64_t n4, const int32_t *cfg, pm_stream_t stream);
 
+/* Host only (no GPU work): the step list fk's wide walk would run for this topology (fkwide.hip: a wave per frame, up to 16 joints a
+ * step, a joint at the earliest one step after its parent) -- `jobs` receives (steps + 2) * 16 words, joint | parent << 16 (the root takes no step;
+ * idle quads: J + 1 | J << 16), room for 50 * 16.  Returns the number of steps, PM_EUNSUPPORTED when the tree needs more
+ * than the kernel's list holds (fk then keeps its tile kernels), another error code on a bad topology.  For tests of the scheduler; the reference has no
+ * counterpart (ops/skeleton.py:51-58 is a loop over joints). */
+int pm_fk_wide_plan_debug(const int32_t *parents, int32_t J, uint32_t *jobs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,6 +96,8 @@ SIGNATURES = {
     "pm_stream_ceiling_f32": [_f, _f, _i64, _i32, _i32, _strm],
     "pm_stream_plain_f32": [_f, _f, _i64, _i32, _i32, _strm],
     "pm_store_probe_f32": [_f, _f, _i64, C.c_void_p, _strm],
+    # host-only introspection (tests of the wide walk's scheduler)
+    "pm_fk_wide_plan_debug": [C.c_void_p, _i32, C.c_void_p],
 }
 
 _lib = None

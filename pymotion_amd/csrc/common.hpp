@@ -551,6 +551,11 @@ struct IntC { static constexpr int value = V; };  // a compile-time int as a fun
 // spare; beyond (centimetre mocap, creatures with metre-long bones, far-away roots) a tile takes more precise rotations and a
 // translation chain in 32-bit FIXED POINT: integer adds do not round.  Both tests are ballots on values a tile loads anyway.
 constexpr float kBigOffset = 1.0f, kBigRoot = 16.0f;
+// |t_j|_1 of a joint-table entry {-, t0, t1, t2} (what it adds to the position bound) and whether it trips the "big" test
+__device__ __forceinline__ float const_l1(const v4f c) { return fabsf(c.y) + fabsf(c.z) + fabsf(c.w); }
+__device__ __forceinline__ bool const_is_big(const v4f c) {
+    return !(fabsf(c.y) < kBigOffset) || !(fabsf(c.z) < kBigOffset) || !(fabsf(c.w) < kBigOffset);  // NaN counts as big
+}
 
 // Scale of the fixed-point positions of one tile: every coordinate is bounded by B = max |root| + (bound of |p_j - root|)
 // (rotations have unit rows), so with B < 2^e the words p * 2^(30-e) stay below 2^30.
@@ -744,6 +749,10 @@ struct DeepTopo {                    // by value in the kernarg segment: one s_l
 };                                   // load: where joint j's parent state comes from -- a slot, DEEP_CHAIN (the previous joint), DEEP_LOCAL /
                                      // DEEP_ROOT (none); save: the slot joint j's state is kept in for later children, or DEEP_NONE
 int deep_plan(const Parents &par, int J, bool root_is_identity, DeepTopo &t);
+// ---- fkwide.hip: fk with a wave per frame and its lanes over the joints (long, wide trees) -------------------------------------
+bool try_fk_wide(const float *rot, const float *root_pos, const float *offsets, float *pos, float *rotmats, int64_t F, int32_t J, int32_t depth,
+                 const Parents &par, int ablate, int max_quad_steps_per_joint_x10, hipStream_t s, int &rc);
+int fk_wide_plan(const Parents &par, int J, uint32_t *jobs);
 int launch_to_root_deep(const float *rot, const float *root_pos, const float *offsets, float *dq, int64_t F, int32_t J,
                         const DeepTopo &topo, hipStream_t s);
 

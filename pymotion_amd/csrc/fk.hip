@@ -417,12 +417,6 @@ __device__ __forceinline__ void image_load(const float *__restrict__ g, float *l
     }
 }
 
-// |t_j|_1 of a joint-table entry (what it adds to the position bound) and whether it trips the "big" test
-__device__ __forceinline__ float const_l1(const v4f c) { return fabsf(c.y) + fabsf(c.z) + fabsf(c.w); }
-__device__ __forceinline__ bool const_is_big(const v4f c) {
-    return !(fabsf(c.y) < kBigOffset) || !(fabsf(c.z) < kBigOffset) || !(fabsf(c.w) < kBigOffset);  // NaN counts as big
-}
-
 // max |x| over a per-frame offsets tile in LDS (pads hold stale finite-or-not words of earlier tiles: skipped)
 __device__ __forceinline__ float tile_abs_max(const float *sOff, const int nf, const int per_frame, const int pad, const int lane) {
     float m = 0.0f;
@@ -1391,6 +1385,7 @@ constexpr int kFkEightFramesMaxJ = 39, kFkEightFramesMaxJO6d = 39, kFkEightFrame
 // 2^19 frames, stream / pipelined tile kernel on one box: J = 64 64.6 / 59.6 %, 96 68.0 / 55.9, 100 56.2 / 52.1, 104 57.2 / 53.1, 112 58.7 / 46.4,
 // 120 58.4 / 48.1, 128 69.2 / 47.3; 80 54.1 / 57.9, 97 53.9 / 56.4, 127 50.2 / 47.4)
 constexpr int kFkStreamMinJ = 96, kFkStreamMinLinesJ = 64;
+constexpr int kFkWideMinJ = 92;  // fk_wide_kernel (fkwide.hip) beyond (up to 92 joints the six-records-a-lane pipelined tiles read 57-63 % on the same trees)
 static bool fk_stream_wanted(const int J) { return J > 128 || (J >= kFkStreamMinJ && J % 4 == 0) || (J >= kFkStreamMinLinesJ && J % 32 == 0); }
 
 template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT, bool PAD, int PREC>
@@ -1589,16 +1584,31 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
     if ((size_t)pick * frame_bytes(pad3) + fixed > kMaxLds) pick = 4;
     a.pad = (pick == 4) ? pad12 : pad3;
     const size_t per_frame = frame_bytes(a.pad);
+    // wide trees from 93 joints on (fkwide.hip: a wave per frame, its lanes over the joints of a host-made step list), FIRST when the list keeps
+    // the quads busy -- at most 2.5 quad-steps per joint: random trees (parents[j] uniform in [0, j)) 59-70 % of the HBM spec at J = 96...128 where
+    // the pipelined tile kernel reads 46-56 %, 63-73 % at J = 129...512 where the streamed walk declines them and the four-frame tiles read 9-34 %
+    // (profiles/r05_fk_wide_sweep.txt); deep, narrow trees go to the streamed walk below.  PM_FK_WIDE (PM_TUNING build only): 0 never, 1 from any
+    // joint count and any list.
+    const int wd = tune_env("PM_FK_WIDE", -1);
+    const bool wide_ok = SRC == SRC_QUAT && !pfo && vec && a.quat_out == nullptr;
+    // long skeletons: the streamed three-lane walk (fk_stream_kernel) where the topology's cross-chunk branch points fit its register
+    // slots; PM_FK_STREAM (PM_TUNING build only): 0 never, 1 from any joint count
+    const int st = tune_env("PM_FK_STREAM", -1);
+    // (and only with the joint-frames to fill the chip: sixteen frames to a wave that walks all J joints -- chain-like J = 64 / 128 / 256 at
+    // 2^10 frames: 16 / 28 / 54 us against 9 / 15 / 26 us for the four-frame tiles; the crossovers sit at F J = 0.7-1.0 M)
+    const bool stream_ok = SRC == SRC_QUAT && !pfo && vec && a.quat_out == nullptr && st != 0 &&
+                           (st == 1 || (fk_stream_wanted(a.J) && lane_per_frame_pays(a.F, a.J, kFkStreamMinJointFrames)));
+    // (whole-line rows of 96 / 128 joints: the streamed walk first -- a humanoid with hands reads 59.6 / 62.8 % there against 55.8 / 61.3 %)
+    const bool stream_first = a.J % 32 == 0 && a.J <= 128 && wd != 1;
     if constexpr (SRC == SRC_QUAT) {
-        // long skeletons: the streamed three-lane walk (fk_stream_kernel) where the topology's cross-chunk branch points fit its register
-        // slots; PM_FK_STREAM (PM_TUNING build only): 0 never, 1 from any joint count
-        const int st = tune_env("PM_FK_STREAM", -1);
-        // (and only with the joint-frames to fill the chip: sixteen frames to a wave that walks all J joints -- chain-like J = 64 / 128 / 256 at
-        // 2^10 frames: 16 / 28 / 54 us against 9 / 15 / 26 us for the four-frame tiles; the crossovers sit at F J = 0.7-1.0 M)
-        if (!pfo && vec && a.quat_out == nullptr && st != 0 && (st == 1 || (fk_stream_wanted(a.J) && lane_per_frame_pays(a.F, a.J, kFkStreamMinJointFrames)))) {
-            int rc = PM_OK;
-            if (try_fk_stream(a, s, rc)) return rc;
-        }
+        int rc = PM_OK;
+        if (stream_ok && stream_first && try_fk_stream(a, s, rc)) return rc;
+        if (wide_ok && wd != 0 && (wd == 1 || a.J > kFkWideMinJ) &&
+            try_fk_wide(a.src, a.root_pos, a.offsets, a.pos, a.rotmats, a.F, a.J, a.depth, a.parents, a.ablate, wd == 1 ? 0 : 25, s, rc)) return rc;
+        if (stream_ok && !stream_first && try_fk_stream(a, s, rc)) return rc;
+        // whatever the streamed walk declined beyond 128 joints: the wide walk if its step list holds the tree at all (the four-frame tiles that
+        // are left read 9-34 % there)
+        if (wide_ok && a.J > 128 && wd != 0 && try_fk_wide(a.src, a.root_pos, a.offsets, a.pos, a.rotmats, a.F, a.J, a.depth, a.parents, a.ablate, 0, s, rc)) return rc;
     }
     if (pick == 4 && a.J <= 128) {
         // mid-size skeletons: registers-first phase A and tiles pipelined inside a workgroup (fk_pipe_kernel; 4 records

@@ -176,17 +176,21 @@ def test_to_root_dual_quat_lane_per_frame_through_the_torch_door_and_an_unaligne
 
 # ---- fk on long skeletons: the streamed three-lane walk (fk.hip: fk_stream_kernel) ----------------------------------------------
 
+# which kernel: "stream" (fk_stream_kernel), "wide" (fk_wide_kernel, fkwide.hip: from 93 joints on, trees whose step list keeps the quads
+# busy go there first -- a humanoid with hands reads 58-71 % that way against 46-63 % streamed; whole-line rows of 96 / 128 joints keep the
+# streamed walk), "tile"
 FK_STREAM_CASES = [
-    (64, "chain_like", True), (64, "humanoid", True), (80, "chain_like", False),         # multiples of 32 from 64 on
-    (96, "chain_like", True), (100, "humanoid", True), (128, "chain_like", True), (129, "chain_like", True), (130, "humanoid", True),
-    (131, "chain_like", True), (160, "humanoid", True), (250, "humanoid", True), (300, "chain_like", True), (512, "chain_like", True),
-    (97, "chain_like", False), (127, "humanoid", False), (92, "chain_like", False),   # below 129 only multiples of four from 96 on
-    (200, "random", False),                                                            # more cross-chunk branch points than register slots
+    (64, "chain_like", "stream"), (64, "humanoid", "stream"), (80, "chain_like", "tile"),         # multiples of 32 from 64 on
+    (96, "chain_like", "stream"), (96, "humanoid", "stream"), (100, "humanoid", "wide"), (128, "chain_like", "stream"), (128, "humanoid", "stream"),
+    (129, "chain_like", "stream"), (130, "humanoid", "wide"),
+    (131, "chain_like", "stream"), (160, "humanoid", "wide"), (250, "humanoid", "wide"), (300, "chain_like", "stream"), (512, "chain_like", "stream"),
+    (97, "chain_like", "tile"), (127, "humanoid", "wide"), (92, "chain_like", "tile"),   # below 129 the streamed walk takes only multiples of four from 96 on
+    (200, "random", "wide"),                                                             # more cross-chunk branch points than the streamed walk has register slots
 ]
 
 
-@pytest.mark.parametrize("J,kind,stream", FK_STREAM_CASES)
-def test_fk_streamed_walk_on_long_skeletons(J, kind, stream):
+@pytest.mark.parametrize("J,kind,which", FK_STREAM_CASES)
+def test_fk_streamed_walk_on_long_skeletons(J, kind, which):
     """beyond 128 joints (and for multiples of four from 96 on) fk walks three lanes per frame over an image that holds 32 joints at a time:
     which kernel ran, parity with the float64 oracle on metre and centimetre data (float64 rotations + fixed-point chain on big tiles),
     single frames, partial tiles of 16 frames, every alignment of a frame's rows (J mod 4), the root position bit for bit"""
@@ -200,7 +204,7 @@ def test_fk_streamed_walk_on_long_skeletons(J, kind, stream):
         rot = (rot * np.random.default_rng(F).uniform(0.5, 2.0, (F, J, 1))).astype(np.float32)  # fk normalises (skeleton.py:45)
         pos, rm = sk.fk(rot, root, off, parents)
         name = _lib.last_kernel_name()
-        assert ("fk_stream_kernel" in name) == stream, (name, J, kind)
+        assert ("stream" if "fk_stream_kernel" in name else "wide" if "fk_wide_kernel" in name else "tile") == which, (name, J, kind)
         p_o, r_o = co.fk(rot.astype(np.float64), root.astype(np.float64), off.astype(np.float64), parents)
         # rotations: an fp32 chain of `depth` 3 x 3 products; positions: those errors times the bones, or 2 ulp of the largest coordinate
         assert np.abs(rm - r_o).max() <= max(2e-6, 2.5e-7 * depth), (F, np.abs(rm - r_o).max())

@@ -197,7 +197,25 @@ def test_to_root_dual_quat_one_chain_tile_kernel_against_the_oracle():
     assert np.abs(d - d_o).max() <= 1e-5
 
 
-ALL_SKELETON_KERNELS = {"to_root_dq_kernel", "to_root_dq_sched_kernel", "to_root_dq_deep_kernel", "to_root_dq_ring_kernel", "gather_parent_kernel",
+def test_fk_wide_walk_on_bushy_trees():
+    """beyond 128 joints a tree the streamed walk declines takes a wave per frame with its lanes over the joints (fkwide.hip), at any
+    batch size; tied to the oracle here on slices of a production-size call (the full suite: tests/test_gpu_wide.py)"""
+    import pymotion_amd.ops.skeleton as sk
+    from pymotion_amd import synthetic as syn
+
+    J = 256
+    par = syn.random_parents(J, np.random.default_rng(J))
+    depth = int(syn.depth_of(par).max())
+    rot, root, off = _batch(6_000, J, 21)
+    pos, rm = sk.fk(rot, root, off, par)
+    assert "fk_wide_kernel" in _note(), _lib.last_kernel_name()
+    for sl in _slices(len(rot)):
+        p_o, r_o = co.fk(*_f64(rot[sl], root[sl], off), par)
+        assert np.abs(rm[sl] - r_o).max() <= max(2e-6, 2.5e-7 * depth)
+        assert np.abs(pos[sl] - p_o).max() <= max(1e-5, 3 * _ulp_of(p_o))
+
+
+ALL_SKELETON_KERNELS = {"fk_wide_kernel", "to_root_dq_kernel", "to_root_dq_sched_kernel", "to_root_dq_deep_kernel", "to_root_dq_ring_kernel", "gather_parent_kernel",
                         "fk_kernel", "fk_pipe_kernel", "fk_stream_kernel", "mirror_kernel", "mirror_deep_kernel", "from_root_positions_kernel",
                         "from_root_positions_order_kernel"}
 

@@ -448,6 +448,7 @@ def test_fk_pipelined_tiles_ragged_groups(monkeypatch, nt, F, J):
     from pymotion_amd import synthetic as syn
 
     monkeypatch.setenv("PM_FK_NT", nt)
+    monkeypatch.setenv("PM_FK_WIDE", "0")  # (random trees of more than 92 joints take fkwide.hip's kernel otherwise: tests/test_gpu_wide.py)
     with _lib.variant("tuning"):
         _fk_pipelined_body(F, J)
 

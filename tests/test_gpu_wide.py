@@ -1,0 +1,210 @@
+"""GPU: fk on long skeletons whose tree is wide (fkwide.hip: a wave per frame, its lanes over the joints of a host-made step list).
+
+Beyond 128 joints a tree the streamed walk declines (more cross-chunk branch points than register sets: random / bushy trees) used to
+fall to the four-frame tile kernels (34 % of the HBM spec at J = 129, 8.6 % at 512).  Checked here on the PRODUCTION library: which kernel
+ran, parity with the float64 C oracle on metre and centimetre data (per-frame PREC_DYN: float64 rotations + fixed-point chain), every
+alignment of a frame's rows (J mod 4, F odd), single frames, the root position bit for bit, NaN / Inf where the reference has them,
+outputs that are views into bigger buffers (nothing written outside), trees too deep for the step list falling back, and the host
+scheduler's invariants (CPU)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from pymotion_amd import _lib
+from pymotion_amd import synthetic as syn
+
+
+def _ulp_of(x):
+    return 2.0 ** (np.floor(np.log2(np.abs(x).max())) - 23)
+
+
+def _batch(F, J, seed, osc, rsc):
+    rng = np.random.default_rng(seed)
+    rot = rng.standard_normal((F, J, 4))
+    rot = (rot / np.linalg.norm(rot, axis=-1, keepdims=True) * rng.uniform(0.5, 2.0, (F, J, 1))).astype(np.float32)  # fk normalises (skeleton.py:45)
+    root = rng.uniform(-rsc, rsc, (F, 3)).astype(np.float32)
+    off = rng.uniform(-osc, osc, (J, 3)).astype(np.float32)
+    off[0] = 0
+    return rot, root, off
+
+
+def bushy(J, seed=None):
+    return syn.random_parents(J, np.random.default_rng(J if seed is None else seed))
+
+
+def broom(J, handle):
+    """a chain of `handle` joints with everything else hanging off its last joint: depth handle + 1, one very wide level"""
+    p = np.maximum(np.arange(J) - 1, 0).astype(np.int32)
+    p[handle:] = handle - 1
+    return p
+
+
+def comb(J):
+    """a spine of J / 4 joints, each with a three-joint tooth: parents far back in the table"""
+    n = J // 4
+    p = [0] + list(range(0, n - 1))
+    for s in range(n):
+        p += [s, len(p), len(p) + 1]
+    while len(p) < J:
+        p.append(len(p) - 1)
+    return np.asarray(p[:J], dtype=np.int32)
+
+
+WIDE_CASES = [(129, "bushy"), (130, "bushy"), (131, "bushy"), (160, "bushy"), (200, "bushy"), (255, "bushy"), (256, "bushy"), (300, "bushy"),
+              (400, "bushy"), (511, "bushy"), (512, "bushy"), (300, "broom"), (512, "broom")]
+
+
+def _parents(kind, J):
+    return {"bushy": bushy, "broom": lambda j: broom(j, 10), "comb": comb}[kind](J)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("J,kind", WIDE_CASES)
+def test_fk_wide_walk_against_the_oracle(J, kind):
+    import pymotion_amd.ops.skeleton as sk
+
+    parents = _parents(kind, J)
+    assert (parents[1:] < np.arange(1, J)).all()
+    depth = int(syn.depth_of(parents).max())
+    for F, osc, rsc in ((1, 0.1, 2.0), (3, 10.0, 200.0), (16, 0.1, 2.0), (77, 10.0, 200.0), (333, 0.1, 2.0), (1001, 10.0, 2.0)):
+        rot, root, off = _batch(F, J, 9000 * J + F, osc, rsc)
+        pos, rm = sk.fk(rot, root, off, parents)
+        name = _lib.last_kernel_name()
+        assert "fk_wide_kernel" in name, (name, J, kind)
+        p_o, r_o = co.fk(rot.astype(np.float64), root.astype(np.float64), off.astype(np.float64), parents)
+        # rotations: an fp32 chain of `depth` 3 x 3 products; positions: those errors times the bones, or 2 ulp of the largest coordinate
+        assert np.abs(rm - r_o).max() <= max(2e-6, 2.5e-7 * depth), (F, np.abs(rm - r_o).max())
+        bar = max(1e-5, 3 * _ulp_of(p_o)) if osc < 1 else max(1e-5, 2 * _ulp_of(p_o), 4e-7 * depth * osc * 3)
+        assert np.abs(pos - p_o).max() <= bar, (F, osc, np.abs(pos - p_o).max() / _ulp_of(p_o), "ulp")
+        np.testing.assert_array_equal(pos[:, 0].astype(np.float32), root)  # the root is the caller's value (skeleton.py:49)
+
+
+@pytest.mark.gpu
+def test_fk_wide_walk_does_not_depend_on_a_frames_place_in_the_batch():
+    """frames are independent: a frame's result must not depend on its place in the batch (XCD tile order, the alignment of its rows in
+    HBM and in the LDS image).  (The wide walk against the tile kernels on the same arrays, bit for bit on metre data -- same local
+    rotations, same products in the same order: tools/fk_wide_sweep.py, profiles/r05_fk_wide_sweep.txt.)"""
+    import pymotion_amd.ops.skeleton as sk
+
+    J, F = 200, 500
+    parents = bushy(J, 5)
+    rot, root, off = _batch(F, J, 4242, 0.1, 2.0)
+    pos, rm = sk.fk(rot, root, off, parents)
+    assert "fk_wide_kernel" in _lib.last_kernel_name()
+    perm = np.random.default_rng(1).permutation(F)
+    pos2, rm2 = sk.fk(rot[perm], root[perm], off, parents)
+    np.testing.assert_array_equal(pos2, pos[perm])
+    np.testing.assert_array_equal(rm2, rm[perm])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("J,shift_pos,shift_rot", [(129, 4, 0), (200, 0, 12), (131, 20, 8), (511, 28, 28)])
+def test_fk_wide_walk_with_outputs_inside_bigger_buffers(J, shift_pos, shift_rot):
+    """raw ABI: `pos` / `rotmats` 16-byte aligned views into bigger buffers: same bits, nothing written outside the arrays (the first and
+    last floats of a frame's rows are written one by one)"""
+    import torch
+
+    F = 77
+    parents = bushy(J)
+    rot, root, off = _batch(F, J, 31 * J, 10.0, 200.0)
+    dev = torch.device("cuda:0")
+    rot_d, root_d, off_d = (torch.from_numpy(x).to(dev) for x in (rot, root, off))
+    pp = parents.astype(np.int32).ctypes.data_as(C.c_void_p)
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    pos0 = torch.empty(F * J * 3, device=dev)
+    rm0 = torch.empty(F * J * 9, device=dev)
+    _lib.call("pm_fk_f32", P(rot_d), P(root_d), P(off_d), 0, pp, F, J, P(pos0), P(rm0), None)
+    assert "fk_wide_kernel" in _lib.last_kernel_name()
+    pad = 64
+    pos_b = torch.full((F * J * 3 + 2 * pad,), -7.0, device=dev)
+    rm_b = torch.full((F * J * 9 + 2 * pad,), -7.0, device=dev)
+    pos1 = pos_b[pad + shift_pos: pad + shift_pos + F * J * 3]
+    rm1 = rm_b[pad + shift_rot: pad + shift_rot + F * J * 9]
+    assert pos1.data_ptr() % 16 == 0 and rm1.data_ptr() % 16 == 0
+    _lib.call("pm_fk_f32", P(rot_d), P(root_d), P(off_d), 0, pp, F, J, P(pos1), P(rm1), None)
+    assert "fk_wide_kernel" in _lib.last_kernel_name()
+    torch.cuda.synchronize()
+    assert torch.equal(pos1.view(torch.int32), pos0.view(torch.int32))
+    assert torch.equal(rm1.view(torch.int32), rm0.view(torch.int32))
+    for buf, lo, n in ((pos_b, pad + shift_pos, F * J * 3), (rm_b, pad + shift_rot, F * J * 9)):
+        assert bool((buf[:lo] == -7.0).all()) and bool((buf[lo + n:] == -7.0).all())
+    p_o, r_o = co.fk(rot.astype(np.float64), root.astype(np.float64), off.astype(np.float64), parents)
+    assert np.abs(pos0.cpu().numpy().reshape(F, J, 3) - p_o).max() <= max(1e-5, 2 * _ulp_of(p_o), 4e-7 * 30 * 30)
+
+
+@pytest.mark.gpu
+def test_fk_wide_walk_keeps_nan_and_inf_where_the_reference_has_them():
+    """a NaN quaternion poisons its joint and everything below it, a NaN root coordinate its row of every position of the frame, on metre
+    data and on data that takes the fixed-point chain (a frame with a non-finite input takes the float walk, which propagates them)"""
+    import pymotion_amd.ops.skeleton as sk
+
+    J = 200
+    parents = bushy(J, 11)
+    for osc, rsc in ((0.1, 2.0), (10.0, 200.0)):
+        F = 100
+        rot, root, off = _batch(F, J, 99, osc, rsc)
+        rot[7, 150, 1] = np.nan
+        rot[40, 1, 0] = np.nan       # near the root: much of the skeleton
+        rot[41, 0, 3] = np.inf
+        root[60, 2] = np.nan
+        root[61, 0] = np.inf
+        with np.errstate(all="ignore"):
+            p_o, r_o = co.fk(rot.astype(np.float64), root.astype(np.float64), off.astype(np.float64), parents)
+        pos, rm = sk.fk(rot, root, off, parents)
+        assert "fk_wide_kernel" in _lib.last_kernel_name()
+        assert (np.isnan(rm) == np.isnan(r_o)).all()
+        assert (np.isnan(pos) == np.isnan(p_o)).all()
+        fin = np.isfinite(p_o)
+        assert np.abs(pos[fin] - p_o[fin]).max() <= max(1e-5, 3 * _ulp_of(p_o[fin]))
+
+
+@pytest.mark.gpu
+def test_fk_trees_too_deep_for_the_step_list_fall_back():
+    """a 300-joint comb (parents far back in the table: the streamed walk declines it; depth 78: more than the step list holds) still
+    gets the right answer from the tile kernels; per-frame offsets and the ortho6d source keep them too"""
+    import pymotion_amd.ops.skeleton as sk
+
+    J, F = 300, 50
+    parents = comb(J)
+    rot, root, off = _batch(F, J, 5, 0.1, 2.0)
+    pos, rm = sk.fk(rot, root, off, parents)
+    name = _lib.last_kernel_name()
+    assert "fk_wide_kernel" not in name, name
+    p_o, r_o = co.fk(rot.astype(np.float64), root.astype(np.float64), off.astype(np.float64), parents)
+    assert np.abs(pos - p_o).max() <= 1e-5 and np.abs(rm - r_o).max() <= 2e-5
+    parents = bushy(200)
+    rot, root, off = _batch(F, 200, 6, 0.1, 2.0)
+    offs = np.broadcast_to(off, (F, 200, 3)).copy()
+    pos, rm = sk.fk(rot, root, offs, parents)
+    assert "fk_wide_kernel" not in _lib.last_kernel_name()
+    p_o, r_o = co.fk(rot.astype(np.float64), root.astype(np.float64), off.astype(np.float64), parents)
+    assert np.abs(pos - p_o).max() <= 1e-5
+
+
+def test_fk_wide_plan_schedules_every_joint_once_after_its_parent():
+    """CPU: the host's step list (pm_fk_wide_plan_debug) -- every joint but the root exactly once, a step after its parent's, idle quads on the idle slot, bounded by ceil(J / 16) + depth steps; trees that need more than 48 steps are declined"""
+    h = _lib.lib()
+    buf = (C.c_uint32 * (50 * 16))()
+    for J, parents in [(129, bushy(129)), (512, bushy(512)), (512, broom(512, 30)), (200, bushy(200, 3)), (17, bushy(17)), (1, np.zeros(1, np.int32)),
+                       (300, comb(300)), (512, np.maximum(np.arange(512) - 1, 0).astype(np.int32))]:
+        n = h.pm_fk_wide_plan_debug(parents.astype(np.int32).ctypes.data_as(C.c_void_p), J, buf)
+        depth = int(syn.depth_of(parents).max())
+        if n == -4:  # PM_EUNSUPPORTED: declined: only when the list-scheduling bound itself exceeds the 48 steps the kernel's list holds
+            assert (J + 14) // 16 + depth > 48, (J, depth)
+            continue
+        assert depth <= n <= min(48, (J + 14) // 16 + depth), (J, n, depth)
+        words = np.frombuffer(buf, dtype=np.uint32)[: (n + 2) * 16].reshape(n + 2, 16)
+        step_of = {0: -1}  # the root takes no step (its slot holds R_0 = L_0 as parked)
+        for s in range(n):
+            for w in words[s]:
+                j, p = int(w & 0xFFFF), int(w >> 16)
+                if j == J + 1:
+                    assert p == J
+                    continue
+                assert 0 < j < J and j not in step_of
+                step_of[j] = s
+                assert p == parents[j] and step_of[p] < s
+        assert len(step_of) == J
+        assert (words[n:] == ((J + 1) | (J << 16))).all()
