@@ -327,10 +327,12 @@ void FN(oracle_fk)(const REAL *rot, const REAL *root_pos, const REAL *offsets, i
             }
             const REAL *Rp = R + 9 * parents[j], *Pp = P + 3 * parents[j], *t = off + 3 * j;
             REAL *Rj = R + 9 * j, *Pj = P + 3 * j;
+            /* the reference multiplies homogeneous 4 x 4 matrices (:54-57): row r of the rotation block carries the fourth term
+             * p_parent[r] * 0 -- NaN as soon as the parent's position is NaN / Inf -- and the position p_parent[r] * 1 */
             for (int r = 0; r < 3; ++r) {
                 for (int c = 0; c < 3; ++c)
-                    Rj[3 * r + c] = Rp[3 * r] * L[c] + Rp[3 * r + 1] * L[3 + c] + Rp[3 * r + 2] * L[6 + c];
-                Pj[r] = Rp[3 * r] * t[0] + Rp[3 * r + 1] * t[1] + Rp[3 * r + 2] * t[2] + Pp[r];
+                    Rj[3 * r + c] = Rp[3 * r] * L[c] + Rp[3 * r + 1] * L[3 + c] + Rp[3 * r + 2] * L[6 + c] + Pp[r] * (REAL)0;
+                Pj[r] = Rp[3 * r] * t[0] + Rp[3 * r + 1] * t[1] + Rp[3 * r + 2] * t[2] + Pp[r] * (REAL)1;
             }
         }
     }

@@ -598,6 +598,13 @@ __device__ __forceinline__ bool fx_scale(const float tbound, const float rmax, F
     return B < 1e30f;  // false for NaN / Inf / absurd magnitudes
 }
 
+// the homogeneous product's fourth term of a rotation row: + p_parent[r] * 0 (see `poison` at fk.hip's tree_walk).  The empty asm keeps the branch a
+// branch: folded into selects it would cost every joint of every tile three more vector instructions.
+__device__ __forceinline__ void poison_row(const float pt, float &g0, float &g1, float &g2) {
+    asm volatile("");
+    g0 = __builtin_fmaf(pt, 0.0f, g0); g1 = __builtin_fmaf(pt, 0.0f, g1); g2 = __builtin_fmaf(pt, 0.0f, g2);
+}
+
 // ---- fk's local rotation matrix from a quaternion; PREC_* levels: see fk.hip -----------------------------------
 enum { PREC_FAST = 0, PREC_RESID = 1, PREC_F64 = 2, PREC_FX = 4, PREC_DYN = 16, PREC_BIG_RESID = 32 };  // BIG_RESID: see fk.hip
 

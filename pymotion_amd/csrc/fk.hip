@@ -96,10 +96,14 @@ constexpr int fk_lds_floats() { return 12 + (PFO ? 3 : 0) + (QOUT ? 4 : 0); }
 // sPos receives the positions.  sConst[j] = {parent (int bits), t0, t1, t2}, entry J = clamp copy.
 // Lane (f, r) owns row r of frame f; `gp` = root_pos[f][r].
 // FX: positions in fixed point (see PREC_FX): sPos holds int32 words p * S while the walk runs.
+// `poison` (wave-uniform; float walks only): a translation of the tile is NaN / Inf.  The reference multiplies homogeneous 4 x 4 matrices
+// (skeleton.py:54-57), so row r of a joint's ROTATION carries the term p_parent[r] * 0 -- NaN as soon as the parent's position is not
+// finite (a NaN root coordinate turns row r of every other joint's matrix into NaN).  The walks add that term when, and only when, a tile
+// has such a translation: one scalar branch per joint otherwise.
 template <bool PFO, bool FX>
 __device__ __forceinline__ void tree_walk(float *sRot, float *sPos, const float *sOff, const float *sConst,
                                           const int J, const int pad, const int f, const int r, const float gp, const bool skip,
-                                          const float S) {
+                                          const float S, const bool poison) {
     float *fL = sRot + f * (J * 9 + pad);  // this frame's slots (L before, G after)
     float *fRot = fL + r * 3;              // this lane's row inside a slot
     float *fPos = sPos + f * (J * 3 + pad) + r;
@@ -129,6 +133,7 @@ __device__ __forceinline__ void tree_walk(float *sRot, float *sPos, const float 
             gt = __int_as_float(__float_as_int(pt) + (int)__builtin_rintf(dt * S));
         } else {
             gt = dt + pt;
+            if (poison && j > 0) poison_row(pt, g0, g1, g2);
         }
         // all three lanes of the frame have read slot j (in-order DS) -> overwrite in place
         fRot[j * 9] = g0; fRot[j * 9 + 1] = g1; fRot[j * 9 + 2] = g2;
@@ -164,7 +169,7 @@ __device__ __forceinline__ void tree_walk(float *sRot, float *sPos, const float 
 // the lane's own accumulators.
 template <bool FX>
 __device__ __forceinline__ void tree_walk_q4(float *sRot, float *sPos, const float *sConst, const int J, const int pad, const int f, const int r,
-                                             const float gp, const bool skip, const float S) {
+                                             const float gp, const bool skip, const float S, const bool poison) {
     float *fL = sRot + f * (J * 9 + pad);
     float *fRot = fL + r * 3;  // this lane's row inside a slot: L[r][0..2] before the step, G[r][0..2] after
     float *fPos = sPos + f * (J * 3 + pad) + r;
@@ -192,7 +197,10 @@ __device__ __forceinline__ void tree_walk_q4(float *sRot, float *sPos, const flo
         g2 = dot_bcast(Lr[2], p0, p1, p2);
         const float dt = __builtin_fmaf(p2, c.w, __builtin_fmaf(p1, c.z, p0 * c.y));
         if (FX) gt = __int_as_float(__float_as_int(pt) + (int)__builtin_rintf(dt * S));
-        else gt = dt + pt;
+        else {
+            gt = dt + pt;
+            if (poison && j > 0) poison_row(pt, g0, g1, g2);
+        }
         fRot[j * 9] = g0; fRot[j * 9 + 1] = g1; fRot[j * 9 + 2] = g2;
         fPos[j * 3] = gt;
     };
@@ -241,7 +249,9 @@ __device__ __forceinline__ float quad_dot3(const float e, const float a0, const 
     return acc;
 }
 
-template <bool PFO, bool FX>
+// (POISON is a template parameter here: the twelve-lane kernels are bound by instruction issue, and one scalar branch per step was 2-3 points
+// at J = 52 -- same-box A/B, profiles/r05_poison_ab.txt)
+template <bool PFO, bool FX, bool POISON = false>
 __device__ __forceinline__ void tree_walk_quad(float *sRot, float *sPos, const float *sOff, const float *sConst,
                                                const int J, const int pad, const int f, const int r, const int c, const float seed_in,
                                                const int lane, const float S) {
@@ -278,6 +288,10 @@ __device__ __forceinline__ void tree_walk_quad(float *sRot, float *sPos, const f
             g = (c == 3) ? __int_as_float(gi) : dot;
         } else {
             g = __builtin_fmaf(m3, e, quad_dot3(e, a[0], a[1], a[2]));  // + Gp[r][3] on the position lane
+            if (POISON && j > 0) {  // + Gp[r][3] * 0 on the rotation lanes: the position lane's parent element, across the quad
+                const float pp = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(e), 0xff, 0xf, 0xf, true));  // quad_perm:[3,3,3,3]
+                g = (c < 3) ? __builtin_fmaf(pp, 0.0f, g) : g;
+            }
         }
         if (!last_may_be_dummy || j < J) *own = g;
         own += ostep;
@@ -517,7 +531,7 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
     }
 
     // ---- PREC_DYN: does this tile need the float64 rotations and the fixed-point chain? ------------------------
-    bool big = false;
+    bool big = false, poison = false;
     FxScale fx = {1.0f, 1.0f};
     if constexpr (DYN || (PREC & PREC_FX)) {
         bool mine = tbig || !(fabsf(gp) < kBigRoot);
@@ -532,6 +546,7 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
             const float bsum = wave_sum(tsum), bmax = (float)a.depth * wave_max(tmx);  // (NaN sticks in both)
             const float tbound = PFO ? 3.0f * (float)a.depth * wave_max(tmax) : ((bmax < bsum) ? bmax : bsum);
             big = fx_scale(tbound, fabsf(gp), fx);
+            poison = !big;  // a translation of the tile is NaN / Inf (or absurd): the float walk carries the reference's p_parent[r] * 0 (see tree_walk)
         }
     }
 
@@ -601,16 +616,17 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
             const float seed = (c == 3) ? gp : ((c == r) ? 1.0f : 0.0f);
             if (!PM_ABLATED(a, 2)) {
                 if (FX && fixed) tree_walk_quad<PFO, FX>(sRot, sPos, sOff, sConst, J, pad, f, r, c, seed, lane, fx.S);
+                else if (poison) tree_walk_quad<PFO, false, true>(sRot, sPos, sOff, sConst, J, pad, f, r, c, seed, lane, 1.0f);
                 else tree_walk_quad<PFO, false>(sRot, sPos, sOff, sConst, J, pad, f, r, c, seed, lane, 1.0f);
             }
         } else if (Q4 && q4) {
             if ((lane & 3) < 3 && (lane >> 2) < FPW) {  // (the DPP operands come from lanes 0..2 of the quad only)
-                if (FX && fixed) tree_walk_q4<FX>(sRot, sPos, sConst, J, pad, f, r, gp, PM_ABLATED(a, 2), fx.S);
-                else tree_walk_q4<false>(sRot, sPos, sConst, J, pad, f, r, gp, PM_ABLATED(a, 2), 1.0f);
+                if (FX && fixed) tree_walk_q4<FX>(sRot, sPos, sConst, J, pad, f, r, gp, PM_ABLATED(a, 2), fx.S, false);
+                else tree_walk_q4<false>(sRot, sPos, sConst, J, pad, f, r, gp, PM_ABLATED(a, 2), 1.0f, poison);
             }
         } else {
-            if (FX && fixed) tree_walk<PFO, FX>(sRot, sPos, sOff, sConst, J, pad, f, r, gp, PM_ABLATED(a, 2), fx.S);
-            else tree_walk<PFO, false>(sRot, sPos, sOff, sConst, J, pad, f, r, gp, PM_ABLATED(a, 2), 1.0f);
+            if (FX && fixed) tree_walk<PFO, FX>(sRot, sPos, sOff, sConst, J, pad, f, r, gp, PM_ABLATED(a, 2), fx.S, false);
+            else tree_walk<PFO, false>(sRot, sPos, sOff, sConst, J, pad, f, r, gp, PM_ABLATED(a, 2), 1.0f, poison);
         }
         wave_sync();
         if (FX && fixed) {  // fixed-point words -> fp32 in place; the root is the caller's value, bit for bit (skeleton.py:49)
@@ -771,7 +787,7 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? ((PFO && E
         const float gp_i = gp;
         // PREC_DYN: the arithmetic of THIS tile (see fk_tile): float64 rotations + fixed-point chain when the bones or
         // this tile's root positions are big
-        bool big = false;
+        bool big = false, poison = false;
         FxScale fx = {1.0f, 1.0f};
         if constexpr (DYN || (PREC & PREC_FX)) {
             bool mine = !(fabsf(gp_i) < kBigRoot);
@@ -789,6 +805,7 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? ((PFO && E
             if (big) {
                 const float bound_t = PFO ? 3.0f * (float)a.depth * wave_max(tmax) : tsum;
                 big = fx_scale(bound_t, fabsf(gp_i), fx);
+                poison = !big;  // (see fk_tile)
             }
         }
         // math of tile i, in registers (phase A of fk_tile)
@@ -861,16 +878,17 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? ((PFO && E
             const float seed = (c == 3) ? gp_i : ((c == r) ? 1.0f : 0.0f);
             if (!PM_ABLATED(a, 2)) {
                 if (CAN_FX && fixed) tree_walk_quad<PFO, CAN_FX>(sRot, sPos, sOff, sConst, J, pad, f, r, c, seed, lane, fx.S);
+                else if (poison) tree_walk_quad<PFO, false, true>(sRot, sPos, sOff, sConst, J, pad, f, r, c, seed, lane, 1.0f);
                 else tree_walk_quad<PFO, false>(sRot, sPos, sOff, sConst, J, pad, f, r, c, seed, lane, 1.0f);
             }
         } else if constexpr (Q4) {
             if ((lane & 3) < 3 && (lane >> 2) < FPW) {  // (the DPP operands come from lanes 0..2 of a quad)
-                if (CAN_FX && fixed) tree_walk_q4<CAN_FX>(sRot, sPos, sConst, J, pad, f, r, gp_i, PM_ABLATED(a, 2), fx.S);
-                else tree_walk_q4<false>(sRot, sPos, sConst, J, pad, f, r, gp_i, PM_ABLATED(a, 2), 1.0f);
+                if (CAN_FX && fixed) tree_walk_q4<CAN_FX>(sRot, sPos, sConst, J, pad, f, r, gp_i, PM_ABLATED(a, 2), fx.S, false);
+                else tree_walk_q4<false>(sRot, sPos, sConst, J, pad, f, r, gp_i, PM_ABLATED(a, 2), 1.0f, poison);
             }
         } else {
-            if (CAN_FX && fixed) tree_walk<PFO, CAN_FX>(sRot, sPos, sOff, sConst, J, pad, f, r, gp_i, PM_ABLATED(a, 2), fx.S);
-            else tree_walk<PFO, false>(sRot, sPos, sOff, sConst, J, pad, f, r, gp_i, PM_ABLATED(a, 2), 1.0f);
+            if (CAN_FX && fixed) tree_walk<PFO, CAN_FX>(sRot, sPos, sOff, sConst, J, pad, f, r, gp_i, PM_ABLATED(a, 2), fx.S, false);
+            else tree_walk<PFO, false>(sRot, sPos, sOff, sConst, J, pad, f, r, gp_i, PM_ABLATED(a, 2), 1.0f, poison);
         }
         wave_sync();
         if (CAN_FX && fixed) {  // fixed-point words -> fp32 in place; the root is the caller's value, bit for bit
@@ -1017,13 +1035,13 @@ __global__ __launch_bounds__(PM_WAVE) void fk_stream_kernel(const FkStreamArgs a
     const int64_t fg = f0 + (f < nf ? f : nf - 1);  // frames past a partial tile repeat its last one (their stores are predicated)
     const float gp = a.root_pos[fg * 3 + r];
     if (lane < 3 * FPW || Q4) sRoot[f * 3 + r] = gp;
-    bool big = false;
+    bool big = false, tpoison = false;
     FxScale fx = {1.0f, 1.0f};
     {
         const bool tbig = __builtin_amdgcn_ballot_w64(tbig_l) != 0;
         const float bsum = wave_sum(tsum_l), bmax = (float)a.depth * wave_max(tmx_l);  // (NaN sticks in both)
         big = tbig || __builtin_amdgcn_ballot_w64(!(fabsf(gp) < kBigRoot)) != 0;
-        if (big) big = fx_scale((bmax < bsum) ? bmax : bsum, fabsf(gp), fx);  // false for a non-finite bound: the float walk propagates NaN / Inf
+        if (big) { big = fx_scale((bmax < bsum) ? bmax : bsum, fabsf(gp), fx); tpoison = !big; }  // false for a non-finite bound: the float walk propagates NaN / Inf (tpoison: see tree_walk's `poison`)
     }
 
     v4f in4[EPL];
@@ -1122,6 +1140,7 @@ __global__ __launch_bounds__(PM_WAVE) void fk_stream_kernel(const FkStreamArgs a
                 gt = __int_as_float(poison ? (int)0x80000000 : pw + (int)__builtin_rintf(dt * fx.S));
             } else {
                 gt = dt + pt;
+                if (tpoison && ld != FS_ROOT) poison_row(pt, g0, g1, g2);
             }
             fRot[jl * 9] = g0; fRot[jl * 9 + 1] = g1; fRot[jl * 9 + 2] = g2;
             fPos[jl * 3] = gt;

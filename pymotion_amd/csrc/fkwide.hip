@@ -120,7 +120,7 @@ __device__ __forceinline__ void fw_row_out(float *__restrict__ g, const float *l
 // (J = 512 at 2^18 frames: 2450 us; four steps ahead: 2060 us), and a walk without vector-memory waits is what lets the NEXT frame's
 // quaternions be in flight while this frame walks.
 template <bool FX, int NG>
-__device__ __forceinline__ void fw_walk(float *sRot, float *sPos, const uint32_t (&JW)[NG + 1], const int nsteps, const int lane, const float S) {
+__device__ __forceinline__ void fw_walk(float *sRot, float *sPos, const uint32_t (&JW)[NG + 1], const int nsteps, const int lane, const float S, const bool poison) {
     const int r = (lane & 3) < 3 ? (lane & 3) : 2;  // lane 3 of a quad shadows lane 2 (same reads, same writes): it holds a quarter of the quad's words
     // out = p0 * bcast_0(l) + p1 * bcast_1(l) + p2 * bcast_2(l), l = this lane's element of its row of [L | t] (lane i of the quad: row i)
     auto dot_bcast = [](const float l, const float p0, const float p1, const float p2) __attribute__((always_inline)) {
@@ -149,11 +149,14 @@ __device__ __forceinline__ void fw_walk(float *sRot, float *sPos, const uint32_t
         // the next step's [L | t] row: its slot is written by that step only
         float *an = sRot + __umul24(wn & 0xffffu, 9u) + r * 3, *pn = sPos + __umul24(wn & 0xffffu, 3u) + r;
         const float n0 = an[0], n1 = an[1], n2 = an[2], nt = *pn;
-        const float g0 = dot_bcast(l0, p0, p1, p2), g1 = dot_bcast(l1, p0, p1, p2), g2 = dot_bcast(l2, p0, p1, p2);
         const float dt = dot_bcast(tr, p0, p1, p2);
         float gt;
+        float g0 = dot_bcast(l0, p0, p1, p2), g1 = dot_bcast(l1, p0, p1, p2), g2 = dot_bcast(l2, p0, p1, p2);
         if (FX) gt = __int_as_float(__float_as_int(pt) + (int)__builtin_rintf(dt * S));
-        else gt = dt + pt;
+        else {
+            gt = dt + pt;
+            if (poison) poison_row(pt, g0, g1, g2);  // (wave-uniform) a NaN / Inf translation in the frame: the reference's p_parent[r] * 0, see fk.hip's tree_walk
+        }
         aj[0] = g0; aj[1] = g1; aj[2] = g2;
         *pj = gt;
         aj = an; pj = pn;
@@ -241,12 +244,12 @@ __global__ __launch_bounds__(PM_WAVE) void fk_wide_kernel(const FkWideArgs a, co
         const float gpf = gp;  // this frame's root position (gp is refilled by the next frame's loads)
 
         // PREC_DYN: does this frame need the float64 rotations and the fixed-point chain?  (fk_tile's test, on one frame)
-        bool big = false;
+        bool big = false, poison = false;
         FxScale fx = {1.0f, 1.0f};
         if constexpr (DYN || (PREC & PREC_FX)) {
             const bool mine = lane < 3 && !(fabsf(gpf) < kBigRoot);
             big = table_big || __builtin_amdgcn_ballot_w64(mine) != 0 || !DYN;
-            if (big) big = fx_scale(tbound, lane < 3 ? fabsf(gpf) : 0.0f, fx);
+            if (big) { big = fx_scale(tbound, lane < 3 ? fabsf(gpf) : 0.0f, fx); poison = !big; }
         }
 
         auto rest = [&](auto mode) __attribute__((always_inline)) {
@@ -281,8 +284,8 @@ __global__ __launch_bounds__(PM_WAVE) void fk_wide_kernel(const FkWideArgs a, co
             if (lane < 3) sPos[lane] = (FX && fixed) ? __int_as_float((int)__builtin_rintf(gpf * fx.S)) : gpf;  // the root's position (its slot held offsets[0], which is ignored)
             wave_sync();
             if (!PM_ABLATED(a, 2)) {
-                if (FX && fixed) fw_walk<true, NG>(sRot, sPos, JW, a.nsteps, lane, fx.S);
-                else fw_walk<false, NG>(sRot, sPos, JW, a.nsteps, lane, 1.0f);
+                if (FX && fixed) fw_walk<true, NG>(sRot, sPos, JW, a.nsteps, lane, fx.S, false);
+                else fw_walk<false, NG>(sRot, sPos, JW, a.nsteps, lane, 1.0f, poison);
             }
             wave_sync();
             if (FX && fixed) {  // fixed-point words -> fp32 in place; the root is the caller's value, bit for bit (skeleton.py:49)

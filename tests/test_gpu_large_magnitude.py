@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 from oracle import c_oracle as co
+from pymotion_amd import _lib
 from pymotion_amd import synthetic as syn
 
 pytestmark = pytest.mark.gpu
@@ -118,6 +119,68 @@ def test_non_finite_inputs_propagate_like_the_reference_on_the_big_path(J):
     fin = np.isfinite(p_o)
     assert (np.isinf(pos) == np.isinf(p_o)).all()
     assert np.abs(pos[fin] - p_o[fin]).max() <= max(1e-5, 2 * _ulp_of(p_o[fin]))
+
+
+@pytest.mark.parametrize("J,kind", [(6, "random"), (22, "body"), (36, "random"), (52, "smplh"), (80, "random"), (128, "chain"), (200, "random"), (300, "chain")])
+def test_non_finite_translations_reach_the_rotation_rows_like_the_reference(J, kind):
+    """the reference multiplies homogeneous 4 x 4 matrices (ops/skeleton.py:54-57): row r of a joint's rotation carries p_parent[r] * 0, so a
+    NaN / Inf root coordinate (or offset) turns rotation rows below it into NaN and Inf positions into NaN one level further down -- on every
+    walk (three lanes / quad / twelve lanes per frame, pipelined, streamed, wide), shared and per-frame offsets, quaternion and ortho6d source,
+    metre and centimetre data; frames without such a value in the same tiles are untouched"""
+    import pymotion_amd.ops.skeleton as sk
+    from oracle import c_oracle as co
+
+    rng = np.random.default_rng(J)
+    if kind == "chain":
+        parents = np.maximum(np.arange(J) - 1, 0).astype(np.int32)
+        parents[J // 2] = 0
+        parents[3 * J // 4] = J // 4
+    else:
+        parents = {"body": syn.PARENTS_22, "smplh": syn.PARENTS_52}.get(kind)
+        if parents is None:
+            parents = syn.random_parents(J, rng)
+    F = 131
+    depth = int(syn.depth_of(parents).max())
+    f64 = lambda x: x.astype(np.float64)  # noqa: E731
+    for osc, rsc in ((0.2, 2.0), (20.0, 150.0)):
+        rot = rng.standard_normal((F, J, 4)).astype(np.float32)
+        root = rng.uniform(-rsc, rsc, (F, 3)).astype(np.float32)
+        off = rng.uniform(-osc, osc, (J, 3)).astype(np.float32)
+        off[0] = 0
+        root[5, 1] = np.nan
+        root[40, 0] = np.inf
+        root[41, 2] = -np.inf
+        root[100] = np.nan
+        for offs in (off, np.broadcast_to(off, (F, J, 3)).copy()):
+            if offs.ndim == 3 and J > 1:
+                offs[77, J // 2, 1] = np.inf      # a per-frame offset: positions from that joint down, rotations from its children down
+                offs[90, J - 1, 0] = np.nan       # a leaf: its own position only
+            with np.errstate(all="ignore"):
+                p_o, r_o = co.fk(f64(rot), f64(root), f64(offs), parents)
+            pos, rm = sk.fk(rot, root, offs, parents)
+            name = _lib.last_kernel_name()
+            assert (np.isnan(rm) == np.isnan(r_o)).all(), (name, osc, offs.ndim, np.argwhere(np.isnan(rm) != np.isnan(r_o))[:4])
+            assert (np.isnan(pos) == np.isnan(p_o)).all(), (name, osc, offs.ndim)
+            assert (np.isinf(pos) == np.isinf(p_o)).all(), (name, osc, offs.ndim)
+            fin = np.isfinite(r_o)
+            assert np.abs(rm[fin] - r_o[fin]).max() <= 1e-5
+            fin = np.isfinite(p_o)
+            # (a tile that holds a NaN / Inf translation walks in fp32 -- its finite frames too: the fp32 chain's bound, as in test_gpu_deep.py)
+            assert np.abs(pos[fin] - p_o[fin]).max() <= max(1e-5, 3 * _ulp_of(p_o[fin]), 4e-7 * depth * osc * 3), name
+        if J <= 128:  # the fused ortho6d source shares the walks
+            x = rng.standard_normal((F, J, 3, 2)).astype(np.float32)
+            with np.errstate(all="ignore"):
+                p_o, r_o = co.fk(co.o6d_to_quat(f64(x)), f64(root), f64(off), parents)
+            pos, rm = sk.fk_from_ortho6d(x, root, off, parents)[:2]
+            assert (np.isnan(rm) == np.isnan(r_o)).all() and (np.isnan(pos) == np.isnan(p_o)).all() and (np.isinf(pos) == np.isinf(p_o)).all(), _lib.last_kernel_name()
+    # a NaN in the SHARED offsets table: every frame
+    off2 = off.copy()
+    off2[J // 2 if J > 1 else 0, 2] = np.nan
+    if J > 2:
+        with np.errstate(all="ignore"):
+            p_o, r_o = co.fk(f64(rot), f64(root), f64(off2), parents)
+        pos, rm = sk.fk(rot, root, off2, parents)
+        assert (np.isnan(rm) == np.isnan(r_o)).all() and (np.isnan(pos) == np.isnan(p_o)).all(), _lib.last_kernel_name()
 
 
 def test_per_frame_offsets_at_centimetre_scale():

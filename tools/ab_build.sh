@@ -7,9 +7,9 @@ ref=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 tmp=$(mktemp -d /tmp/pm_ab.XXXXXX)
 mkdir -p "$tmp/pymotion_amd/csrc" "$tmp/include"
-git -C "$root" archive "$ref" pymotion_amd/csrc include | tar -x -C "$tmp"; [ -f "$tmp/pymotion_amd/csrc/deep.hip" ] || cp "$root/pymotion_amd/csrc/deep.hip" "$tmp/pymotion_amd/csrc/"
+git -C "$root" archive "$ref" pymotion_amd/csrc include | tar -x -C "$tmp"; [ -f "$tmp/pymotion_amd/csrc/deep.hip" ] || cp "$root/pymotion_amd/csrc/deep.hip" "$tmp/pymotion_amd/csrc/"; [ -f "$tmp/pymotion_amd/csrc/fkwide.hip" ] || cp "$root/pymotion_amd/csrc/fkwide.hip" "$tmp/pymotion_amd/csrc/"
 objs=""
-for f in fk dq deep mirror elementwise unroll ik interp probe host; do
+for f in fk fkwide dq deep mirror elementwise unroll ik interp probe host; do
   if [[ " $* " == *" $f.hip "* ]]; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC ${AB_FLAGS--fno-slp-vectorize} --offload-arch=gfx950 -c "$tmp/pymotion_amd/csrc/$f.hip" -o "$tmp/$f.o"
     objs="$objs $tmp/$f.o"
