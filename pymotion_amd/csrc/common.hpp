@@ -759,7 +759,7 @@ int deep_plan(const Parents &par, int J, bool root_is_identity, DeepTopo &t);
 // ---- fkwide.hip: fk with a wave per frame and its lanes over the joints (long, wide trees) -------------------------------------
 bool try_fk_wide(const float *rot, const float *root_pos, const float *offsets, float *pos, float *rotmats, int64_t F, int32_t J, int32_t depth,
                  const Parents &par, int ablate, int max_quad_steps_per_joint_x10, hipStream_t s, int &rc);
-int fk_wide_plan(const Parents &par, int J, uint32_t *jobs);
+int fk_wide_plan(const Parents &par, int J, int width, int max_steps, bool dup_idle, uint32_t *jobs);
 int launch_to_root_deep(const float *rot, const float *root_pos, const float *offsets, float *dq, int64_t F, int32_t J,
                         const DeepTopo &topo, hipStream_t s);
 

@@ -33,6 +33,7 @@
 namespace pm {
 
 enum FkSrc { SRC_QUAT = 0, SRC_O6D = 1 };
+constexpr int kW4Groups = 10, kW4Steps = 4 * kW4Groups, kW4Stride = kW4Steps + 4;  // tree_walk_w4: steps its list holds (four to a register), words per slot
 
 struct FkArgs {
     const float *src;       // [F,J,4] quats or [F,J,3,2] ortho6d
@@ -47,7 +48,9 @@ struct FkArgs {
     int32_t ablate;         // PM_TUNING build only (env PM_FK_ABLATE): 2 = no tree walk; always 0 in production
     int32_t pad;            // floats of padding per frame in each per-frame LDS region (0 or 4), set by dispatch_fk
     int32_t depth;          // edges on the longest root-to-leaf path: |p_j - root|_1 <= depth max_j |t_j|_1 (fixed-point scale, PREC_FX)
+    int32_t wsteps;         // fk_pipe_kernel, four frames a wave: > 0 = walk the tree four JOINTS of a frame at a time over this many steps (tree_walk_w4)
     Parents parents;
+    uint32_t wjobs[4 * kW4Stride];  // [slot][step]: joint | parent << 16 (a slot without a joint repeats the step's first one)
 };
 
 // LDS bank conflicts of the walks: lanes of DIFFERENT frames touch the same joint slot in the same instruction, so the
@@ -312,6 +315,74 @@ __device__ __forceinline__ void tree_walk_quad(float *sRot, float *sPos, const f
             step(jb + jj, __builtin_amdgcn_readlane(pv, jj), A, peA, peB, false);
             step(jb + jj + 1, __builtin_amdgcn_readlane(pv, jj + 1), B, peB, peA, true);
         }
+    }
+}
+
+// ---- phase B, four frames a wave, FOUR JOINTS of a frame at a time (round 5) ---------------------------------------------------------------
+// tree_walk_quad visits a frame's J joints one after the other with twelve lanes, ~15 instructions a step for four frames: 3.75 a joint-frame,
+// the biggest item of kernels that are bound by instruction issue (J = 52: ~5.2 a joint-frame at 64 % of the HBM spec).  But a humanoid is not a
+// chain: SMPL-H's 52 joints are 10 levels deep, and list-scheduled four at a time (fk_wide_plan: a joint at the earliest one step after its
+// parent, the longest path below first) they take 15 steps, not 52.  Here a QUAD owns one joint of a step -- sixteen quads: four frames x four
+// slots -- and works like fk_wide_kernel's (fkwide.hip): lane r row r of [R | p], the joint's [L | t] shared across the quad through the DPP
+// operand of the multiply-adds, the parent's row and the next step's [L | t] row read from the image, the step words in registers (lane t of a
+// quad holds the word of step 4 g + t, a quad broadcast hands it out).  ~40 instructions a step for sixteen joint-frames: 2.5 a joint-frame
+// with a full list, and SMPL-H's is 85 % full.  The image holds L row-major here (tree_walk_quad wants it transposed), the root takes no step
+// (its slot holds L_0 = R_0; the caller parks its position), and a slot without a joint repeats the step's first joint (same reads, same writes).
+// Same products in the same order as every other walk: the results are theirs to the bit.
+template <bool PFO, bool FX>
+__device__ __forceinline__ void tree_walk_w4(float *sRot, float *sPos, const float *sOff, const float *sConst, const int J, const int pad,
+                                             const int lane, const uint32_t (&JW)[kW4Groups + 1], const int nsteps, const float S, const bool poison) {
+    const int q = lane >> 2, f = q >> 2, r = (lane & 3) < 3 ? (lane & 3) : 2;  // (lane 3 of a quad shadows lane 2: it holds a quarter of the quad's words)
+    float *fL = sRot + f * (J * 9 + pad) + r * 3, *fP = sPos + f * (J * 3 + pad) + r;
+    const float *fT = PFO ? sOff + f * (J * 3 + pad) + r : sConst + 1 + r;  // t_j[r]: the per-frame offsets tile, or the joint table {parent, t0, t1, t2}
+    constexpr unsigned TS = PFO ? 3u : 4u;
+    auto dot_bcast = [](const float l, const float p0, const float p1, const float p2) __attribute__((always_inline)) {
+        float acc;
+        asm("s_nop 1\n\t"  // (the rows travel from step to step through register copies: a VGPR written by the VALU needs two wait states before a DPP read)
+            "v_mul_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %1, %3 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %0, %1, %4 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf"
+            : "=&v"(acc)
+            : "v"(l), "v"(p0), "v"(p1), "v"(p2));
+        return acc;
+    };
+    auto word = [](const uint32_t v, auto t) __attribute__((always_inline)) {
+        constexpr int T = decltype(t)::value;
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, T * 0x55, 0xf, 0xf, true);  // quad_perm:[T,T,T,T]
+    };
+    uint32_t w = word(JW[0], IntC<0>{});
+    float *aj = fL + __umul24(w & 0xffffu, 9u), *pj = fP + __umul24(w & 0xffffu, 3u);
+    float l0 = aj[0], l1 = aj[1], l2 = aj[2], tr = fT[__umul24(w & 0xffffu, TS)];
+    auto step = [&](const uint32_t wn) __attribute__((always_inline)) {
+        const unsigned par = w >> 16, jn = wn & 0xffffu;
+        const float *ap = fL + __umul24(par, 9u);
+        const float p0 = ap[0], p1 = ap[1], p2 = ap[2], pt = fP[__umul24(par, 3u)];
+        float *an = fL + __umul24(jn, 9u), *pn = fP + __umul24(jn, 3u);  // the next step's [L | t] row: its slot is written by that step only
+        const float n0 = an[0], n1 = an[1], n2 = an[2], nt = fT[__umul24(jn, TS)];
+        float g0 = dot_bcast(l0, p0, p1, p2), g1 = dot_bcast(l1, p0, p1, p2), g2 = dot_bcast(l2, p0, p1, p2);
+        const float dt = dot_bcast(tr, p0, p1, p2);
+        float gt;
+        if (FX) gt = __int_as_float(__float_as_int(pt) + (int)__builtin_rintf(dt * S));
+        else {
+            gt = dt + pt;
+            if (poison) poison_row(pt, g0, g1, g2);
+        }
+        aj[0] = g0; aj[1] = g1; aj[2] = g2;
+        *pj = gt;
+        aj = an; pj = pn;
+        l0 = n0; l1 = n1; l2 = n2; tr = nt;
+        w = wn;
+    };
+#pragma nounroll
+    for (int g = 0; g * 4 < nsteps; ++g) {  // (a finished joint's slot holds R, not L: exactly nsteps steps, no idle ones)
+        const uint32_t cur = JW[g], nxt = JW[g + 1];
+        step(word(cur, IntC<1>{}));
+        if (g * 4 + 1 >= nsteps) break;
+        step(word(cur, IntC<2>{}));
+        if (g * 4 + 2 >= nsteps) break;
+        step(word(cur, IntC<3>{}));
+        if (g * 4 + 3 >= nsteps) break;
+        step(word(nxt, IntC<0>{}));
     }
 }
 
@@ -695,6 +766,19 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? ((PFO && E
     float *sPos = sRot + FJ * 9 + FPW * pad;     // [FPW*(J*3+pad)]
     float *sOff = sPos + FJ * 3 + FPW * pad;     // [FPW*(J*3+pad)]  (PFO: per-frame offsets)
     float *sConst = sOff + (PFO ? FJ * 3 + FPW * pad : 0);  // [(J+4)*4]
+    // four joints of a frame at a time (tree_walk_w4) when the host's step list says so: this quad's step words, for the life of the workgroup
+    const bool wide = QUAD && a.wsteps > 0;
+    uint32_t JW[kW4Groups + 1];
+#pragma unroll
+    for (int g = 0; g <= kW4Groups; ++g) JW[g] = 0u;
+    if constexpr (QUAD) {
+        if (wide) {
+#pragma unroll
+            for (int g = 0; g <= kW4Groups; ++g) JW[g] = a.wjobs[((lane >> 2) & 3) * kW4Stride + 4 * g + (lane & 3)];
+#pragma unroll
+            for (int g = 0; g <= kW4Groups; ++g) asm volatile("" : "+v"(JW[g]));  // settled here: pending, the walk's indexed read would wait for every load in flight
+        }
+    }
     // (QOUT: the quaternions are one 16-byte record per lane with consecutive lanes on consecutive records -- a contiguous stream
     // as they stand -- and leave straight from the conversion's registers.  Round 2 parked them in a fourth LDS region and copied
     // that out: 16 J B more image per frame and 16 more live registers across the walk, 57.9 % against 61.8 % without the output.)
@@ -851,7 +935,8 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? ((PFO && E
         for (int u = 0; u < EPL; ++u) {        // ... and tile i's local rotations take its place (in-order DS)
             const int e = u * PM_WAVE + lane;
             if (e < n) {
-                put_local<QUAD>(sRot + image_slot<PAD>(e, J, invJ, 9, pad), L[u]);
+                if (QUAD && wide) put_local<false>(sRot + image_slot<PAD>(e, J, invJ, 9, pad), L[u]);  // (tree_walk_w4 reads rows of L)
+                else put_local<QUAD>(sRot + image_slot<PAD>(e, J, invJ, 9, pad), L[u]);
                 if constexpr (PFO) {
                     float *o = sOff + image_slot<PAD>(e, J, invJ, 3, pad);
                     o[0] = inO[u].x; o[1] = inO[u].y; o[2] = inO[u].z;
@@ -863,7 +948,8 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? ((PFO && E
             for (int u = 0; u < EPL; ++u) {
                 const int e = u * PM_WAVE + lane, ec = e < n ? e : (n > 0 ? n - 1 : 0);
                 const float xx[6] = {in2[u][0].x, in2[u][0].y, in2[u][1].x, in2[u][1].y, in2[u][2].x, in2[u][2].y};
-                o6d_redo_ill<QOUT, QUAD>(ill[u] && e < n, xx, a.eps, sRot + image_slot<PAD>(ec, J, invJ, 9, pad), QOUT ? gq + 4 * ec : nullptr);
+                if (QUAD && wide) o6d_redo_ill<QOUT, false>(ill[u] && e < n, xx, a.eps, sRot + image_slot<PAD>(ec, J, invJ, 9, pad), QOUT ? gq + 4 * ec : nullptr);
+                else o6d_redo_ill<QOUT, QUAD>(ill[u] && e < n, xx, a.eps, sRot + image_slot<PAD>(ec, J, invJ, 9, pad), QOUT ? gq + 4 * ec : nullptr);
             }
         }
         f0_prev = f0; nf_prev = nf;
@@ -876,7 +962,15 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? ((PFO && E
         constexpr bool CAN_FX = DYN || (PREC & PREC_FX);
         if constexpr (QUAD) {
             const float seed = (c == 3) ? gp_i : ((c == r) ? 1.0f : 0.0f);
-            if (!PM_ABLATED(a, 2)) {
+            if (wide) {  // (wave-uniform) four joints of a frame at a time
+                // the roots' positions (their rotation slots hold L_0 = R_0 as parked): the twelve-lane mapping's position lanes have them
+                if (c == 3 && lane < 12 * FPW) sPos[f * (J * 3 + pad) + r] = (CAN_FX && fixed) ? __int_as_float((int)__builtin_rintf(gp_i * fx.S)) : gp_i;
+                wave_sync();
+                if (!PM_ABLATED(a, 2)) {
+                    if (CAN_FX && fixed) tree_walk_w4<PFO, CAN_FX>(sRot, sPos, sOff, sConst, J, pad, lane, JW, a.wsteps, fx.S, false);
+                    else tree_walk_w4<PFO, false>(sRot, sPos, sOff, sConst, J, pad, lane, JW, a.wsteps, 1.0f, poison);
+                }
+            } else if (!PM_ABLATED(a, 2)) {
                 if (CAN_FX && fixed) tree_walk_quad<PFO, CAN_FX>(sRot, sPos, sOff, sConst, J, pad, f, r, c, seed, lane, fx.S);
                 else if (poison) tree_walk_quad<PFO, false, true>(sRot, sPos, sOff, sConst, J, pad, f, r, c, seed, lane, 1.0f);
                 else tree_walk_quad<PFO, false>(sRot, sPos, sOff, sConst, J, pad, f, r, c, seed, lane, 1.0f);
@@ -1404,7 +1498,7 @@ constexpr int kFkEightFramesMaxJ = 39, kFkEightFramesMaxJO6d = 39, kFkEightFrame
 // 2^19 frames, stream / pipelined tile kernel on one box: J = 64 64.6 / 59.6 %, 96 68.0 / 55.9, 100 56.2 / 52.1, 104 57.2 / 53.1, 112 58.7 / 46.4,
 // 120 58.4 / 48.1, 128 69.2 / 47.3; 80 54.1 / 57.9, 97 53.9 / 56.4, 127 50.2 / 47.4)
 constexpr int kFkStreamMinJ = 96, kFkStreamMinLinesJ = 64;
-constexpr int kFkWideMinJ = 92;  // fk_wide_kernel (fkwide.hip) beyond (up to 92 joints the six-records-a-lane pipelined tiles read 57-63 % on the same trees)
+constexpr int kFkWideMinJ = 100;  // fk_wide_kernel (fkwide.hip) beyond; up to here the four-frame pipelined tiles with tree_walk_w4 are the better shape on the same trees
 static bool fk_stream_wanted(const int J) { return J > 128 || (J >= kFkStreamMinJ && J % 4 == 0) || (J >= kFkStreamMinLinesJ && J % 32 == 0); }
 
 template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT, bool PAD, int PREC>
@@ -1583,6 +1677,26 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
     // FPW 16, 358 us twelve-lane).
     if (pfo) pick = 4;
     pick = tune_env("PM_FK_FPW", pick);  // PM_TUNING build only: 20, 16, 12, 8 or 4
+    // (round 5) four frames a wave and four JOINTS of a frame at a time (fk_pipe_kernel with tree_walk_w4) when the tree is wide enough for that
+    // to take fewer instructions than one joint at a time: ~40 a step for sixteen joint-frames against ~15 for four (twelve lanes a frame) or ~18 for
+    // eight (a quad a frame), i.e. step lists of at most 0.32 J steps -- SMPL-H's 52 joints: 15.  One box, humanoids with hands / random trees, % of
+    // the HBM spec, this walk / what ran before (profiles/r05_fk_w4_sweep.txt): J = 40 66.9 / 63.4 and 72.2 / 63.4, 48 70.2 / 63.1 and 74.6 / 66.1, 52
+    // (SMPL-H) 72.8 / 64.3 and 74.0 / 64.7, 64 67.8 / 54.1 and 69.2 / 58.8, 80 68.9 / 56.4 and 70.1 / 56.9, 92 70.9 / 57.6 and 71.5 / 57.6, 100 66.7 /
+    // 57.5 and 68.8 / 62.7; random trees of 24...36 joints 64-70 / 56-62 (the sixteen- / eight-frame tiles keep the humanoids there: equal);
+    // chains lose 3-6 points and never qualify.  From 101 joints on fk_wide_kernel is the better shape (112: 62.9 / 58.7, 128: 73.5 / 62.6).
+    // PM_FK_W4 (PM_TUNING build only): 0 never, 1 whenever the list holds the tree (and the four-frame kernel is what runs).
+    a.wsteps = 0;
+    if (const int w4 = tune_env("PM_FK_W4", -1); w4 != 0 && a.J <= 128 && (w4 == 1 || a.J >= (SRC == SRC_QUAT ? 24 : 30))) {
+        uint32_t list[(kW4Steps + 2) * 4];
+        const int n = fk_wide_plan(a.parents, a.J, 4, kW4Steps, true, list);
+        if (n > 0 && (w4 == 1 || 100 * n <= 32 * a.J)) {
+            a.wsteps = n;
+            for (int k = 0; k < 4; ++k)
+                for (int st = 0; st < kW4Stride; ++st) a.wjobs[k * kW4Stride + st] = st < n ? list[st * 4 + k] : 0u;
+            if (w4 != 1) pick = 4;
+        }
+    }
+    const bool w4_first = a.wsteps > 0 && a.J <= kFkWideMinJ;  // (beyond: the wave-per-frame walk first; tree_walk_w4 still serves what it declines)
 #ifdef PM_TUNING
     if constexpr (SRC == SRC_QUAT) {  // the three-lane tile, several tiles per workgroup with the next tile's records prefetched into registers
         const int pnt = tune_env("PM_FK_PIPE3", 0);
@@ -1620,6 +1734,7 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
     // (whole-line rows of 96 / 128 joints: the streamed walk first -- a humanoid with hands reads 59.6 / 62.8 % there against 55.8 / 61.3 %)
     const bool stream_first = a.J % 32 == 0 && a.J <= 128 && wd != 1;
     if constexpr (SRC == SRC_QUAT) {
+      if (!w4_first) {
         int rc = PM_OK;
         if (stream_ok && stream_first && try_fk_stream(a, s, rc)) return rc;
         if (wide_ok && wd != 0 && (wd == 1 || a.J > kFkWideMinJ) &&
@@ -1628,6 +1743,7 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
         // whatever the streamed walk declined beyond 128 joints: the wide walk if its step list holds the tree at all (the four-frame tiles that
         // are left read 9-34 % there)
         if (wide_ok && a.J > 128 && wd != 0 && try_fk_wide(a.src, a.root_pos, a.offsets, a.pos, a.rotmats, a.F, a.J, a.depth, a.parents, a.ablate, 0, s, rc)) return rc;
+      }
     }
     if (pick == 4 && a.J <= 128) {
         // mid-size skeletons: registers-first phase A and tiles pipelined inside a workgroup (fk_pipe_kernel; 4 records
@@ -1669,6 +1785,7 @@ static int fk_common(int src_kind, const float *src, const float *root_pos, cons
     FkArgs a;
     a.src = src; a.root_pos = root_pos; a.offsets = offsets; a.pos = pos; a.rotmats = rotmats;
     a.quat_out = quat_out; a.F = F; a.J = J; a.eps = eps; a.pad = 0;  // set by dispatch_fk, per walk shape
+    a.wsteps = 0;
     a.ablate = tune_env("PM_FK_ABLATE", 0);
     if (int e = pack_parents(parents, J, a.parents)) return e;
     {

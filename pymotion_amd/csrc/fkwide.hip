@@ -36,8 +36,10 @@ struct FkWideArgs {
 };
 
 // Host: list scheduling, at most 16 joints a step, a joint at the earliest one step after its parent; ready joints with the longest
-// path below them first (a binary heap on (height, lower index first): J log J per call).  Returns the number of steps (-1: more than kFwSteps).
-int fk_wide_plan(const Parents &par, const int J, uint32_t *jobs) {
+// path below them first (a binary heap on (height, lower index first): J log J per call).  Returns the number of steps (-1: more than max_steps).
+// `width` joints a step, at most `max_steps` steps; `jobs`: [steps + 2][width] words joint | parent << 16.  A slot without a joint holds the idle
+// word J + 1 | J << 16 (fk_wide_kernel's spare slots) or, with `dup_idle`, the step's first joint again (tree_walk_w4 of fk.hip: same reads, same writes).
+int fk_wide_plan(const Parents &par, const int J, const int width, const int max_steps, const bool dup_idle, uint32_t *jobs) {
     int height[PM_MAX_JOINTS], heap[PM_MAX_JOINTS], nheap = 0, fresh[PM_MAX_JOINTS], nfresh = 0;
     int first_child[PM_MAX_JOINTS], sibling[PM_MAX_JOINTS];
     for (int j = 0; j < J; ++j) { height[j] = 0; first_child[j] = -1; sibling[j] = -1; }
@@ -73,22 +75,22 @@ int fk_wide_plan(const Parents &par, const int J, uint32_t *jobs) {
     int steps = 0, done = 1;
     const uint32_t idle = (uint32_t)(J + 1) | ((uint32_t)J << 16);
     while (done < J) {
-        if (steps == kFwSteps) return -1;
+        if (steps == max_steps) return -1;
         nfresh = 0;
-        for (int k = 0; k < 16; ++k) {
+        for (int k = 0; k < width; ++k) {
             if (nheap > 0) {
                 const int j = pop();
-                jobs[steps * 16 + k] = (uint32_t)j | ((uint32_t)par.p[j] << 16);
+                jobs[steps * width + k] = (uint32_t)j | ((uint32_t)par.p[j] << 16);
                 for (int c = first_child[j]; c >= 0; c = sibling[c]) fresh[nfresh++] = c;  // ready from the next step on
                 ++done;
             } else {
-                jobs[steps * 16 + k] = idle;
+                jobs[steps * width + k] = dup_idle ? jobs[steps * width] : idle;
             }
         }
         for (int i = 0; i < nfresh; ++i) push(fresh[i]);
         ++steps;
     }
-    for (int k = 0; k < 32; ++k) jobs[steps * 16 + k] = idle;  // (two steps of padding: what pm_fk_wide_plan_debug's callers may read past the list)
+    for (int k = 0; k < 2 * width; ++k) jobs[steps * width + k] = dup_idle ? 0u : idle;  // (two steps of padding: what a look-ahead may read past the list)
     return steps;
 }
 
@@ -329,7 +331,7 @@ bool try_fk_wide(const float *rot, const float *root_pos, const float *offsets, 
                  const int32_t depth, const Parents &par, const int ablate, const int max_quad_steps_per_joint_x10, hipStream_t s, int &rc) {
     FkWideArgs a;
     uint32_t list[(kFwSteps + 2) * 16];
-    a.nsteps = fk_wide_plan(par, J, list);
+    a.nsteps = fk_wide_plan(par, J, 16, kFwSteps, false, list);
     if (a.nsteps < 0) return false;
     // quad-steps the list spends per joint (1: every quad of every step has a joint; a deep, narrow tree idles most of them)
     if (max_quad_steps_per_joint_x10 > 0 && a.nsteps * 16 * 10 > max_quad_steps_per_joint_x10 * J) return false;
@@ -359,6 +361,6 @@ extern "C" int pm_fk_wide_plan_debug(const int32_t *parents, int32_t J, uint32_t
     PM_CHECK_ARGS(parents && jobs && J >= 1 && J <= PM_MAX_JOINTS, "fk_wide_plan: need parents, jobs and 1 <= J <= PM_MAX_JOINTS");
     pm::Parents par;
     if (int e = pm::pack_parents(parents, J, par)) return e < 0 ? e : -e;
-    const int n = pm::fk_wide_plan(par, J, jobs);
+    const int n = pm::fk_wide_plan(par, J, 16, pm::kFwSteps, false, jobs);
     return n < 0 ? PM_EUNSUPPORTED : n;
 }

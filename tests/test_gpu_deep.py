@@ -176,12 +176,13 @@ def test_to_root_dual_quat_lane_per_frame_through_the_torch_door_and_an_unaligne
 
 # ---- fk on long skeletons: the streamed three-lane walk (fk.hip: fk_stream_kernel) ----------------------------------------------
 
-# which kernel: "stream" (fk_stream_kernel), "wide" (fk_wide_kernel, fkwide.hip: from 93 joints on, trees whose step list keeps the quads
+# which kernel: "stream" (fk_stream_kernel), "wide" (fk_wide_kernel, fkwide.hip: from 101 joints on, trees whose step list keeps the quads
 # busy go there first -- a humanoid with hands reads 58-71 % that way against 46-63 % streamed; whole-line rows of 96 / 128 joints keep the
 # streamed walk), "tile"
 FK_STREAM_CASES = [
-    (64, "chain_like", "stream"), (64, "humanoid", "stream"), (80, "chain_like", "tile"),         # multiples of 32 from 64 on
-    (96, "chain_like", "stream"), (96, "humanoid", "stream"), (100, "humanoid", "wide"), (128, "chain_like", "stream"), (128, "humanoid", "stream"),
+    (64, "chain_like", "stream"), (64, "humanoid", "tile"), (80, "chain_like", "tile"),         # multiples of 32 from 64 on; up to 100 joints a tree that is
+    (96, "chain_like", "stream"), (96, "humanoid", "tile"), (100, "humanoid", "tile"),           # wide enough takes the four-frame tiles with four joints a step (tree_walk_w4)
+    (104, "humanoid", "wide"), (128, "chain_like", "stream"), (128, "humanoid", "stream"),
     (129, "chain_like", "stream"), (130, "humanoid", "wide"),
     (131, "chain_like", "stream"), (160, "humanoid", "wide"), (250, "humanoid", "wide"), (300, "chain_like", "stream"), (512, "chain_like", "stream"),
     (97, "chain_like", "tile"), (127, "humanoid", "wide"), (92, "chain_like", "tile"),   # below 129 the streamed walk takes only multiples of four from 96 on

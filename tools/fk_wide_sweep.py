@@ -28,7 +28,8 @@ def humanoid(J):
 def chain_like(J):
     p = np.maximum(np.arange(J) - 1, 0).astype(np.int32); p[J // 2] = 0; p[3 * J // 4] = J // 4
     return p
-for J in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "64,96,128,129,130,160,192,200,256,300,384,400,511,512").split(",")]:
+if __name__ == "__main__":
+  for J in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "64,96,128,129,130,160,192,200,256,300,384,400,511,512").split(",")]:
     for kind in kinds:
         par = chain_like(J) if kind == "chain" else humanoid(J) if kind == "humanoid" else syn.random_parents(J, np.random.default_rng(J)).astype(np.int32)
         depth = int(syn.depth_of(par).max())
