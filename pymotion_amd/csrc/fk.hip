@@ -336,15 +336,25 @@ __device__ __forceinline__ void tree_walk_w4(float *sRot, float *sPos, const flo
     float *fL = sRot + f * (J * 9 + pad) + r * 3, *fP = sPos + f * (J * 3 + pad) + r;
     const float *fT = PFO ? sOff + f * (J * 3 + pad) + r : sConst + 1 + r;  // t_j[r]: the per-frame offsets tile, or the joint table {parent, t0, t1, t2}
     constexpr unsigned TS = PFO ? 3u : 4u;
-    auto dot_bcast = [](const float l, const float p0, const float p1, const float p2) __attribute__((always_inline)) {
-        float acc;
-        asm("s_nop 1\n\t"  // (the rows travel from step to step through register copies: a VGPR written by the VALU needs two wait states before a DPP read)
-            "v_mul_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %0, %1, %3 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %0, %1, %4 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf"
-            : "=&v"(acc)
-            : "v"(l), "v"(p0), "v"(p1), "v"(p2));
-        return acc;
+    // the four products of a step -- three rows of L and t against the parent's row -- as ONE block: the rows travel from step to step through
+    // register copies, a VGPR written by the VALU needs two wait states before a DPP read, and nothing can be scheduled into the block
+    auto dot4 = [](const float l0, const float l1, const float l2, const float tr, const float p0, const float p1, const float p2, float &g0, float &g1,
+                   float &g2, float &dt) __attribute__((always_inline)) {
+        asm volatile("s_nop 1\n\t"
+                     "v_mul_f32_dpp %0, %4, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_mul_f32_dpp %1, %5, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_mul_f32_dpp %2, %6, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_mul_f32_dpp %3, %7, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %0, %4, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %1, %5, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %2, %6, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %3, %7, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %0, %4, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %1, %5, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %2, %6, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %3, %7, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf"
+                     : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(dt)
+                     : "v"(l0), "v"(l1), "v"(l2), "v"(tr), "v"(p0), "v"(p1), "v"(p2));
     };
     auto word = [](const uint32_t v, auto t) __attribute__((always_inline)) {
         constexpr int T = decltype(t)::value;
@@ -359,8 +369,8 @@ __device__ __forceinline__ void tree_walk_w4(float *sRot, float *sPos, const flo
         const float p0 = ap[0], p1 = ap[1], p2 = ap[2], pt = fP[__umul24(par, 3u)];
         float *an = fL + __umul24(jn, 9u), *pn = fP + __umul24(jn, 3u);  // the next step's [L | t] row: its slot is written by that step only
         const float n0 = an[0], n1 = an[1], n2 = an[2], nt = fT[__umul24(jn, TS)];
-        float g0 = dot_bcast(l0, p0, p1, p2), g1 = dot_bcast(l1, p0, p1, p2), g2 = dot_bcast(l2, p0, p1, p2);
-        const float dt = dot_bcast(tr, p0, p1, p2);
+        float g0, g1, g2, dt;
+        dot4(l0, l1, l2, tr, p0, p1, p2, g0, g1, g2, dt);
         float gt;
         if (FX) gt = __int_as_float(__float_as_int(pt) + (int)__builtin_rintf(dt * S));
         else {
@@ -373,16 +383,21 @@ __device__ __forceinline__ void tree_walk_w4(float *sRot, float *sPos, const flo
         l0 = n0; l1 = n1; l2 = n2; tr = nt;
         w = wn;
     };
+    // (a finished joint's slot holds R, not L: exactly nsteps steps, no idle ones.  The group counter goes through readfirstlane: left to
+    // itself the compiler kept it in a vector register and wrapped every indexed read of JW in a waterfall loop)
+    const int ng = (nsteps + 3) >> 2;
 #pragma nounroll
-    for (int g = 0; g * 4 < nsteps; ++g) {  // (a finished joint's slot holds R, not L: exactly nsteps steps, no idle ones)
-        const uint32_t cur = JW[g], nxt = JW[g + 1];
+    for (int g = 0; g < ng; ++g) {
+        const int gu = __builtin_amdgcn_readfirstlane(g), left = nsteps - 4 * gu;
+        const uint32_t cur = JW[gu], nxt = JW[gu + 1];
         step(word(cur, IntC<1>{}));
-        if (g * 4 + 1 >= nsteps) break;
-        step(word(cur, IntC<2>{}));
-        if (g * 4 + 2 >= nsteps) break;
-        step(word(cur, IntC<3>{}));
-        if (g * 4 + 3 >= nsteps) break;
-        step(word(nxt, IntC<0>{}));
+        if (left > 1) {
+            step(word(cur, IntC<2>{}));
+            if (left > 2) {
+                step(word(cur, IntC<3>{}));
+                if (left > 3) step(word(nxt, IntC<0>{}));
+            }
+        }
     }
 }
 

@@ -124,16 +124,26 @@ __device__ __forceinline__ void fw_row_out(float *__restrict__ g, const float *l
 template <bool FX, int NG>
 __device__ __forceinline__ void fw_walk(float *sRot, float *sPos, const uint32_t (&JW)[NG + 1], const int nsteps, const int lane, const float S, const bool poison) {
     const int r = (lane & 3) < 3 ? (lane & 3) : 2;  // lane 3 of a quad shadows lane 2 (same reads, same writes): it holds a quarter of the quad's words
-    // out = p0 * bcast_0(l) + p1 * bcast_1(l) + p2 * bcast_2(l), l = this lane's element of its row of [L | t] (lane i of the quad: row i)
-    auto dot_bcast = [](const float l, const float p0, const float p1, const float p2) __attribute__((always_inline)) {
-        float acc;
-        asm("s_nop 1\n\t"  // (the rows travel from step to step through register copies: a VGPR written by the VALU needs two wait states before a DPP read)
-            "v_mul_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %0, %1, %3 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %0, %1, %4 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf"
-            : "=&v"(acc)
-            : "v"(l), "v"(p0), "v"(p1), "v"(p2));
-        return acc;
+    // out = p0 * bcast_0(l) + p1 * bcast_1(l) + p2 * bcast_2(l), l = this lane's element of its row of [L | t] (lane i of the quad: row i);
+    // the four products of a step -- three rows of L and t against the parent's row -- as ONE block: the rows travel from step to step through
+    // register copies, a VGPR written by the VALU needs two wait states before a DPP read, and nothing can be scheduled into the block
+    auto dot4 = [](const float l0, const float l1, const float l2, const float tr, const float p0, const float p1, const float p2, float &g0, float &g1,
+                   float &g2, float &dt) __attribute__((always_inline)) {
+        asm volatile("s_nop 1\n\t"
+                     "v_mul_f32_dpp %0, %4, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_mul_f32_dpp %1, %5, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_mul_f32_dpp %2, %6, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_mul_f32_dpp %3, %7, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %0, %4, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %1, %5, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %2, %6, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %3, %7, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %0, %4, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %1, %5, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %2, %6, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %3, %7, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf"
+                     : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(dt)
+                     : "v"(l0), "v"(l1), "v"(l2), "v"(tr), "v"(p0), "v"(p1), "v"(p2));
     };
     // word of step 4 g + T: lane T of the quad holds it in JW[g]
     auto word = [](const uint32_t v, auto t) __attribute__((always_inline)) {
@@ -151,9 +161,9 @@ __device__ __forceinline__ void fw_walk(float *sRot, float *sPos, const uint32_t
         // the next step's [L | t] row: its slot is written by that step only
         float *an = sRot + __umul24(wn & 0xffffu, 9u) + r * 3, *pn = sPos + __umul24(wn & 0xffffu, 3u) + r;
         const float n0 = an[0], n1 = an[1], n2 = an[2], nt = *pn;
-        const float dt = dot_bcast(tr, p0, p1, p2);
+        float g0, g1, g2, dt;
+        dot4(l0, l1, l2, tr, p0, p1, p2, g0, g1, g2, dt);
         float gt;
-        float g0 = dot_bcast(l0, p0, p1, p2), g1 = dot_bcast(l1, p0, p1, p2), g2 = dot_bcast(l2, p0, p1, p2);
         if (FX) gt = __int_as_float(__float_as_int(pt) + (int)__builtin_rintf(dt * S));
         else {
             gt = dt + pt;
