@@ -260,6 +260,18 @@ int pm_stream_plain_f32(const float *src, float *dst, int64_t n4, int32_t ratio,
  * [11] bytes of unused LDS per workgroup (bounds the resident workgroups per CU like a kernel's LDS tile).  Bench / tuning only. */
 int pm_store_probe_f32(const float *src, float *dst, int64_t n4, const int32_t *cfg, pm_stream_t stream);
 
+/* The one-pass scans of quat.unroll / dual_quat.unroll / the BVH ingest WITHOUT the reset launch in front of them (reference: rotations/quat.py:426-462,
+ * dual_quat.py:139-167, io/bvh.py:352-359; a clip of real length is 7-19 us on the device of which that launch is ~3).  The caller owns a PAIR of
+ * workspaces per stream -- each at least pm_quat_unroll_batched_workspace_bytes(B, T, S) bytes, 8-byte aligned, both zero-filled once (pm_memset) --
+ * and alternates them: `ws_zeroed` is the clean one, `ws_other` the one the call before left dirty.  This launch zeroes the first `ws_other_words`
+ * 8-byte words of `ws_other` on the way and reports in *ws_words_dirtied how many words of `ws_zeroed` it leaves non-zero -- the count to pass as
+ * ws_other_words of the NEXT call, with the roles swapped.  kind: 0 quat.unroll, 1 dual_quat.unroll (in / out [B, T, S, 4 | 8], clips scanned
+ * independently), 2 the BVH ingest (B = 1, in = Euler degrees [T, S, 3], `order` as for pm_bvh_rotations_f32; otherwise null).  S <= 64
+ * (PM_EUNSUPPORTED beyond: pm_quat_unroll_f32's three-pass scan has no reset to save).  A workspace that is not zero on entry makes the scan
+ * wait for words nobody writes: the pair is the caller's to keep private to one stream. */
+int pm_unroll_onepass_f32(int32_t kind, const float *in, const uint8_t *order, int64_t B, int64_t T, int32_t S, float *out, void *ws_zeroed,
+                          int64_t *ws_words_dirtied, void *ws_other, int64_t ws_other_words, pm_stream_t stream);
+
 /* Host only (no GPU work): the step list fk's wide walk would run for this topology (fkwide.hip: a wave per frame, up to 16 joints a
  * step, a joint at the earliest one step after its parent) -- `jobs` receives (steps + 2) * 16 words, joint | parent << 16 (the root takes no step;
  * idle quads: J + 1 | J << 16), room for 50 * 16.  Returns the number of steps, PM_EUNSUPPORTED when the tree needs more

@@ -487,6 +487,50 @@ def _arena_for(dev):
     return a
 
 
+# ---- the one-pass scans' workspace pair (pm_unroll_onepass_f32): two zeroed device blocks per thread, device and stream, alternated call by
+# call -- the scan then needs no reset launch in front of it (~3 us of the 7-19 us a clip of real length takes).  A pair is private to the
+# thread that made it and to one stream: launches of one thread on one stream run in the order they were made, which is all the alternation needs.
+_UNROLL_WS_BYTES = 1 << 20   # covers clips of 2^21 frames x 22 series; bigger calls keep the plain entry points (their reset launch is noise there)
+_unroll_pairs = threading.local()
+
+
+class _UnrollPair:
+    def __init__(self, ptr0, ptr1, keep):
+        self.ptr = (ptr0, ptr1)
+        self.dirty = [0, 0]   # 8-byte words each block holds non-zero
+        self.cur = 0          # the clean one
+        self.keep = keep
+
+    def take(self):
+        o = 1 - self.cur
+        return C.c_void_p(self.ptr[self.cur]), C.c_void_p(self.ptr[o]), self.dirty[o]
+
+    def done(self, words):
+        self.dirty[1 - self.cur] = 0
+        self.dirty[self.cur] = int(words)
+        self.cur = 1 - self.cur
+
+
+def _unroll_pair(key, nbytes, make):
+    if nbytes > _UNROLL_WS_BYTES or os.environ.get("PM_NO_UNROLL_PAIR") == "1" or os.environ.get("PM_UNROLL_ONEPASS") == "0":
+        return None  # (PM_UNROLL_ONEPASS=0: the tuning build's three-pass scan for few series -- it has no reset to save)
+    table = getattr(_unroll_pairs, "table", None)
+    if table is None:
+        table = _unroll_pairs.table = {}
+    p = table.get(key)
+    if p is None:
+        if len(table) >= 16:
+            table.clear()  # (streams come and go: start over rather than grow)
+        p = table[key] = make()
+    return p
+
+
+def _unroll_pair_drop(key):
+    table = getattr(_unroll_pairs, "table", None)
+    if table is not None:
+        table.pop(key, None)
+
+
 class NumpyBackend:
     name = "numpy"
 
@@ -616,6 +660,21 @@ class NumpyBackend:
         finally:
             _stage.put(st)
         return out
+
+    def unroll_pair(self, nbytes):
+        """(pair, key) for pm_unroll_onepass_f32 on this backend's stream, or (None, None)"""
+        key = ("numpy", self._dev)
+
+        def make():
+            ptrs = []
+            for _ in range(2):
+                d = C.c_void_p()
+                _lib.call("pm_malloc", C.byref(d), _UNROLL_WS_BYTES)
+                _lib.call("pm_memset", d, 0, _UNROLL_WS_BYTES, None)
+                ptrs.append(d.value)
+            return _UnrollPair(ptrs[0], ptrs[1], None)  # (kept for the life of the thread, like the arena)
+
+        return _unroll_pair(key, nbytes, make), key
 
     def scratch(self, nbytes):
         buf = _DevBuf(max(int(nbytes), 4), self._dev)
@@ -760,6 +819,18 @@ class TorchBackend:
         if self.home.type != "cuda":
             t = t.to(self.home)
         return t
+
+    def unroll_pair(self, nbytes):
+        """(pair, key) for pm_unroll_onepass_f32 on the current stream of the tensors' device, or (None, None)"""
+        if self.torch.cuda.is_current_stream_capturing():  # (a captured launch is replayed with the SAME blocks: the alternation is the caller's sequence of calls)
+            return None, None
+        key = ("torch", self.dev.index, self.stream().value or 0)
+
+        def make():
+            t = self.torch.zeros((2, _UNROLL_WS_BYTES), dtype=self.torch.uint8, device=self.dev)  # (zeroed on the current stream: in order with the launches)
+            return _UnrollPair(t[0].data_ptr(), t[1].data_ptr(), t)
+
+        return _unroll_pair(key, nbytes, make), key
 
     def scratch(self, nbytes):
         t = self.torch.empty(max(int(nbytes), 4), dtype=self.torch.uint8, device=self.dev)

@@ -253,8 +253,7 @@ def _unroll(be, x, axis, width, fname):
             xp = be.dev_in(x)
             op, oh = be.dev_out(shp)
             if B > 0 and T > 0 and S > 0:
-                ws = be.scratch(_lib.lib().pm_quat_unroll_batched_workspace_bytes(B, T, S))
-                _lib.call(fname.replace("_f32", "_batched_f32"), xp, B, T, S, op, ws, be.stream())
+                _unroll_scan(be, 0 if width == 4 else 1, xp, None, B, T, S, op, fname.replace("_f32", "_batched_f32"))
             res = be.result(oh, dt)
         finally:
             be.end()
@@ -272,6 +271,30 @@ def _unroll(be, x, axis, width, fname):
     finally:
         be.end()
     return be.moveaxis(res, 0, ax)
+
+
+def _unroll_scan(be, kind, xp, order, B, T, S, op, plain):
+    """one one-pass scan (kind 0 quat.unroll, 1 dual_quat.unroll, 2 the BVH ingest; S <= 64) through the backend's workspace pair -- no reset
+    launch in front of it (pm_unroll_onepass_f32) -- or, for calls too big for the pair, through the plain entry point `plain`"""
+    from . import _backend
+
+    nbytes = _lib.lib().pm_quat_unroll_batched_workspace_bytes(B, T, S)
+    pair, key = be.unroll_pair(nbytes)
+    if pair is None:
+        ws = be.scratch(nbytes)
+        if kind == 2:
+            _lib.call(plain, xp, order, T, S, op, ws, be.stream())
+        else:
+            _lib.call(plain, xp, B, T, S, op, ws, be.stream())
+        return
+    use, other, other_words = pair.take()
+    dirtied = C.c_int64(0)
+    try:
+        _lib.call("pm_unroll_onepass_f32", kind, xp, order, B, T, S, op, use, C.byref(dirtied), other, other_words, be.stream())
+    except Exception:
+        _backend._unroll_pair_drop(key)  # (whatever state the blocks are in: the next call makes a fresh pair)
+        raise
+    pair.done(dirtied.value)
 
 
 def bvh_rotations(be, euler_deg, order_table):
@@ -305,8 +328,7 @@ def bvh_rotations(be, euler_deg, order_table):
         xp = be.dev_in(euler_deg)
         op, oh = be.dev_out((T, J, 4))
         if T > 0 and J > 0:
-            ws = be.scratch(_lib.lib().pm_quat_unroll_workspace_bytes(T, J))
-            _lib.call("pm_bvh_rotations_f32", xp, table.ctypes.data_as(C.c_void_p), T, J, op, ws, be.stream())
+            _unroll_scan(be, 2, xp, table.ctypes.data_as(C.c_void_p), 1, T, J, op, "pm_bvh_rotations_f32")
         res = be.result(oh, dt)
     finally:
         be.end()

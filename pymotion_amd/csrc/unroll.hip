@@ -286,6 +286,8 @@ struct OnePassArgs {
     int32_t ngroups;   // ceil(S / 31)
     int32_t static_order;  // PM_TUNING build only: tiles by blockIdx (what the ticket costs)
     int32_t single;        // every clip is ONE tile: nobody waits for anybody, tiles by blockIdx and no ticket
+    unsigned long long *zero_next;  // pm_unroll_onepass_f32: the OTHER workspace of the caller's pair, zeroed on the way (null: nothing)
+    int64_t n_zero_next, ntiles;    // its words in use; workgroups of this launch (each zeroes a slice)
     uint32_t order_pk[64]; // EULER source (pm_bvh_rotations_f32): per series the three axis codes of its Euler order, o0 | o1 << 8 | o2 << 16
 };
 
@@ -401,6 +403,10 @@ __global__ __launch_bounds__(NT, PM_OP_MINW) void unroll_onepass_kernel(const On
     if (tid == 0) s_tile = (a.single || PM_ABLATED_FLAG(a.static_order & 1)) ? blockIdx.x : __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int i = tid; i < 2 * S * words; i += NT) flip[i] = 0u;
     __syncthreads();
+    if (a.zero_next != nullptr) {  // (tickets / block indices 0 .. ntiles - 1, one each: the slices cover the words whatever order the workgroups start in)
+        const int64_t per = (a.n_zero_next + a.ntiles - 1) / a.ntiles, lo = (int64_t)s_tile * per, hi = (lo + per) < a.n_zero_next ? (lo + per) : a.n_zero_next;
+        for (int64_t i = lo + tid; i < hi; i += NT) a.zero_next[i] = 0ull;
+    }
     // tickets run over (clip, tile of the clip): a tile only ever waits for earlier tiles of its own clip, i.e. lower tickets
     const int64_t clip = (int64_t)s_tile / a.tpc;
     if (clip >= a.nclips) return;  // (uniform)
@@ -542,13 +548,13 @@ __global__ __launch_bounds__(NT, PM_OP_MINW) void unroll_onepass_kernel(const On
         unsigned long long *me = st0 + tile * a.ngroups;
         for (int g = 0; g < a.ngroups; ++g) {
             const unsigned long long p = (agg_par >> (OP_GROUP * g)) & 0x7fffffffull, r = (agg_rst >> (OP_GROUP * g)) & 0x7fffffffull;
-            if (lane == 0) __hip_atomic_store(me + g, (1ull << 62) | (r << 31) | p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0 && !a.single) __hip_atomic_store(me + g, (1ull << 62) | (r << 31) | p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (a clip of one tile: nobody reads its words, and a caller's workspace pair stays clean)
         }
         unsigned long long enter = 0ull;
         for (int g = 0; g < a.ngroups; ++g) {
             const unsigned long long p = (agg_par >> (OP_GROUP * g)) & 0x7fffffffull, r = (agg_rst >> (OP_GROUP * g)) & 0x7fffffffull;
             const unsigned long long e = PM_ABLATED_FLAG(a.static_order & 4) ? 0ull : unroll_look_back(st0, st1, a.ngroups, g, tile, (unsigned)p, (unsigned)r, lane);
-            if (lane == 0) {
+            if (lane == 0 && !a.single) {
                 const unsigned long long leaving = (2ull << 62) | ((e & ~r) ^ p);
                 __hip_atomic_store(me + g, leaving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((tile & 63) == 63) __hip_atomic_store(st1 + (tile >> 6) * a.ngroups + g, leaving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the block's word becomes absolute
@@ -596,10 +602,15 @@ extern "C" int64_t pm_quat_unroll_batched_workspace_bytes(int64_t B, int64_t T, 
 }
 extern "C" int64_t pm_quat_unroll_workspace_bytes(int64_t T, int32_t S) { return pm_quat_unroll_batched_workspace_bytes(1, T, S); }
 
+// `pair` (pm_unroll_onepass_f32): `workspace` is all zero on entry -- no reset launch in front of the scan --, *pair->dirtied receives the 8-byte
+// words this call leaves non-zero in it, and the first pair->other_words words of pair->other are zeroed on the way (a slice per workgroup).
+struct UnrollPair { int64_t *dirtied; void *other; int64_t other_words; };
 template <int W, bool EULER = false>
-static int unroll_launch(const float *q, int64_t B, int64_t T, int32_t S, float *out, void *workspace, pm_stream_t stream, const uint8_t *order = nullptr) {
+static int unroll_launch(const float *q, int64_t B, int64_t T, int32_t S, float *out, void *workspace, pm_stream_t stream, const uint8_t *order = nullptr,
+                         const UnrollPair *pair = nullptr) {
     PM_CHECK_ARGS(B >= 0 && T >= 0 && S >= 0, "quat_unroll: negative size");
-    if (B == 0 || T == 0 || S == 0) return PM_OK;
+    if (pair) *pair->dirtied = 0;
+    if (B == 0 || T == 0 || S == 0) return PM_OK;  // (the other workspace keeps its words: the caller's count stands)
     PM_CHECK_ARGS(q && out && workspace, "quat_unroll: null pointer");
     PM_CHECK_ARGS((EULER || aligned16(q)) && aligned16(out), "quat_unroll: q and out must be 16-byte aligned");
     PM_CHECK_ARGS((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, "quat_unroll: the workspace must be 8-byte aligned");
@@ -660,7 +671,11 @@ static int unroll_launch(const float *q, int64_t B, int64_t T, int32_t S, float 
         if (tpc > 64 && lds < 52 * 1024 && tune_env("PM_UNROLL_RESERVE", 1)) lds = 52 * 1024;
         lds += (size_t)tune_env("PM_UNROLL_LDS_PAD", 0);  // PM_TUNING build only: more unused LDS
         const int64_t nwords = 8 + (ntiles + B * bpc) * a.ngroups;  // the ticket's 64-byte line, then the words
-        if (!a.single)  // (single-tile clips read neither the ticket nor a status word)
+        a.zero_next = nullptr; a.n_zero_next = 0; a.ntiles = ntiles;
+        if (pair) {
+            *pair->dirtied = a.single ? 0 : nwords;
+            if (pair->other && pair->other_words > 0) { a.zero_next = static_cast<unsigned long long *>(pair->other); a.n_zero_next = pair->other_words; }
+        } else if (!a.single)  // (single-tile clips read neither the ticket nor a status word)
             hipLaunchKernelGGL(unroll_reset_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, s, static_cast<unsigned long long *>(workspace), nwords);
         PM_SET_LDS(lds);
         if (NTsel == 128) {
@@ -678,6 +693,7 @@ static int unroll_launch(const float *q, int64_t B, int64_t T, int32_t S, float 
         else hipLaunchKernelGGL((unroll_onepass_kernel<W, 4, NT, EULER>), dim3((unsigned)ntiles), dim3(NT), lds, s, a);
         return PM_AFTER_LAUNCH("quat_unroll");
     }
+    if (pair) { set_error("unroll_onepass: more than 64 series take the three-pass scan (pm_quat_unroll_f32 / pm_dq_unroll_f32)"); return PM_EUNSUPPORTED; }
     const int64_t nchunks = (T + UR_CHUNK - 1) / UR_CHUNK;
     // mask pass: series per block from the size of the grid it leaves (>= ~8 K waves if the problem has them)
     int p1_sb = UR_P1_SB;
@@ -720,4 +736,24 @@ extern "C" int pm_dq_unroll_batched_f32(const float *dq, int64_t B, int64_t T, i
 // io/bvh.py:352-359 get_data: quat.normalize(quat.unroll(quat.from_euler(np.radians(rotations), order), axis = 0)) as ONE launch.
 extern "C" int pm_bvh_rotations_f32(const float *euler_deg, const uint8_t *order, int64_t T, int32_t J, float *out, void *workspace, pm_stream_t stream) {
     return unroll_launch<4, true>(euler_deg, 1, T, J, out, workspace, stream, order);
+}
+
+// The one-pass scans without the reset launch in front of them (a clip of real length is 7-19 us of which that launch is ~3): the caller owns a
+// PAIR of workspaces per stream, both zeroed once (pm_memset), and alternates them -- `ws_zeroed` is the clean one, `ws_other` the one the call
+// before dirtied: this launch zeroes its first `ws_other_words` words on the way (every workgroup a slice) and reports in *ws_words_dirtied how
+// many 8-byte words of `ws_zeroed` it leaves non-zero.  kind: 0 quat.unroll, 1 dual_quat.unroll (batched: [B, T, S, 4 | 8]), 2 the BVH ingest
+// (B = 1, `order` as in pm_bvh_rotations_f32).  At most 64 series (PM_EUNSUPPORTED beyond: the three-pass scan has no reset to save).
+extern "C" int pm_unroll_onepass_f32(int32_t kind, const float *in, const uint8_t *order, int64_t B, int64_t T, int32_t S, float *out, void *ws_zeroed,
+                                     int64_t *ws_words_dirtied, void *ws_other, int64_t ws_other_words, pm_stream_t stream) {
+    PM_CHECK_ARGS(ws_words_dirtied && ws_other_words >= 0 && (ws_other || ws_other_words == 0), "unroll_onepass: bad workspace pair");
+    PM_CHECK_ARGS(ws_other == nullptr || (reinterpret_cast<uintptr_t>(ws_other) & 7) == 0, "unroll_onepass: the workspaces must be 8-byte aligned");
+    PM_CHECK_ARGS(ws_other == nullptr || ws_other != ws_zeroed, "unroll_onepass: the two workspaces must differ");
+    const UnrollPair pair = {ws_words_dirtied, ws_other, ws_other_words};
+    if (S > 64) { *ws_words_dirtied = 0; set_error("unroll_onepass: more than 64 series take the three-pass scan"); return PM_EUNSUPPORTED; }
+    switch (kind) {
+        case 0: return unroll_launch<4>(in, B, T, S, out, ws_zeroed, stream, nullptr, &pair);
+        case 1: return unroll_launch<8>(in, B, T, S, out, ws_zeroed, stream, nullptr, &pair);
+        case 2: PM_CHECK_ARGS(B == 1, "unroll_onepass: the BVH ingest takes one clip"); return unroll_launch<4, true>(in, 1, T, S, out, ws_zeroed, stream, order, &pair);
+        default: set_error("unroll_onepass: kind must be 0, 1 or 2"); return PM_EINVAL;
+    }
 }

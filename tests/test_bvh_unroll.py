@@ -169,6 +169,94 @@ def test_gpu_fused_bvh_rotations_raw_abi():
 
 
 @pytest.mark.gpu
+def test_gpu_one_pass_scans_without_the_reset_launch():
+    """pm_unroll_onepass_f32: the scans of quat.unroll / dual_quat.unroll / the BVH ingest on a PAIR of zeroed workspaces the caller
+    alternates -- no reset launch.  A sequence of calls of different kinds and shapes (one tile, many tiles, batches of clips, a call that
+    dirties nothing) gives the plain entry points' results bit for bit; after every call the block it used holds non-zero words only below
+    the count it reported and the other block is zero again; the argument checks"""
+    import ctypes as C
+
+    import torch
+
+    from pymotion_amd import _lib
+
+    h = _lib.lib()
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    cap = 1 << 20
+    pair = torch.zeros((2, cap // 8), dtype=torch.int64, device="cuda")
+    dirty = [0, 0]
+    cur = 0
+    rng = np.random.default_rng(3)
+
+    def walk(n, w):
+        base = np.cumsum(rng.normal(0, 0.3, n + (w,)), axis=-3) + rng.normal(0, 1, n[:-2] + (1, n[-1], w))
+        return (base * rng.choice([-1.0, 1.0], n + (1,))).astype(np.float32)
+
+    calls = [(0, 1, 3000, 22), (1, 1, 50_000, 22), (0, 64, 300, 22), (2, 1, 1000, 22), (0, 1, 40, 5), (0, 1, 200_000, 22), (1, 7, 9000, 31), (2, 1, 70_000, 64),
+             (0, 1, 3000, 22)]
+    for kind, B, T, S in calls:
+        w = 8 if kind == 1 else 4
+        order = None
+        if kind == 2:
+            x = torch.from_numpy(rng.uniform(-180, 180, (T, S, 3)).astype(np.float32)).cuda()
+            order_np = np.ascontiguousarray(rng.integers(0, 3, (S, 3)).astype(np.uint8))
+            order_np[:, 1] = (order_np[:, 0] + 1) % 3
+            order_np[:, 2] = (order_np[:, 0] + 2) % 3
+            order = order_np.ctypes.data_as(C.c_void_p)
+        else:
+            x = torch.from_numpy(walk((B, T, S), w)).cuda()
+        out = torch.empty((B, T, S, w if kind != 2 else 4), device="cuda")
+        ref = torch.empty_like(out)
+        ws = torch.empty(int(h.pm_quat_unroll_batched_workspace_bytes(B, T, S)), dtype=torch.uint8, device="cuda")
+        if kind == 2:
+            assert h.pm_bvh_rotations_f32(p(x), order, T, S, p(ref), p(ws), None) == _lib.PM_OK
+        else:
+            assert getattr(h, "pm_quat_unroll_batched_f32" if kind == 0 else "pm_dq_unroll_batched_f32")(p(x), B, T, S, p(ref), p(ws), None) == _lib.PM_OK
+        n = C.c_int64(-1)
+        rc = h.pm_unroll_onepass_f32(kind, p(x), order, B, T, S, p(out), p(pair[cur]), C.byref(n), p(pair[1 - cur]), dirty[1 - cur], None)
+        assert rc == _lib.PM_OK, h.pm_last_error_string()
+        torch.cuda.synchronize()
+        assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), (kind, B, T, S)
+        assert 0 <= n.value <= cap // 8
+        assert not bool(pair[1 - cur].any()), "the other workspace was not zeroed"
+        assert not bool(pair[cur][n.value:].any()), ("non-zero words beyond the reported count", kind, B, T, S, n.value, pair[cur].nonzero().flatten()[-4:].tolist())
+        dirty[1 - cur], dirty[cur] = 0, n.value
+        cur = 1 - cur
+    assert any(d > 0 for d in dirty)
+    x = torch.zeros((1, 10, 65, 4), device="cuda")
+    n = C.c_int64(-1)
+    assert h.pm_unroll_onepass_f32(0, p(x), None, 1, 10, 65, p(x), p(pair[0]), C.byref(n), p(pair[1]), 0, None) == _lib.PM_EUNSUPPORTED
+    assert h.pm_unroll_onepass_f32(0, p(x), None, 1, 10, 22, p(x), p(pair[0]), C.byref(n), p(pair[0]), 4, None) == _lib.PM_EINVAL
+    assert h.pm_unroll_onepass_f32(3, p(x), None, 1, 10, 22, p(x), p(pair[0]), C.byref(n), p(pair[1]), 0, None) == _lib.PM_EINVAL
+    assert h.pm_unroll_onepass_f32(0, p(x), None, 1, 10, 22, p(x), p(pair[0]), None, p(pair[1]), 0, None) == _lib.PM_EINVAL
+
+
+@pytest.mark.gpu
+def test_gpu_unroll_doors_alternate_their_workspace_pair():
+    """both doors keep a pair per thread, device and stream: repeated calls of changing shapes agree with the oracle (a pair out of step would
+    make the scan wait for words nobody writes -- the suite runs under a timeout), and a second stream gets a pair of its own"""
+    import torch
+
+    import pymotion_amd.rotations.quat as quat
+    import pymotion_amd.rotations.quat_torch as quat_t
+
+    rng = np.random.default_rng(9)
+    side = torch.cuda.Stream()
+    for T, S in ((5000, 22), (90_000, 22), (300, 4), (70_000, 40), (5000, 22), (100_000, 3)):
+        base = np.cumsum(rng.normal(0, 0.3, (T, S, 4)), axis=0) + rng.normal(0, 1, (1, S, 4))
+        q = (base * rng.choice([-1.0, 1.0], (T, S, 1))).astype(np.float32)
+        want = co.quat_unroll(q.astype(np.float64), 0).astype(np.float32)
+        np.testing.assert_array_equal(quat.unroll(q, 0).astype(np.float32), want)
+        qt = torch.from_numpy(q).cuda()
+        np.testing.assert_array_equal(quat_t.unroll(qt, 0).cpu().numpy(), want)
+        with torch.cuda.stream(side):
+            side.wait_stream(torch.cuda.current_stream())
+            got = quat_t.unroll(qt, 0)
+        side.synchronize()
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.gpu
 def test_config1_bvh_1000_frames_gpu_vs_numpy_cpu_reference(tmp_path):
     """BASELINE.json configs[0]: NumPy fk on a 22-joint BVH, 1000 frames (CPU) -- the same arrays through the
     GPU path must agree to 1e-5.  The file is generated on the fly (seeded), read by the build's own loader."""

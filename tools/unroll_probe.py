@@ -21,7 +21,19 @@ for lg in (10, 12, 14, 16, 18, 20):
     out = torch.empty_like(q)
     ws = torch.empty(int(_lib.lib().pm_quat_unroll_workspace_bytes(T, S)) + 16, dtype=torch.uint8, device="cuda")
     ms, _ = pp.timeit(lambda: _lib.call("pm_quat_unroll_f32", P(q), T, S, P(out), P(ws), None))
-    print(f"[{tag}] T=2^{lg} S={S}: {ms * 1e3:8.1f} us  {T * S * 32 / ms / 1e6 / 80:5.1f}% of 8 TB/s on 32 B/quaternion", flush=True)
+    # the same scan on a caller-owned pair of zeroed workspaces, alternated call by call: no reset launch (pm_unroll_onepass_f32)
+    pair = torch.zeros((2, 1 << 17), dtype=torch.int64, device="cuda")
+    st = {"cur": 0, "dirty": [0, 0]}
+
+    def no_reset(kind=0, x=q, o=out, order=None):
+        c = st["cur"]
+        n = C.c_int64(0)
+        _lib.call("pm_unroll_onepass_f32", kind, P(x), order, 1, T, S, P(o), P(pair[c]), C.byref(n), P(pair[1 - c]), st["dirty"][1 - c], None)
+        st["dirty"][1 - c], st["dirty"][c], st["cur"] = 0, n.value, 1 - c
+
+    ms_p = pp.timeit(no_reset)[0] if (T * S * 2 + 1023) // 1024 * 10 < (1 << 17) else float("nan")
+    print(f"[{tag}] T=2^{lg} S={S}: {ms * 1e3:8.1f} us  {T * S * 32 / ms / 1e6 / 80:5.1f}% of 8 TB/s on 32 B/quaternion;  without the reset launch "
+          f"(workspace pair) {ms_p * 1e3:8.1f} us  {T * S * 32 / ms_p / 1e6 / 80:5.1f}%", flush=True)
 # batches of clips [B, T, S, 4] along T: one launch, nothing transposed (raw ABI), and the torch door end to end
 import pymotion_amd.rotations.quat_torch as quat_t
 
@@ -52,6 +64,16 @@ for lg in (10, 12, 14, 16, 18, 20):
         _lib.call("pm_quat_normalize_f32", P(q2), T * S, C.c_float(1e-8), P(out), None)
 
     fused = lambda: _lib.call("pm_bvh_rotations_f32", P(deg), order_h.ctypes.data_as(C.c_void_p), T, S, P(out), P(ws), None)  # noqa: E731
+    pair = torch.zeros((2, 1 << 17), dtype=torch.int64, device="cuda")
+    st = {"cur": 0, "dirty": [0, 0]}
+
+    def fused_pair():
+        c = st["cur"]
+        n = C.c_int64(0)
+        _lib.call("pm_unroll_onepass_f32", 2, P(deg), order_h.ctypes.data_as(C.c_void_p), 1, T, S, P(out), P(pair[c]), C.byref(n), P(pair[1 - c]), st["dirty"][1 - c], None)
+        st["dirty"][1 - c], st["dirty"][c], st["cur"] = 0, n.value, 1 - c
+
+    ms1p, _ = pp.timeit(fused_pair)
     ms1, _ = pp.timeit(fused)
     ms3, _ = pp.timeit(three)
     ms1b, _ = pp.timeit(fused)  # (again, after the three launches: the order must not matter)
@@ -65,4 +87,5 @@ for lg in (10, 12, 14, 16, 18, 20):
         ms1, ms1b = sorted((ms1, ms1b, ms1c))[:2]
     ms1, ms1b = min(ms1, ms1b), max(ms1, ms1b)
     print(f"[{tag}] get_data fused T=2^{lg} S={S}: {ms1 * 1e3:8.1f} us ({T * S * 28 / ms1 / 1e6 / 80:5.1f}% of 8 TB/s on 28 B per joint-frame)"
-          f"  three launches {ms3 * 1e3:8.1f} us  -> {ms3 / ms1:4.2f}x   (fused before / after: {ms1 * 1e3:.1f} / {ms1b * 1e3:.1f}){note}", flush=True)
+          f"  three launches {ms3 * 1e3:8.1f} us  -> {ms3 / ms1:4.2f}x   (fused before / after: {ms1 * 1e3:.1f} / {ms1b * 1e3:.1f}){note};"
+          f"  without the reset launch {ms1p * 1e3:8.1f} us -> {ms3 / ms1p:4.2f}x", flush=True)
