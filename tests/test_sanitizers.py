@@ -94,6 +94,18 @@ for T, S in ((1000, 22), (5, 64), (70000, 65), (3, 100000)):  # one-pass and thr
         assert h.pm_quat_unroll_batched_workspace_bytes(B, T, S) >= h.pm_quat_unroll_workspace_bytes(T, S)
         assert h.pm_quat_unroll_batched_f32(p, B, T, S, p, p, None) == _lib.PM_EHIP
         assert h.pm_dq_unroll_batched_f32(p, B, T, S, p, p, None) == _lib.PM_EHIP
+n = C.c_int64(-1)
+for kind, B, T, S in ((0, 1, 1000, 22), (1, 3, 70000, 5), (2, 1, 5000, 64), (0, 64, 30, 22)):  # the scans on a workspace pair: host side
+    order = np.zeros((64, 3), np.uint8)
+    assert h.pm_unroll_onepass_f32(kind, p, order.ctypes.data_as(C.c_void_p), B, T, S, p, p, C.byref(n), C.c_void_p(p.value + 4096), 100, None) == _lib.PM_EHIP
+    assert n.value >= 0
+assert h.pm_unroll_onepass_f32(0, p, None, 1, 10, 65, p, p, C.byref(n), C.c_void_p(p.value + 4096), 0, None) == _lib.PM_EUNSUPPORTED
+jobs = (C.c_uint32 * (50 * 16))()
+for J in (1, 2, 17, 52, 129, 512):  # the wide walk's step list (width 16; fk's dispatch above ran width 4 too)
+    for par in trees(J):
+        st = h.pm_fk_wide_plan_debug(par.ctypes.data_as(C.c_void_p), J, jobs)
+        assert st >= 0 or st == _lib.PM_EUNSUPPORTED
+        calls += 1
 print("host paths exercised:", calls)
 """
 
