@@ -27,6 +27,7 @@
 // frame: 16 J + 12 read, 48 J written -- nothing is read or written twice, and the LDS
 // footprint is just the output tile (48 J B per frame: 16.5 KiB for 16 frames of J = 22 -> 9 waves per CU).
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.hpp"
 
@@ -1701,6 +1702,7 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
     // chains lose 3-6 points and never qualify.  From 101 joints on fk_wide_kernel is the better shape (112: 62.9 / 58.7, 128: 73.5 / 62.6).
     // PM_FK_W4 (PM_TUNING build only): 0 never, 1 whenever the list holds the tree (and the four-frame kernel is what runs).
     a.wsteps = 0;
+    memset(a.wjobs, 0, sizeof(a.wjobs));  // (the kernarg copy takes the whole struct: no uninitialised words in it)
     if (const int w4 = tune_env("PM_FK_W4", -1); w4 != 0 && a.J <= 128 && (w4 == 1 || a.J >= (SRC == SRC_QUAT ? 24 : 30))) {
         uint32_t list[(kW4Steps + 2) * 4];
         const int n = fk_wide_plan(a.parents, a.J, 4, kW4Steps, true, list);

@@ -32,7 +32,7 @@ struct FkWideArgs {
     float *pos, *rotmats;
     int64_t F;
     int32_t J, depth, nsteps, ablate;
-    uint32_t jobs[16 * kFwStride];  // [quad][step]: joint | parent << 16 -- a quad reads four steps with one dwordx4, eight steps ahead
+    uint32_t jobs[16 * kFwStride];  // [quad][step]: joint | parent << 16 -- lane t of a quad keeps the word of step 4 g + t in register g
 };
 
 // Host: list scheduling, at most 16 joints a step, a joint at the earliest one step after its parent; ready joints with the longest
