@@ -1703,7 +1703,7 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
     // PM_FK_W4 (PM_TUNING build only): 0 never, 1 whenever the list holds the tree (and the four-frame kernel is what runs).
     a.wsteps = 0;
     memset(a.wjobs, 0, sizeof(a.wjobs));  // (the kernarg copy takes the whole struct: no uninitialised words in it)
-    if (const int w4 = tune_env("PM_FK_W4", -1); w4 != 0 && a.J <= 128 && (w4 == 1 || a.J >= (SRC == SRC_QUAT ? 24 : 30))) {
+    if (const int w4 = tune_env("PM_FK_W4", -1); w4 != 0 && a.J <= 128 && (w4 == 1 || a.J >= (pfo ? 8 : (SRC == SRC_QUAT ? 24 : 30)))) {  // (per-frame offsets take the four-frame kernel at any joint count: the 22-joint body 61.2 -> 64.4 %)
         uint32_t list[(kW4Steps + 2) * 4];
         const int n = fk_wide_plan(a.parents, a.J, 4, kW4Steps, true, list);
         if (n > 0 && (w4 == 1 || 100 * n <= 32 * a.J)) {
