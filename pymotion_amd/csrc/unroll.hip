@@ -610,7 +610,13 @@ static int unroll_launch(const float *q, int64_t B, int64_t T, int32_t S, float 
                          const UnrollPair *pair = nullptr) {
     PM_CHECK_ARGS(B >= 0 && T >= 0 && S >= 0, "quat_unroll: negative size");
     if (pair) *pair->dirtied = 0;
-    if (B == 0 || T == 0 || S == 0) return PM_OK;  // (the other workspace keeps its words: the caller's count stands)
+    if (B == 0 || T == 0 || S == 0) {
+        // nothing to scan -- but a successful pm_unroll_onepass_f32 promises the other workspace clean: the caller swaps the two on PM_OK
+        if (pair && pair->other && pair->other_words > 0)
+            hipLaunchKernelGGL(unroll_reset_kernel, dim3((unsigned)((pair->other_words + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                               static_cast<unsigned long long *>(pair->other), pair->other_words);
+        return pair ? PM_AFTER_LAUNCH("unroll_onepass") : PM_OK;
+    }
     PM_CHECK_ARGS(q && out && workspace, "quat_unroll: null pointer");
     PM_CHECK_ARGS((EULER || aligned16(q)) && aligned16(out), "quat_unroll: q and out must be 16-byte aligned");
     PM_CHECK_ARGS((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, "quat_unroll: the workspace must be 8-byte aligned");

@@ -223,6 +223,12 @@ def test_gpu_one_pass_scans_without_the_reset_launch():
         dirty[1 - cur], dirty[cur] = 0, n.value
         cur = 1 - cur
     assert any(d > 0 for d in dirty)
+    # an empty scan still leaves the other workspace clean (the caller swaps the two on PM_OK)
+    x0 = torch.zeros((1, 0, 22, 4), device="cuda")
+    n = C.c_int64(-1)
+    assert h.pm_unroll_onepass_f32(0, p(x0), None, 1, 0, 22, p(x0), p(pair[cur]), C.byref(n), p(pair[1 - cur]), dirty[1 - cur], None) == _lib.PM_OK
+    torch.cuda.synchronize()
+    assert n.value == 0 and not bool(pair[1 - cur].any())
     x = torch.zeros((1, 10, 65, 4), device="cuda")
     n = C.c_int64(-1)
     assert h.pm_unroll_onepass_f32(0, p(x), None, 1, 10, 65, p(x), p(pair[0]), C.byref(n), p(pair[1]), 0, None) == _lib.PM_EUNSUPPORTED
