@@ -692,6 +692,7 @@ int schedule_chains(const Parents &par, const int J, const int C, uint8_t *sched
     return K;
 }
 
+constexpr int kSchedEightMinJ = 104, kSchedSixteenMinJ = 192;  // to_root_dual_quat: eight / sixteen chains per frame from these joint counts on (see to_root_dq_impl)
 template <int C>
 static int launch_to_root_sched(const SchedArgs &a, bool vec, hipStream_t s) {
     constexpr int FPW = 16 / C;
@@ -699,7 +700,9 @@ static int launch_to_root_sched(const SchedArgs &a, bool vec, hipStream_t s) {
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
     // tiles per workgroup: the joint table and the program cost ~7 % of a tile's instructions; big batches share them
     // (measured at 2^18 frames, 1 / 2 / 4 / 8 tiles: J = 52 149 / 139 / 143 / 150 us, J = 128 507 / 441 / 409 / 401 us)
-    int nt = ntiles >= 16384 ? (C == 4 ? 4 : 2) : 1;
+    // (eight / sixteen chains -- two / one frame a tile -- want many more: the table and the program are rebuilt per workgroup; J = 128 with eight
+    // chains 481 us at two tiles, 382 at eight; J = 200 with sixteen 1058 / 718 / 681 us at 2 / 16 / 64)
+    int nt = ntiles >= 16384 ? (C == 4 ? 4 : (C == 8 ? 8 : (C == 16 ? 32 : 2))) : 1;
     nt = tune_env("PM_DQ_NT", nt);  // PM_TUNING build only
     if (nt < 1) nt = 1;
     const int64_t ngroups = (ntiles + nt - 1) / nt;
@@ -875,16 +878,24 @@ static int to_root_dq_impl(const float *rot, const float *root_pos, const int32_
     // (cost of the walk per frame ~ steps x chains / 16; a pure chain stays on the one-chain kernel).  Measured at 2^20 / 2^18
     // frames, one chain (16 frames per wave) against the scheduled walk: J = 16: 142 / 158 us, 20: 195 / 191, 22: 217 / 211,
     // 24: 238 / 225, 26: 73 / 69, 32: 94 / 87, 36: 115 / 96; four chains only pay from ~36 joints (J = 28: 71 us with two, 76-79 with four).
-    int chains = tune_env("PM_DQ_CHAINS", -1);  // PM_TUNING build only: 0 = the one-chain kernel, 2 / 4
-    if ((chains < 0 ? (pick != 16 || J >= tune_env("PM_DQ_SCHED_MINJ", 20)) : (chains == 2 || chains == 4)) && J <= kSchedMaxJoints) {
+    int chains = tune_env("PM_DQ_CHAINS", -1);  // PM_TUNING build only: 0 = the one-chain kernel, 2 / 4 / 8 / 16
+    if ((chains < 0 ? (pick != 16 || J >= tune_env("PM_DQ_SCHED_MINJ", 20)) : (chains == 2 || chains == 4 || chains == 8 || chains == 16)) && J <= kSchedMaxJoints) {
         SchedArgs sa;
-        int K2 = 0, K4 = 0;
-        uint8_t s2[kSchedMax], s4[kSchedMax];
-        if (chains != 4) K2 = schedule_chains(a.parents, J, 2, s2, true);
-        if (chains != 2) K4 = schedule_chains(a.parents, J, 4, s4, true);
+        int K2 = 0, K4 = 0, K8 = 0, K16 = 0;
+        uint8_t s2[kSchedMax], s4[kSchedMax], s8[kSchedMax], s16[kSchedMax];
+        if (chains < 0 || chains == 2) K2 = schedule_chains(a.parents, J, 2, s2, true);
+        if (chains < 0 || chains == 4) K4 = schedule_chains(a.parents, J, 4, s4, true);
+        // (round 5) EIGHT / SIXTEEN chains -- two / one frame a wave -- for long WIDE trees, with many tiles per workgroup (launch_to_root_sched):
+        // random trees, 2^18 frames, % of the HBM spec, four / eight / sixteen chains: J = 112 50.4 / 52.6 / 40.0, 128 46.8 / 51.0 / 44.9, 160 38.9 /
+        // 44.6 / 42.8, 200 31.8 / 42.4 / 44.4, 250 26.0 / 33.5 / 39.4 (centimetre data 31.3 / 35.8 / 28.7 at 128, 17.1 / 21.6 / 25.9 at 250;
+        // profiles/r05_to_root_dq_chains16.txt); only when the wider schedule is not much emptier (a deep tree's is: K does not shrink)
+        if ((chains < 0 && J >= kSchedEightMinJ) || chains == 8) K8 = schedule_chains(a.parents, J, 8, s8, true);
+        if ((chains < 0 && J >= kSchedSixteenMinJ) || chains == 16) K16 = schedule_chains(a.parents, J, 16, s16, true);
         int use = 0;
         if (chains == 2) use = K2 ? 2 : 0;
         else if (chains == 4) use = K4 ? 4 : 0;
+        else if (chains == 8) use = K8 ? 8 : 0;
+        else if (chains == 16) use = K16 ? 16 : 0;
         else {  // walk cost per frame in sixteenths of a step: J x 2 today (8 frames per wave)
             const int c1 = 2 * J, c2 = K2 ? 2 * K2 : 1 << 30, c4 = K4 ? 4 * K4 : 1 << 30;
             // near-ties go to four chains: the tile is half the size, twice as many waves are resident (measured, 2^18 frames:
@@ -893,14 +904,17 @@ static int to_root_dq_impl(const float *rot, const float *root_pos, const int32_
             // 128-joint tree, two / four chains: 727 / 650 us)
             if (K4 && J >= 36 && ((20 * c4 <= 23 * c2 && 4 * c4 <= 3 * c1) || (J > 100 && c4 <= 2 * c2))) use = 4;
             else if (K2 && 4 * c2 <= 3 * c1) use = 2;
+            if (use == 4 && K8 && 4 * (8 * K8) <= 5 * (4 * K4)) use = 8;
+            if (use == 8 && K16 && 10 * (16 * K16) <= 14 * (8 * K8)) use = 16;
         }
         if (use) {
             sa.rot = rot; sa.root_pos = root_pos; sa.offsets = offsets; sa.dq = dq; sa.F = F; sa.J = J;
-            sa.K = use == 2 ? K2 : K4;
+            sa.K = use == 2 ? K2 : (use == 4 ? K4 : (use == 8 ? K8 : K16));
             sa.depth = a.depth;
-            memcpy(sa.sched, use == 2 ? s2 : s4, (size_t)sa.K * use);
+            memcpy(sa.sched, use == 2 ? s2 : (use == 4 ? s4 : (use == 8 ? s8 : s16)), (size_t)sa.K * use);
             for (int j = 0; j < J; ++j) sa.parent[j] = (int16_t)a.parents.p[j];
-            if (sched_lds_bytes(J, sa.K, use) <= kMaxLds) return use == 2 ? launch_to_root_sched<2>(sa, vec, s) : launch_to_root_sched<4>(sa, vec, s);
+            if (sched_lds_bytes(J, sa.K, use) <= kMaxLds)
+                return use == 2 ? launch_to_root_sched<2>(sa, vec, s) : (use == 4 ? launch_to_root_sched<4>(sa, vec, s) : (use == 8 ? launch_to_root_sched<8>(sa, vec, s) : launch_to_root_sched<16>(sa, vec, s)));
         }
     }
     if (const int v = tune_env("PM_DQ_FPW", 0); v == 16 || v == 8 || v == 4) pick = v;  // PM_TUNING build only
