@@ -353,6 +353,79 @@ def test_fuzz_from_root_positions_reproduces_the_pose(sk_):
 @settings(max_examples=200 * _SCALE, deadline=None, derandomize=_DERAND)
 @given(skeletons(), st.sampled_from([0.05, 0.9, 1.0, 7.0, 30.0, 4.0e3, 2.5e6]), st.sampled_from([0.0, 3.0, 16.0, 900.0, 1.0e7]), st.booleans())
 def test_fuzz_fk_at_every_magnitude(sk_, bone_scale, root_scale, per_frame_offsets):
+    _check_fk_at_a_magnitude(sk_, bone_scale, root_scale, per_frame_offsets)
+
+
+@st.composite
+def wide_skeletons(draw):
+    """24 ... 512 joints, trees wider than deep in several ways (what round 5's joint-parallel fk walks and the eight / sixteen-chain
+    to_root_dual_quat take) next to ones that must be declined (windowed parents: deep; chains)"""
+    J = draw(st.one_of(st.integers(24, 128), st.integers(129, 512), st.sampled_from([52, 92, 93, 100, 101, 104, 128, 129, 192, 250, 251, 511, 512])))
+    kind = draw(st.sampled_from(["random", "random", "bfs", "star", "broom", "fingers", "window8", "chain2"]))
+    seed = draw(st.integers(0, 2**16))
+    rng = np.random.default_rng(seed)
+    if kind == "random":
+        par = np.array([0] + [rng.integers(0, i) for i in range(1, J)])
+    elif kind == "bfs":
+        k = int(rng.integers(2, 6))
+        par = np.maximum((np.arange(J) - 1) // k, 0)
+    elif kind == "star":
+        par = np.zeros(J, dtype=np.int64)
+    elif kind == "broom":
+        h = int(rng.integers(2, 30))
+        par = np.maximum(np.arange(J) - 1, 0)
+        par[h:] = h - 1
+    elif kind == "fingers":  # a short trunk with chains of three hanging off random trunk joints
+        t = int(rng.integers(3, 20))
+        par = list(np.maximum(np.arange(t) - 1, 0))
+        while len(par) < J:
+            a = int(rng.integers(0, t))
+            for i in range(3):
+                if len(par) < J:
+                    par.append(a if i == 0 else len(par) - 1)
+        par = np.array(par)
+    elif kind == "window8":
+        par = np.array([0] + [rng.integers(max(0, i - 8), i) for i in range(1, J)])
+    else:
+        par = np.maximum(np.arange(J) - 1, 0)
+        par[J // 2] = 0
+    lead = draw(st.sampled_from([(1,), (3,), (4,), (5,), (17,), (2, 5), (61,), (130,)]))
+    return J, par.astype(np.int32), lead, rng
+
+
+@settings(max_examples=120 * _SCALE, deadline=None, derandomize=_DERAND)
+@given(wide_skeletons(), st.sampled_from([0.05, 0.9, 1.0, 30.0, 4.0e3]), st.sampled_from([0.0, 3.0, 16.0, 900.0]), st.booleans())
+def test_fuzz_fk_joint_parallel_walks_at_every_magnitude(sk_, bone_scale, root_scale, per_frame_offsets):
+    """the same statement on the skeletons of round 5's walks (four joints of a frame at a time in the pipelined kernel, a wave per frame with its
+    lanes over the joints): whichever kernel the table takes"""
+    _check_fk_at_a_magnitude(sk_, bone_scale, root_scale, per_frame_offsets)
+
+
+@FUZZ
+@given(wide_skeletons(), st.sampled_from([0.3, 30.0]))
+def test_fuzz_dual_quat_on_wide_skeletons(sk_, scale):
+    """to_root_dual_quat / from_root_dual_quat on the same skeletons (two ... sixteen chains per frame, the lane-per-frame kernels at test sizes
+    decline most of them): the oracle's value within max(1e-5, 3 ulp of the largest component), and the round trip"""
+    J, par, lead, rng = sk_
+    rot = rng.standard_normal(lead + (J, 4))
+    rot = (rot / np.linalg.norm(rot, axis=-1, keepdims=True)).astype(np.float32)
+    gpos = (rng.uniform(-7, 7, lead + (3,)) * scale).astype(np.float32)
+    off = (rng.uniform(-1, 1, (J, 3)) * scale).astype(np.float32)
+    off[0] = 0
+    d = sk.to_root_dual_quat(rot, gpos, par, off)
+    F = int(np.prod(lead))
+    d_o = co.to_root_dual_quat(f64(rot).reshape(F, J, 4), f64(gpos).reshape(F, 3), par, f64(off))
+    ulp = 2.0 ** (np.floor(np.log2(np.abs(d_o).max())) - 23)
+    dd = np.zeros(J, int)
+    for j in range(1, J):
+        dd[j] = dd[par[j]] + 1
+    # (chains: a randomised run of this test read 3.6 ulp on a 65-deep chain of 30-unit bones -- the tile kernels' precise step; INTEGRATION.md)
+    assert np.abs(d.reshape(F, J, 8) - d_o).max() <= max(1e-5, 3 * ulp) * max(1.0, dd.max() / 48.0)
+    t, q = sk.from_root_dual_quat(d, par)
+    assert np.abs(q - rot).max() <= 4e-6 * max(1.0, dd.max() / 32.0)
+
+
+def _check_fk_at_a_magnitude(sk_, bone_scale, root_scale, per_frame_offsets):
     """the per-tile arithmetic of fk (fp32 walk / float64 rotations + fixed-point chain) over bone and root
     magnitudes from millimetres to thousands of kilometres, both sides of the decision thresholds, every walk shape:
     rotations <= 2e-6 whatever the positions do; positions within max(1e-5, 3 ulp of the largest coordinate) of what those
