@@ -661,6 +661,58 @@ __device__ __forceinline__ void local_from_quat(const float (&qi)[4], float (&L)
 
 
 
+// ---- fk's local rotation from an ortho6d record (fk.hip, fkwide.hip) -----------------------------------------------------------------
+// ortho6d record -> local rotation (and, with QOUT, the quaternion the reference would have produced):
+// rotations/ortho6d.py:50-64 (6D -> matrix -> quaternion, itself normalised), then fk's own normalise and to_matrix.
+template <bool TRANSPOSED>
+__device__ __forceinline__ void put_local(float *slot, const float (&L)[9]);
+
+template <bool QOUT, int M>
+__device__ __forceinline__ bool local_from_o6d(const float (&xx)[6], const float eps, float (&L)[9], float (&Q)[4]) {
+    // The trip matrix -> quaternion -> normalise -> matrix is the identity on an orthonormal matrix up to fp32 rounding (~2e-7, two
+    // orders inside the parity budget): the Gram-Schmidt result IS the local rotation, with or without the quaternion output
+    // (round 2 went through the quaternion when it was asked for: ~80 more VALU operations per joint and 40 more live registers,
+    // 57.9 % against 61.8 %).  The quaternion, when wanted, is from_matrix of it (ortho6d.py:50-64).  None of this holds for what
+    // Gram-Schmidt returns on degenerate columns (zeros, NaN, rounding noise): those records are re-done (o6d_redo_ill).
+    // M & PREC_F64 (big-magnitude tiles: centimetre mocap, far-away roots): Gram-Schmidt in float64 like the reference's chain, as
+    // local_from_quat does for the quaternion source -- the rotation error is multiplied by the bone lengths down the chain.
+    bool ill;
+    if constexpr ((M & PREC_F64) != 0) o6d2m_precise(xx, L, ill);
+    else o6d2m(xx, L, ill);
+    if constexpr (QOUT) m2q(L, Q);
+    return ill;
+}
+
+// Zero / non-finite / (anti-)parallel columns: the reference's answer is decided by its eps floors and NaN rules and, for
+// near-parallel columns, by digits fp32 does not have -- such a record's whole chain is re-done in float64, so that both
+// variants of the fused kernel equal ortho6d.to_quat -> fk on EVERY input.  Called AFTER the tile's local rotations have
+// been parked, on the record's LDS slot: the float64 chain is register-hungry, and inside the conversion loop it would set
+// the register budget of the whole kernel (166 VGPRs = three waves per SIMD) for a branch ~1e-4 of the records take.
+template <bool QOUT, bool TRANSPOSED>
+__device__ __forceinline__ void o6d_redo_ill(const bool ill, const float (&xx)[6], const float eps, float *slot, float *qslot) {
+    if (__builtin_amdgcn_ballot_w64(ill) == 0) return;  // wave-uniform
+    float Ld[9], Qd[4];
+    o6d_chain_f64(xx, eps, Ld, Qd);
+    if (ill) {
+        put_local<TRANSPOSED>(slot, Ld);
+        // qslot: the record's LDS slot (fk_tile) or its place in HBM (fk_pipe_kernel: the only store of that record, the plain
+        // conversion skips the records it flags)
+        if (QOUT) { qslot[0] = Qd[0]; qslot[1] = Qd[1]; qslot[2] = Qd[2]; qslot[3] = Qd[3]; }
+    }
+}
+
+// local rotation -> its slot of the image: as is for the three-lane walk, transposed for tree_walk_quad
+template <bool TRANSPOSED>
+__device__ __forceinline__ void put_local(float *slot, const float (&L)[9]) {
+    if (TRANSPOSED) {
+        const float T[9] = {L[0], L[3], L[6], L[1], L[4], L[7], L[2], L[5], L[8]};
+        lds_put<9>(slot, 0, T);
+    } else {
+        lds_put<9>(slot, 0, L);
+    }
+}
+
+
 // ---- host-side helpers -------------------------------------------------------------------------------
 
 // Tuning aids (frames per wave, tiles per workgroup, ablations) exist ONLY in the -DPM_TUNING build
@@ -757,8 +809,9 @@ struct DeepTopo {                    // by value in the kernarg segment: one s_l
                                      // DEEP_ROOT (none); save: the slot joint j's state is kept in for later children, or DEEP_NONE
 int deep_plan(const Parents &par, int J, bool root_is_identity, DeepTopo &t);
 // ---- fkwide.hip: fk with a wave per frame and its lanes over the joints (long, wide trees) -------------------------------------
-bool try_fk_wide(const float *rot, const float *root_pos, const float *offsets, float *pos, float *rotmats, int64_t F, int32_t J, int32_t depth,
-                 const Parents &par, int ablate, int max_quad_steps_per_joint_x10, hipStream_t s, int &rc);
+bool try_fk_wide(int src_kind, const float *rot, const float *root_pos, const float *offsets, bool offsets_per_frame, float *pos, float *rotmats,
+                 float *quat_out, float eps, int64_t F, int32_t J, int32_t depth, const Parents &par, int ablate, int max_quad_steps_per_joint_x10,
+                 hipStream_t s, int &rc);
 int fk_wide_plan(const Parents &par, int J, int width, int max_steps, bool dup_idle, uint32_t *jobs);
 int launch_to_root_deep(const float *rot, const float *root_pos, const float *offsets, float *dq, int64_t F, int32_t J,
                         const DeepTopo &topo, hipStream_t s);

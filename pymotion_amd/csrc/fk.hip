@@ -415,45 +415,6 @@ __device__ __forceinline__ v4f load_joint_const(const Parents &parents, const fl
     return c;
 }
 
-// ortho6d record -> local rotation (and, with QOUT, the quaternion the reference would have produced):
-// rotations/ortho6d.py:50-64 (6D -> matrix -> quaternion, itself normalised), then fk's own normalise and to_matrix.
-template <bool TRANSPOSED>
-__device__ __forceinline__ void put_local(float *slot, const float (&L)[9]);
-
-template <bool QOUT, int M>
-__device__ __forceinline__ bool local_from_o6d(const float (&xx)[6], const float eps, float (&L)[9], float (&Q)[4]) {
-    // The trip matrix -> quaternion -> normalise -> matrix is the identity on an orthonormal matrix up to fp32 rounding (~2e-7, two
-    // orders inside the parity budget): the Gram-Schmidt result IS the local rotation, with or without the quaternion output
-    // (round 2 went through the quaternion when it was asked for: ~80 more VALU operations per joint and 40 more live registers,
-    // 57.9 % against 61.8 %).  The quaternion, when wanted, is from_matrix of it (ortho6d.py:50-64).  None of this holds for what
-    // Gram-Schmidt returns on degenerate columns (zeros, NaN, rounding noise): those records are re-done (o6d_redo_ill).
-    // M & PREC_F64 (big-magnitude tiles: centimetre mocap, far-away roots): Gram-Schmidt in float64 like the reference's chain, as
-    // local_from_quat does for the quaternion source -- the rotation error is multiplied by the bone lengths down the chain.
-    bool ill;
-    if constexpr ((M & PREC_F64) != 0) o6d2m_precise(xx, L, ill);
-    else o6d2m(xx, L, ill);
-    if constexpr (QOUT) m2q(L, Q);
-    return ill;
-}
-
-// Zero / non-finite / (anti-)parallel columns: the reference's answer is decided by its eps floors and NaN rules and, for
-// near-parallel columns, by digits fp32 does not have -- such a record's whole chain is re-done in float64, so that both
-// variants of the fused kernel equal ortho6d.to_quat -> fk on EVERY input.  Called AFTER the tile's local rotations have
-// been parked, on the record's LDS slot: the float64 chain is register-hungry, and inside the conversion loop it would set
-// the register budget of the whole kernel (166 VGPRs = three waves per SIMD) for a branch ~1e-4 of the records take.
-template <bool QOUT, bool TRANSPOSED>
-__device__ __forceinline__ void o6d_redo_ill(const bool ill, const float (&xx)[6], const float eps, float *slot, float *qslot) {
-    if (__builtin_amdgcn_ballot_w64(ill) == 0) return;  // wave-uniform
-    float Ld[9], Qd[4];
-    o6d_chain_f64(xx, eps, Ld, Qd);
-    if (ill) {
-        put_local<TRANSPOSED>(slot, Ld);
-        // qslot: the record's LDS slot (fk_tile) or its place in HBM (fk_pipe_kernel: the only store of that record, the plain
-        // conversion skips the records it flags)
-        if (QOUT) { qslot[0] = Qd[0]; qslot[1] = Qd[1]; qslot[2] = Qd[2]; qslot[3] = Qd[3]; }
-    }
-}
-
 // ---- PREC_DYN: which arithmetic a tile gets (kBigOffset / kBigRoot, FxScale, fx_scale: common.hpp) ------------
 // fixed-point words of the position region -> fp32, in place (the region is then the output tile); n4 dwordx4
 __device__ __forceinline__ void fx_to_float(float *sPos, const int n4, const float invS, const int lane) {
@@ -461,17 +422,6 @@ __device__ __forceinline__ void fx_to_float(float *sPos, const int n4, const flo
     for (int i = lane; i < n4; i += PM_WAVE) {
         const v4i w = reinterpret_cast<const v4i *>(sPos)[i];
         reinterpret_cast<v4f *>(sPos)[i] = v4f{(float)w.x * invS, (float)w.y * invS, (float)w.z * invS, (float)w.w * invS};
-    }
-}
-
-// local rotation -> its slot of the image: as is for the three-lane walk, transposed for tree_walk_quad
-template <bool TRANSPOSED>
-__device__ __forceinline__ void put_local(float *slot, const float (&L)[9]) {
-    if (TRANSPOSED) {
-        const float T[9] = {L[0], L[3], L[6], L[1], L[4], L[7], L[2], L[5], L[8]};
-        lds_put<9>(slot, 0, T);
-    } else {
-        lds_put<9>(slot, 0, L);
     }
 }
 
@@ -1740,7 +1690,7 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
     // (profiles/r05_fk_wide_sweep.txt); deep, narrow trees go to the streamed walk below.  PM_FK_WIDE (PM_TUNING build only): 0 never, 1 from any
     // joint count and any list.
     const int wd = tune_env("PM_FK_WIDE", -1);
-    const bool wide_ok = SRC == SRC_QUAT && !pfo && vec && a.quat_out == nullptr;
+    const bool wide_plain = SRC == SRC_QUAT && !pfo && vec && a.quat_out == nullptr;
     // long skeletons: the streamed three-lane walk (fk_stream_kernel) where the topology's cross-chunk branch points fit its register
     // slots; PM_FK_STREAM (PM_TUNING build only): 0 never, 1 from any joint count
     const int st = tune_env("PM_FK_STREAM", -1);
@@ -1750,17 +1700,20 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
                            (st == 1 || (fk_stream_wanted(a.J) && lane_per_frame_pays(a.F, a.J, kFkStreamMinJointFrames)));
     // (whole-line rows of 96 / 128 joints: the streamed walk first -- a humanoid with hands reads 59.6 / 62.8 % there against 55.8 / 61.3 %)
     const bool stream_first = a.J % 32 == 0 && a.J <= 128 && wd != 1;
-    if constexpr (SRC == SRC_QUAT) {
-      if (!w4_first) {
+    auto wide = [&](const int bound, int &rc) {
+        return try_fk_wide(SRC == SRC_QUAT ? 0 : 1, a.src, a.root_pos, a.offsets, pfo, a.pos, a.rotmats, a.quat_out, a.eps, a.F, a.J, a.depth, a.parents,
+                           a.ablate, bound, s, rc);
+    };
+    if (!w4_first) {
         int rc = PM_OK;
-        if (stream_ok && stream_first && try_fk_stream(a, s, rc)) return rc;
-        if (wide_ok && wd != 0 && (wd == 1 || a.J > kFkWideMinJ) &&
-            try_fk_wide(a.src, a.root_pos, a.offsets, a.pos, a.rotmats, a.F, a.J, a.depth, a.parents, a.ablate, wd == 1 ? 0 : 25, s, rc)) return rc;
-        if (stream_ok && !stream_first && try_fk_stream(a, s, rc)) return rc;
-        // whatever the streamed walk declined beyond 128 joints: the wide walk if its step list holds the tree at all (the four-frame tiles that
-        // are left read 9-34 % there)
-        if (wide_ok && a.J > 128 && wd != 0 && try_fk_wide(a.src, a.root_pos, a.offsets, a.pos, a.rotmats, a.F, a.J, a.depth, a.parents, a.ablate, 0, s, rc)) return rc;
-      }
+        if constexpr (SRC == SRC_QUAT)
+            if (stream_ok && stream_first && try_fk_stream(a, s, rc)) return rc;
+        if (wide_plain && wd != 0 && (wd == 1 || a.J > kFkWideMinJ) && wide(wd == 1 ? 0 : 25, rc)) return rc;
+        if constexpr (SRC == SRC_QUAT)
+            if (stream_ok && !stream_first && try_fk_stream(a, s, rc)) return rc;
+        // whatever is left beyond 128 joints -- trees the streamed walk declined, the ortho6d source, per-frame offsets: the wide walk if its
+        // step list holds the tree at all (the four-frame tiles that are left read 9-34 % there)
+        if (vec && wd != 0 && (a.J > 128 || (wd == 1 && !wide_plain)) && wide(0, rc)) return rc;
     }
     if (pick == 4 && a.J <= 128) {
         // mid-size skeletons: registers-first phase A and tiles pipelined inside a workgroup (fk_pipe_kernel; 4 records
@@ -1788,6 +1741,17 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
         case 16: return dispatch_fk2<16, SRC>(a, vec, pfo, s);
         case 12: if constexpr (SRC == SRC_QUAT || kAllFkShapes) return dispatch_fk2<12, SRC>(a, vec, pfo, s); else break;
         case 4: if (4 * per_frame + fixed <= kMaxLds) return dispatch_fk2<4, SRC>(a, vec, pfo, s);
+    }
+    if constexpr (SRC == SRC_O6D) {
+        if (a.quat_out) {
+            // 511 / 512 joints with per-frame offsets AND the quaternion output on a tree the wide walk's step list does not hold: four frames
+            // of 19 floats a joint are 164 KB.  The reference's own two steps instead (rotations/ortho6d.py:50-64, then ops/skeleton.py:13-61):
+            // the quaternions go to the caller's array and fk reads them back
+            if (int e = pm_o6d_to_quat_f32(a.src, a.F * a.J, a.eps, a.quat_out, s)) return e;
+            FkArgs b = a_in;
+            b.src = a.quat_out; b.quat_out = nullptr;
+            return dispatch_fk<SRC_QUAT>(b, vec, pfo, s);
+        }
     }
     set_error("fk: J=%d does not fit the LDS tile", a.J);
     return PM_EUNSUPPORTED;

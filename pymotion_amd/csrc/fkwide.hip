@@ -28,10 +28,12 @@ namespace pm {
 constexpr int kFwSteps = 48;               // steps the list holds
 constexpr int kFwStride = kFwSteps + 8;    // words per quad in the kernarg segment: its steps, then idle words for the look-ahead (16 x 56 x 4 = 3584 B)
 struct FkWideArgs {
-    const float *rot, *root_pos, *offsets;
-    float *pos, *rotmats;
+    const float *rot, *root_pos, *offsets;  // rot: [F, J, 4] quaternions or [F, J, 3, 2] ortho6d records; offsets: [J, 3] or (PFO) [F, J, 3]
+    float *pos, *rotmats, *quat_out;        // quat_out: [F, J, 4] or null (ortho6d source only)
     int64_t F;
     int32_t J, depth, nsteps, ablate;
+    float eps;                              // ortho6d Gram-Schmidt floor
+    int32_t pad_;
     uint32_t jobs[16 * kFwStride];  // [quad][step]: joint | parent << 16 -- lane t of a quad keeps the word of step 4 g + t in register g
 };
 
@@ -186,10 +188,15 @@ __device__ __forceinline__ void fw_walk(float *sRot, float *sPos, const uint32_t
 }
 
 // NB: batches of 64 joints (J <= 64 NB); NG: groups of four steps (nsteps <= 4 NG).  A workgroup (one wave) takes `nt` consecutive frames.
-template <int PREC, int NB, int NG>
+// SRC 0 / 1: quaternions / ortho6d records (rotations/ortho6d.py:50-64 -> fk: the fused kernel of BASELINE config 4, here for long skeletons);
+// QOUT: the quaternions ortho6d.to_quat would have returned, stored straight from the conversion's registers; PFO: per-frame offsets.
+template <int PREC, int NB, int NG, int SRC, bool QOUT, bool PFO>
 __global__ __launch_bounds__(PM_WAVE) void fk_wide_kernel(const FkWideArgs a, const int nt) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool DYN = (PREC & PREC_DYN) != 0;
+    // the next frame's records are requested before a frame's walk only where they are one quaternion a joint: six floats (or three more of
+    // offsets) a joint in flight across the walk would double the kernel's registers
+    constexpr bool AHEAD = SRC == 0 && !PFO;
     const int lane = threadIdx.x, J = a.J;
     const int64_t ngroups = (a.F + nt - 1) / nt;
     const int64_t grp = PM_ABLATED(a, 4) ? ((int64_t)blockIdx.x < ngroups ? (int64_t)blockIdx.x : -1) : xcd_tile(ngroups);
@@ -198,55 +205,67 @@ __global__ __launch_bounds__(PM_WAVE) void fk_wide_kernel(const FkWideArgs a, co
     const int nf = (int)((a.F - f0) < nt ? (a.F - f0) : nt);
     const int nR = ((J + 2) * 9 + 3 + 3) & ~3;  // floats reserved for the rotation image (placed 0..3 floats into it)
 
-    // a frame's global loads: quaternions (one per lane and batch) and the root position
-    v4f q[NB];
+    // a frame's global loads: rotation records (one per lane and batch), the root position, (PFO) the frame's offsets
+    v4f q[SRC == 0 ? NB : 1];
+    v2f x[SRC == 1 ? NB : 1][3];
+    v3f_a4 po[PFO ? NB : 1];
     float gp = 0.0f;
     auto issue = [&](const int64_t f) __attribute__((always_inline)) {
-        const v4f *src = reinterpret_cast<const v4f *>(a.rot) + f * J;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const int j = b * PM_WAVE + lane;
-            if (b * PM_WAVE < J) q[b] = __builtin_nontemporal_load(src + (j < J ? j : J - 1));
+            const int j = b * PM_WAVE + lane, jc = j < J ? j : J - 1;
+            if (b * PM_WAVE < J) {
+                if constexpr (SRC == 0) q[b] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(a.rot) + f * J + jc);
+                else {
+                    const v2f *p = reinterpret_cast<const v2f *>(a.rot) + (f * J + jc) * 3;  // 24-byte records are 8-byte aligned
+                    x[b][0] = __builtin_nontemporal_load(p); x[b][1] = __builtin_nontemporal_load(p + 1); x[b][2] = __builtin_nontemporal_load(p + 2);
+                }
+                if constexpr (PFO) po[b] = __builtin_nontemporal_load(reinterpret_cast<const v3f_a4 *>(a.offsets + (f * J + jc) * 3));
+            }
         }
         gp = a.root_pos[f * 3 + (lane < 3 ? lane : 2)];
     };
     issue(f0);
-    // once per workgroup: the step list (this quad's words) and the offsets (one joint per lane and batch, like the quaternions; slots J
-    // and J + 1 -- what idle quads read and write -- get zeros), all requested before the first is used
+    // once per workgroup: the step list (this quad's words) and -- shared offsets -- the table (one joint per lane and batch, like the rotations;
+    // slots J and J + 1, what idle quads read and write, get zeros), all requested before the first is used
     uint32_t JW[NG + 1];  // lane (k, t): quad k's word of step 4 g + t
 #pragma unroll
     for (int g = 0; g <= NG; ++g) JW[g] = a.jobs[(lane >> 2) * kFwStride + 4 * g + (lane & 3)];
-    float o[NB + 1][3];
+    float o[PFO ? 1 : NB + 1][3];
+    if constexpr (!PFO) {
 #pragma unroll
-    for (int b = 0; b <= NB; ++b) {  // (loads only: a select behind each load would make the table nine round trips instead of one)
-        const int j = b * PM_WAVE + lane, jc = j < J ? j : J - 1;
-        if (b * PM_WAVE < J + 2) { o[b][0] = a.offsets[3 * jc]; o[b][1] = a.offsets[3 * jc + 1]; o[b][2] = a.offsets[3 * jc + 2]; }
+        for (int b = 0; b <= NB; ++b) {  // (loads only: a select behind each load would make the table nine round trips instead of one)
+            const int j = b * PM_WAVE + lane, jc = j < J ? j : J - 1;
+            if (b * PM_WAVE < J + 2) { o[b][0] = a.offsets[3 * jc]; o[b][1] = a.offsets[3 * jc + 1]; o[b][2] = a.offsets[3 * jc + 2]; }
+        }
     }
     // settle the list and the table here: left pending, the walk's first indexed read of JW would wait for EVERY vector-memory operation in
     // flight -- the next frame's quaternions among them
 #pragma unroll
     for (int g = 0; g <= NG; ++g) asm volatile("" : "+v"(JW[g]));
-#pragma unroll
-    for (int b = 0; b <= NB; ++b) {
-        const int j = b * PM_WAVE + lane;
-        const bool none = j == 0 || j >= J;  // offsets[0] is ignored (skeleton.py:49); idle slots: no translation
-        if (b * PM_WAVE < J + 2) { o[b][0] = none ? 0.0f : o[b][0]; o[b][1] = none ? 0.0f : o[b][1]; o[b][2] = none ? 0.0f : o[b][2]; }
-    }
     bool tbig = false;
     float tsum = 0.0f, tmx = 0.0f;
+    if constexpr (!PFO) {
 #pragma unroll
-    for (int b = 0; b <= NB; ++b) {
-        const int j = b * PM_WAVE + lane;
-        if (b * PM_WAVE < J && j < J) {
-            const v4f cj = v4f{0.0f, o[b][0], o[b][1], o[b][2]};
-            const float l1 = const_l1(cj);
-            tbig = tbig || const_is_big(cj); tsum += l1; tmx = (l1 > tmx || l1 != l1) ? l1 : tmx;
+        for (int b = 0; b <= NB; ++b) {
+            const int j = b * PM_WAVE + lane;
+            const bool none = j == 0 || j >= J;  // offsets[0] is ignored (skeleton.py:49); idle slots: no translation
+            if (b * PM_WAVE < J + 2) { o[b][0] = none ? 0.0f : o[b][0]; o[b][1] = none ? 0.0f : o[b][1]; o[b][2] = none ? 0.0f : o[b][2]; }
+        }
+#pragma unroll
+        for (int b = 0; b <= NB; ++b) {
+            const int j = b * PM_WAVE + lane;
+            if (b * PM_WAVE < J && j < J) {
+                const v4f cj = v4f{0.0f, o[b][0], o[b][1], o[b][2]};
+                const float l1 = const_l1(cj);
+                tbig = tbig || const_is_big(cj); tsum += l1; tmx = (l1 > tmx || l1 != l1) ? l1 : tmx;
+            }
         }
     }
     // what the joint table says about the arithmetic a frame needs (PREC_DYN, see fk_tile): the same for every frame of the workgroup
     const bool table_big = __builtin_amdgcn_ballot_w64(tbig) != 0;
     const float bsum = wave_sum(tsum), bmax = (float)a.depth * wave_max(tmx);  // (NaN sticks in both)
-    const float tbound = (bmax < bsum) ? bmax : bsum;
+    const float tbound_table = (bmax < bsum) ? bmax : bsum;
 
     for (int i = 0; i < nf; ++i) {
         const int64_t f = f0 + i;
@@ -259,7 +278,22 @@ __global__ __launch_bounds__(PM_WAVE) void fk_wide_kernel(const FkWideArgs a, co
         bool big = false, poison = false;
         FxScale fx = {1.0f, 1.0f};
         if constexpr (DYN || (PREC & PREC_FX)) {
-            const bool mine = lane < 3 && !(fabsf(gpf) < kBigRoot);
+            bool mine = lane < 3 && !(fabsf(gpf) < kBigRoot);
+            float tbound = tbound_table;
+            if constexpr (PFO) {  // the frame's own offsets: their largest magnitude (NaN sticks), bound 3 depth max |t| like fk_tile
+                float tmax = 0.0f;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const int j = b * PM_WAVE + lane;
+                    if (b * PM_WAVE < J && j > 0 && j < J) {
+                        const float m = fmaxf(fmaxf(fabsf(po[b].x), fabsf(po[b].y)), fabsf(po[b].z));
+                        const bool nan = po[b].x != po[b].x || po[b].y != po[b].y || po[b].z != po[b].z;
+                        tmax = (nan || tmax != tmax) ? __builtin_nanf("") : ((m > tmax) ? m : tmax);
+                    }
+                }
+                mine = mine || !(tmax < kBigOffset);
+                tbound = 3.0f * (float)a.depth * wave_max(tmax);
+            }
             big = table_big || __builtin_amdgcn_ballot_w64(mine) != 0 || !DYN;
             if (big) { big = fx_scale(tbound, lane < 3 ? fabsf(gpf) : 0.0f, fx); poison = !big; }
         }
@@ -271,27 +305,50 @@ __global__ __launch_bounds__(PM_WAVE) void fk_wide_kernel(const FkWideArgs a, co
 #pragma unroll
             for (int b = 0; b <= NB; ++b) {
                 const int j = b * PM_WAVE + lane;
-                if (b * PM_WAVE < J + 2 && j < J + 2) { sPos[3 * j] = o[b][0]; sPos[3 * j + 1] = o[b][1]; sPos[3 * j + 2] = o[b][2]; }
+                if (b * PM_WAVE < J + 2 && j < J + 2) {
+                    if constexpr (PFO) {
+                        const bool none = j == 0 || j >= J;
+                        const int bb = b < NB ? b : NB - 1;  // (batch NB only ever holds idle slots)
+                        sPos[3 * j] = none ? 0.0f : po[bb].x; sPos[3 * j + 1] = none ? 0.0f : po[bb].y; sPos[3 * j + 2] = none ? 0.0f : po[bb].z;
+                    } else {
+                        sPos[3 * j] = o[b][0]; sPos[3 * j + 1] = o[b][1]; sPos[3 * j + 2] = o[b][2];
+                    }
+                }
             }
             if (lane < 18) sRot[J * 9 + lane] = (lane == 0 || lane == 4 || lane == 8) ? 1.0f : 0.0f;  // idle quads: parent slot J (identity), own slot J + 1 (zeros)
             bool bad = false;  // FX only: a non-finite local rotation somewhere in the frame
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 if (b * PM_WAVE < J) {  // wave-uniform
-                    const int j = b * PM_WAVE + lane;
-                    const float qi[4] = {q[b].x, q[b].y, q[b].z, q[b].w};
+                    const int j = b * PM_WAVE + lane, jc = j < J ? j : J - 1;
                     float L[9];
-                    local_from_quat<M>(qi, L);
-                    if (FX) bad = bad || !(fabsf(qi[0]) + fabsf(qi[1]) + fabsf(qi[2]) + fabsf(qi[3]) < 3e38f);  // NaN / Inf input
-                    if (j < J && !PM_ABLATED(a, 8)) {  // (& 8, tuning build: without phase A's LDS writes)
-                        float *slot = sRot + j * 9;
+                    float *slot = sRot + jc * 9;
+                    if constexpr (SRC == 0) {
+                        const float qi[4] = {q[b].x, q[b].y, q[b].z, q[b].w};
+                        local_from_quat<M>(qi, L);
+                        if (FX) bad = bad || !(fabsf(qi[0]) + fabsf(qi[1]) + fabsf(qi[2]) + fabsf(qi[3]) < 3e38f);  // NaN / Inf input
+                        if (j < J && !PM_ABLATED(a, 8)) {  // (& 8, tuning build: without phase A's LDS writes)
 #pragma unroll
-                        for (int e = 0; e < 9; ++e) slot[e] = L[e];
+                            for (int e = 0; e < 9; ++e) slot[e] = L[e];
+                        }
+                    } else {
+                        const float xx[6] = {x[b][0].x, x[b][0].y, x[b][1].x, x[b][1].y, x[b][2].x, x[b][2].y};
+                        float Q[4];
+                        const bool ill = local_from_o6d<QOUT, M>(xx, a.eps, L, Q);
+                        if (FX) bad = bad || !(fabsf(xx[0]) + fabsf(xx[1]) + fabsf(xx[2]) + fabsf(xx[3]) + fabsf(xx[4]) + fabsf(xx[5]) < 3e38f);
+                        float *qslot = QOUT ? a.quat_out + (f * J + jc) * 4 : nullptr;
+                        if (j < J) {
+#pragma unroll
+                            for (int e = 0; e < 9; ++e) slot[e] = L[e];
+                            if constexpr (QOUT) { if (!ill) __builtin_nontemporal_store(v4f{Q[0], Q[1], Q[2], Q[3]}, reinterpret_cast<v4f *>(qslot)); }
+                        }
+                        // the rare float64 redo of a degenerate record, on its parked slot (in-order DS: after the plain values); its quaternion's only store
+                        o6d_redo_ill<QOUT, false>(ill && j < J, xx, a.eps, slot, qslot);
                     }
                 }
             }
             // the next frame's quaternions: in flight while this frame walks (the walk waits for LDS only)
-            if (i + 1 < nf && !PM_ABLATED(a, 32)) issue(f + 1);
+            if (AHEAD && i + 1 < nf && !PM_ABLATED(a, 32)) issue(f + 1);
             const bool fixed = FX && __builtin_amdgcn_ballot_w64(bad) == 0;  // NaN / Inf rotations: the float walk propagates them
             if (lane < 3) sPos[lane] = (FX && fixed) ? __int_as_float((int)__builtin_rintf(gpf * fx.S)) : gpf;  // the root's position (its slot held offsets[0], which is ignored)
             wave_sync();
@@ -310,7 +367,7 @@ __global__ __launch_bounds__(PM_WAVE) void fk_wide_kernel(const FkWideArgs a, co
                 fw_row_out(a.rotmats + gr, sRot, J * 9, lane);
                 fw_row_out(a.pos + gq, sPos, J * 3, lane);
             }
-            if (i + 1 < nf && PM_ABLATED(a, 32)) issue(f + 1);  // (& 32, tuning build: no prefetch across the walk)
+            if (i + 1 < nf && (!AHEAD || PM_ABLATED(a, 32))) issue(f + 1);  // (& 32, tuning build: no prefetch across the walk)
             wave_sync();  // the next frame's parks come after this frame's copy-out reads (in-order DS; this keeps the compiler from mixing them)
         };
         if constexpr (DYN) {
@@ -323,22 +380,34 @@ __global__ __launch_bounds__(PM_WAVE) void fk_wide_kernel(const FkWideArgs a, co
     }
 }
 
-template <int NB, int NG>
+template <int NB, int NG, int SRC, bool QOUT, bool PFO>
 static int launch_fk_wide(const FkWideArgs &a, const int nt, const size_t lds, hipStream_t s) {
     constexpr int PREC = PREC_DYN | PREC_RESID;
-    auto k = fk_wide_kernel<PREC, NB, NG>;
+    auto k = fk_wide_kernel<PREC, NB, NG, SRC, QOUT, PFO>;
     if (int e = allow_lds(k, lds)) return e;
     const int64_t ngroups = (a.F + nt - 1) / nt, grid = ((ngroups + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
     if (grid > 0x7fffffffLL) { set_error("fk: %lld workgroups exceed the grid limit", (long long)grid); return PM_EUNSUPPORTED; }
-    set_kernel_name("void pm::fk_wide_kernel<%d, %d, %d>(pm::FkWideArgs, int)", PREC, NB, NG);
+    set_kernel_name("void pm::fk_wide_kernel<%d, %d, %d, %d, %s, %s>(pm::FkWideArgs, int)", PREC, NB, NG, SRC, tf(QOUT), tf(PFO));
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a, nt);
     return PM_AFTER_LAUNCH("fk launch");
 }
 
-// fk for a quaternion source, shared offsets, 16-byte aligned arrays.  Returns false (nothing launched) when the tree needs more than
-// kFwSteps steps, or more than max_quad_steps_per_joint_x10 / 10 quad-steps per joint (0: no such bound); true with rc set otherwise.
-bool try_fk_wide(const float *rot, const float *root_pos, const float *offsets, float *pos, float *rotmats, const int64_t F, const int32_t J,
-                 const int32_t depth, const Parents &par, const int ablate, const int max_quad_steps_per_joint_x10, hipStream_t s, int &rc) {
+// the variants other than the plain one (quaternion source, shared offsets) come with the long step list only
+template <int NB>
+static int launch_fk_wide_v(const FkWideArgs &a, const int nt, const size_t lds, const int src, const bool pfo, const bool short_list, hipStream_t s) {
+    const bool qout = a.quat_out != nullptr;
+    if (src == 0 && !pfo) return short_list ? launch_fk_wide<NB, 6, 0, false, false>(a, nt, lds, s) : launch_fk_wide<NB, 12, 0, false, false>(a, nt, lds, s);
+    if (src == 0) return launch_fk_wide<NB, 12, 0, false, true>(a, nt, lds, s);
+    if (!qout) return pfo ? launch_fk_wide<NB, 12, 1, false, true>(a, nt, lds, s) : launch_fk_wide<NB, 12, 1, false, false>(a, nt, lds, s);
+    return pfo ? launch_fk_wide<NB, 12, 1, true, true>(a, nt, lds, s) : launch_fk_wide<NB, 12, 1, true, false>(a, nt, lds, s);
+}
+
+// fk on 16-byte aligned arrays: src_kind 0 quaternions / 1 ortho6d records (eps, quat_out or null), shared or per-frame offsets.  Returns false
+// (nothing launched) when the tree needs more than kFwSteps steps, or more than max_quad_steps_per_joint_x10 / 10 quad-steps per joint (0: no
+// such bound); true with rc set otherwise.
+bool try_fk_wide(const int src_kind, const float *rot, const float *root_pos, const float *offsets, const bool offsets_per_frame, float *pos, float *rotmats,
+                 float *quat_out, const float eps, const int64_t F, const int32_t J, const int32_t depth, const Parents &par, const int ablate,
+                 const int max_quad_steps_per_joint_x10, hipStream_t s, int &rc) {
     FkWideArgs a;
     uint32_t list[(kFwSteps + 2) * 16];
     a.nsteps = fk_wide_plan(par, J, 16, kFwSteps, false, list);
@@ -348,8 +417,8 @@ bool try_fk_wide(const float *rot, const float *root_pos, const float *offsets, 
     const uint32_t idle = (uint32_t)(J + 1) | ((uint32_t)J << 16);
     for (int k = 0; k < 16; ++k)
         for (int st = 0; st < kFwStride; ++st) a.jobs[k * kFwStride + st] = st < a.nsteps ? list[st * 16 + k] : idle;
-    a.rot = rot; a.root_pos = root_pos; a.offsets = offsets; a.pos = pos; a.rotmats = rotmats;
-    a.F = F; a.J = J; a.depth = depth; a.ablate = ablate;
+    a.rot = rot; a.root_pos = root_pos; a.offsets = offsets; a.pos = pos; a.rotmats = rotmats; a.quat_out = src_kind == 1 ? quat_out : nullptr;
+    a.F = F; a.J = J; a.depth = depth; a.ablate = ablate; a.eps = eps; a.pad_ = 0;
     const size_t lds = ((size_t)(((J + 2) * 9 + 6) & ~3) + (size_t)(((J + 2) * 3 + 6) & ~3)) * sizeof(float);
     // frames per workgroup: the next frame's quaternions are requested before a frame's walk, so a workgroup wants a few -- while the launch
     // still has several workgroups per wave slot of the chip (PM_FKW_NT, PM_TUNING build only)
@@ -357,11 +426,11 @@ bool try_fk_wide(const float *rot, const float *root_pos, const float *offsets, 
     nt = tune_env("PM_FKW_NT", nt);
     if (nt < 1) nt = 1;
     const bool short_list = a.nsteps <= 24;
-    if (J <= 128) rc = short_list ? launch_fk_wide<2, 6>(a, nt, lds, s) : launch_fk_wide<2, 12>(a, nt, lds, s);
-    else if (J <= 192) rc = short_list ? launch_fk_wide<3, 6>(a, nt, lds, s) : launch_fk_wide<3, 12>(a, nt, lds, s);
-    else if (J <= 256) rc = short_list ? launch_fk_wide<4, 6>(a, nt, lds, s) : launch_fk_wide<4, 12>(a, nt, lds, s);
-    else if (J <= 384) rc = short_list ? launch_fk_wide<6, 6>(a, nt, lds, s) : launch_fk_wide<6, 12>(a, nt, lds, s);
-    else rc = short_list ? launch_fk_wide<8, 6>(a, nt, lds, s) : launch_fk_wide<8, 12>(a, nt, lds, s);
+    if (J <= 128) rc = launch_fk_wide_v<2>(a, nt, lds, src_kind, offsets_per_frame, short_list, s);
+    else if (J <= 192) rc = launch_fk_wide_v<3>(a, nt, lds, src_kind, offsets_per_frame, short_list, s);
+    else if (J <= 256) rc = launch_fk_wide_v<4>(a, nt, lds, src_kind, offsets_per_frame, short_list, s);
+    else if (J <= 384) rc = launch_fk_wide_v<6>(a, nt, lds, src_kind, offsets_per_frame, short_list, s);
+    else rc = launch_fk_wide_v<8>(a, nt, lds, src_kind, offsets_per_frame, short_list, s);
     return true;
 }
 

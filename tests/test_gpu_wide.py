@@ -82,6 +82,87 @@ def test_fk_wide_walk_against_the_oracle(J, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("J,kind", [(129, "bushy"), (131, "bushy"), (160, "comb"), (192, "bushy"), (200, "bushy"), (256, "bushy"), (300, "broom"), (384, "bushy"),
+                                    (400, "bushy"), (512, "bushy")])
+def test_fk_wide_walk_other_sources_against_the_oracle(J, kind):
+    """per-frame offsets, the fused ortho6d source with and without its quaternions, both together: the same walk (same kernel template),
+    metre and centimetre data, single frames and odd batches"""
+    import pymotion_amd.ops.skeleton as sk
+
+    parents = _parents(kind, J)
+    depth = int(syn.depth_of(parents).max())
+    f64 = lambda a: a.astype(np.float64)  # noqa: E731
+    for F, osc, rsc in ((1, 0.1, 2.0), (5, 10.0, 200.0), (77, 0.1, 2.0), (602, 10.0, 2.0)):
+        rot, root, off = _batch(F, J, 77 * J + F, osc, rsc)
+        rng = np.random.default_rng(J + F)
+        x6 = rng.standard_normal((F, J, 3, 2)).astype(np.float32)
+        offs = (off[None] * np.linspace(0.7, 1.3, F, dtype=np.float32)[:, None, None]).astype(np.float32)
+        rot_bar = max(2e-6, 2.5e-7 * depth)
+
+        def pos_bar(p_o):
+            return max(1e-5, 3 * _ulp_of(p_o)) if osc < 1 else max(1e-5, 2 * _ulp_of(p_o), 4e-7 * depth * osc * 3)
+
+        pos, rm = sk.fk(rot, root, offs, parents)
+        assert "fk_wide_kernel" in _lib.last_kernel_name() and "true>" in _lib.last_kernel_name(), _lib.last_kernel_name()
+        p_o, r_o = co.fk(f64(rot), f64(root), f64(offs), parents)
+        assert np.abs(rm - r_o).max() <= rot_bar and np.abs(pos - p_o).max() <= pos_bar(p_o), (F, osc, np.abs(pos - p_o).max() / _ulp_of(p_o))
+        np.testing.assert_array_equal(pos[:, 0].astype(np.float32), root)
+        q_o = co.o6d_to_quat(f64(x6))
+        for o_in in (off, offs):
+            p_o, r_o = co.fk(q_o, f64(root), f64(o_in), parents)
+            for want_q in (False, True):
+                out = sk.fk_from_ortho6d(x6, root, o_in, parents, return_quat=want_q)
+                assert "fk_wide_kernel" in _lib.last_kernel_name(), _lib.last_kernel_name()
+                # (the conversion's own fp32 error, 1e-6 a record, rides the chain)
+                assert np.abs(out[1] - r_o).max() <= max(1e-5, 4 * rot_bar), (F, np.abs(out[1] - r_o).max())
+                assert np.abs(out[0] - p_o).max() <= max(2e-5, 4 * pos_bar(p_o)), (F, osc, np.abs(out[0] - p_o).max())
+                np.testing.assert_array_equal(out[0][:, 0].astype(np.float32), root)
+                if want_q:
+                    assert np.minimum(np.abs(out[2] - q_o).max(-1), np.abs(out[2] + q_o).max(-1)).max() <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("J", [131, 256, 500])
+def test_fk_wide_walk_with_degenerate_ortho6d_records(J):
+    """zero / parallel records sprinkled over a batch: the frames without any are bit-identical to the batch without them, the fused kernel
+    equals the GPU's own two-launch chain (ortho6d.to_quat, then fk) on every frame, and so do its quaternions"""
+    import torch
+
+    import pymotion_amd.ops.skeleton_torch as skt
+    import pymotion_amd.rotations.ortho6d_torch as o6t
+
+    F = 3001
+    parents = bushy(J)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(J)
+    x = torch.randn((F, J, 3, 2), generator=g, device="cuda")
+    root = torch.rand((F, 3), generator=g, device="cuda") * 4 - 2
+    off = torch.from_numpy(syn.make_offsets(J, np.random.default_rng(4), 0.15)).cuda()
+    par = torch.from_numpy(parents)
+    p0, r0, q0 = skt.fk_from_ortho6d(x, root, off, par, return_quat=True)
+    assert "fk_wide_kernel" in _lib.last_kernel_name()
+    x2 = x.clone()
+    hit = torch.rand((F, J), generator=g, device="cuda") < 1e-3
+    x2[hit] = 0.0
+    par_hit = torch.rand((F, J), generator=g, device="cuda") < 1e-3
+    x2[..., 1] = torch.where(par_hit[..., None], -2.0 * x2[..., 0], x2[..., 1])  # exactly anti-parallel columns
+    hit = hit | par_hit
+    p1, r1, q1 = skt.fk_from_ortho6d(x2, root, off, par, return_quat=True)
+    clean = ~hit.any(dim=1)
+    assert int(clean.sum()) > 100 and int((~clean).sum()) > 100
+    assert bool(torch.equal(p0[clean], p1[clean])) and bool(torch.equal(r0[clean], r1[clean])) and bool(torch.equal(q0[clean], q1[clean]))
+    assert bool(torch.isfinite(r1).all()) and bool(torch.isfinite(q1).all())
+    pa, ra = skt.fk_from_ortho6d(x2, root, off, par)  # without the quaternion output: the same function
+    assert bool(torch.equal(pa, p1)) and bool(torch.equal(ra, r1))
+    q2 = o6t.to_quat(x2)
+    p2, r2 = skt.fk(q2, root, off, par)
+    keep = ~par_hit  # exactly (anti-)parallel columns have no stable answer in the reference itself (tests/test_gpu_degenerate.py)
+    assert float((torch.minimum((q1 - q2).abs().amax(-1), (q1 + q2).abs().amax(-1)))[keep].max()) < 1e-5
+    ok = ~par_hit.any(dim=1)
+    assert float((r1 - r2)[ok].abs().max()) < 2e-5 and float((p1 - p2)[ok].abs().max()) < 2e-5
+
+
+@pytest.mark.gpu
 def test_fk_wide_walk_does_not_depend_on_a_frames_place_in_the_batch():
     """frames are independent: a frame's result must not depend on its place in the batch (XCD tile order, the alignment of its rows in
     HBM and in the LDS image).  (The wide walk against the tile kernels on the same arrays, bit for bit on metre data -- same local
@@ -163,24 +244,59 @@ def test_fk_wide_walk_keeps_nan_and_inf_where_the_reference_has_them():
 @pytest.mark.gpu
 def test_fk_trees_too_deep_for_the_step_list_fall_back():
     """a 300-joint comb (parents far back in the table: the streamed walk declines it; depth 78: more than the step list holds) still
-    gets the right answer from the tile kernels; per-frame offsets and the ortho6d source keep them too"""
+    gets the right answer from the tile kernels, whatever the source"""
     import pymotion_amd.ops.skeleton as sk
 
     J, F = 300, 50
     parents = comb(J)
     rot, root, off = _batch(F, J, 5, 0.1, 2.0)
+    f64 = lambda a: a.astype(np.float64)  # noqa: E731
     pos, rm = sk.fk(rot, root, off, parents)
     name = _lib.last_kernel_name()
     assert "fk_wide_kernel" not in name, name
-    p_o, r_o = co.fk(rot.astype(np.float64), root.astype(np.float64), off.astype(np.float64), parents)
+    p_o, r_o = co.fk(f64(rot), f64(root), f64(off), parents)
     assert np.abs(pos - p_o).max() <= 1e-5 and np.abs(rm - r_o).max() <= 2e-5
-    parents = bushy(200)
-    rot, root, off = _batch(F, 200, 6, 0.1, 2.0)
-    offs = np.broadcast_to(off, (F, 200, 3)).copy()
+    offs = (off[None] * np.linspace(0.8, 1.2, F, dtype=np.float32)[:, None, None]).astype(np.float32)
     pos, rm = sk.fk(rot, root, offs, parents)
     assert "fk_wide_kernel" not in _lib.last_kernel_name()
-    p_o, r_o = co.fk(rot.astype(np.float64), root.astype(np.float64), off.astype(np.float64), parents)
-    assert np.abs(pos - p_o).max() <= 1e-5
+    p_o, r_o = co.fk(f64(rot), f64(root), f64(offs), parents)
+    assert np.abs(pos - p_o).max() <= 1e-5 and np.abs(rm - r_o).max() <= 2e-5
+    x6 = np.random.default_rng(3).standard_normal((F, J, 3, 2)).astype(np.float32)
+    pos, rm, q = sk.fk_from_ortho6d(x6, root, offs, parents, return_quat=True)
+    assert "fk_wide_kernel" not in _lib.last_kernel_name()
+    q_o = co.o6d_to_quat(f64(x6))
+    p_o, r_o = co.fk(q_o, f64(root), f64(offs), parents)
+    assert np.abs(pos - p_o).max() <= 2e-5 and np.abs(rm - r_o).max() <= 4e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("J", [510, 511, 512])
+@pytest.mark.parametrize("kind", ["chain", "bushy"])
+def test_fk_every_source_at_the_maximum_joint_count(J, kind):
+    """PM_MAX_JOINTS and the two counts below it, every source and output of fk, on a chain (the step list declines it) and a random tree:
+    the ortho6d source with per-frame offsets AND the quaternion output needs 164 KB for a four-frame tile at 511 / 512 joints -- a chain
+    there runs as the reference's own two steps (ortho6d.to_quat, then fk) instead of being refused"""
+    import pymotion_amd.ops.skeleton as sk
+
+    F = 37
+    parents = np.maximum(np.arange(J) - 1, 0).astype(np.int32) if kind == "chain" else bushy(J)
+    rot, root, off = _batch(F, J, J, 0.02, 2.0)
+    f64 = lambda a: a.astype(np.float64)  # noqa: E731
+    offs = (off[None] * np.linspace(0.8, 1.2, F, dtype=np.float32)[:, None, None]).astype(np.float32)
+    x6 = np.random.default_rng(J).standard_normal((F, J, 3, 2)).astype(np.float32)
+    q_o = co.o6d_to_quat(f64(x6))
+    depth = int(syn.depth_of(parents).max())
+    rot_bar, pos_bar = max(2e-5, 5e-7 * depth), max(2e-5, 1e-6 * depth)
+    for o_in in (off, offs):
+        pos, rm = sk.fk(rot, root, o_in, parents)
+        p_o, r_o = co.fk(f64(rot), f64(root), f64(o_in), parents)
+        assert np.abs(pos - p_o).max() <= pos_bar and np.abs(rm - r_o).max() <= rot_bar
+        p_o, r_o = co.fk(q_o, f64(root), f64(o_in), parents)
+        for want_q in (False, True):
+            out = sk.fk_from_ortho6d(x6, root, o_in, parents, return_quat=want_q)
+            assert np.abs(out[0] - p_o).max() <= 2 * pos_bar and np.abs(out[1] - r_o).max() <= 2 * rot_bar, (np.abs(out[0] - p_o).max(), np.abs(out[1] - r_o).max())
+            if want_q:
+                assert np.minimum(np.abs(out[2] - q_o).max(-1), np.abs(out[2] + q_o).max(-1)).max() <= 1e-5
 
 
 def test_fk_wide_plan_schedules_every_joint_once_after_its_parent():
