@@ -1663,7 +1663,10 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
             if (w4 != 1) pick = 4;
         }
     }
-    const bool w4_first = a.wsteps > 0 && a.J <= kFkWideMinJ;  // (beyond: the wave-per-frame walk first; tree_walk_w4 still serves what it declines)
+    // (the ortho6d source with per-frame offsets and quaternions: eight records a lane AND nineteen floats a joint in LDS from 93 joints on)
+    const bool all_three = SRC == SRC_O6D && pfo && a.quat_out != nullptr;
+    const int wide_min = all_three ? 92 : kFkWideMinJ;
+    const bool w4_first = a.wsteps > 0 && a.J <= wide_min;  // (beyond: the wave-per-frame walk first; tree_walk_w4 still serves what it declines)
 #ifdef PM_TUNING
     if constexpr (SRC == SRC_QUAT) {  // the three-lane tile, several tiles per workgroup with the next tile's records prefetched into registers
         const int pnt = tune_env("PM_FK_PIPE3", 0);
@@ -1700,6 +1703,12 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
                            (st == 1 || (fk_stream_wanted(a.J) && lane_per_frame_pays(a.F, a.J, kFkStreamMinJointFrames)));
     // (whole-line rows of 96 / 128 joints: the streamed walk first -- a humanoid with hands reads 59.6 / 62.8 % there against 55.8 / 61.3 %)
     const bool stream_first = a.J % 32 == 0 && a.J <= 128 && wd != 1;
+    // the other sources at 101...128 joints: where the four-frame image is padded (multiples of sixteen joints) and for the ortho6d source with
+    // per-frame offsets and quaternions (eight records a lane AND nineteen floats a joint in LDS: 47-51 % on the pipelined tiles).  Random
+    // trees / a body with hands, 2^18 frames, wide / pipelined tiles: per-frame offsets J = 112 62.9 / 61.2, 128 66.1 / 51.6 (104: 63.6 / 71.1,
+    // 120: 59.6 / 63.6); ortho6d 112 66.0 / 62.9, 128 66.7 / 62.4 (104: 64.3 / 68.8); with quaternions 112 66.4 / 61.4, 128 65.5 / 61.1; all
+    // three 96 65.0 / 46.8, 100 60.2 / 38-47, 104 66.4 / 48.4, 112 69.5 / 49.3, 120 60.5 / 51.3, 128 66.1 / 50.8 (profiles/r05_fk_wide_variants_mid.txt)
+    const bool wide_mid = !wide_plain && vec && a.J > wide_min && a.J <= 128 && (a.J % 16 == 0 || all_three);
     auto wide = [&](const int bound, int &rc) {
         return try_fk_wide(SRC == SRC_QUAT ? 0 : 1, a.src, a.root_pos, a.offsets, pfo, a.pos, a.rotmats, a.quat_out, a.eps, a.F, a.J, a.depth, a.parents,
                            a.ablate, bound, s, rc);
@@ -1708,7 +1717,7 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
         int rc = PM_OK;
         if constexpr (SRC == SRC_QUAT)
             if (stream_ok && stream_first && try_fk_stream(a, s, rc)) return rc;
-        if (wide_plain && wd != 0 && (wd == 1 || a.J > kFkWideMinJ) && wide(wd == 1 ? 0 : 25, rc)) return rc;
+        if ((wide_plain || wide_mid) && wd != 0 && (wd == 1 || a.J > wide_min) && wide(wd == 1 ? 0 : 25, rc)) return rc;
         if constexpr (SRC == SRC_QUAT)
             if (stream_ok && !stream_first && try_fk_stream(a, s, rc)) return rc;
         // whatever is left beyond 128 joints -- trees the streamed walk declined, the ortho6d source, per-frame offsets: the wide walk if its

@@ -82,7 +82,7 @@ def test_fk_wide_walk_against_the_oracle(J, kind):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("J,kind", [(129, "bushy"), (131, "bushy"), (160, "comb"), (192, "bushy"), (200, "bushy"), (256, "bushy"), (300, "broom"), (384, "bushy"),
+@pytest.mark.parametrize("J,kind", [(96, "bushy"), (100, "bushy"), (104, "bushy"), (112, "bushy"), (120, "bushy"), (128, "bushy"), (129, "bushy"), (131, "bushy"), (160, "comb"), (192, "bushy"), (200, "bushy"), (256, "bushy"), (300, "broom"), (384, "bushy"),
                                     (400, "bushy"), (512, "bushy")])
 def test_fk_wide_walk_other_sources_against_the_oracle(J, kind):
     """per-frame offsets, the fused ortho6d source with and without its quaternions, both together: the same walk (same kernel template),
@@ -102,8 +102,13 @@ def test_fk_wide_walk_other_sources_against_the_oracle(J, kind):
         def pos_bar(p_o):
             return max(1e-5, 3 * _ulp_of(p_o)) if osc < 1 else max(1e-5, 2 * _ulp_of(p_o), 4e-7 * depth * osc * 3)
 
+        # up to 128 joints the pipelined tiles keep these sources except where their image is padded (multiples of sixteen joints, from 101 on)
+        # and, from 93 joints on, for the ortho6d source with per-frame offsets AND quaternions (fk.hip: wide_mid)
+        def wide_expected(all_three):
+            return J > 128 or (J > 100 and J % 16 == 0) or (all_three and J > 92)
+
         pos, rm = sk.fk(rot, root, offs, parents)
-        assert "fk_wide_kernel" in _lib.last_kernel_name() and "true>" in _lib.last_kernel_name(), _lib.last_kernel_name()
+        assert ("fk_wide_kernel" in _lib.last_kernel_name() and "true>" in _lib.last_kernel_name()) == wide_expected(False), _lib.last_kernel_name()
         p_o, r_o = co.fk(f64(rot), f64(root), f64(offs), parents)
         assert np.abs(rm - r_o).max() <= rot_bar and np.abs(pos - p_o).max() <= pos_bar(p_o), (F, osc, np.abs(pos - p_o).max() / _ulp_of(p_o))
         np.testing.assert_array_equal(pos[:, 0].astype(np.float32), root)
@@ -112,7 +117,7 @@ def test_fk_wide_walk_other_sources_against_the_oracle(J, kind):
             p_o, r_o = co.fk(q_o, f64(root), f64(o_in), parents)
             for want_q in (False, True):
                 out = sk.fk_from_ortho6d(x6, root, o_in, parents, return_quat=want_q)
-                assert "fk_wide_kernel" in _lib.last_kernel_name(), _lib.last_kernel_name()
+                assert ("fk_wide_kernel" in _lib.last_kernel_name()) == wide_expected(want_q and o_in is offs), (_lib.last_kernel_name(), want_q)
                 # (the conversion's own fp32 error, 1e-6 a record, rides the chain)
                 assert np.abs(out[1] - r_o).max() <= max(1e-5, 4 * rot_bar), (F, np.abs(out[1] - r_o).max())
                 assert np.abs(out[0] - p_o).max() <= max(2e-5, 4 * pos_bar(p_o)), (F, osc, np.abs(out[0] - p_o).max())

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """fk's other sources on long wide trees -- per-frame offsets, the fused ortho6d source with / without its quaternions, both -- on the wide walk
 (fk_wide_kernel, the production dispatch) against what ran before (PM_FK_WIDE=0: the four-frame tiles), same box, same arrays, tuning build.
+FKW_FORCE=1: the second column forces the wide walk (joint counts where the dispatch does not pick it); FKW_KIND=humanoid: a body with hands.
 Per cent of the 8 TB/s spec on each variant's own algorithmic bytes; whether the two results agree to the bit."""
 import ctypes as C, os, sys
 os.environ["PMHIP_VARIANT"] = "tuning"
@@ -15,7 +16,11 @@ P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
 
 def main():
     for J in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "129,160,200,256,384,512").split(",")]:
-        par = syn.random_parents(J, np.random.default_rng(J)).astype(np.int32)
+        if os.environ.get("FKW_KIND") == "humanoid":
+            from tools.fk_wide_sweep import humanoid
+            par = humanoid(J)
+        else:
+            par = syn.random_parents(J, np.random.default_rng(J)).astype(np.int32)
         F = int(os.environ.get("FKW_F", 1 << 17))
         rot = torch.randn((F, J, 4), device="cuda"); x6 = torch.randn((F, J, 3, 2), device="cuda"); root = torch.rand((F, 3), device="cuda") * 4 - 2
         off = torch.randn((J, 3), device="cuda") * 0.1; off[0] = 0
@@ -30,7 +35,7 @@ def main():
         ]
         for label, bpj, fn in variants:
             row, outs = [], []
-            for env in ({"PM_FK_WIDE": "0"}, {}):
+            for env in ({"PM_FK_WIDE": "0"}, {"PM_FK_WIDE": os.environ["FKW_FORCE"]} if os.environ.get("FKW_FORCE") else {}):
                 os.environ.pop("PM_FK_WIDE", None)
                 os.environ.update(env)
                 qo.zero_()
