@@ -1,3 +1,8 @@
-# the per-process timing levels of the J = 52 kernels: kernel or launch gap?  each process times 2^18 frames (8000 launches) and 2^21 frames (1000 launches)
-export FKC_NOSMI=1 FKC_SIZES=1
-for i in 1 2 3 4 5 6 7 8; do echo "## process $i"; timeout 120 python tools/fk_clock_probe.py 2>&1 | grep "J="; done
+# the per-process timing levels of the J = 52 kernels: do they come with the address-space layout?  processes alternate between the default
+# (randomised mmap base: torch's allocations, the code object and the kernel-argument pool land elsewhere each time) and `setarch -R`
+export FKC_NOSMI=1 FKC_ONLY52=1
+setarch x86_64 -R true && echo "setarch -R works" || echo "setarch -R refused"
+for i in 1 2 3 4 5 6; do
+echo "## process $i default"; timeout 120 python tools/fk_clock_probe.py 2>&1 | grep "J="
+echo "## process $i setarch -R"; setarch x86_64 -R timeout 120 python tools/fk_clock_probe.py 2>&1 | grep "J="
+done
