@@ -32,6 +32,7 @@ python $R/tools/store_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/r${RN}_store_pat
 python $R/tools/fk_shape_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/r${RN}_fk_tile_shapes.txt
 python $R/tools/fk_long_sweep.py 2>&1 | grep -v amdgpu.ids > $OUT/r${RN}_fk_long_sweep.txt
 FKW_KINDS=humanoid,bushy,chain python $R/tools/fk_wide_sweep.py 96,100,112,128,129,130,160,200,250,256,300,400,511,512 2>&1 | grep -v amdgpu.ids > $OUT/r${RN}_fk_wide_final.txt
+python $R/tools/fk_wide_variants.py 96,104,112,128,129,160,200,256,384,512 2>&1 | grep -v amdgpu.ids > $OUT/r${RN}_fk_wide_variants_final.txt
 python $R/tools/fk_w4_sweep.py 24,28,32,36,40,44,48,52,56,64,72,80,92,100 2>&1 | grep -v amdgpu.ids > $OUT/r${RN}_fk_w4_final.txt
 FKW_SRC=o6d FKW_KINDS=humanoid,bushy python $R/tools/fk_w4_sweep.py 24,32,40,48,52,64,80 2>&1 | grep -v amdgpu.ids >> $OUT/r${RN}_fk_w4_final.txt
 python $R/tools/door_latency_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/r${RN}_door_latency_final.txt
