@@ -31,6 +31,26 @@ def smi():
     return got
 
 
+def amd_smi_clocks():
+    """per-XCD shader clocks (amd-smi metric --clock: GFX_0 ... GFX_7), as text"""
+    try:
+        out = subprocess.run(["/opt/rocm/bin/amd-smi", "metric", "--clock", "--json"], capture_output=True, text=True, timeout=30).stdout
+        import json
+        j = json.loads(out)
+        rec = j[0] if isinstance(j, list) else j
+        if isinstance(rec, dict) and "gpu_data" in rec: rec = rec["gpu_data"][0]
+        clk = rec.get("clock", rec)
+        got = []
+        for k in sorted(clk):
+            if k.lower().startswith("gfx"):
+                v = clk[k]
+                c = v.get("clk", v) if isinstance(v, dict) else v
+                got.append(f"{k}={c.get('value', c) if isinstance(c, dict) else c}")
+        return " ".join(got) or out[:600]
+    except Exception as ex:  # noqa: BLE001
+        return repr(ex)[:300]
+
+
 def sysfs_poll():
     """what the first version of this probe did every 1000 launches: read every card's DPM tables and hwmon files (each read is a message to
     the power-management firmware)"""
@@ -67,18 +87,20 @@ def main():
         for _ in range(50): fn()
         torch.cuda.synchronize()
         for rep in range(2):
-            n = 8000 if F <= (1 << 18) else 1000
+            n = (20000 if os.environ.get('FKC_XCD') == '1' else 8000) if F <= (1 << 18) else 1000
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for i in range(n):
                 fn()
                 if POLL and i % 1000 == 999: sysfs_poll()
             e1.record()
+            xcd = amd_smi_clocks() if os.environ.get("FKC_XCD") == "1" else None
             seen = [smi(), smi()]  # (the queue holds seconds of launches: both samples fall inside the run -- `busy` below says so)
             busy = not e1.query()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) / n * 1e3
             print(f"J={J} F={F}: {us:7.1f} us a launch, {F * (64 * J + 12) / us / 1e3 / 80:5.1f} % | still running at the 2nd sample: {busy} | {seen}", flush=True)
+            if xcd: print("   per-XCD clocks while it ran:", xcd, flush=True)
             time.sleep(0.2 if NOSMI else 1.0)
         del src, pos, rm
 
