@@ -168,6 +168,18 @@ def test_fuzz_torch_door_dtypes_and_devices(sk_, dtype, device):
 @FUZZ
 @given(skeletons(), st.booleans(), st.booleans())
 def test_fuzz_fk_from_ortho6d(sk_, per_frame_offsets, want_quat):
+    _check_fk_from_ortho6d(sk_, per_frame_offsets, want_quat)
+
+
+@settings(max_examples=60 * _SCALE, deadline=None, derandomize=_DERAND)
+@given(st.data(), st.booleans(), st.booleans())
+def test_fuzz_fk_from_ortho6d_on_wide_skeletons(data, per_frame_offsets, want_quat):
+    """the fused ortho6d source on 24 ... 512 joints: the pipelined tiles' four-joints-a-step walk, the wave-per-frame walk beyond 128 joints
+    (and where it goes first below), the four-frame tiles for what both decline, the two-launch path at 511 / 512 joints"""
+    _check_fk_from_ortho6d(data.draw(wide_skeletons()), per_frame_offsets, want_quat)
+
+
+def _check_fk_from_ortho6d(sk_, per_frame_offsets, want_quat):
     import pymotion_amd.rotations.ortho6d as o6
 
     J, par, lead, rng = sk_
@@ -419,8 +431,9 @@ def test_fuzz_dual_quat_on_wide_skeletons(sk_, scale):
     dd = np.zeros(J, int)
     for j in range(1, J):
         dd[j] = dd[par[j]] + 1
-    # (chains: a randomised run of this test read 3.6 ulp on a 65-deep chain of 30-unit bones -- the tile kernels' precise step)
-    assert np.abs(d.reshape(F, J, 8) - d_o).max() <= max(1e-5, 3 * ulp) * max(1.0, dd.max() / 48.0)
+    # (chains: randomised runs of this test read 3.6 ulp on a 65-deep chain of 30-unit bones and 4.1 ulp on a 55-deep one -- the tile kernels'
+    # precise step, one rounding a joint)
+    assert np.abs(d.reshape(F, J, 8) - d_o).max() <= max(1e-5, 3 * ulp) * max(1.0, dd.max() / 32.0)
     t, q = sk.from_root_dual_quat(d, par)
     assert np.abs(q - rot).max() <= 4e-6 * max(1.0, dd.max() / 32.0)
 
