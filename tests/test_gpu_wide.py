@@ -247,6 +247,46 @@ def test_fk_wide_walk_keeps_nan_and_inf_where_the_reference_has_them():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("J", [200, 512])
+def test_fk_wide_walk_other_sources_keep_nan_and_inf(J):
+    """the same on per-frame offsets (a NaN / Inf offset: its joint's position and everything below, and -- the reference's 4 x 4 products --
+    row r of the rotations below it) and on the ortho6d source (a NaN record), metre and centimetre data"""
+    import pymotion_amd.ops.skeleton as sk
+
+    parents = bushy(J, 11)
+    f64 = lambda a: a.astype(np.float64)  # noqa: E731
+    for osc, rsc in ((0.1, 2.0), (10.0, 200.0)):
+        F = 90
+        rot, root, off = _batch(F, J, 98, osc, rsc)
+        offs = (off[None] * np.linspace(0.7, 1.3, F, dtype=np.float32)[:, None, None]).astype(np.float32)
+        offs[5, 3, 1] = np.nan
+        offs[6, J - 1, 0] = np.nan     # a leaf: nothing below
+        offs[7, 2, 2] = np.inf
+        offs[8, 0, 0] = np.nan         # offsets[0] is ignored (skeleton.py:49)
+        rot[20, 17, 2] = np.nan
+        root[30, 1] = np.inf
+        with np.errstate(all="ignore"):
+            p_o, r_o = co.fk(f64(rot), f64(root), f64(offs), parents)
+        pos, rm = sk.fk(rot, root, offs, parents)
+        assert "fk_wide_kernel" in _lib.last_kernel_name()
+        assert (np.isnan(rm) == np.isnan(r_o)).all() and (np.isnan(pos) == np.isnan(p_o)).all()
+        assert (np.isinf(pos) == np.isinf(p_o)).all()
+        fin = np.isfinite(p_o)
+        assert np.abs(pos[fin] - p_o[fin]).max() <= max(1e-5, 3 * _ulp_of(p_o[fin]))
+        assert np.isfinite(pos[8]).all()
+        x6 = np.random.default_rng(J).standard_normal((F, J, 3, 2)).astype(np.float32)
+        x6[11, 9, 1, 0] = np.nan
+        with np.errstate(all="ignore"):
+            q_o = co.o6d_to_quat(f64(x6))
+            p_o, r_o = co.fk(q_o, f64(root), f64(offs), parents)
+        pos, rm, q = sk.fk_from_ortho6d(x6, root, offs, parents, return_quat=True)
+        assert "fk_wide_kernel" in _lib.last_kernel_name()
+        assert (np.isnan(rm) == np.isnan(r_o)).all() and (np.isnan(pos) == np.isnan(p_o)).all() and (np.isnan(q) == np.isnan(q_o)).all()
+        fin = np.isfinite(p_o)
+        assert np.abs(pos[fin] - p_o[fin]).max() <= max(2e-5, 3 * _ulp_of(p_o[fin]))
+
+
+@pytest.mark.gpu
 def test_fk_trees_too_deep_for_the_step_list_fall_back():
     """a 300-joint comb (parents far back in the table: the streamed walk declines it; depth 78: more than the step list holds) still
     gets the right answer from the tile kernels, whatever the source"""
