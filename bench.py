@@ -211,8 +211,15 @@ def secondary_configs(torch, _lib, syn, dev, rot, root, off, parents, sptr):
     out["fused_ortho6d_fk_J52_quat_out"] = {"frames": F4, "ms": t4q, "frames_per_s": F4 / (t4q * 1e-3),
                                             "hbm_frac": F4 * (88 * 52 + 12) / (t4q * 1e-3) / 1e9 / HBM_PEAK_GBPS}
     t52 = timed(lambda: _lib.call("pm_fk_f32", p(q4), p(root4), p(off4), 0, pp4, F4, 52, p(pos4), p(rm4), sptr))
+    # the copy kernel of fk's own shape at this joint count, in this process: the J = 52 kernels read 0.65 or 0.70-0.72 by the process (a state
+    # of the box, profiles/r05_fk_mode_probe.txt) while this pure stream does not move -- the ratio says which level a run was on
+    big52 = torch.empty(F4 * 52 * 12, device=dev)
+    t52c = timed(lambda: _lib.call("pm_stream_ceiling_f32", p(q4), p(big52), F4, 4 * 52, 12 * 52, sptr))
+    del big52
     out["fk_J52"] = {"frames": F4, "ms": t52, "frames_per_s": F4 / (t52 * 1e-3),
-                     "hbm_frac": F4 * (64 * 52 + 12) / (t52 * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+                     "hbm_frac": F4 * (64 * 52 + 12) / (t52 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "copy_ceiling_ms": t52c, "copy_ceiling_hbm_frac": F4 * 64 * 52 / (t52c * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "kernel_over_copy_ceiling": t52 / t52c}
     # from_root_positions (positions -> local rotations) on the fk output just made: SMPL-H's 52-joint table AS STORED
     # (level order -- round 3: 30.5 % on the two-chain tile kernel) on the operation-driven lane-per-frame kernel, 28 J B per frame
     ik4 = torch.empty((F4, 52, 4), device=dev)
