@@ -52,6 +52,9 @@ struct FkArgs {
     int32_t wsteps;         // fk_pipe_kernel, four frames a wave: > 0 = walk the tree four JOINTS of a frame at a time over this many steps (tree_walk_w4)
     Parents parents;
     uint32_t wjobs[4 * kW4Stride];  // [slot][step]: joint | parent << 16 (a slot without a joint repeats the step's first one)
+#ifdef PM_TUNING
+    uint64_t *times;        // fk_pipe_kernel, env PM_FK_TIMES_PTR (a device address, tools/fk_xcd_time_probe.py): [workgroup][3] = XCC id, start, end (s_memrealtime)
+#endif
 };
 
 // LDS bank conflicts of the walks: lanes of DIFFERENT frames touch the same joint slot in the same instruction, so the
@@ -725,6 +728,9 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? ((PFO && E
     if (group < 0) return;
     const int64_t t0 = group * nt;
     const int cnt = (int)((ntiles - t0) < nt ? (ntiles - t0) : nt);
+#ifdef PM_TUNING
+    const uint64_t wg_start = a.times ? __builtin_amdgcn_s_memrealtime() : 0;
+#endif
 
     const int pad = PAD ? a.pad : 0;             // see FkArgs::pad
     const float invJ = 1.0f / (float)J;
@@ -958,6 +964,15 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? ((PFO && E
         }
     }
     copy_out(f0_prev, nf_prev);
+#ifdef PM_TUNING
+    if (a.times) {  // which XCD ran this workgroup, from when to when (100 MHz counter): are the eight XCDs done at the same time?
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        __builtin_amdgcn_s_waitcnt(0);
+        const uint64_t wg_end = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) { a.times[3 * (uint64_t)blockIdx.x] = xcc & 15u; a.times[3 * (uint64_t)blockIdx.x + 1] = wg_start; a.times[3 * (uint64_t)blockIdx.x + 2] = wg_end; }
+    }
+#endif
 }
 
 
@@ -1776,6 +1791,10 @@ static int fk_common(int src_kind, const float *src, const float *root_pos, cons
     a.src = src; a.root_pos = root_pos; a.offsets = offsets; a.pos = pos; a.rotmats = rotmats;
     a.quat_out = quat_out; a.F = F; a.J = J; a.eps = eps; a.pad = 0;  // set by dispatch_fk, per walk shape
     a.wsteps = 0;
+#ifdef PM_TUNING
+    a.times = nullptr;
+    if (const char *e = getenv("PM_FK_TIMES_PTR")) a.times = reinterpret_cast<uint64_t *>(strtoull(e, nullptr, 0));
+#endif
     a.ablate = tune_env("PM_FK_ABLATE", 0);
     if (int e = pack_parents(parents, J, a.parents)) return e;
     {
