@@ -726,10 +726,21 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? ((PFO && E
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
     const int64_t group = xcd_tile((ntiles + nt - 1) / nt);
     if (group < 0) return;
-    const int64_t t0 = group * nt;
-    const int cnt = (int)((ntiles - t0) < nt ? (ntiles - t0) : nt);
+    int64_t t0 = group * nt;
+    int cnt = (int)((ntiles - t0) < nt ? (ntiles - t0) : nt);
 #ifdef PM_TUNING
     const uint64_t wg_start = a.times ? __builtin_amdgcn_s_memrealtime() : 0;
+    // PM_FK_ABLATE & 64 (an experiment, two tiles a workgroup): the first `stagger` workgroups of every XCD take one, two and three tiles in turn
+    // (triples over the same six tiles) instead of two each -- do 3584 workgroups that load, walk and store in step cost the launch its fixed 18 us?
+    if (PM_ABLATED(a, 64) && nt == 2) {
+        const int64_t per_xcd = ((ntiles + 1) / 2 + PM_NXCD - 1) / PM_NXCD, i = blockIdx.x / PM_NXCD, k = i / 3;
+        const int64_t base = (group - i) * 2;  // the XCD's first tile
+        if (i < 447 && 3 * k + 2 < per_xcd && base + 6 * k + 6 <= ntiles) {
+            const int m = (int)(i - 3 * k);
+            t0 = base + 6 * k + (m == 0 ? 0 : (m == 1 ? 1 : 3));
+            cnt = m + 1;
+        }
+    }
 #endif
 
     const int pad = PAD ? a.pad : 0;             // see FkArgs::pad
