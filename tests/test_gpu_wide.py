@@ -5,7 +5,9 @@ fall to the four-frame tile kernels (34 % of the HBM spec at J = 129, 8.6 % at 5
 ran, parity with the float64 C oracle on metre and centimetre data (per-frame PREC_DYN: float64 rotations + fixed-point chain), every
 alignment of a frame's rows (J mod 4, F odd), single frames, the root position bit for bit, NaN / Inf where the reference has them,
 outputs that are views into bigger buffers (nothing written outside), trees too deep for the step list falling back, and the host
-scheduler's invariants (CPU)."""
+scheduler's invariants (CPU).  Later in round 5 the same walk took fk's other sources -- per-frame offsets, the fused ortho6d source with and
+without its quaternions -- beyond 128 joints and where it measured faster below: oracle parity, degenerate and NaN records, NaN / Inf offsets,
+every source at 510 / 511 / 512 joints (the two-launch path where nothing else fits)."""
 import ctypes as C
 
 import numpy as np
