@@ -269,7 +269,8 @@ int pm_store_probe_f32(const float *src, float *dst, int64_t n4, const int32_t *
  * independently), 2 the BVH ingest (B = 1, in = Euler degrees [T, S, 3], `order` as for pm_bvh_rotations_f32; otherwise null).  S <= 64
  * (PM_EUNSUPPORTED beyond: pm_quat_unroll_f32's three-pass scan has no reset to save).  A workspace that is not zero on entry makes the scan
  * wait for words nobody writes: the pair is the caller's to keep private to one stream.  On PM_OK (an empty scan included) `ws_other` is clean and the
- * roles swap; on an error return neither workspace was touched. */
+ * roles swap.  On PM_EINVAL / PM_EUNSUPPORTED (argument checks, before any launch) neither workspace was touched, though *ws_words_dirtied may have
+ * been written; after PM_EHIP (a failed launch) the state of both is unknown: zero-fill them again, or drop the pair. */
 int pm_unroll_onepass_f32(int32_t kind, const float *in, const uint8_t *order, int64_t B, int64_t T, int32_t S, float *out, void *ws_zeroed,
                           int64_t *ws_words_dirtied, void *ws_other, int64_t ws_other_words, pm_stream_t stream);
 

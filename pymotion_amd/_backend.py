@@ -116,12 +116,8 @@ def trim():
     _pool.trim()
     _stage.trim()
     _pinned.trim()
-    table = getattr(_arenas, "table", None)  # (the calling thread's small-call arenas; other threads keep theirs: 8 MB per thread and device)
-    if table:
-        for a in table.values():
-            _lib.call("pm_free", C.c_void_p(a.dptr))
-            _lib.call("pm_host_free", C.c_void_p(a.hptr))
-        table.clear()
+    _arenas.trim()      # every idle small-call arena of the process (one in use by an op elsewhere is handed back later and kept)
+    _np_pairs_trim()    # and every idle workspace pair of the one-pass scans
 
 
 # ---- host side of the NumPy door: staging buffers that are reused (no page faults on the copy path) and
@@ -469,29 +465,71 @@ class _Arena:
         d = C.c_void_p()
         _lib.call("pm_malloc", C.byref(d), _ARENA_BYTES)
         h = C.c_void_p()
-        _lib.call("pm_host_alloc", C.byref(h), _ARENA_BYTES)
+        try:
+            _lib.call("pm_host_alloc", C.byref(h), _ARENA_BYTES)
+        except Exception:
+            _lib.call("pm_free", d)
+            raise
         self.dptr, self.hptr = d.value, h.value
         self.host = np.ctypeslib.as_array(C.cast(h.value, C.POINTER(C.c_uint8)), shape=(_ARENA_BYTES,))
 
+    def free(self):
+        if self.dptr is not None:
+            d, h = self.dptr, self.hptr
+            self.dptr = self.hptr = self.host = None
+            _lib.call("pm_free", C.c_void_p(d))
+            _lib.call("pm_host_free", C.c_void_p(h))
 
-_arenas = threading.local()
+    def __del__(self):  # an arena that never came back (an op that died between begin() and end()): the memory does
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
 
 
-def _arena_for(dev):
-    table = getattr(_arenas, "table", None)
-    if table is None:
-        table = _arenas.table = {}
-    a = table.get(dev)
-    if a is None:
-        a = table[dev] = _Arena(dev)
-    return a
+class _ArenaPool:
+    """Process-wide, per device: an op checks an arena out in begin() and hands it back in end(), so threads that come and go reuse
+    the same few arenas (as many as ops were ever in flight at once) instead of leaving 8 MB of device + page-locked memory each."""
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.idle = {}
+
+    def get(self, dev):
+        with self.lock:
+            lst = self.idle.get(dev)
+            if lst:
+                return lst.pop()
+        return _Arena(dev)
+
+    def put(self, a):
+        if a is None or a.dptr is None:
+            return
+        with self.lock:
+            lst = self.idle.setdefault(a.dev, [])
+            if len(lst) < 8:
+                lst.append(a)
+                return
+        a.free()
+
+    def trim(self):
+        with self.lock:
+            arenas = [a for lst in self.idle.values() for a in lst]
+            self.idle.clear()
+        for a in arenas:
+            a.free()
+
+
+_arenas = _ArenaPool()
 
 
 # ---- the one-pass scans' workspace pair (pm_unroll_onepass_f32): two zeroed device blocks per thread, device and stream, alternated call by
 # call -- the scan then needs no reset launch in front of it (~3 us of the 7-19 us a clip of real length takes).  A pair is private to the
 # thread that made it and to one stream: launches of one thread on one stream run in the order they were made, which is all the alternation needs.
 _UNROLL_WS_BYTES = 1 << 20   # covers clips of 2^21 frames x 22 series; bigger calls keep the plain entry points (their reset launch is noise there)
-_unroll_pairs = threading.local()
+_unroll_pairs = threading.local()   # torch door: pairs are torch tensors keyed by (device, stream), dropped with the thread's table
+_np_pairs_lock = threading.Lock()
+_np_pairs_idle = {}                 # NumPy door: device -> idle pairs (pm_malloc'd; checked out per call, so short-lived threads do not leak them)
 
 
 class _UnrollPair:
@@ -499,7 +537,7 @@ class _UnrollPair:
         self.ptr = (ptr0, ptr1)
         self.dirty = [0, 0]   # 8-byte words each block holds non-zero
         self.cur = 0          # the clean one
-        self.keep = keep
+        self.keep = keep      # the torch tensor that owns the blocks, or None: pm_malloc'd, freed by free()
 
     def take(self):
         o = 1 - self.cur
@@ -510,10 +548,29 @@ class _UnrollPair:
         self.dirty[self.cur] = int(words)
         self.cur = 1 - self.cur
 
+    def free(self):
+        if self.keep is None and self.ptr is not None:
+            ptrs, self.ptr = self.ptr, None
+            for p in ptrs:
+                _lib.call("pm_free", C.c_void_p(p))
+        self.keep = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def _unroll_pair_wanted(nbytes):
+    # (PM_UNROLL_ONEPASS=0: the tuning build's three-pass scan for few series -- it has no reset to save)
+    return not (nbytes > _UNROLL_WS_BYTES or os.environ.get("PM_NO_UNROLL_PAIR") == "1" or os.environ.get("PM_UNROLL_ONEPASS") == "0")
+
 
 def _unroll_pair(key, nbytes, make):
-    if nbytes > _UNROLL_WS_BYTES or os.environ.get("PM_NO_UNROLL_PAIR") == "1" or os.environ.get("PM_UNROLL_ONEPASS") == "0":
-        return None  # (PM_UNROLL_ONEPASS=0: the tuning build's three-pass scan for few series -- it has no reset to save)
+    """torch door: the calling thread's pair for `key`"""
+    if not _unroll_pair_wanted(nbytes):
+        return None
     table = getattr(_unroll_pairs, "table", None)
     if table is None:
         table = _unroll_pairs.table = {}
@@ -525,10 +582,47 @@ def _unroll_pair(key, nbytes, make):
     return p
 
 
-def _unroll_pair_drop(key):
+def _np_pair_get(dev, nbytes, make):
+    """NumPy door: check a pair out of the process-wide list (every launch of this door is on the null stream: in order whoever made it)"""
+    if not _unroll_pair_wanted(nbytes):
+        return None
+    with _np_pairs_lock:
+        lst = _np_pairs_idle.get(dev)
+        if lst:
+            return lst.pop()
+    return make()
+
+
+def _unroll_pair_release(key, pair):
+    """after a successful scan: the NumPy door's pair goes back to the list (the torch door's stays in its thread's table)"""
+    if key is not None and key[0] == "numpy" and pair is not None:
+        with _np_pairs_lock:
+            lst = _np_pairs_idle.setdefault(key[1], [])
+            if len(lst) < 8:
+                lst.append(pair)
+                return
+        pair.free()
+
+
+def _unroll_pair_drop(key, pair=None):
+    """after a failed scan the blocks' state is unknown: the torch door forgets its pair (the tensor goes with it), the NumPy door frees it"""
     table = getattr(_unroll_pairs, "table", None)
     if table is not None:
         table.pop(key, None)
+    if pair is not None and key is not None and key[0] == "numpy":
+        try:
+            _lib.call("pm_stream_synchronize", None)  # nothing of the failed call may still be writing the blocks
+        except Exception:  # noqa: BLE001
+            pass
+        pair.free()
+
+
+def _np_pairs_trim():
+    with _np_pairs_lock:
+        pairs = [p for lst in _np_pairs_idle.values() for p in lst]
+        _np_pairs_idle.clear()
+    for p in pairs:
+        p.free()
 
 
 class NumpyBackend:
@@ -538,6 +632,8 @@ class NumpyBackend:
         self._live = []
         self._stages = []
         self._ar = None
+        self._ar_top = self._ar_in = self._ar_sent = 0
+        self._ar_out0 = self._ar_out1 = self._ar_got = 0
 
     # -- introspection
     @staticmethod
@@ -570,7 +666,9 @@ class NumpyBackend:
         self._live = []
         self._stages = []
         # the small-call arena: [0, _ar_top) is in use, [_ar_sent, _ar_in) holds staged operands not yet sent, [_ar_out0, _ar_out1) results
-        self._ar = _arena_for(self._dev) if os.environ.get("PM_NO_ARENA") != "1" else None
+        if self._ar is not None:  # (a begin() without its end(): hand the old arena back first)
+            _arenas.put(self._ar)
+        self._ar = _arenas.get(self._dev) if os.environ.get("PM_NO_ARENA") != "1" else None
         self._ar_top = self._ar_in = self._ar_sent = 0
         self._ar_out0 = self._ar_out1 = self._ar_got = 0
 
@@ -620,6 +718,9 @@ class NumpyBackend:
         return C.c_void_p(buf.ptr)
 
     def dev_out(self, shape):
+        # (operands staged in the arena go over the bus no later than here: after the first result range dev_in takes the plain path, so a
+        # launch that got its stream from somewhere else than be.stream() still finds every operand on the device)
+        self._ar_flush()
         nb = _prod(shape) * 4
         if 0 < nb and self._ar_got == 0:
             off = self._ar_take(nb)
@@ -667,16 +768,22 @@ class NumpyBackend:
 
         def make():
             ptrs = []
-            for _ in range(2):
-                d = C.c_void_p()
-                _lib.call("pm_malloc", C.byref(d), _UNROLL_WS_BYTES)
-                _lib.call("pm_memset", d, 0, _UNROLL_WS_BYTES, None)
-                ptrs.append(d.value)
-            return _UnrollPair(ptrs[0], ptrs[1], None)  # (kept for the life of the thread, like the arena)
+            try:
+                for _ in range(2):
+                    d = C.c_void_p()
+                    _lib.call("pm_malloc", C.byref(d), _UNROLL_WS_BYTES)
+                    ptrs.append(d.value)
+                    _lib.call("pm_memset", d, 0, _UNROLL_WS_BYTES, None)
+            except Exception:
+                for p in ptrs:
+                    _lib.call("pm_free", C.c_void_p(p))
+                raise
+            return _UnrollPair(ptrs[0], ptrs[1], None)  # (checked out for this call; _unroll_pair_release puts it back)
 
-        return _unroll_pair(key, nbytes, make), key
+        return _np_pair_get(self._dev, nbytes, make), key
 
     def scratch(self, nbytes):
+        self._ar_flush()
         buf = _DevBuf(max(int(nbytes), 4), self._dev)
         self._live.append((buf, None))
         return C.c_void_p(buf.ptr)
@@ -691,6 +798,7 @@ class NumpyBackend:
 
     def flags_alloc(self, n=3):
         """Zeroed device int32[n] for kernels that report batch-wide predicates."""
+        self._ar_flush()
         buf = _DevBuf(4 * n, self._dev)
         _lib.call("pm_memset", C.c_void_p(buf.ptr), 0, 4 * n, None)
         self._live.append((buf, None))
@@ -704,13 +812,17 @@ class NumpyBackend:
         return [int(v) for v in out]
 
     def end(self):
-        _lib.call("pm_stream_synchronize", None)
-        for buf, _ in self._live:
-            buf.release()
-        self._live = []
-        for st in self._stages:
-            _stage.put(st)
-        self._stages = []
+        try:
+            _lib.call("pm_stream_synchronize", None)
+        finally:
+            for buf, _ in self._live:
+                buf.release()
+            self._live = []
+            for st in self._stages:
+                _stage.put(st)
+            self._stages = []
+            ar, self._ar = self._ar, None
+            _arenas.put(ar)  # (results were copied out of it by result(): free for the next op of any thread)
 
     @staticmethod
     def host_ints(x, slot="parents"):

@@ -292,9 +292,10 @@ def _unroll_scan(be, kind, xp, order, B, T, S, op, plain):
     try:
         _lib.call("pm_unroll_onepass_f32", kind, xp, order, B, T, S, op, use, C.byref(dirtied), other, other_words, be.stream())
     except Exception:
-        _backend._unroll_pair_drop(key)  # (whatever state the blocks are in: the next call makes a fresh pair)
+        _backend._unroll_pair_drop(key, pair)  # (whatever state the blocks are in: the next call makes a fresh pair; the NumPy door's blocks are freed)
         raise
     pair.done(dirtied.value)
+    _backend._unroll_pair_release(key, pair)
 
 
 def bvh_rotations(be, euler_deg, order_table):
@@ -323,6 +324,11 @@ def bvh_rotations(be, euler_deg, order_table):
             k = np.rint(a * (1.0 / 720.0))
             k *= 720.0
             euler_deg = a - k
+    elif be.name == "torch":
+        torch = be.torch
+        if euler_deg.dtype == torch.float64 and euler_deg.numel() and float(euler_deg.abs().max()) > 360.0:
+            # the same exact wrap for float64 tensors (the two doors then agree on wound-up channels)
+            euler_deg = euler_deg - 720.0 * torch.round(euler_deg * (1.0 / 720.0))
     be.begin(euler_deg)
     try:
         xp = be.dev_in(euler_deg)

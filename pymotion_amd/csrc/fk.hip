@@ -50,6 +50,7 @@ struct FkArgs {
     int32_t pad;            // floats of padding per frame in each per-frame LDS region (0 or 4), set by dispatch_fk
     int32_t depth;          // edges on the longest root-to-leaf path: |p_j - root|_1 <= depth max_j |t_j|_1 (fixed-point scale, PREC_FX)
     int32_t wsteps;         // fk_pipe_kernel, four frames a wave: > 0 = walk the tree four JOINTS of a frame at a time over this many steps (tree_walk_w4)
+    uint64_t fmap;          // tree_walk_q4, sixteen frames a wave: nibble q = the frame quad q walks (q4_frame_map: which eight frames share a half-wave)
     Parents parents;
     uint32_t wjobs[4 * kW4Stride];  // [slot][step]: joint | parent << 16 (a slot without a joint repeats the step's first one)
 #ifdef PM_TUNING
@@ -507,7 +508,8 @@ __device__ __forceinline__ void fk_tile(const FkArgs &a, float *smem, const int6
     // Lanes >= 3*FPW shadow lanes 0.. (same frame, same row, same values, same addresses) and frames
     // past the end of a partial tile walk uninitialised slots of their own: phase B needs no masking.
     const int wl = q4 ? lane : lane % ((QUAD ? 12 : 3) * FPW);
-    const int f = q4 ? ((lane >> 2) < FPW ? (lane >> 2) : FPW - 1) : (QUAD ? wl / 12 : wl / 3);  // (q4, fewer than sixteen frames: the quads past the tile shadow its last frame and sit the walk out)
+    // (q4, sixteen frames: quad q walks frame fmap[q] -- see q4_frame_map; fewer: the quads past the tile shadow its last frame and sit the walk out)
+    const int f = q4 ? (FPW == 16 ? (int)((a.fmap >> (4 * (lane >> 2))) & 15u) : ((lane >> 2) < FPW ? (lane >> 2) : FPW - 1)) : (QUAD ? wl / 12 : wl / 3);
     const int r = q4 ? ((lane & 3) < 3 ? (lane & 3) : 2) : (QUAD ? (wl - 12 * f) / 4 : wl - 3 * f);  // (q4: lane 3 of a quad shadows lane 2's loads and sits the walk out)
     const int c = wl & 3;  // QUAD only: column of [R | p]
     const float gp = (f < nf) ? a.root_pos[f0 * 3 + f * 3 + r] : 0.0f;
@@ -783,7 +785,7 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? ((PFO && E
 
     constexpr bool Q4 = (FPW == 16 || FPW == 12 || FPW == 8) && !PFO;  // a quad per frame, L shared through DPP (tree_walk_q4; see fk_tile)
     const int wl = lane % ((QUAD ? 12 : 3) * FPW);
-    const int f = Q4 ? ((lane >> 2) < FPW ? (lane >> 2) : FPW - 1) : (QUAD ? wl / 12 : wl / 3);
+    const int f = Q4 ? (FPW == 16 ? (int)((a.fmap >> (4 * (lane >> 2))) & 15u) : ((lane >> 2) < FPW ? (lane >> 2) : FPW - 1)) : (QUAD ? wl / 12 : wl / 3);
     const int r = Q4 ? ((lane & 3) < 3 ? (lane & 3) : 2) : (QUAD ? (wl - 12 * f) / 4 : wl - 3 * f);
     const int c = wl & 3;  // QUAD only: column of [R | p]
 
@@ -1493,6 +1495,48 @@ constexpr int kFkStreamMinJ = 96, kFkStreamMinLinesJ = 64;
 constexpr int kFkWideMinJ = 100;  // fk_wide_kernel (fkwide.hip) beyond; up to here the four-frame pipelined tiles with tree_walk_w4 are the better shape on the same trees
 static bool fk_stream_wanted(const int J) { return J > 128 || (J >= kFkStreamMinJ && J % 4 == 0) || (J >= kFkStreamMinLinesJ && J % 32 == 0); }
 
+// ---- tree_walk_q4, sixteen frames a wave: which eight frames share a half-wave (round 6) -------------------------------------------------
+// Every DS instruction of that walk is a ds_read_b32 / ds_write_b32 whose 64 lanes touch the SAME joint slot of sixteen frames: lane (q, r) row r of
+// frame q's slot, i.e. float  frame * S + 9 j + 3 r + k  of the rotation image (S = 9 J + pad floats between frames) and  frame * S' + 3 j + r  of the
+// position image (S' = 3 J + pad).  The LDS serves a b32 instruction as two groups of 32 lanes over 32 banks of one dword, one cycle a group plus
+// one for every further distinct address on the busiest bank: with frames 0..7 in the first half-wave and S = 198 (J = 22) frame f + 1's row 0 sits on
+// the bank of frame f's row 2 -- 6 f + 6 -- and every row read and write of the walk takes twice its cycles (rocprofv3, round 5: SQ_LDS_BANK_CONFLICT
+// 22.7 M cycles against 23.7 M SQ_ACTIVE_INST_LDS on the headline kernel).  Which frames share a half-wave is free: quad q may walk any frame of the
+// tile.  With the EVEN frames in one half and the odd ones in the other the strides double (12 and 4 at J = 22) and the 24 addresses of a group fall on
+// 24 different banks.  The host picks, per joint count, the split with the fewest extra cycles from a few families (brute force over all 6435 splits
+// finds nothing better for any J <= 29 but J = 9 / 23, whose optimum is the fifth candidate); J = 11, 15, 17, 21, 25, 29 have no conflict-free split.
+static uint64_t q4_frame_map(const int J, const int pad) {
+    static const uint8_t kSplits[5][16] = {
+        {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15},   // blocks (rounds 4-5)
+        {0, 2, 4, 6, 8, 10, 12, 14, 1, 3, 5, 7, 9, 11, 13, 15},   // even | odd
+        {0, 1, 4, 5, 8, 9, 12, 13, 2, 3, 6, 7, 10, 11, 14, 15},   // pairs
+        {0, 3, 4, 7, 8, 11, 12, 15, 1, 2, 5, 6, 9, 10, 13, 14},
+        {0, 2, 4, 5, 7, 9, 12, 14, 1, 3, 6, 8, 10, 11, 13, 15}};
+    const int Sr = 9 * J + pad, Sp = 3 * J + pad;
+    auto extra = [](const uint8_t *fr, const int S, const int rstep) {  // extra LDS cycles of one b32 instruction over one 32-lane group
+        int addr[32][4], n[32];
+        for (int b = 0; b < 32; ++b) n[b] = 0;
+        int worst = 1;
+        for (int i = 0; i < 8; ++i)
+            for (int r = 0; r < 3; ++r) {
+                const int a = fr[i] * S + r * rstep, b = a & 31;
+                bool seen = false;
+                for (int k = 0; k < n[b]; ++k) seen = seen || addr[b][k] == a;
+                if (!seen && n[b] < 4) { addr[b][n[b]++] = a; if (n[b] > worst) worst = n[b]; }
+            }
+        return worst - 1;
+    };
+    int best = 0, best_cost = 1 << 30;
+    for (int c = 0; c < 5; ++c) {
+        const int cost = 3 * (extra(kSplits[c], Sr, 3) + extra(kSplits[c] + 8, Sr, 3)) + extra(kSplits[c], Sp, 1) + extra(kSplits[c] + 8, Sp, 1);
+        if (cost < best_cost) { best_cost = cost; best = c; }
+    }
+    best = tune_env("PM_FK_FMAP", best);  // PM_TUNING build only: 0...4
+    uint64_t m = 0;
+    for (int q = 0; q < 16; ++q) m |= (uint64_t)kSplits[best < 0 || best > 4 ? 0 : best][q] << (4 * q);
+    return m;
+}
+
 template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT, bool PAD, int PREC>
 static int launch_fk_pp(const FkArgs &a, hipStream_t s) {
     const size_t lds = ((size_t)FPW * (a.J * fk_lds_floats<SRC, PFO, QOUT>() + a.pad * (PFO ? 3 : 2)) + 4 * (a.J + 4)) * sizeof(float);
@@ -1698,6 +1742,7 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
         const int pnt = tune_env("PM_FK_PIPE3", 0);
         if (pnt > 0 && !pfo) {
             a.pad = pad3;
+            if (pick == 16) a.fmap = q4_frame_map(a.J, a.pad);
             if (pick == 20 && a.J <= 22) return dispatch_fk_pipe<20, 7, SRC>(a, vec, pfo, pnt, s);
             if (pick == 16 && a.J <= 24) return dispatch_fk_pipe<16, 6, SRC>(a, vec, pfo, pnt, s);
             if (pick == 12 && a.J <= 26) return dispatch_fk_pipe<12, 5, SRC>(a, vec, pfo, pnt, s);
@@ -1712,6 +1757,7 @@ static int dispatch_fk(const FkArgs &a_in, bool vec, bool pfo, hipStream_t s) {
     if (pick != 20 && pick != 16 && pick != 12 && pick != 8 && pick != 4) { set_error("PM_FK_FPW must be 20, 16, 12, 8 or 4"); return PM_EINVAL; }
     if ((size_t)pick * frame_bytes(pad3) + fixed > kMaxLds) pick = 4;
     a.pad = (pick == 4) ? pad12 : pad3;
+    if (pick == 16) a.fmap = q4_frame_map(a.J, a.pad);
     const size_t per_frame = frame_bytes(a.pad);
     // wide trees from 93 joints on (fkwide.hip: a wave per frame, its lanes over the joints of a host-made step list), FIRST when the list keeps
     // the quads busy -- at most 2.5 quad-steps per joint: random trees (parents[j] uniform in [0, j)) 59-70 % of the HBM spec at J = 96...128 where
@@ -1802,6 +1848,7 @@ static int fk_common(int src_kind, const float *src, const float *root_pos, cons
     a.src = src; a.root_pos = root_pos; a.offsets = offsets; a.pos = pos; a.rotmats = rotmats;
     a.quat_out = quat_out; a.F = F; a.J = J; a.eps = eps; a.pad = 0;  // set by dispatch_fk, per walk shape
     a.wsteps = 0;
+    a.fmap = 0xfedcba9876543210ull;
 #ifdef PM_TUNING
     a.times = nullptr;
     if (const char *e = getenv("PM_FK_TIMES_PTR")) a.times = reinterpret_cast<uint64_t *>(strtoull(e, nullptr, 0));

@@ -139,3 +139,110 @@ def test_device_pool_never_hands_a_block_to_another_device(monkeypatch):
     pool.put(p1, c1, dev=1)
     pool.trim()
     assert sorted(freed) == sorted([p0, p1]) and pool.cached == 0
+
+
+def _fake_allocator(monkeypatch):
+    """_lib.call with pm_malloc / pm_host_alloc / pm_free / pm_host_free backed by real host memory and counted"""
+    import ctypes as C
+
+    from pymotion_amd import _lib
+
+    live = {}
+    stats = {"dev": 0, "host": 0, "freed": []}
+
+    def fake_call(name, *args):
+        if name in ("pm_malloc", "pm_host_alloc"):
+            buf = (C.c_uint8 * int(args[1]))()
+            addr = C.addressof(buf)
+            live[addr] = buf
+            C.cast(args[0], C.POINTER(C.c_void_p))[0] = addr
+            stats["dev" if name == "pm_malloc" else "host"] += 1
+        elif name in ("pm_free", "pm_host_free"):
+            a = args[0].value if hasattr(args[0], "value") else args[0]
+            assert a in live, "freed twice or never allocated"
+            del live[a]
+            stats["freed"].append(a)
+
+    monkeypatch.setattr(_lib, "call", fake_call)
+    return live, stats
+
+
+def test_small_call_arenas_are_shared_by_threads_that_come_and_go(monkeypatch):
+    """an arena (4 MB device + 4 MB page-locked) is checked out per op and handed back, not kept per thread: fifty
+    short-lived threads leave one arena behind, and trim() frees it"""
+    import threading
+
+    from pymotion_amd import _backend
+
+    live, stats = _fake_allocator(monkeypatch)
+    pool = _backend._ArenaPool()
+    monkeypatch.setattr(_backend, "_arenas", pool)
+
+    def op():
+        a = pool.get(0)
+        assert a.host.shape == (_backend._ARENA_BYTES,)
+        pool.put(a)
+
+    for _ in range(50):
+        t = threading.Thread(target=op)
+        t.start()
+        t.join()
+    assert stats["dev"] == 1 and stats["host"] == 1
+    a, b = pool.get(0), pool.get(0)          # two ops in flight at once: two arenas
+    assert a is not b and stats["dev"] == 2
+    c = pool.get(1)                          # another device never takes device 0's
+    assert c.dev == 1 and stats["dev"] == 3
+    for x in (a, b, c):
+        pool.put(x)
+    pool.trim()
+    assert not live and len(stats["freed"]) == 6
+    d = pool.get(0)                          # one that is never handed back frees itself
+    del d
+    import gc
+
+    gc.collect()
+    assert not live
+
+
+def test_numpy_door_unroll_pairs_are_pooled_and_freed_on_failure(monkeypatch):
+    """the one-pass scans' workspace pair of the NumPy door is checked out of a process-wide list per call; a failed
+    call frees its blocks instead of dropping them"""
+    import threading
+
+    from pymotion_amd import _backend
+
+    live, stats = _fake_allocator(monkeypatch)
+    monkeypatch.setattr(_backend, "_np_pairs_idle", {})
+
+    def make():
+        import ctypes as C
+
+        ptrs = []
+        for _ in range(2):
+            d = C.c_void_p()
+            _backend._lib.call("pm_malloc", C.byref(d), 1 << 10)
+            ptrs.append(d.value)
+        return _backend._UnrollPair(ptrs[0], ptrs[1], None)
+
+    key = ("numpy", 0)
+
+    def scan():
+        p = _backend._np_pair_get(0, 100, make)
+        use, other, words = p.take()
+        p.done(7)
+        _backend._unroll_pair_release(key, p)
+
+    for _ in range(20):
+        t = threading.Thread(target=scan)
+        t.start()
+        t.join()
+    assert stats["dev"] == 2                          # one pair for all of them
+    p = _backend._np_pair_get(0, 100, make)
+    assert p.dirty[1 - p.cur] in (0, 7) and stats["dev"] == 2   # and its alternation state travelled with it
+    _backend._unroll_pair_drop(key, p)                # a failed scan
+    assert len(live) == 0 and len(stats["freed"]) == 2
+    assert _backend._np_pair_get(0, _backend._UNROLL_WS_BYTES + 1, make) is None   # too big for a pair: the plain entry point
+    q = _backend._np_pair_get(0, 100, make)
+    _backend._unroll_pair_release(key, q)
+    _backend._np_pairs_trim()
+    assert not live
