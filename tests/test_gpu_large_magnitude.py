@@ -415,3 +415,83 @@ def test_root_dual_quaternions_raw_abi_with_and_without_the_scale_hint(J, kind):
     if kind == "body":  # (random trees may hold more open branch points than the lane-per-frame kernel's register slots: they stay on the tile kernels)
         assert "ring_kernel" in names[1] or "deep_kernel" in names[1], names  # the hint routes big bones to the lane-per-frame kernel
     assert names[0] == names[2] == names[3] and "ring_kernel" not in names[0] and "deep_kernel" not in names[0], names
+
+
+@pytest.mark.parametrize("J", [110, 130])
+def test_root_dual_quaternions_on_the_deep_chains_the_fuzz_run_found(J):
+    """round 5's randomised fuzz runs read 4.1 ulp on a 110-joint skeleton of two 55-deep chains of 30-unit bones and 3.6 ulp on a 65-deep one
+    (gpurun_out/dq_fuzz_fail.txt: the tile kernels' precise step rotates each bone in fp32, one rounding a joint, a random walk down the chain).
+    Pinned here, seeded, batch shapes that fill one tile and several: the law INTEGRATION.md states for to_root_dual_quat,
+
+        |error| <= max(1e-5, 3 ulp_fp32(largest |component|)) x max(1, depth / 32),
+
+    and the measured worst case in ulps printed beside it."""
+    import pymotion_amd.ops.skeleton as sk
+
+    par = np.maximum(np.arange(J) - 1, 0).astype(np.int32)
+    par[J // 2] = 0                                   # two chains off the root, as tests/test_gpu_fuzz.py::wide_skeletons draws them
+    depth = J // 2
+    worst = 0.0
+    for seed in range(8):
+        for lead in ((1,), (17,), (130,)):
+            rng = np.random.default_rng(1000 * J + seed)
+            rot = rng.standard_normal(lead + (J, 4))
+            rot = (rot / np.linalg.norm(rot, axis=-1, keepdims=True)).astype(np.float32)
+            gpos = (rng.uniform(-7, 7, lead + (3,)) * 30.0).astype(np.float32)
+            off = (rng.uniform(-1, 1, (J, 3)) * 30.0).astype(np.float32)
+            off[0] = 0
+            d = sk.to_root_dual_quat(rot, gpos, par, off)
+            d_o = co.to_root_dual_quat(rot.astype(np.float64), gpos.astype(np.float64), par, off.astype(np.float64))
+            ulp = _ulp_of(d_o)
+            err = np.abs(d - d_o).max()
+            worst = max(worst, err / ulp)
+            assert err <= max(1e-5, 3 * ulp) * max(1.0, depth / 32.0), (seed, lead, err, err / ulp, "ulp")
+            assert np.abs(d[..., :4] - d_o[..., :4]).max() <= 2e-7   # the float64 quaternion chain: the real part to fp32 rounding
+    print(f"J={J} depth={depth}: worst {worst:.2f} ulp of the largest component (bar {3 * max(1.0, depth / 32.0):.2f})")
+
+
+# which walks give an all-NaN ROOT matrix for a root quaternion with an infinite component (INTEGRATION.md, "Which kernel a call takes"):
+# the reference's to_matrix((nan, 0, 0, 0)) keeps 1 on the diagonal (quat.py:293-315: 1 - (0 + 0)) and copies that matrix into the root's
+# transform as it is (skeleton.py:46-49).  Walks in which the root takes NO step (four joints of a frame at a time, a wave per frame) do the
+# same; walks that run the root through the common step multiply it with the seed row e_r, and 0 x NaN = NaN fills the row.
+_INF_ROOT_CASES = [  # (J, kind, F, kernel-name fragment, root matrix like the reference?)
+    (6, "random", 4000, "fk_kernel<16", False),
+    (22, "body", 4000, "fk_kernel<16", False),
+    (36, "chain", 4000, "fk_kernel<8", False),
+    (52, "smplh", 4000, "fk_pipe_kernel<4, 4", True),     # tree_walk_w4: the root's slot holds L_0 as parked
+    (60, "chain", 4000, "fk_pipe_kernel<4, 4", False),    # a chain keeps the twelve-lane walk (seed row)
+    (200, "random", 600, "fk_wide_kernel", True),
+    (256, "chain", 4200, "fk_stream_kernel", False),
+]
+
+
+@pytest.mark.parametrize("J,kind,F,kernel,like_reference", _INF_ROOT_CASES)
+def test_infinite_root_quaternion_which_kernels_keep_the_reference_diagonal(J, kind, F, kernel, like_reference):
+    import pymotion_amd.ops.skeleton as sk
+
+    parents = {"body": syn.PARENTS_22, "smplh": syn.PARENTS_52, "chain": _chain(J)}.get(kind)
+    if parents is None:
+        parents = syn.random_parents(J, np.random.default_rng(J))
+    rng = np.random.default_rng(J)
+    rot = rng.standard_normal((F, J, 4)).astype(np.float32)
+    root = rng.uniform(-2, 2, (F, 3)).astype(np.float32)
+    off = rng.uniform(-0.3, 0.3, (J, 3)).astype(np.float32)
+    off[0] = 0
+    f = F // 3
+    rot[f, 0] = (np.inf, 0.0, 0.0, 0.0)
+    with np.errstate(all="ignore"):
+        p_o, r_o = _oracle(rot, root, off, parents)
+    pos, rm = sk.fk(rot, root, off, parents)
+    assert kernel in _lib.last_kernel_name(), _lib.last_kernel_name()
+    want = r_o[f, 0]
+    assert np.isnan(want).sum() == 6 and (np.diag(want) == 1).all()          # the reference: NaN off the diagonal, 1 on it
+    if like_reference:
+        assert (np.isnan(rm[f, 0]) == np.isnan(want)).all() and (np.diag(rm[f, 0]) == 1).all()
+    else:
+        assert np.isnan(rm[f, 0]).all()                                        # the stated divergence, on these kernels only
+    # everything else is the reference's either way: the root's position, every joint below it (NaN x anything), the other frames
+    np.testing.assert_array_equal(pos[f, 0].astype(np.float32), root[f])
+    assert np.isnan(rm[f, 1:]).all() and np.isnan(r_o[f, 1:]).all()
+    others = np.arange(F) != f
+    assert np.abs(rm[others] - r_o[others]).max() <= 2e-6 * max(1.0, J / 12.0)
+    assert (np.isnan(pos[others]) == np.isnan(p_o[others])).all()

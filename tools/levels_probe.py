@@ -28,12 +28,13 @@ sys.path.insert(0, ROOT)
 
 SECONDS = float(os.environ.get("LP_SECONDS", "2.5"))
 PMC_SETS = [
-    "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_WRITE_REQ_LATENCY_sum TCP_TCC_WRITE_REQ_sum GRBM_GUI_ACTIVE",
     "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS_sum GRBM_GUI_ACTIVE",
     "TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_LEVEL_sum TCC_EA0_WRREQ_sum GRBM_GUI_ACTIVE",
     "TCC_EA0_WRREQ_STALL_sum TCC_TAG_STALL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum GRBM_GUI_ACTIVE",
-    "TCP_TCP_LATENCY_sum TCP_TA_TCP_STATE_READ_sum TCP_UTCL1_TRANSLATION_MISS_UNDER_MISS_sum TCP_UTCL1_STALL_INFLIGHT_MAX_sum GRBM_UTCL2_BUSY GRBM_GUI_ACTIVE",
-]
+    "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_sum GRBM_GUI_ACTIVE",
+    "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_BUSY_sum GRBM_GUI_ACTIVE",
+    "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCR_TCP_STALL_CYCLES_sum GRBM_GUI_ACTIVE",
+]  # (TCP_TCC_READ_REQ_LATENCY_sum / TCP_TCC_WRITE_REQ_LATENCY_sum: that pass never finished on two boxes -- left out)
 
 
 # ---------------------------------------------------------------------------------------------------------------- child
@@ -127,12 +128,15 @@ def child(pmc_mode):
         return us, w
 
     if pmc_mode:
-        for J, F, par in ((22, 1 << 20, syn.PARENTS_22), (52, 1 << 18, syn.PARENTS_52)):
-            fk, cp, keep = workload(J, F, par)
-            for _ in range(40): fk()
-            for _ in range(40): cp()
-            torch.cuda.synchronize()
-            del keep
+        # (one warm-up workload first so that the three J = 52 sets are allocations made "later", like the slow ones of the timing mode)
+        fk, cp, keep22 = workload(22, 1 << 20, syn.PARENTS_22)
+        for _ in range(5): fk()
+        sets = [workload(52, 1 << 18, syn.PARENTS_52) for _ in range(3)]
+        for rep in range(2):
+            for fk, cp, keep in sets:
+                for _ in range(20): fk()
+                torch.cuda.synchronize()
+        print("PMCSETS " + json.dumps([[hex(t.data_ptr()) for t in keep[:5] if hasattr(t, "data_ptr")] for _, _, keep in sets]), flush=True)
         return
     smp = Sampler(); smp.start()
     rec = {"pid": os.getpid()}
@@ -149,14 +153,22 @@ def child(pmc_mode):
         rec[f"fk{J}_us"], rec[f"fk{J}_clk"] = round(us, 2), w
         us, w = sustained(cp, SECONDS, smp)
         rec[f"copy{J}_us"], rec[f"copy{J}_clk"] = round(us, 2), w
-    # the J = 52 kernel on allocations made later in the same process (earlier ones stay alive)
-    later = []
+    # the J = 52 kernel on allocations made later in the same process (earlier ones stay alive), then every set AGAIN in the same order:
+    # is the level the allocation's (it comes back with the set) or the moment's (it follows the clock / the time under load)?
+    sets = [(fk, keep)]
     for _ in range(2):
-        fk, cp, keep = workload(52, 1 << 18, syn.PARENTS_52)
-        keepalive.append(keep)
-        later.append(round(sustained(fk, 0.5)[0], 2))
-    rec["fk52_us_later_allocations"] = later
-    # and the FIRST set again (did the process drift, or is it the allocation?)
+        fk2, cp2, keep2 = workload(52, 1 << 18, syn.PARENTS_52)
+        keepalive.append(keep2)
+        sets.append((fk2, keep2))
+    visits = []
+    for rep in range(3):
+        for si, (f, keep) in enumerate(sets):
+            us, w = sustained(f, 0.8, smp)
+            visits.append({"set": si, "us": round(us, 2), "gfx": w.get("current_gfxclks"), "W": w.get("current_socket_power"), "n": w.get("n"),
+                           "Thot": w.get("temperature_hotspot"), "Tmem": w.get("temperature_mem")})
+    rec["fk52_visits"] = visits
+    rec["fk52_us_later_allocations"] = [v["us"] for v in visits[1:3]]
+    rec["fk52_set_pointers"] = [[hex(t.data_ptr()) for t in keep[:5] if hasattr(t, "data_ptr")] for _, keep in sets]
     smp.stop_flag = True
     rec["sampler_error"] = smp.err
     rec["samples"] = len(smp.samples)
@@ -173,11 +185,14 @@ def run_children(n):
             print(f"process {i}: no record (rc {r.returncode}) {r.stderr[-400:]}", flush=True)
             continue
         rec = json.loads(line[7:]); recs.append(rec)
+        print("RAW " + line[7:], flush=True)
         c22, c52 = rec.get("fk22_clk") or {}, rec.get("fk52_clk") or {}
         print(f"process {i}: fk22 {rec['fk22_us']:.1f} us (copy {rec['copy22_us']:.1f}) gfx {c22.get('current_gfxclks')} uclk {c22.get('current_uclk')} soc "
               f"{c22.get('current_socclks')} W {c22.get('current_socket_power')} n {c22.get('n')} | fk52 {rec['fk52_us']:.1f} us (copy {rec['copy52_us']:.1f}; later "
               f"allocations {rec['fk52_us_later_allocations']}) gfx {c52.get('current_gfxclks')} uclk {c52.get('current_uclk')} soc {c52.get('current_socclks')} "
               f"W {c52.get('current_socket_power')} n {c52.get('n')}", flush=True)
+        print("   fk52 by allocation set, visited in turn: " + "  ".join(f"set{v['set']} {v['us']:.1f}us gfx {v['gfx']} W {v['W']} Tmem {v['Tmem']}" for v in rec.get("fk52_visits", [])), flush=True)
+        print("   pointers (src, root, off, pos, rotmats) per set: " + str(rec.get("fk52_set_pointers")), flush=True)
         time.sleep(1.0)
     return recs
 
@@ -216,24 +231,30 @@ def run_pmc(n):
         d = f"/tmp/lp/p{i}"
         subprocess.run(["rm", "-rf", d])
         env = dict(os.environ, PYTHONPATH=ROOT, TMPDIR="/tmp")
-        cmd = ["rocprofv3", "--kernel-trace", "--pmc", *cset.split(), "-d", d, "-o", "q", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__), "--child", "--pmc"]
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd="/tmp", env=env)
-        dur, cnt = {}, {}
+        cmd = ["rocprofv3", "--kernel-trace", "--kernel-include-regex", "pm::", "--pmc", *cset.split(), "-d", d, "-o", "q", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__), "--child", "--pmc"]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=float(os.environ.get("LP_PMC_TIMEOUT", "150")), cwd="/tmp", env=env)
+        except subprocess.TimeoutExpired:
+            print(f"pmc process {i} ({cset.split()[0]} ...): timed out", flush=True); continue
+        rows, tr = [], {}
         for path in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
             for row in csv.DictReader(open(path, newline="")):
-                nm = row["Kernel_Name"]
-                if "pm::" not in nm: continue
-                dur.setdefault(short(nm, row.get("Grid_Size", "")), []).append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
+                if "fk_pipe_kernel" in row["Kernel_Name"]:
+                    tr[row.get("Dispatch_Id")] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
+        cnt = {}
         for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(path, newline="")):
-                nm = row["Kernel_Name"]
-                if "pm::" not in nm: continue
-                cnt.setdefault(short(nm, row.get("Grid_Size", "")), {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-        if not cnt:
-            print(f"pmc process {i}: nothing collected (rc {r.returncode}) {r.stderr[-300:]}", flush=True); continue
-        for k in sorted(cnt):
-            if len(dur.get(k, [])) < 20: continue
-            rec = {"proc": i, "kernel": k, "us": round(statistics.median(dur[k]), 2), **{c: statistics.median(v) for c, v in cnt[k].items()}}
+                if "fk_pipe_kernel" in row["Kernel_Name"]:
+                    cnt.setdefault(int(row["Dispatch_Id"]), {})[row["Counter_Name"]] = float(row["Counter_Value"])
+        ids = sorted(cnt)
+        if len(ids) < 120:
+            print(f"pmc process {i} ({cset.split()[0]} ...): {len(ids)} dispatches collected (rc {r.returncode}) {r.stderr[-200:]}", flush=True); continue
+        ids = ids[-120:]  # three sets x 20 launches, twice
+        for seg in range(6):
+            seg_ids = ids[20 * seg + 5:20 * seg + 20]  # (the first launches of a visit run on the clocks of the one before)
+            rec = {"proc": i, "kernel": f"fk52 set{seg % 3} visit{seg // 3}", "us": round(statistics.median(tr.get(str(x), float("nan")) for x in seg_ids), 2)}
+            for c in cnt[seg_ids[0]]:
+                rec[c] = statistics.median(cnt[x].get(c, float("nan")) for x in seg_ids)
             table.append(rec)
             print("PMC " + json.dumps(rec), flush=True)
     # derived per-request figures
@@ -246,7 +267,9 @@ def run_pmc(n):
                  "wr_latency_cycles_per_req": ratio("TCP_TCC_WRITE_REQ_LATENCY_sum", "TCP_TCC_WRITE_REQ_sum"),
                  "utcl1_miss_per_request": ratio("TCP_UTCL1_TRANSLATION_MISS_sum", "TCP_UTCL1_REQUEST_sum"),
                  "ea_rd_level_per_req": ratio("TCC_EA0_RDREQ_LEVEL_sum", "TCC_EA0_RDREQ_sum"),
-                 "ea_wr_level_per_req": ratio("TCC_EA0_WRREQ_LEVEL_sum", "TCC_EA0_WRREQ_sum")}
+                 "ea_wr_level_per_req": ratio("TCC_EA0_WRREQ_LEVEL_sum", "TCC_EA0_WRREQ_sum"),
+                 "rd_dram_fraction": ratio("TCC_EA0_RDREQ_DRAM_sum", "TCC_EA0_RDREQ_sum"), "wr_dram_fraction": ratio("TCC_EA0_WRREQ_DRAM_sum", "TCC_EA0_WRREQ_sum"),
+                 "tcc_hit_rate": ratio("TCC_HIT_sum", "TCC_REQ_sum")}
         print(rec["proc"], rec["kernel"], rec["us"], {k: v for k, v in extra.items() if v is not None})
 
 
