@@ -66,6 +66,10 @@ def parse():
     ap.add_argument("--oracle-slice-frames", type=int, default=1 << 16,
                     help="N>1: frames of its own shard every rank checks against the CPU oracle (SURVEY 8d config 5: 2^16)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--batches", type=int, default=0,
+                    help="independently allocated synthetic batches the steps cycle through (step i takes batch i %% B); 0 = 3 up to 2^21 frames per GPU, "
+                         "1 beyond.  A launch's time depends on WHERE the allocator put its arrays (profiles/r06_levels.txt: 150 or 167 us on the "
+                         "same J = 52 kernel, allocation by allocation): with several batches ms_per_step averages over placements instead of drawing one")
     return ap.parse_args()
 
 
@@ -194,32 +198,41 @@ def secondary_configs(torch, _lib, syn, dev, rot, root, off, parents, sptr):
                                    "root": float((tr[:, 0] - root).abs().max())},
     }
     del dq, tr, qo, rotn
+    # configs[3] on THREE independently allocated sets of arrays: a launch's time follows the placement of its arrays (profiles/r06_levels.txt:
+    # the same kernel reads 150 us on one set and 167 us on the next, visit after visit), so `ms` is the mean over the placements and
+    # `ms_by_placement` says what each one read
     F4, par52 = 1 << 18, syn.PARENTS_52
-    x = torch.randn((F4, 52, 3, 2), device=dev)
-    root4 = torch.rand((F4, 3), device=dev) * 4 - 2
     off4 = torch.from_numpy(syn.make_offsets(52, np.random.default_rng(4), 0.15)).to(dev)
-    pos4 = torch.empty((F4, 52, 3), device=dev)
-    rm4 = torch.empty((F4, 52, 3, 3), device=dev)
     pp4 = par52.ctypes.data_as(C.c_void_p)
-    t4 = timed(lambda: _lib.call("pm_fk_from_ortho6d_f32", p(x), p(root4), p(off4), 0, pp4, F4, 52, C.c_float(0.0), p(pos4), p(rm4),
-                                 None, sptr))
-    out["fused_ortho6d_fk_J52"] = {"frames": F4, "ms": t4, "frames_per_s": F4 / (t4 * 1e-3),
+    sets4 = []
+    for b in range(3):
+        sets4.append({"x": torch.randn((F4, 52, 3, 2), device=dev), "root": torch.rand((F4, 3), device=dev) * 4 - 2,
+                      "pos": torch.empty((F4, 52, 3), device=dev), "rm": torch.empty((F4, 52, 3, 3), device=dev),
+                      "q": torch.empty((F4, 52, 4), device=dev), "big": torch.empty(F4 * 52 * 12, device=dev)})
+
+    def over_sets(make):
+        ts = [timed(make(d)) for d in sets4]
+        return sum(ts) / len(ts), ts
+
+    t4, t4s = over_sets(lambda d: (lambda: _lib.call("pm_fk_from_ortho6d_f32", p(d["x"]), p(d["root"]), p(off4), 0, pp4, F4, 52, C.c_float(0.0),
+                                                       p(d["pos"]), p(d["rm"]), None, sptr)))
+    out["fused_ortho6d_fk_J52"] = {"frames": F4, "ms": t4, "ms_by_placement": t4s, "frames_per_s": F4 / (t4 * 1e-3),
                                    "hbm_frac": F4 * (72 * 52 + 12) / (t4 * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-    q4 = torch.empty((F4, 52, 4), device=dev)
-    t4q = timed(lambda: _lib.call("pm_fk_from_ortho6d_f32", p(x), p(root4), p(off4), 0, pp4, F4, 52, C.c_float(0.0), p(pos4), p(rm4),
-                                  p(q4), sptr))
-    out["fused_ortho6d_fk_J52_quat_out"] = {"frames": F4, "ms": t4q, "frames_per_s": F4 / (t4q * 1e-3),
+    t4q, t4qs = over_sets(lambda d: (lambda: _lib.call("pm_fk_from_ortho6d_f32", p(d["x"]), p(d["root"]), p(off4), 0, pp4, F4, 52, C.c_float(0.0),
+                                                         p(d["pos"]), p(d["rm"]), p(d["q"]), sptr)))
+    out["fused_ortho6d_fk_J52_quat_out"] = {"frames": F4, "ms": t4q, "ms_by_placement": t4qs, "frames_per_s": F4 / (t4q * 1e-3),
                                             "hbm_frac": F4 * (88 * 52 + 12) / (t4q * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-    t52 = timed(lambda: _lib.call("pm_fk_f32", p(q4), p(root4), p(off4), 0, pp4, F4, 52, p(pos4), p(rm4), sptr))
-    # the copy kernel of fk's own shape at this joint count, in this process: the J = 52 kernels read 0.65 or 0.70-0.72 by the process (a state
-    # of the box, profiles/r05_fk_mode_probe.txt) while this pure stream does not move -- the ratio says which level a run was on
-    big52 = torch.empty(F4 * 52 * 12, device=dev)
-    t52c = timed(lambda: _lib.call("pm_stream_ceiling_f32", p(q4), p(big52), F4, 4 * 52, 12 * 52, sptr))
-    del big52
-    out["fk_J52"] = {"frames": F4, "ms": t52, "frames_per_s": F4 / (t52 * 1e-3),
+    t52, t52s = over_sets(lambda d: (lambda: _lib.call("pm_fk_f32", p(d["q"]), p(d["root"]), p(off4), 0, pp4, F4, 52, p(d["pos"]), p(d["rm"]), sptr)))
+    # the copy kernel of fk's own shape at this joint count on the same arrays (it follows the placement too, half as much)
+    t52c, t52cs = over_sets(lambda d: (lambda: _lib.call("pm_stream_ceiling_f32", p(d["q"]), p(d["big"]), F4, 4 * 52, 12 * 52, sptr)))
+    out["fk_J52"] = {"frames": F4, "ms": t52, "ms_by_placement": t52s, "frames_per_s": F4 / (t52 * 1e-3),
                      "hbm_frac": F4 * (64 * 52 + 12) / (t52 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                     "copy_ceiling_ms": t52c, "copy_ceiling_hbm_frac": F4 * 64 * 52 / (t52c * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "copy_ceiling_ms": t52c, "copy_ceiling_ms_by_placement": t52cs,
+                     "copy_ceiling_hbm_frac": F4 * 64 * 52 / (t52c * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "kernel_over_copy_ceiling": t52 / t52c}
+    x, root4, pos4, rm4, q4 = (sets4[0][k] for k in ("x", "root", "pos", "rm", "q"))
+    for d in sets4:
+        del d["big"]
     # from_root_positions (positions -> local rotations) on the fk output just made: SMPL-H's 52-joint table AS STORED
     # (level order -- round 3: 30.5 % on the two-chain tile kernel) on the operation-driven lane-per-frame kernel, 28 J B per frame
     ik4 = torch.empty((F4, 52, 4), device=dev)
@@ -227,7 +240,7 @@ def secondary_configs(torch, _lib, syn, dev, rot, root, off, parents, sptr):
     t_ik = timed(lambda: _lib.call("pm_from_root_positions_f32", p(pos4), pp4, p(off4), F4, 52, p(ik4), sptr))
     out["from_root_positions_J52_level_order"] = {"frames": F4, "ms": t_ik, "frames_per_s": F4 / (t_ik * 1e-3),
                                                    "hbm_frac": F4 * 28 * 52 / (t_ik * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel": _lib.last_kernel_name()}
-    del x, root4, off4, pos4, rm4, q4, ik4
+    del x, root4, off4, pos4, rm4, q4, ik4, sets4
     # a LONG, chain-like skeleton (128 joints: one chain, a second one off the root, a third off joint 32; 2^18 frames): what the
     # tile kernels are worst at (round 2: to_root_dual_quat 31 %, fk 46 %).  to_root_dual_quat: the lane-per-frame kernel of deep.hip.
     F5, J5 = 1 << 18, 128
@@ -625,25 +638,32 @@ def main():
                 one_gpu = {"error": repr(exc)[:300]}
             torch.cuda.empty_cache()
         dist.barrier()
-    # synthetic workload born on the device from (seed, rank): no host->device copy is ever timed
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(a.seed * 1000 + rank)
-    rot = torch.randn((F, J, 4), generator=gen, device=dev, dtype=torch.float32)
-    root = torch.rand((F, 3), generator=gen, device=dev, dtype=torch.float32) * 4 - 2
+    # synthetic workload born on the device from (seed, rank): no host->device copy is ever timed.  B batches, each its own allocations
+    # (see --batches); batch 0 is the one every check below reads
+    NB = a.batches if a.batches > 0 else (3 if F <= (1 << 21) else 1)
     off_np = syn.make_offsets(J, np.random.default_rng(a.seed), 0.3 if J == 22 else 0.15)
     off = torch.from_numpy(off_np).to(dev)
     par_t = torch.from_numpy(parents)
-
-    # steady-state launch path = what skeleton_torch.fk does after its tensor plumbing: one C-ABI call
-    pos = torch.empty((F, J, 3), device=dev, dtype=torch.float32)
-    rm = torch.empty((F, J, 3, 3), device=dev, dtype=torch.float32)
+    batches = []
+    for b in range(NB):
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(a.seed * 1000 + rank + 7919 * b)
+        rot_b = torch.randn((F, J, 4), generator=gen, device=dev, dtype=torch.float32)
+        root_b = torch.rand((F, 3), generator=gen, device=dev, dtype=torch.float32) * 4 - 2
+        # steady-state launch path = what skeleton_torch.fk does after its tensor plumbing: one C-ABI call
+        pos_b = torch.empty((F, J, 3), device=dev, dtype=torch.float32)
+        rm_b = torch.empty((F, J, 3, 3), device=dev, dtype=torch.float32)
+        batches.append((rot_b, root_b, pos_b, rm_b))
+    rot, root, pos, rm = batches[0]
     stream = torch.cuda.current_stream(dev)
     sptr = C.c_void_p(stream.cuda_stream)
     pp = parents.ctypes.data_as(C.c_void_p)
+    calls = [(C.c_void_p(r.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(p.data_ptr()), C.c_void_p(m.data_ptr())) for r, g, p, m in batches]
+    offp = C.c_void_p(off.data_ptr())
 
-    def step():
-        _lib.call("pm_fk_f32", C.c_void_p(rot.data_ptr()), C.c_void_p(root.data_ptr()), C.c_void_p(off.data_ptr()), 0, pp,
-                  F, J, C.c_void_p(pos.data_ptr()), C.c_void_p(rm.data_ptr()), sptr)
+    def step(i=0):
+        r, g, p, m = calls[i % NB]
+        _lib.call("pm_fk_f32", r, g, offp, 0, pp, F, J, p, m, sptr)
 
     # the public front door (tensor plumbing + the same kernel on a small batch) and the raw C-ABI call used
     # in the timed loop must agree to fp32 rounding
@@ -660,21 +680,21 @@ def main():
     if a.prewarm_ms > 0:  # DVFS settling: untimed, not part of W or K
         tp = time.perf_counter()
         while (time.perf_counter() - tp) * 1e3 < a.prewarm_ms:
-            for _ in range(20):
-                step()
+            for i in range(20):
+                step(i)
             torch.cuda.synchronize()
     ev0, ev1 = C.c_void_p(), C.c_void_p()
     _lib.call("pm_event_create", C.byref(ev0))
     _lib.call("pm_event_create", C.byref(ev1))
     barrier()  # a warm one: an idle gap of >= 3 ms before the timed region would cost ~20 ms of re-ramp
-    for _ in range(a.warmup):
-        step()
+    for i in range(a.warmup):
+        step(i)
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
     _lib.call("pm_event_record", ev0, sptr)
-    for _ in range(a.steps):
-        step()
+    for i in range(a.steps):
+        step(i)
     _lib.call("pm_event_record", ev1, sptr)
     torch.cuda.synchronize()
     barrier()
@@ -708,6 +728,33 @@ def main():
         et = torch.tensor([err], device=cdev, dtype=torch.float64)
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
         extra["max_abs_err_vs_oracle_slice"] = {"value": float(et[0]), "frames_per_rank": n_chk}
+    by_batch = None
+    if NB > 1 and not shared:
+        # outside the timed region: every batch on its own (same events, 30 launches each) -- the spread IS the placement lottery -- and a slice of
+        # every other batch against the oracle (batch 0 is checked on all its frames below)
+        by_batch = []
+        for b in range(NB):
+            for _ in range(5):
+                step(b)
+            _lib.call("pm_event_record", ev0, sptr)
+            for _ in range(30):
+                step(b)
+            _lib.call("pm_event_record", ev1, sptr)
+            _lib.call("pm_event_elapsed_ms", ev0, ev1, C.byref(ms))
+            by_batch.append(ms.value / 30)
+        if world == 1:
+            try:
+                from oracle import c_oracle as co
+
+                worst = 0.0
+                for b in range(1, NB):
+                    rb, gb, pb, mb = batches[b]
+                    sl = slice(F // 3, F // 3 + min(F - F // 3, 1 << 14))
+                    p_o, r_o = co.fk(rb[sl].cpu().numpy().astype(np.float64), gb[sl].cpu().numpy().astype(np.float64), off_np.astype(np.float64), parents)
+                    worst = max(worst, float(np.abs(pb[sl].cpu().numpy() - p_o).max()), float(np.abs(mb[sl].cpu().numpy() - r_o).max()))
+                extra["max_abs_err_other_batches_vs_oracle_slice"] = worst
+            except Exception as exc:  # noqa: BLE001
+                extra["max_abs_err_other_batches_vs_oracle_slice"] = repr(exc)[:200]
     ceil = None
     if world == 1 and not a.no_secondary:
         ceil = stream_ceilings(torch, _lib, dev, rot, rm, F, J, sptr)
@@ -749,13 +796,18 @@ def main():
             "data": "synthetic",
             "prewarm_ms": a.prewarm_ms,
             "config": {"workload": "fk: %d frames x %d joints per GPU, fp32 (%s)" % (F, J, workload),
-                       "frames_per_gpu": F, "frames_total": F * world, "joints": J, "sharding": "frames, no data-path collective"},
+                       "frames_per_gpu": F, "frames_total": F * world, "joints": J, "sharding": "frames, no data-path collective",
+                       "batches": NB},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes": bytes_per_frame * F,
                          "kernel": kernel_name, "kernel_ms": kern_ms,
                          "bytes_per_frame": bytes_per_frame},
         }
+        if by_batch is not None:
+            # (the steps of the timed region cycle through these batches: kernel_ms is their mean; a launch's time follows the placement of
+            # its arrays -- profiles/r06_levels.txt)
+            line["roofline"]["kernel_ms_by_batch"] = by_batch
         if one_gpu is not None:
             line["one_gpu_same_total"] = one_gpu
             if "frames_per_s" in one_gpu:

@@ -64,6 +64,16 @@ __device__ __forceinline__ int64_t xcd_tile(int64_t ntiles) {
     return t < ntiles ? t : -1;
 }
 
+// The same with the XCDs' ranges cut into CHUNKS of `chunk` tiles that take turns: XCD x owns tiles [(8 c + x) chunk, (8 c + x + 1) chunk) for
+// c = 0, 1, ... -- neighbours inside a chunk still share an L2, but the eight XCDs sweep ONE window of the arrays together (8 chunk tiles wide)
+// instead of eight windows an eighth of the array apart.  chunk <= 0: the contiguous eighths of xcd_tile.
+__device__ __forceinline__ int64_t xcd_tile_chunked(const int64_t ntiles, const int chunk) {
+    if (chunk <= 0) return xcd_tile(ntiles);
+    const int64_t b = blockIdx.x, i = b / PM_NXCD, c = i / chunk;
+    const int64_t t = (c * PM_NXCD + (b % PM_NXCD)) * chunk + (i - c * chunk);
+    return t < ntiles ? t : -1;
+}
+
 // ---- DPP arithmetic inside a quad (4 consecutive lanes): register-to-register, no LDS ---------------
 // quad_perm:[a,b,c,d] = lane i of every quad reads the operand of lane {a,b,c,d}[i] of the same quad.  The
 // exchange rides on the DPP operand of the multiply(-add) itself (inline asm: the compiler would emit a

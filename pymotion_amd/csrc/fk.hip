@@ -50,6 +50,8 @@ struct FkArgs {
     int32_t pad;            // floats of padding per frame in each per-frame LDS region (0 or 4), set by dispatch_fk
     int32_t depth;          // edges on the longest root-to-leaf path: |p_j - root|_1 <= depth max_j |t_j|_1 (fixed-point scale, PREC_FX)
     int32_t wsteps;         // fk_pipe_kernel, four frames a wave: > 0 = walk the tree four JOINTS of a frame at a time over this many steps (tree_walk_w4)
+    int32_t xchunk;         // tiles (fk_kernel) / tile groups (fk_pipe_kernel) per XCD chunk, 0 = one contiguous eighth per XCD (xcd_tile_chunked)
+    int32_t pad2_;
     uint64_t fmap;          // tree_walk_q4, sixteen frames a wave: nibble q = the frame quad q walks (q4_frame_map: which eight frames share a half-wave)
     Parents parents;
     uint32_t wjobs[4 * kW4Stride];  // [slot][step]: joint | parent << 16 (a slot without a joint repeats the step's first one)
@@ -694,7 +696,7 @@ template <int FPW, bool VEC, bool PFO, int SRC, bool QOUT, bool PAD, int PREC>
 __global__ __launch_bounds__(PM_WAVE) void fk_kernel(const FkArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
-    const int64_t tile = PM_ABLATED(a, 4) ? ((int64_t)blockIdx.x < ntiles ? (int64_t)blockIdx.x : -1) : xcd_tile(ntiles);  // tuning: linear tile order
+    const int64_t tile = PM_ABLATED(a, 4) ? ((int64_t)blockIdx.x < ntiles ? (int64_t)blockIdx.x : -1) : xcd_tile_chunked(ntiles, a.xchunk);  // tuning: linear tile order
     if (tile < 0) return;
     const int64_t f0 = tile * FPW;
     const int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
@@ -726,7 +728,8 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? ((PFO && E
     const int J = a.J;
     const int FJ = FPW * J;
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
-    const int64_t group = xcd_tile((ntiles + nt - 1) / nt);
+    const int64_t ngroups_ = (ntiles + nt - 1) / nt;
+    const int64_t group = PM_ABLATED(a, 4) ? ((int64_t)blockIdx.x < ngroups_ ? (int64_t)blockIdx.x : -1) : xcd_tile_chunked(ngroups_, a.xchunk);  // tuning: linear group order
     if (group < 0) return;
     int64_t t0 = group * nt;
     int cnt = (int)((ntiles - t0) < nt ? (ntiles - t0) : nt);
@@ -1849,6 +1852,7 @@ static int fk_common(int src_kind, const float *src, const float *root_pos, cons
     a.quat_out = quat_out; a.F = F; a.J = J; a.eps = eps; a.pad = 0;  // set by dispatch_fk, per walk shape
     a.wsteps = 0;
     a.fmap = 0xfedcba9876543210ull;
+    a.xchunk = tune_env("PM_FK_XCHUNK", 0); a.pad2_ = 0;  // PM_TUNING build only
 #ifdef PM_TUNING
     a.times = nullptr;
     if (const char *e = getenv("PM_FK_TIMES_PTR")) a.times = reinterpret_cast<uint64_t *>(strtoull(e, nullptr, 0));
