@@ -455,7 +455,8 @@ def test_root_dual_quaternions_on_the_deep_chains_the_fuzz_run_found(J):
 # transform as it is (skeleton.py:46-49).  Walks in which the root takes NO step (four joints of a frame at a time, a wave per frame) do the
 # same; walks that run the root through the common step multiply it with the seed row e_r, and 0 x NaN = NaN fills the row.
 _INF_ROOT_CASES = [  # (J, kind, F, kernel-name fragment, root matrix like the reference?)
-    (6, "random", 4000, "fk_kernel<16", False),
+    (6, "random", 4000, "fk_kernel<20", False),
+    (10, "random", 4000, "fk_kernel<16", False),
     (22, "body", 4000, "fk_kernel<16", False),
     (36, "chain", 4000, "fk_kernel<8", False),
     (52, "smplh", 4000, "fk_pipe_kernel<4, 4", True),     # tree_walk_w4: the root's slot holds L_0 as parked
