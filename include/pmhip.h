@@ -260,6 +260,14 @@ int pm_stream_plain_f32(const float *src, float *dst, int64_t n4, int32_t ratio,
  * [11] bytes of unused LDS per workgroup (bounds the resident workgroups per CU like a kernel's LDS tile).  Bench / tuning only. */
 int pm_store_probe_f32(const float *src, float *dst, int64_t n4, const int32_t *cfg, pm_stream_t stream);
 
+/* The latency floor of a one-pass scan (tools/unroll_probe.py): the scan's grid and chain of dependencies -- ticket, one dwordx4 load per thread,
+ * publish a status word, wait for the predecessor's, one dwordx4 store per thread -- and none of its work.  ntiles workgroups of `threads` (64, 128,
+ * 192, 256) threads, tile t on dwordx4 [t * stride4, t * stride4 + threads) of src / dst; ws: ntiles + 129 32-bit words zero-filled once; epoch = 0, 1,
+ * 2, ... call by call on the same ws, ntiles and mode (the words are self-resetting).  mode 0: one ticket counter for the launch, 1: no ticket
+ * (tile = workgroup index), 2: one counter per XCD.  Bench / tuning only. */
+int pm_scan_floor_probe(const float *src, float *dst, void *ws, int64_t ntiles, int64_t stride4, int32_t threads, uint32_t epoch, int32_t mode,
+                        pm_stream_t stream);
+
 /* The one-pass scans of quat.unroll / dual_quat.unroll / the BVH ingest WITHOUT the reset launch in front of them (reference: rotations/quat.py:426-462,
  * dual_quat.py:139-167, io/bvh.py:352-359; a clip of real length is 7-19 us on the device of which that launch is ~3).  The caller owns a PAIR of
  * workspaces per stream -- each at least pm_quat_unroll_batched_workspace_bytes(B, T, S) bytes, 8-byte aligned, both zero-filled once (pm_memset) --

@@ -96,6 +96,7 @@ SIGNATURES = {
     "pm_stream_ceiling_f32": [_f, _f, _i64, _i32, _i32, _strm],
     "pm_stream_plain_f32": [_f, _f, _i64, _i32, _i32, _strm],
     "pm_store_probe_f32": [_f, _f, _i64, C.c_void_p, _strm],
+    "pm_scan_floor_probe": [_f, _f, C.c_void_p, _i64, _i64, _i32, C.c_uint32, _i32, _strm],
     "pm_unroll_onepass_f32": [_i32, _f, C.c_void_p, _i64, _i64, _i32, _f, C.c_void_p, C.c_void_p, C.c_void_p, _i64, _strm],
     # host-only introspection (tests of the wide walk's scheduler)
     "pm_fk_wide_plan_debug": [C.c_void_p, _i32, C.c_void_p],

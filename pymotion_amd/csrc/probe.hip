@@ -150,9 +150,63 @@ static int launch_probe_b(const ProbeArgs &a, const int pol, const int grid, con
     return PM_EINVAL;
 }
 
+// ---- the latency floor of a one-pass scan (tools/unroll_probe.py, profiles/r06_unroll_sweep.txt) -----------------------------------------
+// quat.unroll on a clip of real length (2^14 ... 2^18 frames) is 10-45 us: a handful of DEPENDENT memory round trips, not a stream -- "% of 8 TB/s"
+// is the wrong ruler there.  This kernel has the scan's grid and its chain of dependencies and none of its work: a workgroup takes a ticket, loads
+// ONE dwordx4 per thread (its tile's first row), publishes a status word, waits for its predecessor's (the look-back's one read, at the depth the
+// real scan pays when nothing is aggregated yet), and stores one dwordx4 per thread.  `epoch` makes the words self-resetting (a word counts as
+// published when it holds this call's epoch), so the probe needs no reset launch either.
+struct FloorArgs { const v4f *src; v4f *dst; unsigned *ticket; unsigned *status; int64_t stride4; unsigned ntiles, epoch; int mode; };
+// mode 0: one ticket counter for the launch (what the scans did up to round 5); 1: no ticket, tile = blockIdx.x (only safe while every workgroup of the
+// launch is resident); 2: one counter per XCD, tile = 8 * ticket + XCC_ID (see unroll.hip)
+__global__ __launch_bounds__(256) void scan_floor_kernel(const FloorArgs a) {
+    __shared__ unsigned s_tile;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        if (a.mode == 1) s_tile = blockIdx.x;
+        else if (a.mode == 2) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            xcc &= 7u;
+            const unsigned per = (a.ntiles + 7u - xcc) / 8u;  // tiles of this XCD: xcc, xcc + 8, ...
+            s_tile = (__hip_atomic_fetch_add(a.ticket + 16u * xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.epoch * per) * 8u + xcc;
+        } else s_tile = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.epoch * a.ntiles;
+    }
+    __syncthreads();
+    const unsigned tile = s_tile;
+    if (tile >= a.ntiles) return;  // (mode 2: an XCD that started more workgroups than it has tiles -- see pm_scan_floor_probe)
+    const v4f x = __builtin_nontemporal_load(a.src + (int64_t)tile * a.stride4 + tid);
+    // (the status word is published after the tile's own load has returned, like the scan's map of its tile; relaxed agent-scope words like the scan's)
+    const unsigned dep = __float_as_uint(x.x) & 0u;
+    if (tid == 0) {
+        __hip_atomic_store(a.status + tile, a.epoch + 1u + dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tile > 0)
+            while (__hip_atomic_load(a.status + tile - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch + 1u) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    __builtin_nontemporal_store(x, a.dst + (int64_t)tile * a.stride4 + tid);
+}
+
 }  // namespace pm
 
 using namespace pm;
+
+// ntiles workgroups of `threads` (64 ... 256) threads; tile t touches dwordx4 [t * stride4, t * stride4 + threads) of src / dst; ws: ntiles + 129 words,
+// zero-filled ONCE; epoch: 0, 1, 2, ... call by call on the same ws with the same ntiles and mode.  mode: see scan_floor_kernel.
+// (mode 2 counts on the dispatcher's round robin -- workgroup b on XCD b % 8 -- for every XCD to start exactly its share of the workgroups; an XCD that
+// starts more drops the surplus and the tiles of the XCD that started fewer are never taken: a probe, not a scan -- unroll.hip's version hands the
+// surplus on.)
+extern "C" int pm_scan_floor_probe(const float *src, float *dst, void *ws, int64_t ntiles, int64_t stride4, int32_t threads, uint32_t epoch, int32_t mode,
+                                   pm_stream_t stream) {
+    PM_CHECK_ARGS(src && dst && ws && ntiles >= 1 && ntiles <= 0x7fffffffLL && stride4 >= threads && threads >= 64 && threads <= 256 && threads % 64 == 0 &&
+                  aligned16(src) && aligned16(dst) && mode >= 0 && mode <= 2, "scan_floor_probe: bad arguments");
+    FloorArgs a;
+    a.src = reinterpret_cast<const v4f *>(src); a.dst = reinterpret_cast<v4f *>(dst);
+    a.ticket = reinterpret_cast<unsigned *>(ws); a.status = a.ticket + 128;
+    a.stride4 = stride4; a.ntiles = (unsigned)ntiles; a.epoch = epoch; a.mode = mode;
+    hipLaunchKernelGGL(scan_floor_kernel, dim3((unsigned)ntiles), dim3((unsigned)threads), 0, static_cast<hipStream_t>(stream), a);
+    return PM_AFTER_LAUNCH("scan_floor_probe launch");
+}
 
 // cfg (host ints): [0] burst KiB per wave and chunk (1, 2, 3, 4, 6, 8, 12, 16, 24, 32), [1] rd4, [2] store policy (0 plain, 1 nt, 2 sc1, 3 sc0 sc1,
 // 4 sc0 sc1 nt, 5 sc0, 6 sc1 nt, 10 / 11 buffer_store plain / nt; -1: hipMemsetD32Async of the same bytes instead of a kernel),

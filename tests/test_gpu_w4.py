@@ -143,3 +143,31 @@ def test_fk_chains_keep_the_one_joint_at_a_time_walk():
     pos, rm = sk.fk(rot, root, off, parents)
     p_o, r_o = co.fk(rot.astype(np.float64), root.astype(np.float64), off.astype(np.float64), parents)
     assert np.abs(pos - p_o).max() <= 1e-5 and np.abs(rm - r_o).max() <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("J", [8, 9, 10, 11, 14, 16, 18, 21, 22, 23, 26, 27, 29])
+def test_fk_sixteen_frame_walk_gives_the_same_bits_whichever_frames_share_a_half_wave(J, monkeypatch):
+    """round 6: quad q of the sixteen-frame tile walks frame fmap[q] (fk.hip: q4_frame_map -- the split of the frames over the two half-waves with
+    the fewest LDS bank conflicts, per joint count).  Which quad walks a frame changes nothing but the banks: every one of the five candidate
+    splits (PM_FK_FMAP on the tuning build) and the production library's own pick give the block split's results bit for bit, on metre and
+    centimetre data (the fixed-point chain), full and partial tiles -- and the oracle's within the usual bar"""
+    import pymotion_amd.ops.skeleton as sk
+
+    parents = syn.PARENTS_22 if J == 22 else syn.random_parents(J, np.random.default_rng(J))
+    for F, osc, rsc in ((16 * 7 + 5, 0.15, 2.0), (16 * 3 + 15, 25.0, 150.0), (3, 0.15, 2.0)):
+        rot, root, off, _ = _data(F, J, 11 * J + F, osc, rsc)
+        got = {}
+        with _lib.variant("tuning"):
+            for split in ("0", "1", "2", "3", "4"):
+                monkeypatch.setenv("PM_FK_FMAP", split)
+                got[split] = sk.fk(rot, root, off, parents)
+                assert "fk_kernel<16" in _lib.last_kernel_name(), _lib.last_kernel_name()
+            monkeypatch.delenv("PM_FK_FMAP")
+        got["prod"] = sk.fk(rot, root, off, parents)
+        assert "fk_kernel<16" in _lib.last_kernel_name(), _lib.last_kernel_name()
+        for k in ("1", "2", "3", "4", "prod"):
+            np.testing.assert_array_equal(got[k][0], got["0"][0])
+            np.testing.assert_array_equal(got[k][1], got["0"][1])
+        p_o, r_o = co.fk(rot.astype(np.float64), root.astype(np.float64), off.astype(np.float64), parents)
+        assert np.abs(got["prod"][1] - r_o).max() <= 1e-5 and np.abs(got["prod"][0] - p_o).max() <= max(1e-5, 2 * _ulp_of(p_o))

@@ -31,9 +31,28 @@ for lg in (10, 12, 14, 16, 18, 20):
         _lib.call("pm_unroll_onepass_f32", kind, P(x), order, 1, T, S, P(o), P(pair[c]), C.byref(n), P(pair[1 - c]), st["dirty"][1 - c], None)
         st["dirty"][1 - c], st["dirty"][c], st["cur"] = 0, n.value, 1 - c
 
-    ms_p = pp.timeit(no_reset)[0] if (T * S * 2 + 1023) // 1024 * 10 < (1 << 17) else float("nan")
-    print(f"[{tag}] T=2^{lg} S={S}: {ms * 1e3:8.1f} us  {T * S * 32 / ms / 1e6 / 80:5.1f}% of 8 TB/s on 32 B/quaternion;  without the reset launch "
-          f"(workspace pair) {ms_p * 1e3:8.1f} us  {T * S * 32 / ms_p / 1e6 / 80:5.1f}%", flush=True)
+    fits = (T * S * 2 + 1023) // 1024 * 10 < (1 << 17)
+    ms_p = pp.timeit(no_reset)[0] if fits else float("nan")
+    # the latency floor of this launch (pm_scan_floor_probe): the scan's grid -- the tile size dispatch picks -- and its chain of dependencies
+    # (ticket, one load, publish, wait for the predecessor's word, one store), none of its work
+    nv = T * S
+    R = 4 if nv <= 1024 else (8 if nv <= 2048 else (4 if (nv > 4096 and (nv + 4095) // 4096 < 64) else (32 if nv >= (4 << 20) else (8 if nv < (1 << 19) else 16))))
+    ntl = (nv + 256 * R - 1) // (256 * R)
+    floors = []
+    for mode in (0, 1, 2):
+        fws = torch.zeros(ntl + 129, dtype=torch.int32, device="cuda")
+        ep = {"n": 0}
+
+        def floor(mode=mode, fws=fws, ep=ep):
+            _lib.call("pm_scan_floor_probe", P(q), P(out), P(fws), ntl, 256 * R, 256, ep["n"], mode, None)
+            ep["n"] += 1
+
+        floors.append(pp.timeit(floor)[0] if (mode != 1 or ntl <= 1024) else float("nan"))  # (no ticket: only while every workgroup is resident)
+    ms_f = floors[0]
+    nores = (f"{ms_p * 1e3:8.1f} us  {T * S * 32 / ms_p / 1e6 / 80:5.1f}%  = {ms_p / ms_f:4.2f} x floor" if fits else
+             "   (the pair of this probe, 1 MB each, is too small for this clip: the doors fall back to the plain entry point too)")
+    print(f"[{tag}] T=2^{lg} S={S}: {ms * 1e3:8.1f} us  {T * S * 32 / ms / 1e6 / 80:5.1f}% of 8 TB/s on 32 B/quaternion;  latency floor of the launch "
+          f"({ntl} tiles: ticket, load, publish, look back once, store) {ms_f * 1e3:6.1f} us (no ticket {floors[1] * 1e3:5.1f}, a ticket counter per XCD {floors[2] * 1e3:5.1f});  without the reset launch (workspace pair) {nores}", flush=True)
 # batches of clips [B, T, S, 4] along T: one launch, nothing transposed (raw ABI), and the torch door end to end
 import pymotion_amd.rotations.quat_torch as quat_t
 
