@@ -64,17 +64,22 @@ def main():
         torch.cuda.synchronize()
         add(name, ptr["s"], ptr["p"], ptr["r"])
 
-    torch_set("torch, separate #1")
-    torch_set("torch, separate #2")
-    carve("carved, back to back", 0)
-    carve("carved, 64 MB gaps", 16 << 20)
-    carve("carved, 1 GB gaps", 256 << 20)
-    torch_set("torch, sizes + 2 MB", 1 << 19)
-    torch_set("torch, sizes + 96 MB", 24 << 20)
-    raw_set("hipMalloc src, pos, rotmats", "spr")
-    raw_set("hipMalloc rotmats, pos, src", "rps")
-    torch_set("torch, separate #3")
-    torch_set("torch, separate #4")
+    if os.environ.get("AKP_ALTERNATE") == "1":   # torch / hipMalloc / torch / hipMalloc ...: is it the allocator?
+        for i in range(6):
+            torch_set(f"torch, separate #{i + 1}")
+            raw_set(f"hipMalloc #{i + 1}", "spr" if i % 2 == 0 else "rps")
+    else:
+        torch_set("torch, separate #1")
+        torch_set("torch, separate #2")
+        carve("carved, back to back", 0)
+        carve("carved, 64 MB gaps", 16 << 20)
+        carve("carved, 1 GB gaps", 256 << 20)
+        torch_set("torch, sizes + 2 MB", 1 << 19)
+        torch_set("torch, sizes + 96 MB", 24 << 20)
+        raw_set("hipMalloc src, pos, rotmats", "spr")
+        raw_set("hipMalloc rotmats, pos, src", "rps")
+        torch_set("torch, separate #3")
+        torch_set("torch, separate #4")
     print(f"fk J = {J}, F = {F}: us a launch, two visits; pointers src / pos / rotmats")
     res = [[] for _ in sets]
     for rep in range(2):
