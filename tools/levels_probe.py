@@ -28,6 +28,8 @@ sys.path.insert(0, ROOT)
 
 SECONDS = float(os.environ.get("LP_SECONDS", "2.5"))
 PMC_SETS = [
+    "GRBM_UTCL2_BUSY GRBM_GUI_ACTIVE TCP_UTCL1_TRANSLATION_MISS_UNDER_MISS_sum TCP_UTCL1_STALL_INFLIGHT_MAX_sum TCP_UTCL1_REQUEST_sum",
+    "TCP_UTCL1_LFIFO_FULL_sum TCP_UTCL1_STALL_MULTI_MISS_sum TCP_UTCL1_SERIALIZATION_STALL_sum TCP_UTCL1_THRASHING_STALL_sum GRBM_GUI_ACTIVE",
     "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS_sum GRBM_GUI_ACTIVE",
     "TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_LEVEL_sum TCC_EA0_WRREQ_sum GRBM_GUI_ACTIVE",
     "TCC_EA0_WRREQ_STALL_sum TCC_TAG_STALL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum GRBM_GUI_ACTIVE",
@@ -270,6 +272,7 @@ def run_pmc(n):
                  "ea_wr_level_per_req": ratio("TCC_EA0_WRREQ_LEVEL_sum", "TCC_EA0_WRREQ_sum"),
                  "rd_dram_fraction": ratio("TCC_EA0_RDREQ_DRAM_sum", "TCC_EA0_RDREQ_sum"), "wr_dram_fraction": ratio("TCC_EA0_WRREQ_DRAM_sum", "TCC_EA0_WRREQ_sum"),
                  "tcc_hit_rate": ratio("TCC_HIT_sum", "TCC_REQ_sum")}
+        extra["utcl2_busy_fraction"] = ratio("GRBM_UTCL2_BUSY", "GRBM_GUI_ACTIVE")
         print(rec["proc"], rec["kernel"], rec["us"], {k: v for k, v in extra.items() if v is not None})
 
 
