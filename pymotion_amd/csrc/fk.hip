@@ -810,7 +810,7 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? ((PFO && E
                 const float *g = a.src + f0 * J * 4;
                 in4[u] = v4f{1.0f, 0.0f, 0.0f, 0.0f};
                 if (e < n) {
-                    if (VEC) in4[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(g) + e);
+                    if (VEC) in4[u] = PM_ABLATED(a, 512) ? reinterpret_cast<const v4f *>(g)[e] : __builtin_nontemporal_load(reinterpret_cast<const v4f *>(g) + e);  // & 512 (tuning build): plain loads
                     else in4[u] = v4f{g[4 * e], g[4 * e + 1], g[4 * e + 2], g[4 * e + 3]};
                 }
             } else {
@@ -841,6 +841,13 @@ __global__ __launch_bounds__(PM_WAVE, (EPL <= 4 && SRC == SRC_QUAT) ? ((PFO && E
             const v4f *lr = reinterpret_cast<const v4f *>(sRot), *lp = reinterpret_cast<const v4f *>(sPos);
             int ln = lane;
             asm volatile("" : "+v"(ln));
+            if (PM_ABLATED(a, 256)) {  // PM_FK_ABLATE & 256 (tuning build): plain instead of nontemporal stores
+#pragma unroll
+                for (int u = 0; u < NR; ++u) { const int i = u * PM_WAVE + ln, ic = i < n4r ? i : n4r - 1; gr[ic] = lr[ic]; }
+#pragma unroll
+                for (int u = 0; u < NP; ++u) { const int i = u * PM_WAVE + ln, ic = i < n4p ? i : n4p - 1; gp4[ic] = lp[ic]; }
+                return;
+            }
 #pragma unroll
             for (int u = 0; u < NR; ++u) { const int i = u * PM_WAVE + ln, ic = i < n4r ? i : n4r - 1; __builtin_nontemporal_store(lr[ic], gr + ic); }
 #pragma unroll

@@ -54,6 +54,8 @@ def main():
     for J, F, par in ((52, 1 << 18, syn.PARENTS_52), (22, 1 << 20, syn.PARENTS_22)):
         sets = [workload(J, F, par) for _ in range(3)]
         modes = [("default", {}), ("linear", {"PM_FK_ABLATE": "4"})] + [(f"chunk {c}", {"PM_FK_XCHUNK": str(c)}) for c in chunks]
+        if J == 52:
+            modes += [("plain stores", {"PM_FK_ABLATE": "256"}), ("plain loads", {"PM_FK_ABLATE": "512"}), ("plain both", {"PM_FK_ABLATE": "768"})]
         print(f"## J = {J}, F = {F}: us a launch per allocation set (set 0 / 1 / 2), % of the HBM spec of the slowest", flush=True)
         ref = None
         for name, env in modes:
