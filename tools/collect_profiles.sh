@@ -35,6 +35,7 @@ FKW_KINDS=humanoid,bushy,chain python $R/tools/fk_wide_sweep.py 96,100,112,128,1
 python $R/tools/fk_wide_variants.py 96,104,112,128,129,160,200,256,384,512 2>&1 | grep -v amdgpu.ids > $OUT/r${RN}_fk_wide_variants_final.txt
 python $R/tools/fk_w4_sweep.py 24,28,32,36,40,44,48,52,56,64,72,80,92,100 2>&1 | grep -v amdgpu.ids > $OUT/r${RN}_fk_w4_final.txt
 FKW_SRC=o6d FKW_KINDS=humanoid,bushy python $R/tools/fk_w4_sweep.py 24,32,40,48,52,64,80 2>&1 | grep -v amdgpu.ids >> $OUT/r${RN}_fk_w4_final.txt
+python $R/tools/fmap_ab.py 22 10 14 18 26 2>&1 | grep -v amdgpu.ids > $OUT/r${RN}_fk_frame_map_ab.txt
 python $R/tools/door_latency_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/r${RN}_door_latency_final.txt
 python $R/bench.py --frames-per-gpu 16777216 --steps 20 --warmup 3 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 > $OUT/r${RN}_bench_16m_frames_1gpu.json
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
