@@ -154,7 +154,8 @@ def test_fk_sixteen_frame_walk_gives_the_same_bits_whichever_frames_share_a_half
     centimetre data (the fixed-point chain), full and partial tiles -- and the oracle's within the usual bar"""
     import pymotion_amd.ops.skeleton as sk
 
-    parents = syn.PARENTS_22 if J == 22 else syn.random_parents(J, np.random.default_rng(J))
+    # (from 24 joints on a wide tree takes the four-frame kernel: chains keep the sixteen-frame tile up to 29)
+    parents = syn.PARENTS_22 if J == 22 else (_tree("chain", J) if J >= 24 else syn.random_parents(J, np.random.default_rng(J)))
     for F, osc, rsc in ((16 * 7 + 5, 0.15, 2.0), (16 * 3 + 15, 25.0, 150.0), (3, 0.15, 2.0)):
         rot, root, off, _ = _data(F, J, 11 * J + F, osc, rsc)
         got = {}
