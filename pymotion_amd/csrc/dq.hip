@@ -100,6 +100,49 @@ __device__ __forceinline__ float dq_step_rot(const float pq, const float w1, con
     return x;
 }
 
+// The scale of the precise step's fixed-point translations (round 6): fk's fx_scale rounds the bound up to a power of two (an exact scaling of its fp32 products)
+// and bounds a bone by its 1-norm; here the increments are float64 anyway, so the words use the range they have -- S = 0.99 x 2^30 / B with B from the bones'
+// 2-NORMS (a coordinate of a rotated bone is at most its length) -- which is 1.4 bits more resolution on random offsets: on a 55-deep chain of 30-unit bones the
+// words' rounding was a random walk of 2 ulp of the largest dual component (resolution 7.6e-6 at coordinates of ~64), now 0.8.  S and 1 / S are doubles:
+// S x (1 / S) must be 1 to far better than an fp32 ulp, or every position comes back scaled.
+struct FxScaleD { double S, invS; };
+__device__ __forceinline__ bool fx_scale_exact(const float tbound, const float rmax, FxScaleD &fx) {
+    const float B = uniform_f32(wave_max(rmax) + tbound);
+    const float Sf = 1.06e9f * frcp(B);  // ~0.99 x 2^30 / B: any S at or below 2^30 / B will do -- one per cent of headroom for the roundings of the chain
+    fx.S = (double)Sf;
+    const double y = (double)frcp(Sf);   // ... but 1 / S must be THIS S's reciprocal: one Newton step in float64 (1e-14) instead of a float64 division per tile
+    fx.invS = __builtin_fma(y, __builtin_fma(-fx.S, y, 1.0), y);
+    return B < 1e30f && B > 0.0f;        // false for NaN / Inf / absurd magnitudes: the fp32 step, which propagates them like the reference
+}
+// shallow skeletons (below kDqF64RotMinDepth) keep fk's power-of-two scale: their increments and the conversion back are exact fp32 scalings
+template <bool DEEP>
+__device__ __forceinline__ bool fx_scale_for(const float tbound, const float rmax, FxScaleD &fx) {
+    if constexpr (DEEP) return fx_scale_exact(tbound, rmax, fx);
+    FxScale f;
+    const bool ok = fx_scale(tbound, rmax, f);
+    fx.S = (double)uniform_f32(f.S); fx.invS = (double)uniform_f32(f.invS);
+    return ok;
+}
+
+// From this depth on the precise step rotates its bones in float64 (below: fp32 -- the 22-joint body is 7 deep, SMPL-H 10: a random walk of 0.5 ulp x sqrt(depth)
+// stays under 2 ulp there, and the float64 rotation costs centimetre-scale tiles 6.5 %: same-box A/B, 2^20 x 22, 267-269 -> 285-286 us)
+constexpr int kDqF64RotMinDepth = 12;
+// The same rotation in float64, for the precise step (round 6).  Rotating a 30-unit bone in fp32 costs ~5e-6 per joint whatever the quaternion's precision, and
+// down a chain that is a random walk: randomised fuzz runs read 3.4 ulp of the largest dual component on a 32-deep chain of 30-unit bones, 4.1 on a 55-deep one
+// (tests/test_gpu_large_magnitude.py pins them).  With the products in float64 (the quaternion component already is; an offset is an exact fp32 input) what is
+// left per joint is the rounding of the fixed-point word.  next = quad_perm [0,2,3,1] (0x78), next-next = [0,3,1,2] (0x9c); one term at a time, see quad_qmul_f64.
+__device__ __forceinline__ double dq_step_rot_f64(const double pqd, const float w1, const float w2) {
+    const double pn = quad_perm_f64<0x78>(pqd), pnn = quad_perm_f64<0x9c>(pqd);
+    double tt = pn * (double)w1;
+    tt = __builtin_fma(-pnn, (double)w2, tt);          // 2 (pv x v)
+    asm volatile("" : "+v"(tt));
+    double x = quad_perm_f64<0x9c>(tt) * pn;
+    asm volatile("" : "+v"(x));
+    x = __builtin_fma(-quad_perm_f64<0x78>(tt), pnn, x);  // pv x tt
+    asm volatile("" : "+v"(x));
+    return __builtin_fma(quad_perm_f64<0x00>(pqd), tt, x);  // + pw tt
+}
+
 // What a precise step leaves in the translation word of its slot: the fixed-point translation -- or, on lane 0 (whose
 // translation component is the zero scalar part), the four 8-bit residuals qd - qh of the quad in units of 2^-31.
 __device__ __forceinline__ int dq_pack_residual(const double qd, const float qh, const int ti, const int c) {
@@ -113,12 +156,18 @@ __device__ __forceinline__ int dq_pack_residual(const double qd, const float qh,
 
 // One PRECISE step for the lane holding component c (see above).  pqd: the parent's component in float64; pti: the parent's
 // fixed-point translation word.  Returns the float64 component; `qh` / `tword` are what goes into the slot.
+template <bool DEEP>
 __device__ __forceinline__ double dq_step_precise(const double pqd, const int pti, const float b, const float sb1, const float sb2,
                                                   const float sb3, const float vc, const float w1, const float w2, const float live,
-                                                  const float S, const int c, float &qh, int &ti, int &tword) {
+                                                  const double S, const int c, float &qh, int &ti, int &tword) {
     const double qd = quad_qmul_f64(pqd, b, sb1, sb2, sb3);
-    const float x = dq_step_rot((float)pqd, w1, w2);
-    ti = pti + (int)__builtin_rintf(__builtin_fmaf(live, x, vc) * S);
+    if constexpr (DEEP) {  // kDqF64RotMinDepth: the bone rotated in float64, the increment scaled in float64
+        const double x = dq_step_rot_f64(pqd, w1, w2);
+        ti = pti + (int)__builtin_rint(__builtin_fma((double)live, x, (double)vc) * S);
+    } else {               // shallow skeletons: fp32 as in rounds 3-5 (S is a power of two there: an exact scaling)
+        const float x = dq_step_rot((float)pqd, w1, w2);
+        ti = pti + (int)__builtin_rintf(__builtin_fmaf(live, x, vc) * (float)S);
+    }
     qh = (float)qd;
     tword = dq_pack_residual(qd, qh, ti, c);
     return qd;
@@ -160,7 +209,10 @@ __device__ __forceinline__ void dq_step_math(const float pq, const float s, cons
         : "v"(pq), "v"(s), "v"(b0), "v"(sb1), "v"(sb2), "v"(sb3), "v"(w1), "v"(w2), "v"(live));
 }
 
-template <int FPW, bool VEC>
+// DEEP: the skeleton is at least kDqF64RotMinDepth deep (chosen by the host: a kernel instance of its own, so that the shallow skeletons' code -- the 22-joint
+// body, SMPL-H -- is rounds 3-5's to the instruction: the float64 rotation as a branch inside the step cost centimetre-scale data 5 %, as a third loop 14 more
+// VGPRs = a wave per SIMD, on metre data too)
+template <int FPW, bool VEC, bool DEEP>
 __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
@@ -183,7 +235,7 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
     const int fq = wl >> 2, c = wl & 3;
     const float rp = (c > 0 && fq < nf) ? a.root_pos[(f0 + fq) * 3 + c - 1] : 0.0f;  // (0, root_pos) component c
     bool tbig = false;                 // a bone of a metre or more (or NaN) somewhere in the table: see kBigOffset
-    float tsum = 0.0f, tmx = 0.0f;     // sum / max over the joints of |t_j|_1 (this lane's share; NaN sticks)
+    float tsum = 0.0f, tmx = 0.0f;     // sum / max over the joints of |t_j|_2 (this lane's share; NaN sticks)
     for (int i = lane; i < 4 * (J + 3); i += PM_WAVE) {  // the joint table: offsets in the form each lane column consumes
         const int j = i >> 2, cc = i & 3, jc = j < J ? j : J - 1;
         const float o[3] = {a.offsets[3 * jc], a.offsets[3 * jc + 1], a.offsets[3 * jc + 2]};
@@ -194,7 +246,7 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
         }
         sTab[3 * i] = vc; sTab[3 * i + 1] = w1; sTab[3 * i + 2] = w2;
         if (cc == 0 && j < J) {
-            const float l1 = fabsf(o[0]) + fabsf(o[1]) + fabsf(o[2]);
+            const float l1 = fsqrt(__builtin_fmaf(o[0], o[0], __builtin_fmaf(o[1], o[1], o[2] * o[2]))) * 1.000001f;  // the bone's LENGTH (see fx_scale_exact), rounded up
             tbig = tbig || !(fabsf(o[0]) < kBigOffset) || !(fabsf(o[1]) < kBigOffset) || !(fabsf(o[2]) < kBigOffset);
             tsum += l1;
             tmx = (l1 > tmx || l1 != l1) ? l1 : tmx;
@@ -268,12 +320,12 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
     Regs B = {oq[8], tb[12], tb[13], tb[14]};
     // which arithmetic this tile gets (wave-uniform; see "Big-magnitude tiles" above)
     bool precise = false;
-    FxScale fx = {1.0f, 1.0f};
+    FxScaleD fx = {1.0, 1.0};
     // (a NaN / Inf QUATERNION needs no special case: it makes the float64 chain of its joint and of every descendant NaN in all
     // four components, and the dual part 0.5 (0,t) (x) q with them, whatever the fixed-point words hold -- the reference's pattern)
     if (__builtin_amdgcn_ballot_w64(tbig || !(fabsf(rp) < kBigRoot)) != 0 && __builtin_amdgcn_ballot_w64(offunit) == 0) {
         const float bsum = wave_sum(tsum), bmax = (float)a.depth * wave_max(tmx);  // (NaN sticks in both)
-        precise = fx_scale((bmax < bsum) ? bmax : bsum, fabsf(rp), fx);            // false for a non-finite bound: fp32 step
+        precise = fx_scale_for<DEEP>((bmax < bsum) ? bmax : bsum, fabsf(rp), fx);  // false for a non-finite bound: fp32 step
     }
     float gq = 0.0f, gt = 0.0f;                           // previous joint, root space
     double gqd = 0.0;                                     // precise: the same quaternion component in float64
@@ -295,7 +347,7 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
             const double pqd = chain ? gqd : dq_parent_f64(peq, pel, c);
             const int pti = __float_as_int(chain ? gt : pet);
             int ti, tw;
-            gqd = dq_step_precise(pqd, pti, S.b, sb1, sb2, sb3, S.vc, S.w1, S.w2, live, fx.S, c, q, ti, tw);
+            gqd = dq_step_precise<DEEP>(pqd, pti, S.b, sb1, sb2, sb3, S.vc, S.w1, S.w2, live, fx.S, c, q, ti, tw);
             gt = __int_as_float(ti);
             t = __int_as_float(tw);
         } else {
@@ -335,7 +387,8 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
         lds_get<8>(slot, 0, qt);
         if (precise) {  // wave-uniform: the translation words are fixed point
 #pragma unroll
-            for (int k = 4; k < 7; ++k) qt[k] = (float)__float_as_int(qt[k]) * fx.invS;
+            for (int k = 4; k < 7; ++k)
+                qt[k] = DEEP ? (float)((double)__float_as_int(qt[k]) * fx.invS) : (float)__float_as_int(qt[k]) * (float)fx.invS;
         }
         const float q[4] = {qt[0], qt[1], qt[2], qt[3]}, t[3] = {qt[4], qt[5], qt[6]};
         rt2dq(q, t, d);
@@ -361,16 +414,15 @@ static int launch_to_root(const ToRootArgs &a, bool vec, hipStream_t s) {
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
     const int64_t grid = ((ntiles + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
     if (grid > 0x7fffffffLL) { set_error("to_root_dq: grid too large"); return PM_EUNSUPPORTED; }
-    set_kernel_name("void pm::to_root_dq_kernel<%d, %s>(pm::ToRootArgs)", FPW, tf(vec));
-    if (vec) {
-        auto k = to_root_dq_kernel<FPW, true>;
+    const bool deep = a.depth >= kDqF64RotMinDepth;
+    set_kernel_name("void pm::to_root_dq_kernel<%d, %s, %s>(pm::ToRootArgs)", FPW, tf(vec), tf(deep));
+    auto go = [&](auto k) {
         if (int e = allow_lds(k, lds)) return e;
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
-    } else {
-        auto k = to_root_dq_kernel<FPW, false>;
-        if (int e = allow_lds(k, lds)) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a);
-    }
+        return (int)PM_OK;
+    };
+    if (int e = vec ? (deep ? go(to_root_dq_kernel<FPW, true, true>) : go(to_root_dq_kernel<FPW, true, false>))
+                    : (deep ? go(to_root_dq_kernel<FPW, false, true>) : go(to_root_dq_kernel<FPW, false, false>))) return e;
     return PM_AFTER_LAUNCH("to_root_dq launch");
 }
 
@@ -408,7 +460,7 @@ struct SchedArgs {
 
 __host__ __device__ constexpr int sched_frame_stride(const int J) { return 8 * J + 20; }  // J slots + identity + idle slot + pad; (FS / 4) odd
 
-template <int C, bool VEC>
+template <int C, bool VEC, bool DEEP>
 __global__ __launch_bounds__(PM_WAVE) void to_root_dq_sched_kernel(const SchedArgs a, const int nt) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef int v4i __attribute__((ext_vector_type(4)));
@@ -444,9 +496,10 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_sched_kernel(const SchedAr
     // bound of |t_j - t_(depth-1 ancestor)| for the fixed-point scale, from the table in LDS: only tiles that take the precise
     // step pay for it (round-3 note: gathering these sums in the loop above for every workgroup cost metre-scale data 4 %)
     auto table_bound = [&]() {
-        float tsum_l = 0.0f, tmx_l = 0.0f;  // sum / max over the joints of |t_j|_1 (this lane's share; NaN sticks)
+        float tsum_l = 0.0f, tmx_l = 0.0f;  // sum / max over the joints of |t_j|_2 (this lane's share; NaN sticks)
         for (int j = 1 + lane; j < J; j += PM_WAVE) {
-            const float l1 = fabsf(sTab[12 * j + 3]) + fabsf(sTab[12 * j + 6]) + fabsf(sTab[12 * j + 9]);
+            const float o0 = sTab[12 * j + 3], o1 = sTab[12 * j + 6], o2 = sTab[12 * j + 9];
+            const float l1 = fsqrt(__builtin_fmaf(o0, o0, __builtin_fmaf(o1, o1, o2 * o2))) * 1.000001f;  // the bone's LENGTH (see fx_scale_exact), rounded up
             tsum_l += l1;
             tmx_l = (l1 > tmx_l || l1 != l1) ? l1 : tmx_l;
         }
@@ -527,11 +580,9 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_sched_kernel(const SchedAr
     const v4i *prog = sProg + k;
     // which arithmetic this tile gets (wave-uniform; "Big-magnitude tiles" above)
     bool precise = false;
-    FxScale fx = {1.0f, 1.0f};
+    FxScaleD fx = {1.0, 1.0};
     if ((tbig || __builtin_amdgcn_ballot_w64(!(fabsf(rp) < kBigRoot)) != 0) && __builtin_amdgcn_ballot_w64(offunit) == 0)
-        precise = fx_scale(table_bound(), (k == 0) ? fabsf(rp) : 0.0f, fx);  // false for a non-finite bound: fp32 step
-    fx.S = uniform_f32(fx.S);
-    fx.invS = uniform_f32(fx.invS);
+        precise = fx_scale_for<DEEP>(table_bound(), (k == 0) ? fabsf(rp) : 0.0f, fx);  // false for a non-finite bound: fp32 step
     const char *bl = reinterpret_cast<const char *>(fD + 7);  // precise: a slot's packed residuals
     struct In { float b, vc, w1, w2, peq, pet; int pel; v4i e; };
     auto fetch = [&](auto tag, const v4i e, In &x, const bool root_lane) {
@@ -555,7 +606,7 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_sched_kernel(const SchedAr
             const double pqd = chain ? gqd : dq_parent_f64(x.peq, x.pel, c);
             const int pti = __float_as_int(chain ? gt : x.pet);
             int ti, tw;
-            gqd = dq_step_precise(pqd, pti, x.b, sb1, sb2, sb3, x.vc, x.w1, x.w2, live, fx.S, c, q, ti, tw);
+            gqd = dq_step_precise<DEEP>(pqd, pti, x.b, sb1, sb2, sb3, x.vc, x.w1, x.w2, live, fx.S, c, q, ti, tw);
             gt = __int_as_float(ti);
             t = __int_as_float(tw);
         } else {
@@ -585,14 +636,14 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_sched_kernel(const SchedAr
                 double pqd = gqd;
                 if (!chain) pqd = dq_parent_f64(*reinterpret_cast<const float *>(bq + e.y), *reinterpret_cast<const int *>(bl + e.y), c);
                 double qd = quad_qmul_f64(pqd, b, sb1, sb2, sb3);
-                float pqf = (float)pqd;
-                asm volatile("" : "+v"(qd), "+v"(pqf));  // the quaternion part is done before the translation's operands are fetched
+                asm volatile("" : "+v"(qd), "+v"(pqd));  // the quaternion part is done before the translation's operands are fetched
                 const float bn = *reinterpret_cast<const float *>(bq + en.x);  // next joint's input quaternion: its slot is untouched until its own step
                 const float *row = reinterpret_cast<const float *>(btab + e.z);
                 const float vc = (st == 0 && k == 0) ? rp : row[0];  // the root's "offset" is the frame's root position (skeleton.py:232)
                 const int pti = chain ? gti : *reinterpret_cast<const int *>(bt + e.y);
-                const float x = dq_step_rot(pqf, row[1], row[2]);
-                const int ti = pti + (int)__builtin_rintf(__builtin_fmaf(live, x, vc) * fx.S);
+                int ti;
+                if constexpr (DEEP) ti = pti + (int)__builtin_rint(__builtin_fma((double)live, dq_step_rot_f64(pqd, row[1], row[2]), (double)vc) * fx.S);
+                else ti = pti + (int)__builtin_rintf(__builtin_fmaf(live, dq_step_rot((float)pqd, row[1], row[2]), vc) * (float)fx.S);
                 const float qh = (float)qd;
                 *reinterpret_cast<float *>(const_cast<char *>(bq) + e.x) = qh;
                 *reinterpret_cast<int *>(const_cast<char *>(bt) + e.x) = dq_pack_residual(qd, qh, ti, c);
@@ -628,7 +679,8 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_sched_kernel(const SchedAr
         lds_get<8>(slot, 0, qt);
         if (precise) {  // wave-uniform: the translation words are fixed point
 #pragma unroll
-            for (int kk = 4; kk < 7; ++kk) qt[kk] = (float)__float_as_int(qt[kk]) * fx.invS;
+            for (int kk = 4; kk < 7; ++kk)
+                qt[kk] = DEEP ? (float)((double)__float_as_int(qt[kk]) * fx.invS) : (float)__float_as_int(qt[kk]) * (float)fx.invS;
         }
         const float q[4] = {qt[0], qt[1], qt[2], qt[3]}, t[3] = {qt[4], qt[5], qt[6]};
         rt2dq(q, t, d);
@@ -708,16 +760,15 @@ static int launch_to_root_sched(const SchedArgs &a, bool vec, hipStream_t s) {
     const int64_t ngroups = (ntiles + nt - 1) / nt;
     const int64_t grid = ((ngroups + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
     if (grid > 0x7fffffffLL) { set_error("to_root_dq: grid too large"); return PM_EUNSUPPORTED; }
-    set_kernel_name("void pm::to_root_dq_sched_kernel<%d, %s>(pm::SchedArgs, int)", C, tf(vec));
-    if (vec) {
-        auto kf = to_root_dq_sched_kernel<C, true>;
+    const bool deep = a.depth >= kDqF64RotMinDepth;
+    set_kernel_name("void pm::to_root_dq_sched_kernel<%d, %s, %s>(pm::SchedArgs, int)", C, tf(vec), tf(deep));
+    auto go = [&](auto kf) {
         if (int e = allow_lds(kf, lds)) return e;
         hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a, nt);
-    } else {
-        auto kf = to_root_dq_sched_kernel<C, false>;
-        if (int e = allow_lds(kf, lds)) return e;
-        hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a, nt);
-    }
+        return (int)PM_OK;
+    };
+    if (int e = vec ? (deep ? go(to_root_dq_sched_kernel<C, true, true>) : go(to_root_dq_sched_kernel<C, true, false>))
+                    : (deep ? go(to_root_dq_sched_kernel<C, false, true>) : go(to_root_dq_sched_kernel<C, false, false>))) return e;
     return PM_AFTER_LAUNCH("to_root_dq launch");
 }
 
