@@ -460,8 +460,13 @@ struct SchedArgs {
 
 __host__ __device__ constexpr int sched_frame_stride(const int J) { return 8 * J + 20; }  // J slots + identity + idle slot + pad; (FS / 4) odd
 
+// (second launch bound: five waves per SIMD = at most 96 VGPRs.  Its tiles are 4-13 KB of LDS, so registers bound residency: 110 VGPRs read 210 -> 228 us at
+// 2^20 x 22 on metre data, round 3; every instance sits at 96 today, the bound keeps it there)
+// (Round 6 tried the schedule fk's wide walks use -- a joint in the very next step after its parent on ANY chain, the parent's slot read after the writes of the
+// step before instead of two steps ahead: K shrinks by the depth, but the read's latency lands on every step: J = 22 210 -> 215 us, random trees of 96 / 128
+// joints 282 -> 293 / 380 -> 401 us on one box.  Not kept.)
 template <int C, bool VEC, bool DEEP>
-__global__ __launch_bounds__(PM_WAVE) void to_root_dq_sched_kernel(const SchedArgs a, const int nt) {
+__global__ __launch_bounds__(PM_WAVE, 5) void to_root_dq_sched_kernel(const SchedArgs a, const int nt) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef int v4i __attribute__((ext_vector_type(4)));
     constexpr int FPW = 16 / C;
