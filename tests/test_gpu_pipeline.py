@@ -170,3 +170,52 @@ def test_a_launch_that_fails_mid_pipeline_gives_everything_back_and_the_next_cal
     pos, rm = sk.fk(rot, root, off, parents)           # same streams, events and slots: still healthy
     p_o, r_o = co.fk(rot.astype(np.float64), root.astype(np.float64), off.astype(np.float64), parents)
     assert np.abs(pos - p_o).max() <= 1e-5 and np.abs(rm - r_o).max() <= 1e-5
+
+
+@pytest.mark.gpu
+def test_numpy_door_from_many_short_lived_threads_shares_its_arenas_and_workspace_pairs():
+    """the small-call arena (4 MB device + 4 MB page-locked) and the one-pass scans' workspace pair used to live in
+    threading.local tables without a finalizer -- a thread that exits leaked them.  Now an op checks them out of process-wide pools.  Forty
+    threads (eight at a time), each a few fk / quat.unroll / to_root_dual_quat calls on clips of real length: every result is the oracle's,
+    at most as many arenas and pairs exist afterwards as threads ran at once, and trim() frees them all."""
+    import threading
+
+    import pymotion_amd
+    import pymotion_amd.ops.skeleton as sk
+    import pymotion_amd.rotations.quat as quat
+    from oracle import c_oracle as co
+    from pymotion_amd import _backend
+    from pymotion_amd import synthetic as syn
+
+    pymotion_amd.trim()
+    errs, lock = [], threading.Lock()
+
+    def work(seed):
+        try:
+            rot, root, off, par = syn.fk_workload(300 + 17 * (seed % 5), seed=seed, normalized=True)
+            for _ in range(3):
+                pos, rm = sk.fk(rot, root, off, par)
+                p_o, r_o = co.fk(rot.astype(np.float64), root.astype(np.float64), off.astype(np.float64), par)
+                assert np.abs(pos - p_o).max() <= 1e-5 and np.abs(rm - r_o).max() <= 1e-5
+                d = sk.to_root_dual_quat(rot, root, par, off)
+                assert np.abs(d - co.to_root_dual_quat(rot.astype(np.float64), root.astype(np.float64), par, off.astype(np.float64))).max() <= 1e-5
+                q = rot * np.where(np.random.default_rng(seed).random(rot.shape[:2] + (1,)) < 0.5, -1.0, 1.0).astype(np.float32)
+                u = quat.unroll(q, 0)
+                np.testing.assert_allclose(u, co.quat_unroll(q.astype(np.float64), 0), atol=1e-6)
+        except Exception as exc:  # noqa: BLE001
+            with lock:
+                errs.append(repr(exc)[:300])
+
+    for wave in range(5):
+        ts = [threading.Thread(target=work, args=(8 * wave + i,)) for i in range(8)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    assert not errs, errs[:3]
+    idle_arenas = sum(len(v) for v in _backend._arenas.idle.values())
+    idle_pairs = sum(len(v) for v in _backend._np_pairs_idle.values())
+    assert 1 <= idle_arenas <= 8 and idle_pairs <= 8, (idle_arenas, idle_pairs)
+    pymotion_amd.trim()
+    assert sum(len(v) for v in _backend._arenas.idle.values()) == 0 and sum(len(v) for v in _backend._np_pairs_idle.values()) == 0
+
