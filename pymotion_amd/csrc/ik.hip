@@ -217,10 +217,12 @@ __global__ __launch_bounds__(PM_WAVE, (NL > 0 && NL <= 12) ? PM_IK_MINW : ((NL >
     const int ch = (C == 1) ? 0 : (lane / FPW) % C;  // which chain of the frame this lane walks
     float *fS = sS + f * FS;
     float g[4] = {1.0f, 0.0f, 0.0f, 0.0f};  // world quaternion of the joint this lane aligned last
-    struct Ops { float gl[4], pj[4], pc[4], a[4], b[4]; };
-    auto fetch = [&](const v4i it, Ops &o) {  // operands of one step: positions are static until their joint is aligned, a
-        const int pp = it.y < 0 ? 0 : it.y;   // finished parent's slot holds its G
-        lds_get<4>(fS, pp, o.gl);
+    struct Ops { float pj[4], pc[4], a[4], b[4]; };
+    // operands of one step that may be requested a step ahead: positions are static until their joint is aligned.  The PARENT's world quaternion is not
+    // among them (round 6): it is read at the top of the step itself, after the write of the step before -- all chains of a frame are lanes of one wave,
+    // whose DS operations execute in order -- so that a joint may follow its parent in the very next step on ANY chain (ik_schedule); against ~170
+    // instructions of arithmetic the read's latency is nothing, and bushy trees' schedules lose a quarter of their steps
+    auto fetch = [&](const v4i it, Ops &o) {
         lds_get<4>(fS, it.x, o.pj);
         lds_get<4>(fS, it.z, o.pc);  // children come later: their slots still hold positions
         lds_get<4>(sOff, 2 * it.z, o.a);      // rest offset u of the first child, 1 / |u|
@@ -263,12 +265,14 @@ __global__ __launch_bounds__(PM_WAVE, (NL > 0 && NL <= 12) ? PM_IK_MINW : ((NL >
     auto step = [&](const int st, v4i &cur, const Ops &oc, const v4i &nxt, Ops &on) {
         const int j = cur.x, par = cur.y;
         const int xs = cur.w & 0xffff, nx = cur.w >> 16;
+        float gl[4];
+        lds_get<4>(fS, par < 0 ? 0 : par, gl);  // a finished parent's slot holds its G
         cur = sItem[(st + 2) * C + ch];
         fetch(nxt, on);
         float gpre[4];
         const bool chain = par == prevj;  // (the root, par = -1, is "chained" to the identity g starts as)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) gpre[k] = chain ? g[k] : oc.gl[k];
+        for (int k = 0; k < 4; ++k) gpre[k] = chain ? g[k] : gl[k];
         const float (&pj)[4] = oc.pj, (&pc)[4] = oc.pc;
         const float u[3] = {oc.a[0], oc.a[1], oc.a[2]};
         const float iu = oc.a[3], lu = oc.b[3];
@@ -847,7 +851,9 @@ static int launch_ik_order(const IkOrderArgs &a, hipStream_t s) {
     return PM_AFTER_LAUNCH("from_root_positions (lane per frame, any order) launch");
 }
 
-static int ik_schedule(const Topo16 &t, const int J, uint8_t *sched, const int C = 2) {
+// (round 6: a joint may follow its parent in the very next step on ANY chain -- the kernel reads the parent's slot at the top of the step, see `fetch`;
+// PM_IK_RELAXED = 0 on the tuning build: rounds 2-5's rule, two steps unless on the parent's own chain)
+static int ik_schedule_rule(const Topo16 &t, const int J, uint8_t *sched, const int C, const bool relaxed, int *cost) {
     int height[PM_MAX_JOINTS], done_step[PM_MAX_JOINTS], done_chain[PM_MAX_JOINTS], items = 0;
     for (int j = 0; j < J; ++j) { height[j] = 0; done_step[j] = -1; done_chain[j] = -1; }
     for (int j = J - 1; j >= 0; --j) {
@@ -869,7 +875,10 @@ static int ik_schedule(const Topo16 &t, const int J, uint8_t *sched, const int C
                 if (j > 0) {
                     const int p = t.parent[j];
                     if (done_step[p] < 0 || done_step[p] == st) continue;
-                    if (done_step[p] == st - 1) { if (done_chain[p] != k) continue; on = 1; }
+                    if (done_step[p] == st - 1) {
+                        if (done_chain[p] == k) on = 1;
+                        else if (!relaxed) continue;
+                    }
                 }
                 if (best < 0 || on > best_on || (on == best_on && height[j] > height[best])) { best = j; best_on = on; }
             }
@@ -878,7 +887,30 @@ static int ik_schedule(const Topo16 &t, const int J, uint8_t *sched, const int C
         }
         K = st + 1;
     }
+    // what the walk costs: a step is one alignment plus as many roll corrections as its busiest chain has further children (~170 / ~150 instructions)
+    *cost = 0;
+    for (int st = 0; st < K; ++st) {
+        int rolls = 0;
+        for (int k = 0; k < C; ++k) {
+            const int j = sched[C * st + k];
+            if (j != 255) { const int nx = t.cstart[j + 1] - t.cstart[j] - 1; rolls = nx > rolls ? nx : rolls; }
+        }
+        *cost += 170 + 150 * rolls;
+    }
     return (C > 2 || 4 * K <= 3 * items) ? K : 0;
+}
+// Both rules are valid programs for the kernel; the list scheduler is greedy, so neither is always the shorter walk (measured, random trees: the next-step rule
+// +2...5 % at 22 / 40 / 64 / 96 / 128 joints, -2...4 % at 55 / 72 / 80): the host builds both and keeps the cheaper one by the model above.
+// PM_IK_RELAXED (tuning build): 0 / 1 = that rule only.
+static int ik_schedule(const Topo16 &t, const int J, uint8_t *sched, const int C = 2) {
+    const int only = tune_env("PM_IK_RELAXED", -1);
+    uint8_t alt[512];
+    int c_two = 1 << 30, c_next = 1 << 30;
+    const int k_next = only == 0 ? 0 : ik_schedule_rule(t, J, sched, C, true, &c_next);
+    if (only == 1) return k_next;
+    const int k_two = ik_schedule_rule(t, J, alt, C, false, &c_two);
+    if (k_two > 0 && (k_next == 0 || c_two < c_next)) { memcpy(sched, alt, sizeof(alt)); return k_two; }
+    return k_next;
 }
 
 template <int FPW, int C>
