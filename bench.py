@@ -804,6 +804,11 @@ def main():
                          "kernel": kernel_name, "kernel_ms": kern_ms,
                          "bytes_per_frame": bytes_per_frame},
         }
+        try:  # which GPU this was: the timing level of a run follows the box as well as the placement (profiles/r06_levels.txt)
+            pr = torch.cuda.get_device_properties(dev)
+            line["config"]["gpu"] = {"name": pr.name, "uuid": str(getattr(pr, "uuid", ""))[-12:], "gcn_arch": getattr(pr, "gcnArchName", "")}
+        except Exception:  # noqa: BLE001
+            pass
         if by_batch is not None:
             # (the steps of the timed region cycle through these batches: kernel_ms is their mean; a launch's time follows the placement of
             # its arrays -- profiles/r06_levels.txt)
