@@ -646,6 +646,14 @@ def main():
     par_t = torch.from_numpy(parents)
     batches = []
     for b in range(NB):
+        if b > 0:
+            try:  # (a further batch is a nicety: a device that cannot hold it runs the line on the batches it has)
+                free_b, _tot = torch.cuda.mem_get_info(dev)
+                if free_b < 2 * F * (64 * J + 12) + (1 << 30):
+                    NB = b
+                    break
+            except Exception:  # noqa: BLE001
+                pass
         gen = torch.Generator(device=dev)
         gen.manual_seed(a.seed * 1000 + rank + 7919 * b)
         rot_b = torch.randn((F, J, 4), generator=gen, device=dev, dtype=torch.float32)
