@@ -817,6 +817,15 @@ def main():
             line["config"]["gpu"] = {"name": pr.name, "uuid": str(getattr(pr, "uuid", ""))[-12:], "gcn_arch": getattr(pr, "gcnArchName", "")}
         except Exception:  # noqa: BLE001
             pass
+        try:  # ... and its VBIOS (of five boxes looked at, the one whose every placement read the slow side ran the oldest one)
+            import amdsmi
+
+            amdsmi.amdsmi_init()
+            hs = amdsmi.amdsmi_get_processor_handles()
+            vb = amdsmi.amdsmi_get_gpu_vbios_info(hs[dev.index if dev.index is not None and dev.index < len(hs) else 0])
+            line["config"].setdefault("gpu", {})["vbios"] = (str(vb.get("part_number", "")) + " " + str(vb.get("version", ""))).strip()[:60]
+        except Exception:  # noqa: BLE001
+            pass
         if by_batch is not None:
             # (the steps of the timed region cycle through these batches: kernel_ms is their mean; a launch's time follows the placement of
             # its arrays -- profiles/r06_levels.txt)
