@@ -817,7 +817,7 @@ def main():
             line["config"]["gpu"] = {"name": pr.name, "uuid": str(getattr(pr, "uuid", ""))[-12:], "gcn_arch": getattr(pr, "gcnArchName", "")}
         except Exception:  # noqa: BLE001
             pass
-        try:  # ... and its VBIOS (of five boxes looked at, the one whose every placement read the slow side ran the oldest one)
+        try:  # ... and its VBIOS (thirteen boxes looked at: five read the slow side on every placement, and it is not the VBIOS that separates them)
             import amdsmi
 
             amdsmi.amdsmi_init()
