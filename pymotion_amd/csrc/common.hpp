@@ -53,26 +53,35 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// blockIdx -> tile index.  Workgroup b runs on XCD b % 8 (observed dispatch order); give every
-// XCD one contiguous range of tiles so that the partial cache lines at tile boundaries are
-// written by neighbours that share an L2 and merge there before going to HBM.
-// Launch with grid = 8 * ceil(ntiles / 8); returns -1 for the padding blocks.
-__device__ __forceinline__ int64_t xcd_tile(int64_t ntiles) {
-    const int64_t per_xcd = (ntiles + PM_NXCD - 1) / PM_NXCD;
-    const int64_t b = blockIdx.x;
-    const int64_t t = (b % PM_NXCD) * per_xcd + b / PM_NXCD;
-    return t < ntiles ? t : -1;
-}
-
-// The same with the XCDs' ranges cut into CHUNKS of `chunk` tiles that take turns: XCD x owns tiles [(8 c + x) chunk, (8 c + x + 1) chunk) for
-// c = 0, 1, ... -- neighbours inside a chunk still share an L2, but the eight XCDs sweep ONE window of the arrays together (8 chunk tiles wide)
-// instead of eight windows an eighth of the array apart.  chunk <= 0: the contiguous eighths of xcd_tile.
+// blockIdx -> tile index.  Workgroup b runs on XCD b % 8 (observed dispatch order), and tiles that are neighbours in memory should run on ONE XCD: the partial
+// cache lines at their boundaries are then written by workgroups that share an L2 and merge there before going to HBM (measured: HBM traffic of every skeleton
+// kernel within 1.1 % of its algorithmic bytes).  Rounds 1-5 gave every XCD one contiguous EIGHTH of the tiles.  Round 6 (profiles/r06_levels.txt): the eight
+// XCDs then sweep eight windows an eighth of the array apart, in step, for the whole launch -- and on most placements of the arrays in physical memory that costs
+// DRAM efficiency (the same kernel reads 150 or 167 us by the allocation; the L2's read queue towards the fabric holds a request 8-15 % longer on the slow ones).
+// With the XCDs' ranges cut into CHUNKS that take turns -- XCD x owns tiles [(8 c + x) chunk, (8 c + x + 1) chunk), c = 0, 1, ... -- neighbours inside a chunk
+// still share an L2 (one boundary in `chunk` is between XCDs) and the eight XCDs sweep ONE window, 8 chunks wide.  Measured on the two fk tile kernels, production
+// libraries of the commits before and after, four allocation sets on each of four boxes (tools/scratch-style A/B, profiles/r06_levels.txt block 12): J = 52 slow
+// placements 166 -> 160.8 us (-3.2 %), fast ones 149-153 -> 150-157 (+0 ... +2 %); J = 22 slow 251-255 -> 245.5 (-3 %), fast 240-243 -> 242-246.5 (+0.5 ... +1.6 %);
+// chunks of 8 ... 64 alike -- the levels move together, and most placements are slow ones (thirteen boxes: ~60 % of the sets).  fk_kernel and fk_pipe_kernel
+// take chunks of kFkXcdChunk (fk.hip); every other kernel keeps the contiguous eighths (PM_XCD_CHUNK = 0): a whole-library A/B on one box read +-4 % either way
+// by the op, i.e. by the placement each op's arrays had drawn -- not enough to move them all in the last round.
+// Launch with grid = 8 * ceil(ntiles / 8); returns -1 for the padding blocks.  chunk <= 0: the contiguous eighths.
+#ifndef PM_XCD_CHUNK
+#define PM_XCD_CHUNK 0
+#endif
 __device__ __forceinline__ int64_t xcd_tile_chunked(const int64_t ntiles, const int chunk) {
-    if (chunk <= 0) return xcd_tile(ntiles);
-    const int64_t b = blockIdx.x, i = b / PM_NXCD, c = i / chunk;
-    const int64_t t = (c * PM_NXCD + (b % PM_NXCD)) * chunk + (i - c * chunk);
+    const int64_t per_xcd = (ntiles + PM_NXCD - 1) / PM_NXCD;
+    const int64_t b = blockIdx.x, x = b % PM_NXCD, i = b / PM_NXCD;
+    int64_t t;
+    if (chunk <= 0) t = x * per_xcd + i;
+    else {
+        const int64_t full = per_xcd / chunk * chunk;  // the i's that lie in whole chunks
+        // (the last, partial round of chunks: r = per_xcd - full tiles per XCD, packed the same way -- every tile index below 8 per_xcd exactly once)
+        t = i < full ? ((i / chunk) * PM_NXCD + x) * chunk + i % chunk : full * PM_NXCD + x * (per_xcd - full) + (i - full);
+    }
     return t < ntiles ? t : -1;
 }
+__device__ __forceinline__ int64_t xcd_tile(const int64_t ntiles) { return xcd_tile_chunked(ntiles, PM_XCD_CHUNK); }
 
 // ---- DPP arithmetic inside a quad (4 consecutive lanes): register-to-register, no LDS ---------------
 // quad_perm:[a,b,c,d] = lane i of every quad reads the operand of lane {a,b,c,d}[i] of the same quad.  The
