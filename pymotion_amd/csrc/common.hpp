@@ -59,12 +59,13 @@ __device__ __forceinline__ void wave_sync() {
 // XCDs then sweep eight windows an eighth of the array apart, in step, for the whole launch -- and on most placements of the arrays in physical memory that costs
 // DRAM efficiency (the same kernel reads 150 or 167 us by the allocation; the L2's read queue towards the fabric holds a request 8-15 % longer on the slow ones).
 // With the XCDs' ranges cut into CHUNKS that take turns -- XCD x owns tiles [(8 c + x) chunk, (8 c + x + 1) chunk), c = 0, 1, ... -- neighbours inside a chunk
-// still share an L2 (one boundary in `chunk` is between XCDs) and the eight XCDs sweep ONE window, 8 chunks wide.  Measured on the two fk tile kernels, production
-// libraries of the commits before and after, four allocation sets on each of four boxes (tools/scratch-style A/B, profiles/r06_levels.txt block 12): J = 52 slow
-// placements 166 -> 160.8 us (-3.2 %), fast ones 149-153 -> 150-157 (+0 ... +2 %); J = 22 slow 251-255 -> 245.5 (-3 %), fast 240-243 -> 242-246.5 (+0.5 ... +1.6 %);
-// chunks of 8 ... 64 alike -- the levels move together, and most placements are slow ones (thirteen boxes: ~60 % of the sets).  fk_kernel and fk_pipe_kernel
-// take chunks of kFkXcdChunk (fk.hip); every other kernel keeps the contiguous eighths (PM_XCD_CHUNK = 0): a whole-library A/B on one box read +-4 % either way
-// by the op, i.e. by the placement each op's arrays had drawn -- not enough to move them all in the last round.
+// still share an L2 (one boundary in `chunk` is between XCDs) and the eight XCDs sweep ONE window, 8 chunks wide.  Measured with production libraries of the commits
+// before and after on three or four allocation sets of each of three or four boxes (profiles/r06_levels.txt blocks 12-14): fk J = 52 slow placements 166 -> 160.8 us
+// (-3.2 %), fast ones 149-153 -> 150-157 (+0 ... +2 %); fk J = 22 slow 251-255 -> 245.5 (-3 %), fast 240-243 -> 242-246.5; from_root_dual_quat J = 22 / 52 240 -> 234 /
+// 144.8 -> 140.3; quat.to_matrix 195.5 -> 186-191 (-2.4 ... -4.8 %); to_root_dual_quat J = 22 -1 ... -2.5 % -- the levels move together, and most placements are slow
+// ones (thirteen boxes: ~60 % of the sets).  The TILE kernels of fk.hip, dq.hip, elementwise.hip and mirror.hip take chunks of kXcdChunk.  The lane-per-frame kernels
+// (deep.hip, the ring / order kernels) keep the contiguous eighths of xcd_tile: to_root_dq_deep_kernel on a 128-joint chain read 329 -> 416 us with chunks (their
+// partial lines are completed by the NEXT tile of the same XCD, a walk later), mirror's deep kernel +2.7 %; the from_root_positions tile kernels read +-0.5 % either way.
 // Launch with grid = 8 * ceil(ntiles / 8); returns -1 for the padding blocks.  chunk <= 0: the contiguous eighths.
 #ifndef PM_XCD_CHUNK
 #define PM_XCD_CHUNK 0
@@ -82,6 +83,7 @@ __device__ __forceinline__ int64_t xcd_tile_chunked(const int64_t ntiles, const 
     return t < ntiles ? t : -1;
 }
 __device__ __forceinline__ int64_t xcd_tile(const int64_t ntiles) { return xcd_tile_chunked(ntiles, PM_XCD_CHUNK); }
+constexpr int kXcdChunk = 32;  // what the tile kernels pass to xcd_tile_chunked
 
 // ---- DPP arithmetic inside a quad (4 consecutive lanes): register-to-register, no LDS ---------------
 // quad_perm:[a,b,c,d] = lane i of every quad reads the operand of lane {a,b,c,d}[i] of the same quad.  The

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
     const int lane = threadIdx.x;
     const int J = a.J;
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
-    const int64_t tile = xcd_tile(ntiles);
+    const int64_t tile = xcd_tile_chunked(ntiles, kXcdChunk);
     if (tile < 0) return;
     const int64_t f0 = tile * FPW;
     const int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(PM_WAVE, 5) void to_root_dq_sched_kernel(const Sche
     const int lane = threadIdx.x;
     const int J = a.J, K = a.K;
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
-    const int64_t group = xcd_tile((ntiles + nt - 1) / nt);  // a workgroup owns `nt` consecutive tiles: table and program are built once
+    const int64_t group = xcd_tile_chunked((ntiles + nt - 1) / nt, kXcdChunk);  // a workgroup owns `nt` consecutive tiles: table and program are built once
     if (group < 0) return;
     const int FS = sched_frame_stride(J);
     float *sDq = smem;                                             // [FPW * FS]
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(PM_WAVE) void gather_parent_kernel(const GatherArgs
     const int lane = threadIdx.x;
     const int J = a.J;
     const int64_t ntiles = (a.F + fpw - 1) / fpw;
-    const int64_t tile = xcd_tile(ntiles);
+    const int64_t tile = xcd_tile_chunked(ntiles, kXcdChunk);
     if (tile < 0) return;
     const int64_t f0 = tile * fpw;
     const int nf = (int)((a.F - f0) < fpw ? (a.F - f0) : fpw);

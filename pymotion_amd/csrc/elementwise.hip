@@ -107,7 +107,7 @@ __global__ __launch_bounds__(PM_WAVE) void ew_kernel(const EwArgs a) {
     constexpr int TILE = EwTileOf<Op>::v, PER_LANE = TILE / PM_WAVE;
     const int lane = threadIdx.x;
     const int64_t ntiles = (a.N + TILE - 1) / TILE;
-    const int64_t tile = xcd_tile(ntiles);
+    const int64_t tile = xcd_tile_chunked(ntiles, kXcdChunk);
     if (tile < 0) return;
     const int64_t e0 = tile * TILE;
     const int n = (int)((a.N - e0) < TILE ? (a.N - e0) : TILE);
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(PM_WAVE) void dq_norm_kernel(const float *__restric
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
     const int64_t ntiles = (N + EW_TILE - 1) / EW_TILE;
-    const int64_t tile = xcd_tile(ntiles);
+    const int64_t tile = xcd_tile_chunked(ntiles, kXcdChunk);
     if (tile < 0) return;
     const int64_t e0 = tile * EW_TILE;
     const int n = (int)((N - e0) < EW_TILE ? (N - e0) : EW_TILE);
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(PM_WAVE) void ceiling_kernel(const float *__restric
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
     const int64_t ntiles = (F + fpw - 1) / fpw;
-    const int64_t tile = xcd_tile(ntiles);
+    const int64_t tile = xcd_tile_chunked(ntiles, kXcdChunk);
     if (tile < 0) return;
     const int64_t f0 = tile * fpw;
     const int nf = (int)((F - f0) < fpw ? (F - f0) : fpw);

@@ -34,7 +34,6 @@
 namespace pm {
 
 enum FkSrc { SRC_QUAT = 0, SRC_O6D = 1 };
-constexpr int kFkXcdChunk = 32;  // fk_kernel / fk_pipe_kernel: tiles / tile groups per XCD chunk (common.hpp: xcd_tile_chunked)
 constexpr int kW4Groups = 10, kW4Steps = 4 * kW4Groups, kW4Stride = kW4Steps + 4;  // tree_walk_w4: steps its list holds (four to a register), words per slot
 
 struct FkArgs {
@@ -1860,7 +1859,7 @@ static int fk_common(int src_kind, const float *src, const float *root_pos, cons
     a.quat_out = quat_out; a.F = F; a.J = J; a.eps = eps; a.pad = 0;  // set by dispatch_fk, per walk shape
     a.wsteps = 0;
     a.fmap = 0xfedcba9876543210ull;
-    a.xchunk = tune_env("PM_FK_XCHUNK", kFkXcdChunk); a.pad2_ = 0;  // tiles (fk_kernel) / tile groups (fk_pipe_kernel) per XCD chunk, see xcd_tile_chunked; PM_TUNING build only: 0 = rounds 1-5's contiguous eighths
+    a.xchunk = tune_env("PM_FK_XCHUNK", kXcdChunk); a.pad2_ = 0;  // tiles (fk_kernel) / tile groups (fk_pipe_kernel) per XCD chunk, see xcd_tile_chunked; PM_TUNING build only: 0 = rounds 1-5's contiguous eighths
 #ifdef PM_TUNING
     a.times = nullptr;
     if (const char *e = getenv("PM_FK_TIMES_PTR")) a.times = reinterpret_cast<uint64_t *>(strtoull(e, nullptr, 0));

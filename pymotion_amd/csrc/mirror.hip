@@ -69,7 +69,7 @@ __global__ __launch_bounds__(PM_WAVE) void mirror_kernel(const MirrorArgs a) {
     const int lane = threadIdx.x;
     const int J = a.J;
     const int64_t ntiles = (a.F + FPW - 1) / FPW;
-    const int64_t tile = xcd_tile(ntiles);
+    const int64_t tile = xcd_tile_chunked(ntiles, kXcdChunk);
     if (tile < 0) return;
     const int64_t f0 = tile * FPW;
     const int nf = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW);
