@@ -834,6 +834,9 @@ bool try_fk_wide(int src_kind, const float *rot, const float *root_pos, const fl
                  float *quat_out, float eps, int64_t F, int32_t J, int32_t depth, const Parents &par, int ablate, int max_quad_steps_per_joint_x10,
                  hipStream_t s, int &rc);
 int fk_wide_plan(const Parents &par, int J, int width, int max_steps, bool dup_idle, uint32_t *jobs);
+// ---- dqwide.hip: to_root_dual_quat from a step list in registers, 16 / fpw joints of a frame a step ---------------------------------
+bool try_to_root_dq_wide(int fpw, const float *rot, const float *root_pos, const float *offsets, float *dq, int64_t F, int32_t J, int32_t depth,
+                         const Parents &par, int ablate, int max_quad_steps_per_joint_x10, hipStream_t s, int &rc);
 int launch_to_root_deep(const float *rot, const float *root_pos, const float *offsets, float *dq, int64_t F, int32_t J,
                         const DeepTopo &topo, hipStream_t s);
 

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include "common.hpp"
+#include "dqstep.hpp"
 
 namespace pm {
 
@@ -47,167 +48,6 @@ struct ToRootArgs {
     Parents parents;
 };
 
-// ---------------------------------------------------------------------------------------------------
-// Big-magnitude tiles (centimetre mocap, far-away roots: the test of fk.hip, kBigOffset / kBigRoot) take a PRECISE step.
-// The reference composes in float64 (skeleton.py:230-241 on float64 arrays, dual_quat.py:32) and its output multiplies the
-// running translation (hundreds of units) with the running quaternion: 0.5 (0, T_j) (x) Q_j.  An fp32 quaternion chain is
-// off by ~4e-7 after ten joints, which TIMES |T| = 400 is 4-5 ulp of the largest dual component (measured 4.3 at J = 52;
-// the accumulation of T itself is the smaller term: an emulation with a float64 quaternion chain and an fp32 translation
-// chain reads 1.6 ulp, the other way round 4.4).  So on those tiles
-//   * the quaternion chain runs in float64: lane c keeps component c as a double, the three foreign components of the
-//     parent arrive as two v_mov_b32_dpp each, and the four products are float64 FMAs (fp32 x fp32 is exact there);
-//   * a parent that is not the previous joint is re-read from the image as hi + lo, lo = an 8-bit residual in units of
-//     2^-31 packed four to a word into the slot's spare eighth float (the fp32 image alone would put back 3e-8 per branch
-//     point: 2.2 ulp at J = 52 in the same emulation);
-//   * translations accumulate in 32-bit fixed point like fk's (integer adds do not round; scale from fx_scale), which is
-//     what keeps a 128-joint chain at the bar (fp32 adds: 6.8 ulp there).
-// The step is ~45 instructions against ~32, ~17 of them at the float64 rate: the walk of such a tile takes about twice as
-// long, the tile as a whole ~20 % more.  Metre-scale tiles keep the fp32 step (their error is 6e-7 absolute).
-// ---------------------------------------------------------------------------------------------------
-template <int CTRL>  // CTRL = quad_perm selector byte: a | b << 2 | c << 4 | d << 6
-__device__ __forceinline__ double quad_perm_f64(const double v) {
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-
-// component c of pq (x) b with pq distributed over the quad in float64 and sb_k = S[c][k] b_{c xor k} as in dq_step_math
-__device__ __forceinline__ double quad_qmul_f64(const double pq, const float b0, const float sb1, const float sb2, const float sb3) {
-    // (one term at a time: left to itself the compiler moves all eight exchanges and the four conversions to the top, and the
-    // sixteen registers that takes set the budget of the whole kernel)
-    double q = quad_perm_f64<0x00>(pq) * (double)b0;
-    asm volatile("" : "+v"(q));
-    q = __builtin_fma(quad_perm_f64<0x55>(pq), (double)sb1, q);
-    asm volatile("" : "+v"(q));
-    q = __builtin_fma(quad_perm_f64<0xaa>(pq), (double)sb2, q);
-    asm volatile("" : "+v"(q));
-    return __builtin_fma(quad_perm_f64<0xff>(pq), (double)sb3, q);
-}
-
-// the rotation part of dq_step_math alone: x = pv x tt + pw tt, tt = 2 (pv x v)  (quat.py:320-334; w1 = 2 v_nextnext, w2 = 2 v_next)
-__device__ __forceinline__ float dq_step_rot(const float pq, const float w1, const float w2) {
-    float tt, an, ann, x;
-    asm("s_nop 1\n\t"
-        "v_mul_f32_dpp %0, %4, %5 quad_perm:[0,2,3,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %0, -%4, %6 quad_perm:[0,3,1,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp %1, %4 quad_perm:[0,2,3,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp %2, %4 quad_perm:[0,3,1,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %3, %0, %1 quad_perm:[0,3,1,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %3, -%0, %2 quad_perm:[0,2,3,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %3, %4, %0 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf"
-        : "=&v"(tt), "=&v"(an), "=&v"(ann), "=&v"(x)
-        : "v"(pq), "v"(w1), "v"(w2));
-    return x;
-}
-
-// The scale of the precise step's fixed-point translations (round 6): fk's fx_scale rounds the bound up to a power of two (an exact scaling of its fp32 products)
-// and bounds a bone by its 1-norm; here the increments are float64 anyway, so the words use the range they have -- S = 0.99 x 2^30 / B with B from the bones'
-// 2-NORMS (a coordinate of a rotated bone is at most its length) -- which is 1.4 bits more resolution on random offsets: on a 55-deep chain of 30-unit bones the
-// words' rounding was a random walk of 2 ulp of the largest dual component (resolution 7.6e-6 at coordinates of ~64), now 0.8.  S and 1 / S are doubles:
-// S x (1 / S) must be 1 to far better than an fp32 ulp, or every position comes back scaled.
-struct FxScaleD { double S, invS; };
-__device__ __forceinline__ bool fx_scale_exact(const float tbound, const float rmax, FxScaleD &fx) {
-    const float B = uniform_f32(wave_max(rmax) + tbound);
-    const float Sf = 1.06e9f * frcp(B);  // ~0.99 x 2^30 / B: any S at or below 2^30 / B will do -- one per cent of headroom for the roundings of the chain
-    fx.S = (double)Sf;
-    const double y = (double)frcp(Sf);   // ... but 1 / S must be THIS S's reciprocal: one Newton step in float64 (1e-14) instead of a float64 division per tile
-    fx.invS = __builtin_fma(y, __builtin_fma(-fx.S, y, 1.0), y);
-    return B < 1e30f && B > 0.0f;        // false for NaN / Inf / absurd magnitudes: the fp32 step, which propagates them like the reference
-}
-// shallow skeletons (below kDqF64RotMinDepth) keep fk's power-of-two scale: their increments and the conversion back are exact fp32 scalings
-template <bool DEEP>
-__device__ __forceinline__ bool fx_scale_for(const float tbound, const float rmax, FxScaleD &fx) {
-    if constexpr (DEEP) return fx_scale_exact(tbound, rmax, fx);
-    FxScale f;
-    const bool ok = fx_scale(tbound, rmax, f);
-    fx.S = (double)uniform_f32(f.S); fx.invS = (double)uniform_f32(f.invS);
-    return ok;
-}
-
-// From this depth on the precise step rotates its bones in float64 (below: fp32 -- the 22-joint body is 7 deep, SMPL-H 10: a random walk of 0.5 ulp x sqrt(depth)
-// stays under 2 ulp there, and the float64 rotation costs centimetre-scale tiles 6.5 %: same-box A/B, 2^20 x 22, 267-269 -> 285-286 us)
-constexpr int kDqF64RotMinDepth = 12;
-// The same rotation in float64, for the precise step (round 6).  Rotating a 30-unit bone in fp32 costs ~5e-6 per joint whatever the quaternion's precision, and
-// down a chain that is a random walk: randomised fuzz runs read 3.4 ulp of the largest dual component on a 32-deep chain of 30-unit bones, 4.1 on a 55-deep one
-// (tests/test_gpu_large_magnitude.py pins them).  With the products in float64 (the quaternion component already is; an offset is an exact fp32 input) what is
-// left per joint is the rounding of the fixed-point word.  next = quad_perm [0,2,3,1] (0x78), next-next = [0,3,1,2] (0x9c); one term at a time, see quad_qmul_f64.
-__device__ __forceinline__ double dq_step_rot_f64(const double pqd, const float w1, const float w2) {
-    const double pn = quad_perm_f64<0x78>(pqd), pnn = quad_perm_f64<0x9c>(pqd);
-    double tt = pn * (double)w1;
-    tt = __builtin_fma(-pnn, (double)w2, tt);          // 2 (pv x v)
-    asm volatile("" : "+v"(tt));
-    double x = quad_perm_f64<0x9c>(tt) * pn;
-    asm volatile("" : "+v"(x));
-    x = __builtin_fma(-quad_perm_f64<0x78>(tt), pnn, x);  // pv x tt
-    asm volatile("" : "+v"(x));
-    return __builtin_fma(quad_perm_f64<0x00>(pqd), tt, x);  // + pw tt
-}
-
-// What a precise step leaves in the translation word of its slot: the fixed-point translation -- or, on lane 0 (whose
-// translation component is the zero scalar part), the four 8-bit residuals qd - qh of the quad in units of 2^-31.
-__device__ __forceinline__ int dq_pack_residual(const double qd, const float qh, const int ti, const int c) {
-    int k = (int)((qd - (double)qh) * 0x1p31);  // |residual| <= 2^-25 for |q| < 1: |k| <= 64
-    k = k < -128 ? -128 : (k > 127 ? 127 : k);
-    int pk = (k & 0xff) << (8 * c);
-    pk |= __builtin_amdgcn_mov_dpp(pk, 0xb1, 0xf, 0xf, true);  // quad_perm:[1,0,3,2]
-    pk |= __builtin_amdgcn_mov_dpp(pk, 0x4e, 0xf, 0xf, true);  // quad_perm:[2,3,0,1]
-    return (c == 0) ? pk : ti;
-}
-
-// One PRECISE step for the lane holding component c (see above).  pqd: the parent's component in float64; pti: the parent's
-// fixed-point translation word.  Returns the float64 component; `qh` / `tword` are what goes into the slot.
-template <bool DEEP>
-__device__ __forceinline__ double dq_step_precise(const double pqd, const int pti, const float b, const float sb1, const float sb2,
-                                                  const float sb3, const float vc, const float w1, const float w2, const float live,
-                                                  const double S, const int c, float &qh, int &ti, int &tword) {
-    const double qd = quad_qmul_f64(pqd, b, sb1, sb2, sb3);
-    if constexpr (DEEP) {  // kDqF64RotMinDepth: the bone rotated in float64, the increment scaled in float64
-        const double x = dq_step_rot_f64(pqd, w1, w2);
-        ti = pti + (int)__builtin_rint(__builtin_fma((double)live, x, (double)vc) * S);
-    } else {               // shallow skeletons: fp32 as in rounds 3-5 (S is a power of two there: an exact scaling)
-        const float x = dq_step_rot((float)pqd, w1, w2);
-        ti = pti + (int)__builtin_rintf(__builtin_fmaf(live, x, vc) * (float)S);
-    }
-    qh = (float)qd;
-    tword = dq_pack_residual(qd, qh, ti, c);
-    return qd;
-}
-
-// a parent re-read from the image: fp32 head + its 8-bit residual (units of 2^-31) out of the packed word
-__device__ __forceinline__ double dq_parent_f64(const float head, const int packed, const int c) {
-    const int k = (packed << (24 - 8 * c)) >> 24;  // sign-extended byte c
-    return __builtin_fma((double)k, 0x1p-31, (double)head);
-}
-
-// One step of the quad walk for the lane holding component c, as ONE block of 12 VALU instructions
-// with the quad exchanges folded into the DPP operand of the multiplies (these kernels sit near the
-// VALU issue limit):
-//   q = pq (x) b                                        quat.py:337-361, component-parallel:
-//       q_c = sum_k S[c][k] pq_k b_{c xor k},  sb_k = S[c][k] b_{c xor k} prepared off the chain
-//   t = live * (pv x tt + pw tt) + s,  tt = 2 (pv x v), s = live v_c + pt      quat.py:320-334
-//       w1 = 2 v_nextnext, w2 = 2 v_next (from the joint table), `next` = quad_perm [0,2,3,1]
-// pq must have been written at least two instructions earlier by VALU (the leading s_nop covers it;
-// inside the block the instruction order keeps every VALU write two slots away from its DPP read).
-__device__ __forceinline__ void dq_step_math(const float pq, const float s, const float b0, const float sb1,
-                                             const float sb2, const float sb3, const float w1, const float w2,
-                                             const float live, float &q, float &t) {
-    float tt, an, ann, x;
-    asm("s_nop 1\n\t"
-        "v_mul_f32_dpp %0, %6, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %2, %6, %12 quad_perm:[0,2,3,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %0, %6, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %2, -%6, %13 quad_perm:[0,3,1,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %0, %6, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp %3, %6 quad_perm:[0,2,3,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %0, %6, %11 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp %4, %6 quad_perm:[0,3,1,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %5, %2, %3 quad_perm:[0,3,1,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %5, -%2, %4 quad_perm:[0,2,3,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %5, %6, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
-        "v_fma_f32 %1, %14, %5, %7"
-        : "=&v"(q), "=&v"(t), "=&v"(tt), "=&v"(an), "=&v"(ann), "=&v"(x)
-        : "v"(pq), "v"(s), "v"(b0), "v"(sb1), "v"(sb2), "v"(sb3), "v"(w1), "v"(w2), "v"(live));
-}
 
 // DEEP: the skeleton is at least kDqF64RotMinDepth deep (chosen by the host: a kernel instance of its own, so that the shallow skeletons' code -- the 22-joint
 // body, SMPL-H -- is rounds 3-5's to the instruction: the float64 rotation as a branch inside the step cost centimetre-scale data 5 %, as a third loop 14 more
@@ -441,6 +281,7 @@ static int launch_to_root(const ToRootArgs &a, bool vec, hipStream_t s) {
 // Everything else (image = output tile + identity slot, phase A / C, copy-out, the 12-instruction DPP step) is the
 // kernel above.
 // ---------------------------------------------------------------------------------------------------
+constexpr int kDqWideMinJ = 16;     // to_root_dq_wide_kernel (dqwide.hip) from here on; below, sixteen frames a wave on the one-chain kernel
 constexpr int kDeepDqHintMinJ = 20;  // ... and from here on when the caller says the bones are big (pm_to_root_dq_hint_f32)
 constexpr int kDeepDqMinJ = 40;  // from here on the lane-per-frame kernels of deep.hip where the topology allows (2^19 frames, chain-like skeleton, deep / scheduled walk: J = 32 159 / 152 us, 40 202 / 206, 48 246 / 256, 56 284 / 309, 64 315 / 383; the 52-joint SMPL-H tree at 2^18: 149 / 146 us on metre data, 148 / 196 us on centimetre data -- the float64 state does not know the difference)
 // (kSchedMax, kSchedMaxJoints: common.hpp -- mirror.hip schedules its walk the same way)
@@ -924,9 +765,39 @@ static int to_root_dq_impl(const float *rot, const float *root_pos, const int32_
     // at every magnitude (2^20 x 22: 235 us against 259 us for the precise step -- and 205 us for the fp32 step on metre data, which
     // is why the raw ABI, which cannot see the scale without reading device memory, keeps the per-tile test below 40 joints).
     const bool big_bones = offsets_abs_max >= kBigOffset && offsets_abs_max < 3e38f;
+    // (round 6) The step-list kernel of dqwide.hip -- 16 / fpw joints of a frame a step, the list in registers, nothing in LDS but the image -- is the
+    // faster shape on metre-scale data at every joint count from kDqWideMinJ on and whatever the tree (profiles/r06_dq_wide_sweep.txt: 22-joint body 212 -> 200 us,
+    // SMPL-H 273 -> 233, random trees of 128 / 250 / 512 joints 54 / 39 / 7.5 % of the HBM spec -> 70 / 64 / 68), and on centimetre-scale data wherever the
+    // tile kernels of this file ran (22 joints 266 -> 227 us).  What it does not beat is the lane-per-frame kernels' float64 state on centimetre-scale data
+    // of skeletons deep enough for the float64 bone rotation (kDqF64RotMinDepth: 64-joint humanoid 321 us at every scale there, 274 / 394 here), and the raw
+    // ABI cannot see the scale: so it goes first when the caller says the bones are small (pm_to_root_dq_hint_f32) or the skeleton is shallow, and otherwise
+    // after the lane-per-frame kernels have declined.  PM_DQ_WIDE (PM_TUNING build only): 0 never, 1 / 2 / 4 / 8 force that many frames a wave.
+    const bool small_bones = offsets_abs_max >= 0.0f && offsets_abs_max < kBigOffset;
+    const int wide_env = tune_env("PM_DQ_WIDE", -1);
+    auto try_wide = [&](int &rc) {
+        if (!vec || wide_env == 0 || (wide_env < 0 && J < kDqWideMinJ)) return false;
+        // (PM_TUNING build only: a test that forces one of the other kernels gets it)
+        if (wide_env < 0 && (tune_env("PM_DQ_CHAINS", -1) >= 0 || tune_env("PM_DQ_FPW", 0) > 0 || tune_env("PM_DQ_DEEP", -1) == 1)) return false;
+        if (wide_env > 0) return try_to_root_dq_wide(wide_env, rot, root_pos, offsets, dq, F, J, a.depth, a.parents, a.ablate, 0, s, rc);
+        // frames a wave: as many as keep a tile at four batches of records (eight where the precise step's registers will not be needed); a narrow tree -- under a
+        // third of its quad-steps busy, or more steps than the list holds -- takes more frames and fewer joints a step
+        // (21-32 joints: eight frames are 3-5 % slower than four on metre-scale data, four 20 % slower than eight where the tiles take the precise step)
+        int fpw = J <= 32 ? ((small_bones && J > 20) ? 4 : 8) : (J <= 64 ? (small_bones ? 8 : 4) : (J <= 128 ? 2 : 1));
+        for (; fpw <= 8; fpw *= 2)
+            if (try_to_root_dq_wide(fpw, rot, root_pos, offsets, dq, F, J, a.depth, a.parents, a.ablate, 30, s, rc)) return true;
+        return false;
+    };
+    if (small_bones || a.depth < kDqF64RotMinDepth || wide_env > 0) {
+        int rc = PM_OK;
+        if (try_wide(rc)) return rc;
+    }
     if (const int deep = tune_env("PM_DQ_DEEP", -1); vec && deep != 0 && (deep == 1 || ((J >= kDeepDqMinJ || (big_bones && J >= kDeepDqHintMinJ)) && lane_per_frame_pays(F, J, kDeepDqMinJointFrames)))) {
         DeepTopo topo;
         if (deep_plan(a.parents, J, true, topo) >= 0) return launch_to_root_deep(rot, root_pos, offsets, dq, F, J, topo, s);
+    }
+    {
+        int rc = PM_OK;
+        if (try_wide(rc)) return rc;
     }
     const size_t per_frame = (size_t)to_root_frame_stride(J) * sizeof(float), fixed = (13 * (size_t)J + 37) * sizeof(float) + 256;
     int pick = (7 * (16 * per_frame + fixed) <= kMaxLds) ? 16 : 8;  // 4 lanes per frame; keep >= 7 waves per CU if possible

@@ -55,22 +55,43 @@ def _batch(F, J, seed):
 
 
 def test_to_root_dual_quat_by_joint_frames():
+    """centimetre-scale bones on a skeleton deep enough for the float64 bone rotation (the front door's hint says so): the lane-per-frame kernel when
+    the call fills the chip, the step-list kernel (dqwide.hip) on a clip of real length"""
     import pymotion_amd.ops.skeleton as sk
 
     J, par = 64, _chain_like(64)
     rot, root, off = _batch(40_000, J, 1)       # 2.56 M joint-frames: above the 2.4 M of deep.hip's kernels
+    root, off = root * 100.0, off * 100.0
     big = sk.to_root_dual_quat(rot, root, par, off)
     assert "to_root_dq_deep_kernel" in _note(), _lib.last_kernel_name()
     small = sk.to_root_dual_quat(rot[:4096], root[:4096], par, off)
-    assert "to_root_dq_sched_kernel" in _note() or "to_root_dq_kernel" in _lib.last_kernel_name(), _lib.last_kernel_name()
-    assert np.abs(big[:4096] - small).max() <= 1e-5
+    assert "to_root_dq_wide_kernel" in _note(), _lib.last_kernel_name()
+    d_o = co.to_root_dual_quat(*_f64(rot[:4096], root[:4096]), par, off.astype(np.float64))
+    assert np.abs(big[:4096] - small).max() <= 3 * _ulp_of(d_o)
+    assert np.abs(small - d_o).max() <= max(1e-5, 3 * _ulp_of(d_o)), np.abs(small - d_o).max() / _ulp_of(d_o)
     for sl in _slices(len(rot)):
         d_o = co.to_root_dual_quat(*_f64(rot[sl], root[sl]), par, off.astype(np.float64))
         # float64 state (deep.hip): the oracle's value rounded once -- test_gpu_deep.py's bar
         assert np.abs(big[sl] - d_o).max() <= _ulp_of(d_o), (sl, np.abs(big[sl] - d_o).max() / _ulp_of(d_o))
         assert np.abs(big[sl][..., :4] - d_o[..., :4]).max() <= 6.1e-8
-    d_o = co.to_root_dual_quat(*_f64(rot[:4096], root[:4096]), par, off.astype(np.float64))
-    assert np.abs(small - d_o).max() <= max(1e-5, 3 * _ulp_of(d_o))
+
+
+def test_to_root_dual_quat_step_list_kernel_against_the_oracle():
+    """dqwide.hip on the production library: a wide 256-joint tree (a frame a wave, sixteen joints a step) and SMPL-H (eight / four frames a wave), metre-scale
+    bones (the fp32 step) and centimetre-scale ones (the precise step: 2 ulp of the largest dual component, tests/test_gpu_large_magnitude.py's bar),
+    first / middle / last tiles of a call big enough for several tiles a workgroup"""
+    import pymotion_amd.ops.skeleton as sk
+    from pymotion_amd import synthetic as syn
+
+    for J, par, F in ((256, syn.random_parents(256, np.random.default_rng(256)), 140_000), (52, np.asarray(syn.PARENTS_52, dtype=np.int32), 140_001)):
+        rot, root, off = _batch(F, J, 31 + J)
+        for scale in (1.0, 100.0):
+            d = sk.to_root_dual_quat(rot, root * scale, par, off * scale)
+            assert "to_root_dq_wide_kernel" in _note(), _lib.last_kernel_name()
+            for sl in _slices(F):
+                d_o = co.to_root_dual_quat(*_f64(rot[sl], root[sl] * np.float32(scale)), par, (off * np.float32(scale)).astype(np.float64))
+                assert np.abs(d[sl] - d_o).max() <= max(1e-5, 2 * _ulp_of(d_o)), (J, scale, sl, np.abs(d[sl] - d_o).max() / _ulp_of(d_o))
+                assert np.abs(d[sl][..., :4] - d_o[..., :4]).max() <= (2e-6 if scale == 1.0 else 1.2e-7)
 
 
 def test_to_root_dual_quat_ring_kernel_by_joint_frames():
@@ -175,7 +196,7 @@ def test_tile_kernels_against_the_oracle():
         assert np.abs(pos - p_o).max() <= 1e-5 and np.abs(rm - r_o).max() <= 1e-5
         rn = (rot / np.linalg.norm(rot, axis=-1, keepdims=True)).astype(np.float32)
         d = sk.to_root_dual_quat(rn, root, par, off)
-        assert "to_root_dq_sched_kernel" in _note(), _lib.last_kernel_name()
+        assert "to_root_dq_wide_kernel" in _note(), _lib.last_kernel_name()
         d_o = co.to_root_dual_quat(*_f64(rn, root), par, off.astype(np.float64))
         assert np.abs(d - d_o).max() <= 1e-5
         t, q = sk.from_root_dual_quat(d_o.astype(np.float32), par)
@@ -193,6 +214,19 @@ def test_to_root_dual_quat_one_chain_tile_kernel_against_the_oracle():
     rot, root, off = _batch(3001, J, 21)
     d = sk.to_root_dual_quat(rot, root, par, off)
     assert "to_root_dq_kernel" in _note(), _lib.last_kernel_name()
+    d_o = co.to_root_dual_quat(*_f64(rot, root), par, off.astype(np.float64))
+    assert np.abs(d - d_o).max() <= 1e-5
+
+
+def test_to_root_dual_quat_scheduled_walk_against_the_oracle():
+    """a long, narrow tree (more steps than the step list of dqwide.hip holds) on a clip of real length (too few joint-frames for the lane-per-frame kernels):
+    the scheduled walk of dq.hip, to_root_dq_sched_kernel"""
+    import pymotion_amd.ops.skeleton as sk
+
+    J, par = 130, _chain_like(130)
+    rot, root, off = _batch(3001, J, 23)
+    d = sk.to_root_dual_quat(rot, root, par, off)
+    assert "to_root_dq_sched_kernel" in _note(), _lib.last_kernel_name()
     d_o = co.to_root_dual_quat(*_f64(rot, root), par, off.astype(np.float64))
     assert np.abs(d - d_o).max() <= 1e-5
 
@@ -215,7 +249,7 @@ def test_fk_wide_walk_on_bushy_trees():
         assert np.abs(pos[sl] - p_o).max() <= max(1e-5, 3 * _ulp_of(p_o))
 
 
-ALL_SKELETON_KERNELS = {"fk_wide_kernel", "to_root_dq_kernel", "to_root_dq_sched_kernel", "to_root_dq_deep_kernel", "to_root_dq_ring_kernel", "gather_parent_kernel",
+ALL_SKELETON_KERNELS = {"fk_wide_kernel", "to_root_dq_kernel", "to_root_dq_sched_kernel", "to_root_dq_wide_kernel", "to_root_dq_deep_kernel", "to_root_dq_ring_kernel", "gather_parent_kernel",
                         "fk_kernel", "fk_pipe_kernel", "fk_stream_kernel", "mirror_kernel", "mirror_deep_kernel", "from_root_positions_kernel",
                         "from_root_positions_order_kernel"}
 
@@ -224,7 +258,7 @@ def test_every_kernel_name_of_the_production_library_is_tied_to_the_oracle(reque
     """every kernel template `pm_last_kernel_name()` can return from libpmhip.so (the `set_kernel_name` sites of csrc/*.hip; asserted against
     the sources in tests/test_abi.py) was dispatched to by an oracle-tied call of this module -- on the production library"""
     ran = {i.name for i in request.session.items if i.module is request.module}
-    if len(ran) < 9:
+    if len(ran) < 11:
         pytest.skip("needs the whole module (the other tests collect the kernel names)")
     assert _lib.lib() is _lib._handles.get("prod"), "this module must run on the production library"
     assert SEEN == ALL_SKELETON_KERNELS, (sorted(ALL_SKELETON_KERNELS - SEEN), sorted(SEEN - ALL_SKELETON_KERNELS))

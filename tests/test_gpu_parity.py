@@ -918,12 +918,21 @@ def _tree(kind, J, rng):
     return p
 
 
+@pytest.mark.parametrize("walk", ["dispatch", "scheduled"])
 @pytest.mark.parametrize("kind", ["chain", "star", "star_off_1", "heap", "two_arms", "random", "random2"])
 @pytest.mark.parametrize("J", [28, 31, 52, 64, 65, 100, 129, 250, 251])
-def test_to_root_dq_chain_scheduler_on_many_topologies(kind, J):
+def test_to_root_dq_chain_scheduler_on_many_topologies(kind, J, walk, monkeypatch):
     """28 <= J <= 250 walks several chains per frame (dq.hip: schedule_chains) when the tree is wide enough; every shape of
     tree -- including the ones that must fall back to one chain -- has to give the oracle's dual quaternions, and the
-    decode has to bring the inputs back"""
+    decode has to bring the inputs back.  `dispatch`: what the production library picks (since round 6 the step-list kernel of dqwide.hip wherever its list
+    holds the tree); `scheduled`: the chain scheduler's kernels (the tuning build with PM_DQ_WIDE=0: what unaligned arrays get)"""
+    import contextlib
+
+    from pymotion_amd import _lib
+
+    if walk == "scheduled":
+        monkeypatch.setenv("PM_DQ_WIDE", "0")
+    ctx = _lib.variant("tuning") if walk == "scheduled" else contextlib.nullcontext()
     rng = np.random.default_rng(hash((kind, J)) % (1 << 31))
     parents = _tree(kind, J, rng)
     F = 37
@@ -932,7 +941,9 @@ def test_to_root_dq_chain_scheduler_on_many_topologies(kind, J):
     gpos = rng.uniform(-2, 2, (F, 3)).astype(np.float32)
     off = rng.uniform(-0.3, 0.3, (J, 3)).astype(np.float32)
     off[0] = 0
-    d = sk.to_root_dual_quat(rot, gpos, parents, off)
+    with ctx:
+        d = sk.to_root_dual_quat(rot, gpos, parents, off)
+        assert walk == "dispatch" or "wide_kernel" not in _lib.last_kernel_name()
     d_o = co.to_root_dual_quat(rot.astype(np.float64), gpos.astype(np.float64), parents, off.astype(np.float64))
     depth = 1
     dd = np.zeros(J, int)
