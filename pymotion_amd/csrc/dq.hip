@@ -779,10 +779,11 @@ static int to_root_dq_impl(const float *rot, const float *root_pos, const int32_
         // (PM_TUNING build only: a test that forces one of the other kernels gets it)
         if (wide_env < 0 && (tune_env("PM_DQ_CHAINS", -1) >= 0 || tune_env("PM_DQ_FPW", 0) > 0 || tune_env("PM_DQ_DEEP", -1) == 1)) return false;
         if (wide_env > 0) return try_to_root_dq_wide(wide_env, rot, root_pos, offsets, dq, F, J, a.depth, a.parents, a.ablate, 0, s, rc);
-        // frames a wave: as many as keep a tile at four batches of records (eight where the precise step's registers will not be needed); a narrow tree -- under a
-        // third of its quad-steps busy, or more steps than the list holds -- takes more frames and fewer joints a step
-        // (21-32 joints: eight frames are 3-5 % slower than four on metre-scale data, four 20 % slower than eight where the tiles take the precise step)
-        int fpw = J <= 32 ? ((small_bones && J > 20) ? 4 : 8) : (J <= 64 ? (small_bones ? 8 : 4) : (J <= 128 ? 2 : 1));
+        // frames a wave (same-box sweeps, profiles/r06_dq_wide_sweep.txt): eight up to 32 joints (22 joints 193 us against 237 with four, on centimetre-scale
+        // data 256 against 330), four up to 128 (SMPL-H 229 against 240 with eight, 64 joints 263 against 293, 128 joints 532 against 547 with two), one beyond
+        // (250 joints 546 against 558 with two); a narrow tree -- under a third of its quad-steps busy, or more steps than the list holds -- takes more frames
+        // and fewer joints a step
+        int fpw = J <= 32 ? 8 : (J <= 128 ? 4 : 1);
         for (; fpw <= 8; fpw *= 2)
             if (try_to_root_dq_wide(fpw, rot, root_pos, offsets, dq, F, J, a.depth, a.parents, a.ablate, 30, s, rc)) return true;
         return false;

@@ -282,10 +282,12 @@ bool try_to_root_dq_wide(const int fpw, const float *rot, const float *root_pos,
             a.jobs[k * kDwStride + st] = w;
         }
     a.rot = rot; a.root_pos = root_pos; a.offsets = offsets; a.dq = dq; a.F = F; a.J = J; a.depth = depth; a.ablate = ablate;
-    // tiles per workgroup: the words and the offsets are loaded once, and the next tile's quaternions are requested before a tile's walk -- while the
-    // launch still has several workgroups per wave slot of the chip (PM_DQW_NT, PM_TUNING build only)
+    // tiles per workgroup: the words and the offsets are loaded once and the next tile's quaternions are requested before a tile's walk, but a launch wants
+    // many more workgroups than the chip has wave slots (the last round of a launch runs part empty).  Same-box sweep at 2^18...2^20 frames, one / two / four
+    // tiles: 22 joints 193 / 190 / 199 us, 32 joints 255 / 276 / 299, 64 joints 263 / 278 / 308, 128 joints 570 / 532 / 605, 250 joints 549 / 546 / 603,
+    // 512 joints 70.3 / 75.2 / 67.4 % of the HBM spec.  (PM_DQW_NT, PM_TUNING build only)
     const int64_t ntiles = (F + fpw - 1) / fpw;
-    int nt = ntiles >= 131072 ? 4 : (ntiles >= 32768 ? 2 : 1);
+    int nt = (J > 100 && ntiles >= 65536) ? 2 : 1;
     nt = tune_env("PM_DQW_NT", nt);
     if (nt < 1) nt = 1;
     rc = fpw == 1 ? launch_dq_wide_nb<1>(a, nt, s) : (fpw == 2 ? launch_dq_wide_nb<2>(a, nt, s) : (fpw == 4 ? launch_dq_wide_nb<4>(a, nt, s) : launch_dq_wide_nb<8>(a, nt, s)));

@@ -139,9 +139,11 @@ def test_step_list_kernel_keeps_nan_and_inf_where_the_reference_has_them(fpw, mo
 
 PICKS = [  # (J, tree, offsets scale, frames a wave the production dispatch picks -- None: another kernel)
     (12, "bushy", 0.3, None),       # below kDqWideMinJ: sixteen frames a wave on the one-chain kernel
-    (22, "body", 0.3, 4), (22, "body", 30.0, 8), (52, "smplh", 0.15, 8), (52, "smplh", 30.0, 4), (64, "chain", 0.3, 8),
-    (100, "bushy", 0.3, 2), (100, "bushy", 30.0, 2), (200, "bushy", 0.3, 1), (512, "bushy", 30.0, 1),
-    (96, "chain", 0.3, 4),          # 48 steps of two-of-eight quads busy: more frames, fewer joints a step
+    (16, "bushy", 0.3, 8), (22, "body", 0.3, 8), (22, "body", 30.0, 8), (33, "bushy", 0.3, 4), (52, "smplh", 0.15, 4), (52, "smplh", 30.0, 4), (64, "chain", 0.3, 4),
+    (100, "bushy", 0.3, 4), (128, "bushy", 30.0, 4), (129, "humanoid", 0.3, 1), (200, "bushy", 0.3, 1), (512, "bushy", 30.0, 1),
+    (96, "chain", 0.3, 4),          # 48 levels: the list holds them at four joints a step, and over a third of the quad-steps are busy
+    (28, "chain", 30.0, 8),         # centimetre-scale bones (the front door's hint says so) on a skeleton deep enough for the float64 bone rotation, but too few
+                                    # joint-frames for the lane-per-frame kernels: they decline, this one takes it
     (130, "chain", 0.3, None),      # 65 levels: more steps than the list holds at any width
 ]
 
