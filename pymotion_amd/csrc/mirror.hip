@@ -24,6 +24,7 @@ struct Map16 { int16_t m[PM_MAX_JOINTS]; };
 constexpr int kMirrorDeepMinJ = 66;   // from here on mode 'all' walks one lane per frame where the topology allows (chain-like skeletons at 2^19 frames, lane per
                                       // frame / scheduled walk, % of the HBM spec: J = 32 75 / 69, 44 69 / 64, 48 67 / 67, 50 56 / 62, 56 61 / 65, 64 60 / 63,
                                       // 65 54 / 58, 66 57 / 55, 72 60 / 58, 80 60 / 55.5, 96 60 / 53, 128 61 / 45; the SMPL-H tree at 2^18: 68 / 60)
+constexpr int kMirrorWideMinJ = 44;   // from here on the step-list walk (mirror_wide_kernel) goes first
 constexpr int kMirrorSchedMinJ = 40;  // from here on the scheduled walk is considered (measured: see pm_mirror_rotations_f32)
 
 struct MirrorArgs {
@@ -368,6 +369,205 @@ static int launch_mirror_deep(const MirrorDeepArgs &a, hipStream_t s) {
     return PM_AFTER_LAUNCH("mirror (lane per frame) launch");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// (round 6) The walk from a STEP LIST in registers, 16 / FPW joints of a frame a step -- the shape of to_root_dq_wide_kernel (dqwide.hip; fk's
+// tree_walk_w4 / fk_wide_kernel before it): the scheduled walk above keeps a program (8 bytes a step and chain) and two tables in LDS, rebuilt by
+// every workgroup, and its schedule stops at kSchedMaxJoints -- beyond, a wide tree fell to the one-chain walk, J dependent steps on four frames a
+// wave.  Here nothing is in LDS but the image (16 bytes a joint, + the identity and the idle slot), the list is fk_wide_plan's (a joint at the earliest
+// one step after its parent; the root takes no step: its slot holds q_0 as parked, which is identity (x) q_0), a quad reads its parent's component at
+// the top of the step and its own local quaternion one step ahead, and a record's place in the image, its mapped slot and its parent's mapped slot
+// (skeleton.py:322-331) are registers of the lane that finishes it.  Same products in the same order as the walks above: their bits.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int kMwSteps = 48, kMwGroups = kMwSteps / 4, kMwStride = kMwSteps + 8;
+struct MirrorWideArgs {
+    const float *rot;
+    float *out;
+    int64_t F;
+    int32_t J, c0, c1, nsteps;
+    Parents parents;
+    Map16 mapping;
+    uint32_t jobs[16 * kMwStride];  // [quad of a frame][step]: own slot | parent slot << 16, in BYTES from the frame's image
+};
+__host__ __device__ constexpr int mirror_wide_frame_stride(const int J) { return 4 * ((J + 2) | 1); }  // an odd number of 16-byte slots: the frames' quads start on different banks
+
+__device__ __forceinline__ void mw_walk(float *fD, const uint32_t (&JW)[kMwGroups + 1], const int nsteps, const int c) {
+    const float s1 = (c == 0 || c == 2) ? -1.0f : 1.0f, s2 = (c == 0 || c == 3) ? -1.0f : 1.0f, s3 = (c == 0 || c == 1) ? -1.0f : 1.0f;
+    char *bq = reinterpret_cast<char *>(fD + c);
+    auto word = [](const uint32_t v, auto t) __attribute__((always_inline)) {
+        constexpr int T = decltype(t)::value;
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, T * 0x55, 0xf, 0xf, true);  // quad_perm:[T,T,T,T]
+    };
+    uint32_t w = word(JW[0], IntC<0>{});
+    unsigned own = w & 0xffffu;
+    float b = *reinterpret_cast<const float *>(bq + own);
+    auto step = [&](const uint32_t wn) __attribute__((always_inline)) {
+        const unsigned par = w >> 16, ownn = wn & 0xffffu;
+        const float pq = *reinterpret_cast<const float *>(bq + par);   // finished a step ago or earlier (in-order DS)
+        const float bn = *reinterpret_cast<const float *>(bq + ownn);  // the next step's joint: its slot holds the local quaternion until its own step
+        const float sb1 = quad_perm_mul<1, 0, 3, 2>(b, s1), sb2 = quad_perm_mul<2, 3, 0, 1>(b, s2), sb3 = quad_perm_mul<3, 2, 1, 0>(b, s3);
+        const float q = quad_qmul(pq, b, sb1, sb2, sb3);
+        *reinterpret_cast<float *>(bq + own) = q;
+        own = ownn; b = bn; w = wn;
+    };
+    // (spelled out group by group, an exit per group: see dw_walk, dqwide.hip)
+#define PM_MW_GROUP(g)                     \
+    if ((g) * 4 >= nsteps) return;         \
+    step(word(JW[(g)], IntC<1>{}));        \
+    step(word(JW[(g)], IntC<2>{}));        \
+    step(word(JW[(g)], IntC<3>{}));        \
+    step(word(JW[(g) + 1], IntC<0>{}));
+    PM_MW_GROUP(0) PM_MW_GROUP(1) PM_MW_GROUP(2) PM_MW_GROUP(3) PM_MW_GROUP(4) PM_MW_GROUP(5)
+    PM_MW_GROUP(6) PM_MW_GROUP(7) PM_MW_GROUP(8) PM_MW_GROUP(9) PM_MW_GROUP(10) PM_MW_GROUP(11)
+#undef PM_MW_GROUP
+    static_assert(kMwGroups == 12, "mw_walk spells out its groups");
+}
+
+// FPW frames a wave (W = 16 / FPW joints of a frame a step), NB batches of 64 records a tile (FPW J <= 64 NB); a workgroup (one wave) takes `nt` tiles.
+template <int FPW, int NB>
+__global__ __launch_bounds__(PM_WAVE) void mirror_wide_kernel(const MirrorWideArgs a, const int nt) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int W = 16 / FPW, NG = kMwGroups;
+    const int lane = threadIdx.x, J = a.J;
+    const int64_t ntiles = (a.F + FPW - 1) / FPW, ngroups = (ntiles + nt - 1) / nt;
+    const int64_t grp = xcd_tile_chunked(ngroups, kXcdChunk);
+    if (grp < 0) return;
+    const int FS = mirror_wide_frame_stride(J), ne = FPW * J;
+    const int quad = lane >> 2, f = quad / W, k = quad % W, c = lane & 3;
+    float *fD = smem + f * FS;
+    const int64_t t0 = grp * nt, t1 = (t0 + nt < ntiles) ? t0 + nt : ntiles;
+    v4f q[NB];
+    auto issue = [&](const int64_t tile) __attribute__((always_inline)) {
+        const int64_t f0 = tile * FPW;
+        const int n = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW) * J;
+        const v4f *src = reinterpret_cast<const v4f *>(a.rot) + f0 * J;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {  // (no branch per batch: loads are clamped, stores guarded)
+            const int e = u * PM_WAVE + lane;
+            q[u] = __builtin_nontemporal_load(src + (e < n ? e : n - 1));
+        }
+    };
+    issue(t0);
+    uint32_t JW[NG + 1];  // lane (k, t): word of step 4 g + t for quad k of every frame
+#pragma unroll
+    for (int g = 0; g <= NG; ++g) JW[g] = a.jobs[k * kMwStride + 4 * g + (lane & 3)];
+    // a record's slot, the slot of the joint it is mapped to and of that joint's... the reference reads mapping[j] and mapping[parents[j]] (skeleton.py:322-331)
+    int so[NB], mo[NB], mp[NB];
+    bool is_root[NB];
+    const float invJ = 1.0f / (float)J;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int e = u * PM_WAVE + lane, ec = e < ne ? e : ne - 1;
+        const int ef = (FPW == 1) ? 0 : (int)(((float)ec + 0.5f) * invJ);  // ec / J, exact for ec < 2^22
+        const int ej = ec - ef * J;
+        so[u] = ef * FS + ej * 4;
+        mo[u] = ef * FS + 4 * a.mapping.m[ej];
+        mp[u] = ef * FS + 4 * a.mapping.m[ej == 0 ? 0 : a.parents.p[ej]];
+        is_root[u] = ej == 0;
+    }
+#pragma unroll
+    for (int g = 0; g <= NG; ++g) asm volatile("" : "+v"(JW[g]));  // settle the list here, not inside the walk (behind the next tile's loads)
+#pragma unroll
+    for (int u = 0; u < NB; ++u) asm volatile("" : "+v"(mo[u]), "+v"(mp[u]));
+    if (k == 0) { fD[J * 4 + c] = (c == 0) ? 1.0f : 0.0f; fD[(J + 1) * 4 + c] = (c == 0) ? 1.0f : 0.0f; }  // identity and idle slots (idle steps keep the idle one at the identity)
+    const float f1 = (a.c0 == 1 || a.c1 == 1) ? -1.0f : 1.0f, f2 = (a.c0 == 2 || a.c1 == 2) ? -1.0f : 1.0f, f3 = (a.c0 == 3 || a.c1 == 3) ? -1.0f : 1.0f;
+
+    for (int64_t tile = t0; tile < t1; ++tile) {
+        const int64_t f0 = tile * FPW;
+        const int n = (int)((a.F - f0) < FPW ? (a.F - f0) : FPW) * J;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int e = u * PM_WAVE + lane;
+            const float qi[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+            float un[4];
+            qnormalize(qi, 1e-8f, un);  // skeleton.py:45
+            if (e < n) *reinterpret_cast<v4f *>(smem + so[u]) = v4f{un[0], un[1], un[2], un[3]};
+        }
+        wave_sync();
+        if (tile + 1 < t1) issue(tile + 1);  // in flight while this tile walks
+        mw_walk(fD, JW, a.nsteps, c);
+        wave_sync();
+        // finish, lane per record: the reference's sign and normalisation ONCE per world quaternion, in place ...
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int e = u * PM_WAVE + lane;
+            float *slot = smem + so[u];
+            const v4f gv = *reinterpret_cast<const v4f *>(slot);
+            const float g[4] = {gv.x, gv.y, gv.z, gv.w};
+            float cg[4];
+            canonical_sign(g, cg);
+            if (e < n) *reinterpret_cast<v4f *>(slot) = v4f{cg[0], cg[1], cg[2], cg[3]};
+            if (u & 1) asm volatile("" ::: "memory");
+        }
+        wave_sync();
+        // ... then the joint permutation, the two negated components and local'_j = conj(g'_parent) (x) g'_j, stored straight from registers
+        v4f *gout = reinterpret_cast<v4f *>(a.out) + f0 * J;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int e = u * PM_WAVE + lane;
+            const v4f gv = *reinterpret_cast<const v4f *>(smem + mo[u]), pv = *reinterpret_cast<const v4f *>(smem + mp[u]);
+            const float cg[4] = {gv.x, gv.y * f1, gv.z * f2, gv.w * f3};  // skeleton.py:310-318
+            const float inv[4] = {pv.x, -pv.y * f1, -pv.z * f2, -pv.w * f3};
+            float o[4];
+            qmul(inv, cg, o);  // skeleton.py:85-91 on the mirrored world rotations
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = is_root[u] ? cg[i] : o[i];  // the root has no parent (select, not branch)
+            if (e < n) __builtin_nontemporal_store(v4f{o[0], o[1], o[2], o[3]}, gout + e);
+            if (u & 1) asm volatile("" ::: "memory");
+        }
+        wave_sync();  // the image is the next tile's
+    }
+}
+
+template <int FPW, int NB>
+static int launch_mirror_wide(const MirrorWideArgs &a, const int nt, hipStream_t s) {
+    const size_t lds = (size_t)FPW * mirror_wide_frame_stride(a.J) * sizeof(float);
+    const int64_t ntiles = (a.F + FPW - 1) / FPW, ngroups = (ntiles + nt - 1) / nt, grid = ((ngroups + PM_NXCD - 1) / PM_NXCD) * PM_NXCD;
+    if (grid > 0x7fffffffLL) { set_error("mirror: grid too large"); return PM_EUNSUPPORTED; }
+    set_kernel_name("void pm::mirror_wide_kernel<%d, %d>(pm::MirrorWideArgs, int)", FPW, NB);
+    auto kf = mirror_wide_kernel<FPW, NB>;
+    if (int e = allow_lds(kf, lds)) return e;
+    hipLaunchKernelGGL(kf, dim3((unsigned)grid), dim3(PM_WAVE), lds, s, a, nt);
+    return PM_AFTER_LAUNCH("mirror launch");
+}
+template <int FPW>
+static int launch_mirror_wide_nb(const MirrorWideArgs &a, const int nt, hipStream_t s) {
+    const int ne = FPW * a.J;
+    if (ne <= 2 * PM_WAVE) return launch_mirror_wide<FPW, 2>(a, nt, s);
+    if (ne <= 3 * PM_WAVE) return launch_mirror_wide<FPW, 3>(a, nt, s);
+    if (ne <= 4 * PM_WAVE) return launch_mirror_wide<FPW, 4>(a, nt, s);
+    if (ne <= 6 * PM_WAVE) return launch_mirror_wide<FPW, 6>(a, nt, s);
+    return launch_mirror_wide<FPW, 8>(a, nt, s);
+}
+// 16-byte aligned arrays, `fpw` = 1, 2, 4 or 8 frames a wave.  false (nothing launched): fpw x J records do not fit eight batches, the tree needs more than
+// kMwSteps steps of 16 / fpw joints, or more than max_quad_steps_per_joint_x10 / 10 quad-steps per joint (0: no such bound); true with rc set otherwise.
+static bool try_mirror_wide(const int fpw, const MirrorArgs &m, const int max_quad_steps_per_joint_x10, hipStream_t s, int &rc) {
+    const int J = m.J;
+    if ((fpw != 1 && fpw != 2 && fpw != 4 && fpw != 8) || fpw * J > 8 * PM_WAVE) return false;
+    const int W = 16 / fpw;
+    MirrorWideArgs a;
+    uint32_t list[(kMwSteps + 2) * 16];
+    a.nsteps = (J == 1) ? 0 : fk_wide_plan(m.parents, J, W, kMwSteps, false, list);
+    if (a.nsteps < 0) return false;
+    if (max_quad_steps_per_joint_x10 > 0 && a.nsteps * W * 10 > max_quad_steps_per_joint_x10 * J) return false;
+    const uint32_t idle = (uint32_t)((J + 1) * 16) | ((uint32_t)(J * 16) << 16);
+    for (int k = 0; k < 16; ++k)
+        for (int st = 0; st < kMwStride; ++st) {
+            uint32_t w = idle;
+            if (k < W && st < a.nsteps) {
+                const uint32_t j = list[st * W + k] & 0xffffu, p = list[st * W + k] >> 16;
+                if ((int)j < J) w = (j * 16u) | (p * 16u) << 16;
+            }
+            a.jobs[k * kMwStride + st] = w;
+        }
+    a.rot = m.rot; a.out = m.out; a.F = m.F; a.J = J; a.c0 = m.c0; a.c1 = m.c1; a.parents = m.parents; a.mapping = m.mapping;
+    const int64_t ntiles = (m.F + fpw - 1) / fpw;
+    int nt = (J > 100 && ntiles >= 65536) ? 2 : 1;  // (to_root_dq_wide_kernel's sweep, dqwide.hip)
+    nt = tune_env("PM_MW_NT", nt);
+    if (nt < 1) nt = 1;
+    rc = fpw == 1 ? launch_mirror_wide_nb<1>(a, nt, s) : (fpw == 2 ? launch_mirror_wide_nb<2>(a, nt, s) : (fpw == 4 ? launch_mirror_wide_nb<4>(a, nt, s) : launch_mirror_wide_nb<8>(a, nt, s)));
+    return true;
+}
+
 static size_t mirror_lds_bytes(const int FPW, const int J, const int K, const int C) {
     return ((size_t)FPW * mirror_frame_stride(J, C) + 3 * (size_t)J + 1 + 8) * sizeof(float) + (C > 1 ? (size_t)(K + 2) * C * 8 + 8 : 0);  // + slack for the walk's look-ahead
 }
@@ -412,6 +612,21 @@ extern "C" int pm_mirror_rotations_f32(const float *rot, const int32_t *parents,
     }
     const bool vec = aligned16(rot) && aligned16(out);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // (round 6) From kMirrorWideMinJ joints on: the walk from a step list in registers, 16 / fpw joints of a frame a step (mirror_wide_kernel), with or without a joint
+    // mapping.  Same-box sweep (profiles/r06_mirror_wide_sweep.txt), this kernel / what ran before, us: random trees of 48 / 64 / 96 / 128 / 250 / 512 joints
+    // 141 / 151, 196 / 210, 294 / 343, 374 / 462, 383 / 707, 753 / 4411 (beyond kSchedMaxJoints a wide tree fell to the one-chain walk); humanoids of 56 / 64 / 128 /
+    // 250 / 512 joints against the lane-per-frame kernel 180 / 193, 191 / 225, 381 / 436, 373 / 467, 797 / 913; SMPL-H 168 / 183; chain-like skeletons a draw
+    // (56: 194 / 194, 72: 260 / 250, 96: 326 / 335); below 44 joints sixteen frames a wave on the one-chain walk stay ahead (22 joints 137 / 132, 32: 195 / 186).
+    // Frames a wave: four up to 64 joints, two up to 100, one beyond; a narrow tree (under a third of its quad-steps busy, or more steps than the list holds)
+    // takes more frames and fewer joints a step, and what no width holds goes on to the kernels below.  PM_MIRROR_WIDE (PM_TUNING build only): 0 never,
+    // 1 / 2 / 4 / 8 force that many frames a wave.
+    if (const int wide = tune_env("PM_MIRROR_WIDE", -1); vec && wide != 0 && (wide > 0 || (J >= kMirrorWideMinJ && tune_env("PM_MIRROR_DEEP", -1) != 1 && tune_env("PM_MIRROR_CHAINS", -1) < 0 && tune_env("PM_MIRROR_FPW", 0) == 0))) {
+        int rc = PM_OK;
+        if (wide > 0) { if (try_mirror_wide(wide, a, 0, s, rc)) return rc; }
+        else
+            for (int fpw = J <= 64 ? 4 : (J <= 100 ? 2 : 1); fpw <= 8; fpw *= 2)
+                if (try_mirror_wide(fpw, a, 30, s, rc)) return rc;
+    }
     // mode 'all' on long skeletons: one lane per frame, joints streamed (mirror_deep_kernel), where the call has the joint-frames to fill the
     // chip (common.hpp).  From 66 joints on, and from 52 when the row is a whole number of 64-byte pieces (round 4, with the kernel's eight
     // waves two to a SIMD: SMPL-H as stored and a chain-like 52 at 2^18 / 2^20 frames 81 / 324 us against 89-95 / 339 us for the scheduled

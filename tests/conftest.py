@@ -75,13 +75,15 @@ def lane_per_frame_at_test_sizes(monkeypatch):
     """The long-skeleton kernels (one lane per frame: deep.hip, mirror_deep_kernel, from_root_positions_order_kernel, and fk's streamed walk)
     only take calls with enough joint-frames to fill the chip (common.hpp: lane_per_frame_pays -- a clip of real length is faster on the tile
     kernels).  Parity tests that want THOSE kernels at sizes the oracle finishes in seconds run on the tuning build with the threshold at 0:
-    same kernels, same dispatch otherwise -- except that to_root_dual_quat's step-list kernel (dqwide.hip), which the dispatch asks before them on small
-    bones and shallow skeletons, stands aside (PM_DQ_WIDE=0): its own suite is tests/test_gpu_dqwide.py.  The production library's choice on either
+    same kernels, same dispatch otherwise -- except that the step-list kernels of round 6 (to_root_dq_wide_kernel, dqwide.hip; mirror_wide_kernel, mirror.hip),
+    which the dispatch asks before them, stand aside (PM_DQ_WIDE=0, PM_MIRROR_WIDE=0): their own suites are tests/test_gpu_dqwide.py and
+    tests/test_gpu_mirror_wide.py.  The production library's choice on either
     side of the threshold: tests/test_gpu_dispatch.py."""
     from pymotion_amd import _lib
 
     monkeypatch.setenv("PM_LPF_MIN_JOINT_FRAMES", "0")
     monkeypatch.setenv("PM_DQ_WIDE", "0")
+    monkeypatch.setenv("PM_MIRROR_WIDE", "0")
     with _lib.variant("tuning"):
         yield
 

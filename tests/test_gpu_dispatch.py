@@ -108,9 +108,21 @@ def test_to_root_dual_quat_ring_kernel_by_joint_frames():
         assert np.abs(big[sl][..., :4] - d_o[..., :4]).max() <= 6.1e-8
 
 
+def _mirror_want(rot, off, par, sl):
+    # the reference's chain rebuilt from oracle pieces (fk -> from_matrix -> negate -> from_global_rotations; axis 0 = X: components 2, 3,
+    # skeleton.py:310-312)
+    _, rm = co.fk(rot[sl].astype(np.float64), np.zeros((len(rot[sl]), 3)), off.astype(np.float64), par)
+    g = co.quat_from_matrix(rm)
+    g[..., 2] *= -1
+    g[..., 3] *= -1
+    return co.from_global_rotations(g, par)
+
+
 def test_mirror_by_joint_frames():
-    J, par = 72, _chain_like(72)
-    rot, root, off = _batch(90_000, J, 2)       # 6.5 M joint-frames
+    """a chain-like skeleton deeper than the step list of mirror_wide_kernel holds: the lane-per-frame kernel when the call fills the chip, the tile kernels
+    on a clip of real length"""
+    J, par = 130, _chain_like(130)
+    rot, root, off = _batch(50_000, J, 2)       # 6.5 M joint-frames
     import torch
 
     dev = torch.device("cuda:0")
@@ -124,19 +136,37 @@ def test_mirror_by_joint_frames():
     assert "mirror_kernel<" in _note(), _lib.last_kernel_name()
     a, b = out[:4096].cpu().numpy(), out_s.cpu().numpy()
     assert np.minimum(np.abs(a - b).max(-1), np.abs(a + b).max(-1)).max() <= 4e-6
-    # the reference's chain rebuilt from oracle pieces (fk -> from_matrix -> negate -> from_global_rotations; axis 0 = X: components 2, 3,
-    # skeleton.py:310-312), up to the sign of each quaternion: test_gpu_parity.py's bar for the big skeletons
+    # up to the sign of each quaternion: test_gpu_parity.py's bar for the big skeletons
     big = out.cpu().numpy()
     for got, sl in [(big[sl], sl) for sl in _slices(rot.shape[0])] + [(b, slice(0, 4096, 16))]:
         if got.shape[0] != 256:
             got = got[::16]
-        _, rm = co.fk(rot[sl].astype(np.float64), np.zeros((256, 3)), off.astype(np.float64), par)
-        g = co.quat_from_matrix(rm)
-        g[..., 2] *= -1
-        g[..., 3] *= -1
-        want = co.from_global_rotations(g, par)
+        want = _mirror_want(rot, off, par, sl)
         err = np.minimum(np.abs(got - want).max(-1), np.abs(got + want).max(-1)).max()
-        assert err <= 1e-5, (sl, err)
+        assert err <= 1e-5 * max(1.0, 65 / 32), (sl, err)
+
+
+def test_mirror_step_list_kernel_against_the_oracle():
+    """mirror_wide_kernel on the production library: SMPL-H (four frames a wave), a 72-joint humanoid (two) and a wide 300-joint tree (one frame a wave, sixteen
+    joints a step, two tiles a workgroup), first / middle / last tiles of a production-size call, up to the sign of each quaternion"""
+    import torch
+
+    from pymotion_amd import synthetic as syn
+
+    dev = torch.device("cuda:0")
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    for J, par, F, fpw in ((52, np.asarray(syn.PARENTS_52, dtype=np.int32), 70_001, 4), (96, syn.random_parents(96, np.random.default_rng(96)).astype(np.int32), 30_000, 2),
+                           (300, syn.random_parents(300, np.random.default_rng(300)).astype(np.int32), 70_000, 1)):
+        rot, root, off = _batch(F, J, 40 + J)
+        tr = torch.from_numpy(rot).to(dev)
+        out = torch.full((F, J, 4), float("nan"), device=dev)
+        _lib.call("pm_mirror_rotations_f32", P(tr), par.ctypes.data_as(C.c_void_p), None, 0, F, J, P(out), None)
+        assert "mirror_wide_kernel<%d," % fpw in _note(), _lib.last_kernel_name()
+        got = out.cpu().numpy()
+        for sl in _slices(F):
+            want = _mirror_want(rot, off, par, sl)
+            err = np.minimum(np.abs(got[sl] - want).max(-1), np.abs(got[sl] + want).max(-1)).max()
+            assert err <= 1e-5, (J, sl, err)
 
 
 def test_from_root_positions_by_joint_frames():
@@ -250,7 +280,7 @@ def test_fk_wide_walk_on_bushy_trees():
 
 
 ALL_SKELETON_KERNELS = {"fk_wide_kernel", "to_root_dq_kernel", "to_root_dq_sched_kernel", "to_root_dq_wide_kernel", "to_root_dq_deep_kernel", "to_root_dq_ring_kernel", "gather_parent_kernel",
-                        "fk_kernel", "fk_pipe_kernel", "fk_stream_kernel", "mirror_kernel", "mirror_deep_kernel", "from_root_positions_kernel",
+                        "fk_kernel", "fk_pipe_kernel", "fk_stream_kernel", "mirror_kernel", "mirror_deep_kernel", "mirror_wide_kernel", "from_root_positions_kernel",
                         "from_root_positions_order_kernel"}
 
 
@@ -258,7 +288,7 @@ def test_every_kernel_name_of_the_production_library_is_tied_to_the_oracle(reque
     """every kernel template `pm_last_kernel_name()` can return from libpmhip.so (the `set_kernel_name` sites of csrc/*.hip; asserted against
     the sources in tests/test_abi.py) was dispatched to by an oracle-tied call of this module -- on the production library"""
     ran = {i.name for i in request.session.items if i.module is request.module}
-    if len(ran) < 11:
+    if len(ran) < 12:
         pytest.skip("needs the whole module (the other tests collect the kernel names)")
     assert _lib.lib() is _lib._handles.get("prod"), "this module must run on the production library"
     assert SEEN == ALL_SKELETON_KERNELS, (sorted(ALL_SKELETON_KERNELS - SEEN), sorted(SEEN - ALL_SKELETON_KERNELS))

@@ -732,11 +732,20 @@ def test_mirror_big_skeletons_vs_oracle_composition(J, kind):
     assert_close(o2, off * np.array([1, -1, 1], np.float32), 0, "offsets")
 
 
+@pytest.mark.parametrize("walk", ["dispatch", "scheduled"])
 @pytest.mark.parametrize("J", [52, 97])
-def test_mirror_symmetry_mapping_on_the_scheduled_walk(J):
+def test_mirror_symmetry_mapping_on_the_scheduled_walk(J, walk, monkeypatch):
     """mode='symmetry' permutes the joints' world rotations before they are made local again (skeleton.py:322-331); on skeletons
-    that take the multi-chain walk, against the same composition of oracle pieces (up to the sign of each quaternion)"""
+    that take the multi-chain walk, against the same composition of oracle pieces (up to the sign of each quaternion).  `dispatch`: what the production
+    library picks (since round 6 the step-list walk, mirror_wide_kernel); `scheduled`: the chain scheduler's kernel (the tuning build with PM_MIRROR_WIDE=0)"""
+    import contextlib
+
+    from pymotion_amd import _lib
     from pymotion_amd import synthetic as syn
+
+    if walk == "scheduled":
+        monkeypatch.setenv("PM_MIRROR_WIDE", "0")
+    ctx = _lib.variant("tuning") if walk == "scheduled" else contextlib.nullcontext()
 
     rng = np.random.default_rng(7 * J)
     parents = syn.PARENTS_52 if J == 52 else syn.random_parents(J, rng)
@@ -748,7 +757,9 @@ def test_mirror_symmetry_mapping_on_the_scheduled_walk(J):
     rot /= np.linalg.norm(rot, axis=-1, keepdims=True)
     root = rng.uniform(-1, 1, (F, 3)).astype(np.float32)
     off = syn.make_offsets(J, rng, 0.1)
-    got, *_ = sk.mirror(rot, root, parents, off, None, mapping, "symmetry", "X")
+    with ctx:
+        got, *_ = sk.mirror(rot, root, parents, off, None, mapping, "symmetry", "X")
+        assert ("mirror_wide_kernel" in _lib.last_kernel_name()) == (walk == "dispatch"), _lib.last_kernel_name()
     _, rm = co.fk(rot.astype(np.float64), np.zeros((F, 3)), off.astype(np.float64), parents)
     g = co.quat_from_matrix(rm)[:, mapping]
     g[..., 2] *= -1  # axis X -> components (2, 3)  (skeleton.py:310-312)

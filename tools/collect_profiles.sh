@@ -23,6 +23,7 @@ PM_SWEEP_ALL=1 PM_SWEEP_TOPO=bushy python $R/tools/jsweep_probe.py 22,40,52,64,6
 DEEP_SWEEP=dq,fk,mirror python $R/tools/deep_sweep.py 56,57,60,63,64,65,66,68,72,80,88,96,97,112,127,128,129,192,250 > $OUT/r${RN}_deep_sweep.txt 2>&1
 python $R/tools/dq_probe.py 22,28,40,48,52,56,64,65,96,128 > $OUT/r${RN}_to_root_dq_sweep.txt 2>&1
 DQW_KINDS=body,bushy,humanoid,chain python $R/tools/dq_wide_sweep.py 16,22,32,52,64,96,128,250,512 2>&1 | grep -v amdgpu.ids > $OUT/r${RN}_dq_wide_sweep.txt
+(MW_KINDS=body python $R/tools/mirror_wide_sweep.py 52; MW_KINDS=bushy,humanoid,chain python $R/tools/mirror_wide_sweep.py 22,40,48,64,96,128,250,512) 2>&1 | grep -v amdgpu.ids > $OUT/r${RN}_mirror_wide_sweep.txt
 python $R/tools/ik_probe.py 4,22,28,52,96,128 2>&1 | grep -v amdgpu.ids > $OUT/r${RN}_from_root_positions_sweep.txt
 python $R/tools/ik_order_probe.py 2>&1 | grep -v amdgpu.ids >> $OUT/r${RN}_from_root_positions_sweep.txt
 python $R/tools/unroll_probe.py > $OUT/r${RN}_unroll_sweep.txt 2>&1
