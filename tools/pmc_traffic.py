@@ -29,11 +29,13 @@ KNOWN = [
     ("ceiling_kernel", None, "ceiling", None),
     ("to_root_dq_kernel<16", _grid(F22, 16), "to_root_dq_J22", F22 * (48 * 22 + 12)),
     ("to_root_dq_sched_kernel<2", _grid(F22, 8, 2), "to_root_dq_J22", F22 * (48 * 22 + 12)),
+    ("to_root_dq_wide_kernel<8, 3", _grid(F22, 8), "to_root_dq_J22", F22 * (48 * 22 + 12)),  # round 6: the step-list kernel (dqwide.hip), one tile a workgroup
     ("gather_parent_kernel<0", _grid(F22, 8), "from_root_dq_J22", F22 * 60 * 22),
     ("fk_pipe_kernel<4, 4, true, 0, false, false, false", _grid(F52, 4, 2), "fk_J52", F52 * (64 * 52 + 12)),
     ("fk_pipe_kernel<4, 4, true, 1, false, false, false", _grid(F52, 4, 2), "fk_from_ortho6d_J52", F52 * (72 * 52 + 12)),
     ("to_root_dq_kernel<8", _grid(F52, 8), "to_root_dq_J52", F52 * (48 * 52 + 12)),
     ("to_root_dq_sched_kernel<2", _grid(F52, 8, 2), "to_root_dq_J52", F52 * (48 * 52 + 12)),
+    ("to_root_dq_wide_kernel<4, 4", _grid(F52, 4), "to_root_dq_J52", F52 * (48 * 52 + 12)),
     ("gather_parent_kernel<0", _grid(F52, 4), "from_root_dq_J52", F52 * 60 * 52),
 ]
 
