@@ -561,7 +561,10 @@ static bool try_mirror_wide(const int fpw, const MirrorArgs &m, const int max_qu
         }
     a.rot = m.rot; a.out = m.out; a.F = m.F; a.J = J; a.c0 = m.c0; a.c1 = m.c1; a.parents = m.parents; a.mapping = m.mapping;
     const int64_t ntiles = (m.F + fpw - 1) / fpw;
-    int nt = (J > 100 && ntiles >= 65536) ? 2 : 1;  // (to_root_dq_wide_kernel's sweep, dqwide.hip)
+    // two tiles a workgroup: a tile is 16 J fpw bytes in and out (2-6 KB), and a workgroup that writes 4-12 KB in one place leaves fewer cache lines shared with
+    // its neighbours -- same-box sweep, one / two tiles: 48 joints 140 / 135 us, SMPL-H 170 / 157, 64 joints 197 / 181, 65 joints 244 / 204, 96 joints 330 / 279,
+    // 128 joints 400 / 374, 512 joints 961 / 753 (four: 767); a clip of real length keeps one (the launch wants its workgroups)
+    int nt = ntiles >= 32768 ? 2 : 1;
     nt = tune_env("PM_MW_NT", nt);
     if (nt < 1) nt = 1;
     rc = fpw == 1 ? launch_mirror_wide_nb<1>(a, nt, s) : (fpw == 2 ? launch_mirror_wide_nb<2>(a, nt, s) : (fpw == 4 ? launch_mirror_wide_nb<4>(a, nt, s) : launch_mirror_wide_nb<8>(a, nt, s)));
@@ -617,14 +620,14 @@ extern "C" int pm_mirror_rotations_f32(const float *rot, const int32_t *parents,
     // 141 / 151, 196 / 210, 294 / 343, 374 / 462, 383 / 707, 753 / 4411 (beyond kSchedMaxJoints a wide tree fell to the one-chain walk); humanoids of 56 / 64 / 128 /
     // 250 / 512 joints against the lane-per-frame kernel 180 / 193, 191 / 225, 381 / 436, 373 / 467, 797 / 913; SMPL-H 168 / 183; chain-like skeletons a draw
     // (56: 194 / 194, 72: 260 / 250, 96: 326 / 335); below 44 joints sixteen frames a wave on the one-chain walk stay ahead (22 joints 137 / 132, 32: 195 / 186).
-    // Frames a wave: four up to 64 joints, two up to 100, one beyond; a narrow tree (under a third of its quad-steps busy, or more steps than the list holds)
+    // Frames a wave: four up to 100 joints, one beyond (96 joints: 279 us with four or two, 128 joints 374 with one against 391); a narrow tree (under a third of its quad-steps busy, or more steps than the list holds)
     // takes more frames and fewer joints a step, and what no width holds goes on to the kernels below.  PM_MIRROR_WIDE (PM_TUNING build only): 0 never,
     // 1 / 2 / 4 / 8 force that many frames a wave.
     if (const int wide = tune_env("PM_MIRROR_WIDE", -1); vec && wide != 0 && (wide > 0 || (J >= kMirrorWideMinJ && tune_env("PM_MIRROR_DEEP", -1) != 1 && tune_env("PM_MIRROR_CHAINS", -1) < 0 && tune_env("PM_MIRROR_FPW", 0) == 0))) {
         int rc = PM_OK;
         if (wide > 0) { if (try_mirror_wide(wide, a, 0, s, rc)) return rc; }
         else
-            for (int fpw = J <= 64 ? 4 : (J <= 100 ? 2 : 1); fpw <= 8; fpw *= 2)
+            for (int fpw = J <= 100 ? 4 : 1; fpw <= 8; fpw *= 2)
                 if (try_mirror_wide(fpw, a, 30, s, rc)) return rc;
     }
     // mode 'all' on long skeletons: one lane per frame, joints streamed (mirror_deep_kernel), where the call has the joint-frames to fill the

@@ -87,6 +87,8 @@ def test_to_root_dual_quat_step_list_kernel_against_the_oracle():
         rot, root, off = _batch(F, J, 31 + J)
         for scale in (1.0, 100.0):
             d = sk.to_root_dual_quat(rot, root * scale, par, off * scale)
+            # (centimetre-scale bones by the front door's hint on a tree the lane-per-frame kernels take -- SMPL-H -- go to them first where a call has their
+            # 2.4 M joint-frames; the NumPy door's pipeline chunks of this call do not)
             assert "to_root_dq_wide_kernel" in _note(), _lib.last_kernel_name()
             for sl in _slices(F):
                 d_o = co.to_root_dual_quat(*_f64(rot[sl], root[sl] * np.float32(scale)), par, (off * np.float32(scale)).astype(np.float64))
@@ -147,15 +149,15 @@ def test_mirror_by_joint_frames():
 
 
 def test_mirror_step_list_kernel_against_the_oracle():
-    """mirror_wide_kernel on the production library: SMPL-H (four frames a wave), a 72-joint humanoid (two) and a wide 300-joint tree (one frame a wave, sixteen
-    joints a step, two tiles a workgroup), first / middle / last tiles of a production-size call, up to the sign of each quaternion"""
+    """mirror_wide_kernel on the production library: SMPL-H and a random 96-joint tree (four frames a wave; one and two tiles a workgroup) and a wide 300-joint
+    tree (one frame a wave, sixteen joints a step), first / middle / last tiles of a production-size call, up to the sign of each quaternion"""
     import torch
 
     from pymotion_amd import synthetic as syn
 
     dev = torch.device("cuda:0")
     P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-    for J, par, F, fpw in ((52, np.asarray(syn.PARENTS_52, dtype=np.int32), 70_001, 4), (96, syn.random_parents(96, np.random.default_rng(96)).astype(np.int32), 30_000, 2),
+    for J, par, F, fpw in ((52, np.asarray(syn.PARENTS_52, dtype=np.int32), 70_001, 4), (96, syn.random_parents(96, np.random.default_rng(96)).astype(np.int32), 140_000, 4),
                            (300, syn.random_parents(300, np.random.default_rng(300)).astype(np.int32), 70_000, 1)):
         rot, root, off = _batch(F, J, 40 + J)
         tr = torch.from_numpy(rot).to(dev)
