@@ -95,10 +95,12 @@ int pm_to_root_dq_f32(const float *rot, const float *root_pos, const int32_t *pa
 
 /* The same with a HOST-side hint: offsets_abs_max = max |offsets[j][k]| when the caller has the table on the host (the NumPy door
  * always has; the torch door remembers it per tensor), < 0 or NaN when unknown (= pm_to_root_dq_f32).  The library never reads
- * device memory to choose a kernel, so without the hint skeletons below 40 joints decide per TILE (bones >= 1 unit or a root >= 16
- * units: float64 quaternion chain + fixed-point translations); with it, big-bone skeletons (centimetre-scale BVH data) of 20 joints
- * or more take the lane-per-frame kernel, whose float64 state costs the same at every magnitude.  Results are within the same
- * bar either way. */
+ * device memory to choose a kernel, so without the hint every skeleton decides per TILE (bones >= 1 unit or a root >= 16
+ * units: float64 quaternion chain + fixed-point translations) on the kernels that are fastest on metre-scale data; with it, big-bone
+ * skeletons (centimetre-scale BVH data) of 20 joints or more take the lane-per-frame kernel where the call has its 2.4 M joint-frames,
+ * whose float64 state costs the same at every magnitude -- 5-25 % faster there than the per-tile precise step, most on skeletons of
+ * twelve levels or more: a C caller who knows its bones are big should say so.  Results are within the same bar either way
+ * (DESIGN.md 3a). */
 int pm_to_root_dq_hint_f32(const float *rot, const float *root_pos, const int32_t *parents, const float *offsets, int64_t F,
                            int32_t J, float *dq, float offsets_abs_max, pm_stream_t stream);
 

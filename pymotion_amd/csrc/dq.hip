@@ -770,10 +770,11 @@ static int to_root_dq_impl(const float *rot, const float *root_pos, const int32_
     // SMPL-H 273 -> 233, random trees of 128 / 250 / 512 joints 54 / 39 / 7.5 % of the HBM spec -> 70 / 64 / 68), and on centimetre-scale data wherever the
     // tile kernels of this file ran (22 joints 266 -> 227 us).  What it does not beat is the lane-per-frame kernels' float64 state on centimetre-scale data
     // of skeletons deep enough for the float64 bone rotation (kDqF64RotMinDepth: 64-joint humanoid 321 us at every scale there, 274 / 394 here), and the raw
-    // ABI cannot see the scale: so it goes first when the caller says the bones are small (pm_to_root_dq_hint_f32), or says nothing and the skeleton is shallow,
-    // and otherwise -- big bones by the hint (22 joints 243 us on the lane-per-frame kernel against 256 here, SMPL-H 144 against 158), or a deep skeleton of unknown
-    // scale -- after the lane-per-frame kernels have declined.  PM_DQ_WIDE (PM_TUNING build only): 0 never, 1 / 2 / 4 / 8 force that many frames a wave.
-    const bool small_bones = offsets_abs_max >= 0.0f && offsets_abs_max < kBigOffset;
+    // ABI cannot see the scale.  So: a caller who says the bones are BIG (pm_to_root_dq_hint_f32: the front doors do) gets the lane-per-frame kernels first where
+    // they take the call (22 joints 228 us there against 242-256 here, SMPL-H 145 against 152-158) and this kernel when they decline; everybody else -- small bones
+    // by the hint, or no hint at all -- gets this kernel first: without a hint a deep skeleton on centimetre-scale data is 10-25 % slower than the lane-per-frame
+    // kernels would have been, one on metre-scale data 15-35 % faster (chain-like skeletons of 40-128 joints 60-63 % of the HBM spec there, 72-76 here), and
+    // include/pmhip.h tells a C caller with big bones to say so.  PM_DQ_WIDE (PM_TUNING build only): 0 never, 1 / 2 / 4 / 8 force that many frames a wave.
     const int wide_env = tune_env("PM_DQ_WIDE", -1);
     auto try_wide = [&](int &rc) {
         if (!vec || wide_env == 0 || (wide_env < 0 && J < kDqWideMinJ)) return false;
@@ -789,7 +790,7 @@ static int to_root_dq_impl(const float *rot, const float *root_pos, const int32_
             if (try_to_root_dq_wide(fpw, rot, root_pos, offsets, dq, F, J, a.depth, a.parents, a.ablate, 30, s, rc)) return true;
         return false;
     };
-    if (small_bones || (!big_bones && a.depth < kDqF64RotMinDepth) || wide_env > 0) {
+    if (!big_bones || wide_env > 0) {
         int rc = PM_OK;
         if (try_wide(rc)) return rc;
     }

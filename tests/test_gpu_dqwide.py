@@ -167,12 +167,13 @@ def test_production_dispatch_of_the_step_list_kernel(J, kind, osc, fpw):
 
 
 def test_raw_abi_without_a_scale_hint():
-    """pm_to_root_dq_f32 cannot see the bones' scale: shallow skeletons take the step-list kernel with the frames a wave that suit the precise step too; deep
-    ones (float64 bone rotation from depth 12 on) only where the lane-per-frame kernels decline"""
+    """pm_to_root_dq_f32 cannot see the bones' scale and is tuned for metre-scale data: the step-list kernel first, whatever the depth (a caller who knows its bones are
+    big says so through pm_to_root_dq_hint_f32 and keeps the lane-per-frame kernels on the calls they take)"""
     import torch
 
     P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-    for J, kind, want in ((22, "body", "to_root_dq_wide_kernel<8,"), (52, "smplh", "to_root_dq_wide_kernel<4,"), (200, "bushy", "to_root_dq_wide_kernel<1,")):
+    for J, kind, want in ((22, "body", "to_root_dq_wide_kernel<8,"), (52, "smplh", "to_root_dq_wide_kernel<4,"), (200, "bushy", "to_root_dq_wide_kernel<1,"),
+                          (64, "chain", "to_root_dq_wide_kernel<4,")):
         parents = _tree(kind, J)
         rot, root, off = _batch(300, J, J, 0.3, 2.0)
         tr, tp, to = (torch.from_numpy(x).cuda() for x in (rot, root, off))
