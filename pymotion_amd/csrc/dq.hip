@@ -171,14 +171,14 @@ __global__ __launch_bounds__(PM_WAVE) void to_root_dq_kernel(const ToRootArgs a)
     double gqd = 0.0;                                     // precise: the same quaternion component in float64
     float peqA = (c == 0) ? 1.0f : 0.0f, petA = 0.0f, peqB = 0.0f, petB = 0.0f;  // the root composes with the identity
     int pelA = 0, pelB = 0;                               // precise: the parent slot's packed residuals
-    const int *fDl = reinterpret_cast<const int *>(fD + 7);
+    const float *fDl = fD + 7;  // (read as the floats they are stored as: an int-typed load does not alias the float-typed stores for the compiler, see dw_walk in dqwide.hip)
     int par = J;
     auto step = [&](auto tag, const int j, const int o, const int parn, Regs &S, const float peq, const float pet, const int pel,
                     float &peqn, float &petn, int &peln, const bool may_be_dummy) {
         constexpr bool PRECISE = decltype(tag)::value != 0;
         peqn = fDq[parn * 8];  // parent of joint j+1, if it is not joint j itself (then: a stale value, unused)
         petn = fDt[parn * 8];
-        if (PRECISE) peln = fDl[parn * 8];
+        if (PRECISE) peln = __float_as_int(fDl[parn * 8]);
         const float sb1 = quad_perm_mul<1, 0, 3, 2>(S.b, s1), sb2 = quad_perm_mul<2, 3, 0, 1>(S.b, s2),
                     sb3 = quad_perm_mul<3, 2, 1, 0>(S.b, s3);
         const bool chain = (par == j - 1);  // wave-uniform

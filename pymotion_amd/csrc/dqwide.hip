@@ -60,7 +60,9 @@ __device__ __forceinline__ void dw_walk(float *fD, const uint32_t (&JW)[kDwGroup
         const unsigned par = w >> 16, ownn = wn & 0xffffu;
         const float peq = *reinterpret_cast<const float *>(bq + par), pet = *reinterpret_cast<const float *>(bq + par + 16);
         int pel = 0;
-        if constexpr (PRECISE) pel = *reinterpret_cast<const int *>(bl + par);
+        // (read as the float it was stored as: an int-typed load may be moved above the float-typed store of the step before -- the two types do not alias for
+        // the compiler -- and then reads the slot's parked zero instead of the residuals: 5-6e-8 on the quaternions at four frames a wave, found by a soak run)
+        if constexpr (PRECISE) pel = __float_as_int(*reinterpret_cast<const float *>(bl + par));
         const float bn = *reinterpret_cast<const float *>(bq + ownn), vn = *reinterpret_cast<const float *>(bq + ownn + 16);
         const float sb1 = quad_perm_mul<1, 0, 3, 2>(b, s1), sb2 = quad_perm_mul<2, 3, 0, 1>(b, s2), sb3 = quad_perm_mul<3, 2, 1, 0>(b, s3);
         const float w1 = quad_perm_mul<0, 3, 1, 2>(vc, two), w2 = quad_perm_mul<0, 2, 3, 1>(vc, two);  // 2 v_nextnext, 2 v_next (lane 0: 2 x 0)
