@@ -240,7 +240,46 @@ def secondary_configs(torch, _lib, syn, dev, rot, root, off, parents, sptr):
     t_ik = timed(lambda: _lib.call("pm_from_root_positions_f32", p(pos4), pp4, p(off4), F4, 52, p(ik4), sptr))
     out["from_root_positions_J52_level_order"] = {"frames": F4, "ms": t_ik, "frames_per_s": F4 / (t_ik * 1e-3),
                                                    "hbm_frac": F4 * 28 * 52 / (t_ik * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel": _lib.last_kernel_name()}
+    # to_root_dual_quat and mirror on the same 52-joint tree (SMPL-H, unit quaternions from the conversion above, metre-scale bones): the step-list kernels of
+    # round 6 (dqwide.hip / mirror_wide_kernel: 16 / fpw joints of a frame a step from a host-made list held in registers), a slice checked against the oracle
+    dq4 = torch.empty((F4, 52, 8), device=dev)
+    t_dq4 = timed(lambda: _lib.call("pm_to_root_dq_f32", p(q4), p(root4), pp4, p(off4), F4, 52, p(dq4), sptr))
+    k_dq4 = _lib.last_kernel_name()
+    from oracle import numpy_ref as nr_
+
+    sl4 = slice(F4 // 2, F4 // 2 + 256)
+    want4 = nr_.to_root_dual_quat(q4[sl4].cpu().numpy().astype(np.float64), root4[sl4].cpu().numpy().astype(np.float64), syn.PARENTS_52, off4.cpu().numpy().astype(np.float64))
+    err_dq4 = float(np.abs(dq4[sl4].cpu().numpy() - want4).max())
+    assert err_dq4 <= 1e-5, err_dq4
+    mir4 = torch.empty((F4, 52, 4), device=dev)
+    t_mir4 = timed(lambda: _lib.call("pm_mirror_rotations_f32", p(q4), pp4, None, 0, F4, 52, p(mir4), sptr))
+    out["to_root_dual_quat_J52"] = {"frames": F4, "ms": t_dq4, "hbm_frac": F4 * (48 * 52 + 12) / (t_dq4 * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel": k_dq4,
+                                    "max_abs_err_vs_oracle_256_frames": err_dq4}
+    out["mirror_J52"] = {"frames": F4, "ms": t_mir4, "hbm_frac": F4 * 32 * 52 / (t_mir4 * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel": _lib.last_kernel_name()}
+    del dq4, mir4
     del x, root4, off4, pos4, rm4, q4, ik4, sets4
+    # ... and on a WIDE 250-joint tree (parents[j] uniform in [0, j): 10 levels), where rounds 1-5 read 39 % / 37 % (sixteen chains a frame in 25 KB of LDS a wave / the
+    # chain scheduler's last joint count)
+    F6, J6 = 1 << 17, 250
+    par6 = syn.random_parents(J6, np.random.default_rng(J6)).astype(np.int32)
+    pp6 = par6.ctypes.data_as(C.c_void_p)
+    rot6 = torch.randn((F6, J6, 4), device=dev)
+    rot6 /= rot6.norm(dim=-1, keepdim=True)
+    root6 = torch.rand((F6, 3), device=dev) * 4 - 2
+    off6 = torch.randn((J6, 3), device=dev) * 0.1
+    off6[0] = 0
+    dq6 = torch.empty((F6, J6, 8), device=dev)
+    t6 = timed(lambda: _lib.call("pm_to_root_dq_f32", p(rot6), p(root6), pp6, p(off6), F6, J6, p(dq6), sptr), n=40)
+    k6 = _lib.last_kernel_name()
+    want6 = nr_.to_root_dual_quat(rot6[:64].cpu().numpy().astype(np.float64), root6[:64].cpu().numpy().astype(np.float64), par6, off6.cpu().numpy().astype(np.float64))
+    err6 = float(np.abs(dq6[:64].cpu().numpy() - want6).max())
+    assert err6 <= 1e-5, err6
+    mir6 = torch.empty((F6, J6, 4), device=dev)
+    t6m = timed(lambda: _lib.call("pm_mirror_rotations_f32", p(rot6), pp6, None, 0, F6, J6, p(mir6), sptr), n=40)
+    out["wide_random_tree_J250"] = {"frames": F6, "to_root_dual_quat_ms": t6, "to_root_dual_quat_hbm_frac": F6 * (48 * J6 + 12) / (t6 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                    "to_root_dual_quat_kernel": k6, "to_root_max_abs_err_vs_oracle_64_frames": err6,
+                                    "mirror_ms": t6m, "mirror_hbm_frac": F6 * 32 * J6 / (t6m * 1e-3) / 1e9 / HBM_PEAK_GBPS, "mirror_kernel": _lib.last_kernel_name()}
+    del rot6, root6, off6, dq6, mir6
     # a LONG, chain-like skeleton (128 joints: one chain, a second one off the root, a third off joint 32; 2^18 frames): what the
     # tile kernels are worst at (round 2: to_root_dual_quat 31 %, fk 46 %).  to_root_dual_quat: the lane-per-frame kernel of deep.hip.
     F5, J5 = 1 << 18, 128
