@@ -786,8 +786,11 @@ static int to_root_dq_impl(const float *rot, const float *root_pos, const int32_
         // (250 joints 546 against 558 with two); a narrow tree -- under a third of its quad-steps busy, or more steps than the list holds -- takes more frames
         // and fewer joints a step
         int fpw = J <= 32 ? 8 : (J <= 128 ? 4 : 1);
-        for (; fpw <= 8; fpw *= 2)
-            if (try_to_root_dq_wide(fpw, rot, root_pos, offsets, dq, F, J, a.depth, a.parents, a.ablate, 30, s, rc)) return true;
+        // (first a width at which at least two thirds of the quad-steps are busy -- a 64-joint chain-like skeleton 274 us at eight frames a wave against 295 at four, a
+        // 128-joint humanoid 574 at two against 604 at one --, then any at which a third are)
+        for (const int bound : {15, 30})
+            for (int w = fpw; w <= 8; w *= 2)
+                if (try_to_root_dq_wide(w, rot, root_pos, offsets, dq, F, J, a.depth, a.parents, a.ablate, bound, s, rc)) return true;
         return false;
     };
     if (!big_bones || wide_env > 0) {

@@ -627,8 +627,9 @@ extern "C" int pm_mirror_rotations_f32(const float *rot, const int32_t *parents,
         int rc = PM_OK;
         if (wide > 0) { if (try_mirror_wide(wide, a, 0, s, rc)) return rc; }
         else
-            for (int fpw = J <= 100 ? 4 : 1; fpw <= 8; fpw *= 2)
-                if (try_mirror_wide(fpw, a, 30, s, rc)) return rc;
+            for (const int bound : {15, 30})  // (a width with two thirds of its quad-steps busy first, then one with a third: to_root_dq_impl, dq.hip)
+                for (int fpw = J <= 100 ? 4 : 1; fpw <= 8; fpw *= 2)
+                    if (try_mirror_wide(fpw, a, bound, s, rc)) return rc;
     }
     // mode 'all' on long skeletons: one lane per frame, joints streamed (mirror_deep_kernel), where the call has the joint-frames to fill the
     // chip (common.hpp).  From 66 joints on, and from 52 when the row is a whole number of 64-byte pieces (round 4, with the kernel's eight

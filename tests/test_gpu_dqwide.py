@@ -141,8 +141,9 @@ def test_step_list_kernel_keeps_nan_and_inf_where_the_reference_has_them(fpw, mo
 
 PICKS = [  # (J, tree, offsets scale, frames a wave the production dispatch picks -- None: another kernel)
     (12, "bushy", 0.3, None),       # below kDqWideMinJ: sixteen frames a wave on the one-chain kernel
-    (16, "bushy", 0.3, 8), (22, "body", 0.3, 8), (22, "body", 30.0, 8), (33, "bushy", 0.3, 4), (52, "smplh", 0.15, 4), (52, "smplh", 30.0, 4), (64, "chain", 0.3, 4),
-    (100, "bushy", 0.3, 4), (128, "bushy", 30.0, 4), (129, "humanoid", 0.3, 1), (200, "bushy", 0.3, 1), (512, "bushy", 30.0, 1),
+    (16, "bushy", 0.3, 8), (22, "body", 0.3, 8), (22, "body", 30.0, 8), (33, "bushy", 0.3, 4), (52, "smplh", 0.15, 4), (52, "smplh", 30.0, 4), (64, "chain", 0.3, 8),   # (a narrow tree: two thirds of the quad-steps busy only at two joints a step)
+   
+    (100, "bushy", 0.3, 4), (128, "bushy", 30.0, 4), (129, "humanoid", 0.3, 2), (200, "bushy", 0.3, 1), (512, "bushy", 30.0, 1),
     (96, "chain", 0.3, 4),          # 48 levels: the list holds them at four joints a step, and over a third of the quad-steps are busy
     (28, "chain", 30.0, 8),         # centimetre-scale bones (the front door's hint says so) on a skeleton deep enough for the float64 bone rotation, but too few
                                     # joint-frames for the lane-per-frame kernels: they decline, this one takes it
@@ -175,7 +176,7 @@ def test_raw_abi_without_a_scale_hint():
 
     P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
     for J, kind, want in ((22, "body", "to_root_dq_wide_kernel<8,"), (52, "smplh", "to_root_dq_wide_kernel<4,"), (200, "bushy", "to_root_dq_wide_kernel<1,"),
-                          (64, "chain", "to_root_dq_wide_kernel<4,")):
+                          (64, "chain", "to_root_dq_wide_kernel<8,")):
         parents = _tree(kind, J)
         rot, root, off = _batch(300, J, J, 0.3, 2.0)
         tr, tp, to = (torch.from_numpy(x).cuda() for x in (rot, root, off))
