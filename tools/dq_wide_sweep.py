@@ -4,7 +4,7 @@
 column is the dispatch's own pick through the raw ABI (no scale hint) and -- `hint` -- with the front doors' hint; says whether the results agree to the bit.
 DQW_KINDS=bushy,humanoid,chain,body picks the trees (body: the 22-joint body / SMPL-H at J = 22 / 52), DQW_FPW the candidates."""
 import ctypes as C, os, sys
-os.environ["PMHIP_VARIANT"] = "tuning"
+os.environ.setdefault("PMHIP_VARIANT", "tuning")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import tools.perf_probe as pp

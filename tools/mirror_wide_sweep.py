@@ -3,7 +3,7 @@
 dispatch picked before it existed (PM_MIRROR_WIDE=0), same box, same arrays; the last column is the dispatch's own pick; says whether the results agree to the bit.
 MW_KINDS=bushy,humanoid,chain,body picks the trees, MW_FPW the candidates, MW_MAP=1 mirrors with a random joint permutation (mode 'symmetry')."""
 import ctypes as C, os, sys
-os.environ["PMHIP_VARIANT"] = "tuning"
+os.environ.setdefault("PMHIP_VARIANT", "tuning")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import tools.perf_probe as pp
