@@ -291,6 +291,14 @@ int pm_unroll_onepass_f32(int32_t kind, const float *in, const uint8_t *order, i
  * counterpart (ops/skeleton.py:51-58 is a loop over joints). */
 int pm_fk_wide_plan_debug(const int32_t *parents, int32_t J, uint32_t *jobs);
 
+/* Host only (no GPU work): the step words the step-list kernels of round 6 would run for this topology -- op 0: to_root_dual_quat (dqwide.hip; ops/skeleton.py:230-241),
+ * op 1: mirror (mirror.hip; ops/skeleton.py:300-331) -- at `fpw` = 1 / 2 / 4 / 8 frames a wave, i.e. 16 / fpw joints of a frame a step.  `jobs` receives 16 x 56 words,
+ * jobs[k * 56 + step] = own slot | parent slot << 16 in BYTES of the frame's image (32-byte slots for op 0, 16-byte slots for op 1): slot J is the identity (op 0: what
+ * the root's children compose with -- they stay local, skeleton.py:236-237), slot J + 1 what idle quads read and write; the root takes no step.  Returns the number of
+ * steps, PM_EUNSUPPORTED when the tree needs more than the 48 the list holds (the dispatch then keeps the other kernels), another error code on a bad topology or
+ * argument.  For tests of the scheduler; the reference has no counterpart (a loop over joints). */
+int pm_step_list_plan_debug(const int32_t *parents, int32_t J, int32_t op, int32_t fpw, uint32_t *jobs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,6 +100,7 @@ SIGNATURES = {
     "pm_unroll_onepass_f32": [_i32, _f, C.c_void_p, _i64, _i64, _i32, _f, C.c_void_p, C.c_void_p, C.c_void_p, _i64, _strm],
     # host-only introspection (tests of the wide walk's scheduler)
     "pm_fk_wide_plan_debug": [C.c_void_p, _i32, C.c_void_p],
+    "pm_step_list_plan_debug": [C.c_void_p, _i32, _i32, _i32, C.c_void_p],
 }
 
 _lib = None

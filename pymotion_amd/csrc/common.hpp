@@ -837,6 +837,8 @@ int fk_wide_plan(const Parents &par, int J, int width, int max_steps, bool dup_i
 // ---- dqwide.hip: to_root_dual_quat from a step list in registers, 16 / fpw joints of a frame a step ---------------------------------
 bool try_to_root_dq_wide(int fpw, const float *rot, const float *root_pos, const float *offsets, float *dq, int64_t F, int32_t J, int32_t depth,
                          const Parents &par, int ablate, int max_quad_steps_per_joint_x10, hipStream_t s, int &rc);
+int dq_wide_words(const Parents &par, int J, int fpw, uint32_t *jobs);      // [16 x 56] step words, dqwide.hip
+int mirror_wide_words(const Parents &par, int J, int fpw, uint32_t *jobs);  // [16 x 56] step words, mirror.hip
 int launch_to_root_deep(const float *rot, const float *root_pos, const float *offsets, float *dq, int64_t F, int32_t J,
                         const DeepTopo &topo, hipStream_t s);
 

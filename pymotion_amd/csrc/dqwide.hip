@@ -261,6 +261,27 @@ static int launch_dq_wide_nb(const DqWideArgs &a, const int nt, hipStream_t s) {
     return launch_dq_wide<FPW, 8>(a, nt, s);
 }
 
+// The kernel's step words for this tree at 16 / fpw joints a step: jobs[k * kDwStride + step] = own slot | parent slot << 16, in bytes of the 32-byte slots (the root's
+// children compose with the identity slot J, skeleton.py:236-237; idle: slot J + 1 composed with the identity).  Returns the number of steps, -1 when the tree needs
+// more than kDwSteps.
+int dq_wide_words(const Parents &par, const int J, const int fpw, uint32_t *jobs) {
+    const int W = 16 / fpw;
+    uint32_t list[(kDwSteps + 2) * 16];
+    const int nsteps = (J == 1) ? 0 : fk_wide_plan(par, J, W, kDwSteps, false, list);
+    if (nsteps < 0) return -1;
+    const uint32_t idle = (uint32_t)((J + 1) * 32) | ((uint32_t)(J * 32) << 16);
+    for (int k = 0; k < 16; ++k)
+        for (int st = 0; st < kDwStride; ++st) {
+            uint32_t w = idle;
+            if (k < W && st < nsteps) {
+                const uint32_t j = list[st * W + k] & 0xffffu, p = list[st * W + k] >> 16;
+                if ((int)j < J) w = (j * 32u) | ((p == 0 ? (uint32_t)J : p) * 32u) << 16;
+            }
+            jobs[k * kDwStride + st] = w;
+        }
+    return nsteps;
+}
+
 // to_root_dual_quat on 16-byte aligned arrays with `fpw` = 1, 2, 4 or 8 frames a wave.  Returns false (nothing launched) when fpw x J records do not fit
 // eight batches or the tree needs more than kDwSteps steps of 16 / fpw joints, or more than max_quad_steps_per_joint_x10 / 10 quad-steps per joint
 // (0: no such bound); true with rc set otherwise.
@@ -269,20 +290,9 @@ bool try_to_root_dq_wide(const int fpw, const float *rot, const float *root_pos,
     if ((fpw != 1 && fpw != 2 && fpw != 4 && fpw != 8) || fpw * J > 8 * PM_WAVE) return false;
     const int W = 16 / fpw;
     DqWideArgs a;
-    uint32_t list[(kDwSteps + 2) * 16];
-    a.nsteps = (J == 1) ? 0 : fk_wide_plan(par, J, W, kDwSteps, false, list);
+    a.nsteps = dq_wide_words(par, J, fpw, a.jobs);
     if (a.nsteps < 0) return false;
     if (max_quad_steps_per_joint_x10 > 0 && a.nsteps * W * 10 > max_quad_steps_per_joint_x10 * J) return false;
-    const uint32_t idle = (uint32_t)((J + 1) * 32) | ((uint32_t)(J * 32) << 16);
-    for (int k = 0; k < 16; ++k)
-        for (int st = 0; st < kDwStride; ++st) {
-            uint32_t w = idle;
-            if (k < W && st < a.nsteps) {
-                const uint32_t j = list[st * W + k] & 0xffffu, p = list[st * W + k] >> 16;
-                if ((int)j < J) w = (j * 32u) | ((p == 0 ? (uint32_t)J : p) * 32u) << 16;  // the root's children compose with the identity slot (skeleton.py:236-237)
-            }
-            a.jobs[k * kDwStride + st] = w;
-        }
     a.rot = rot; a.root_pos = root_pos; a.offsets = offsets; a.dq = dq; a.F = F; a.J = J; a.depth = depth; a.ablate = ablate;
     // tiles per workgroup: the words and the offsets are loaded once and the next tile's quaternions are requested before a tile's walk, but a launch wants
     // many more workgroups than the chip has wave slots (the last round of a launch runs part empty).  Same-box sweep at 2^18...2^20 frames, one / two / four
@@ -297,3 +307,12 @@ bool try_to_root_dq_wide(const int fpw, const float *rot, const float *root_pos,
 }
 
 }  // namespace pm
+
+extern "C" int pm_step_list_plan_debug(const int32_t *parents, int32_t J, int32_t op, int32_t fpw, uint32_t *jobs) {
+    PM_CHECK_ARGS(parents && jobs && J >= 1 && J <= PM_MAX_JOINTS, "step_list_plan: need parents, jobs and 1 <= J <= PM_MAX_JOINTS");
+    PM_CHECK_ARGS((op == 0 || op == 1) && (fpw == 1 || fpw == 2 || fpw == 4 || fpw == 8), "step_list_plan: op 0 (to_root_dual_quat) or 1 (mirror), fpw 1 / 2 / 4 / 8");
+    pm::Parents par;
+    if (int e = pm::pack_parents(parents, J, par)) return e < 0 ? e : -e;
+    const int n = op == 0 ? pm::dq_wide_words(par, J, fpw, jobs) : pm::mirror_wide_words(par, J, fpw, jobs);
+    return n < 0 ? PM_EUNSUPPORTED : n;
+}

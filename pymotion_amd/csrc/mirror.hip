@@ -538,6 +538,26 @@ static int launch_mirror_wide_nb(const MirrorWideArgs &a, const int nt, hipStrea
     if (ne <= 6 * PM_WAVE) return launch_mirror_wide<FPW, 6>(a, nt, s);
     return launch_mirror_wide<FPW, 8>(a, nt, s);
 }
+// The kernel's step words for this tree at 16 / fpw joints a step: jobs[k * kMwStride + step] = own slot | parent slot << 16, in bytes of the 16-byte slots (the root
+// takes no step: its children compose with its slot as parked; idle: slot J + 1 composed with the identity slot J).  Returns the number of steps, -1 beyond kMwSteps.
+int mirror_wide_words(const Parents &par, const int J, const int fpw, uint32_t *jobs) {
+    const int W = 16 / fpw;
+    uint32_t list[(kMwSteps + 2) * 16];
+    const int nsteps = (J == 1) ? 0 : fk_wide_plan(par, J, W, kMwSteps, false, list);
+    if (nsteps < 0) return -1;
+    const uint32_t idle = (uint32_t)((J + 1) * 16) | ((uint32_t)(J * 16) << 16);
+    for (int k = 0; k < 16; ++k)
+        for (int st = 0; st < kMwStride; ++st) {
+            uint32_t w = idle;
+            if (k < W && st < nsteps) {
+                const uint32_t j = list[st * W + k] & 0xffffu, p = list[st * W + k] >> 16;
+                if ((int)j < J) w = (j * 16u) | (p * 16u) << 16;
+            }
+            jobs[k * kMwStride + st] = w;
+        }
+    return nsteps;
+}
+
 // 16-byte aligned arrays, `fpw` = 1, 2, 4 or 8 frames a wave.  false (nothing launched): fpw x J records do not fit eight batches, the tree needs more than
 // kMwSteps steps of 16 / fpw joints, or more than max_quad_steps_per_joint_x10 / 10 quad-steps per joint (0: no such bound); true with rc set otherwise.
 static bool try_mirror_wide(const int fpw, const MirrorArgs &m, const int max_quad_steps_per_joint_x10, hipStream_t s, int &rc) {
@@ -545,20 +565,9 @@ static bool try_mirror_wide(const int fpw, const MirrorArgs &m, const int max_qu
     if ((fpw != 1 && fpw != 2 && fpw != 4 && fpw != 8) || fpw * J > 8 * PM_WAVE) return false;
     const int W = 16 / fpw;
     MirrorWideArgs a;
-    uint32_t list[(kMwSteps + 2) * 16];
-    a.nsteps = (J == 1) ? 0 : fk_wide_plan(m.parents, J, W, kMwSteps, false, list);
+    a.nsteps = mirror_wide_words(m.parents, J, fpw, a.jobs);
     if (a.nsteps < 0) return false;
     if (max_quad_steps_per_joint_x10 > 0 && a.nsteps * W * 10 > max_quad_steps_per_joint_x10 * J) return false;
-    const uint32_t idle = (uint32_t)((J + 1) * 16) | ((uint32_t)(J * 16) << 16);
-    for (int k = 0; k < 16; ++k)
-        for (int st = 0; st < kMwStride; ++st) {
-            uint32_t w = idle;
-            if (k < W && st < a.nsteps) {
-                const uint32_t j = list[st * W + k] & 0xffffu, p = list[st * W + k] >> 16;
-                if ((int)j < J) w = (j * 16u) | (p * 16u) << 16;
-            }
-            a.jobs[k * kMwStride + st] = w;
-        }
     a.rot = m.rot; a.out = m.out; a.F = m.F; a.J = J; a.c0 = m.c0; a.c1 = m.c1; a.parents = m.parents; a.mapping = m.mapping;
     const int64_t ntiles = (m.F + fpw - 1) / fpw;
     // two tiles a workgroup: a tile is 16 J fpw bytes in and out (2-6 KB), and a workgroup that writes 4-12 KB in one place leaves fewer cache lines shared with

@@ -106,6 +106,12 @@ for J in (1, 2, 17, 52, 129, 512):  # the wide walk's step list (width 16; fk's 
         st = h.pm_fk_wide_plan_debug(par.ctypes.data_as(C.c_void_p), J, jobs)
         assert st >= 0 or st == _lib.PM_EUNSUPPORTED
         calls += 1
+        for op in (0, 1):  # the step words of round 6's step-list kernels (to_root_dual_quat, mirror) at every width
+            for fpw in (1, 2, 4, 8):
+                words = (C.c_uint32 * (16 * 56))()
+                st = h.pm_step_list_plan_debug(par.ctypes.data_as(C.c_void_p), J, op, fpw, words)
+                assert st >= 0 or st == _lib.PM_EUNSUPPORTED
+                calls += 1
 print("host paths exercised:", calls)
 """
 
