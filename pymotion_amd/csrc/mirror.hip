@@ -24,7 +24,7 @@ struct Map16 { int16_t m[PM_MAX_JOINTS]; };
 constexpr int kMirrorDeepMinJ = 66;   // from here on mode 'all' walks one lane per frame where the topology allows (chain-like skeletons at 2^19 frames, lane per
                                       // frame / scheduled walk, % of the HBM spec: J = 32 75 / 69, 44 69 / 64, 48 67 / 67, 50 56 / 62, 56 61 / 65, 64 60 / 63,
                                       // 65 54 / 58, 66 57 / 55, 72 60 / 58, 80 60 / 55.5, 96 60 / 53, 128 61 / 45; the SMPL-H tree at 2^18: 68 / 60)
-constexpr int kMirrorWideMinJ = 44;   // from here on the step-list walk (mirror_wide_kernel) goes first
+constexpr int kMirrorWideMinJ = 40;   // from here on the step-list walk (mirror_wide_kernel) goes first
 constexpr int kMirrorSchedMinJ = 40;  // from here on the scheduled walk is considered (measured: see pm_mirror_rotations_f32)
 
 struct MirrorArgs {
@@ -628,7 +628,8 @@ extern "C" int pm_mirror_rotations_f32(const float *rot, const int32_t *parents,
     // mapping.  Same-box sweep (profiles/r06_mirror_wide_sweep.txt), this kernel / what ran before, us: random trees of 48 / 64 / 96 / 128 / 250 / 512 joints
     // 141 / 151, 196 / 210, 294 / 343, 374 / 462, 383 / 707, 753 / 4411 (beyond kSchedMaxJoints a wide tree fell to the one-chain walk); humanoids of 56 / 64 / 128 /
     // 250 / 512 joints against the lane-per-frame kernel 180 / 193, 191 / 225, 381 / 436, 373 / 467, 797 / 913; SMPL-H 168 / 183; chain-like skeletons a draw
-    // (56: 194 / 194, 72: 260 / 250, 96: 326 / 335); below 44 joints sixteen frames a wave on the one-chain walk stay ahead (22 joints 137 / 132, 32: 195 / 186).
+    // (56: 194 / 194, 72: 260 / 250, 96: 326 / 335); 40 joints 116-124 / 125-131; below, sixteen frames a wave on the one-chain walk are a draw or ahead (22 joints
+    // 124-137 / 128-132, 32: 191-203 / 185, 36: 111-113 / 112-115).
     // Frames a wave: four up to 100 joints, one beyond (96 joints: 279 us with four or two, 128 joints 374 with one against 391); a narrow tree (under a third of its quad-steps busy, or more steps than the list holds)
     // takes more frames and fewer joints a step, and what no width holds goes on to the kernels below.  PM_MIRROR_WIDE (PM_TUNING build only): 0 never,
     // 1 / 2 / 4 / 8 force that many frames a wave.

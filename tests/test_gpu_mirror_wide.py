@@ -131,7 +131,7 @@ def test_step_list_walk_keeps_a_nan_in_its_frame(fpw, monkeypatch):
     assert np.minimum(np.abs(got[clean] - want).max(-1), np.abs(got[clean] + want).max(-1)).max() <= ATOL
 
 
-PICKS = [(40, "bushy", None), (44, "bushy", 4), (52, "smplh", 4), (64, "humanoid", 4), (72, "bushy", 4), (96, "chain", 4), (100, "bushy", 4), (128, "humanoid", 2),
+PICKS = [(39, "bushy", None), (40, "bushy", 4), (44, "bushy", 4), (52, "smplh", 4), (64, "humanoid", 4), (72, "bushy", 4), (96, "chain", 4), (100, "bushy", 4), (128, "humanoid", 2),
          (300, "bushy", 1), (130, "chain", None)]
 
 
